@@ -1,0 +1,83 @@
+/*
+ * qpgpu.h — C ABI of libqpgpu, the MI355X (gfx950) backend for the qp-wormhole proving hot path.
+ *
+ * The reference has no FFI: its "operator API" is the qp-plonky2 1.5.5 type surface reached from
+ *   wormhole/prover/src/lib.rs:171-175                         (leaf  prove)
+ *   wormhole/aggregator/src/private_batch/prover/lib.rs:326-330 (private batch prove)
+ *   wormhole/aggregator/src/public_batch/prover/lib.rs:301-305  (public batch prove)
+ * The entry points below are what a patched qp-plonky2 `plonk::prover::prove` would bind, stage by
+ * stage, plus the all-in-one qpgpu_prove. INTEGRATION.md shows the
+ * Rust `extern "C"` block. Plain pointers and sizes only; the caller owns every host buffer; device
+ * memory is owned by the library behind opaque handles (or raw device pointers the caller got from
+ * qpgpu_malloc / its own allocator). All field elements are little-endian u64; inputs may be any
+ * u64 (reduced on load), outputs are canonical (< p), as `to_canonical_u64` would serialise them
+ * (reference common/src/serialization.rs:40-43).
+ *
+ * Every function returns 0 on success or a negative QPGPU_E* code; qpgpu_last_error(ctx) gives the
+ * text. Nothing aborts the process. A ctx is bound to one GPU and one HIP stream and is not
+ * thread-safe; use one ctx per in-flight proof stream.
+ */
+#ifndef QPGPU_H
+#define QPGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qpgpu_ctx qpgpu_ctx;
+
+enum {
+    QPGPU_OK = 0,
+    QPGPU_EINVAL = -1,      /* bad argument (size, null pointer, unsupported log_n) */
+    QPGPU_EDEVICE = -2,     /* HIP runtime error; see qpgpu_last_error */
+    QPGPU_ENOMEM = -3,
+    QPGPU_EUNSAT = -4,      /* witness does not satisfy the circuit (quotient not divisible by Z_H) */
+    QPGPU_EBUFSIZE = -5     /* caller buffer too small */
+};
+
+/* ---- context ---- */
+int qpgpu_ctx_create(int device, qpgpu_ctx **out);
+void qpgpu_ctx_destroy(qpgpu_ctx *ctx);
+const char *qpgpu_last_error(const qpgpu_ctx *ctx);
+/* Use an existing HIP stream (hipStream_t passed as void*); NULL = the ctx's own stream. */
+int qpgpu_ctx_set_stream(qpgpu_ctx *ctx, void *hip_stream);
+int qpgpu_sync(qpgpu_ctx *ctx);
+const char *qpgpu_version(void);
+
+/* ---- device memory plumbing ---- */
+int qpgpu_malloc(qpgpu_ctx *ctx, size_t bytes, void **dptr);
+int qpgpu_free(qpgpu_ctx *ctx, void *dptr);
+int qpgpu_memcpy_h2d(qpgpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int qpgpu_memcpy_d2h(qpgpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- stage s2: plonky2::field::fft ---- */
+enum {
+    QPGPU_NTT_FORWARD = 0,        /* fft:  out[i] = P(w^i), natural order in and out */
+    QPGPU_NTT_INVERSE = 1,        /* ifft: coefficients from values, includes the 1/n */
+    QPGPU_NTT_OUT_BITREV = 2      /* flag: store out[bitrev(i)] (reverse_index_bits order) */
+};
+/*
+ * Batched transform of `batch` polynomials of 2^log_n elements, polynomial c at data + c*2^log_n.
+ * coset_shift: 0 or 1 = plain; otherwise forward = coset_fft(shift) (coefficients scaled by
+ * shift^i first). Replaces fft_with_options / ifft_with_options / coset_fft.
+ * Host-buffer form (copies in and out):
+ */
+int qpgpu_ntt_batch(qpgpu_ctx *ctx, uint64_t *data, unsigned log_n, size_t batch, int flags,
+                    uint64_t coset_shift);
+/* Device-buffer form; d_in == d_out is allowed. Asynchronous on the ctx stream. */
+int qpgpu_ntt_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n,
+                        size_t batch, int flags, uint64_t coset_shift);
+/*
+ * Low-degree extension: coefficients (2^log_n per polynomial) -> values of the zero-padded polynomial
+ * on the coset shift*<w_{n<<rate_bits}>; PolynomialBatch::from_coeffs minus the Merkle step.
+ * flags: 0 or QPGPU_NTT_OUT_BITREV. d_out holds batch << (log_n + rate_bits) elements.
+ */
+int qpgpu_lde_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_out, unsigned log_n,
+                        unsigned rate_bits, size_t batch, int flags, uint64_t coset_shift);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

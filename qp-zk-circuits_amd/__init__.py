@@ -1,0 +1,10 @@
+"""qp-zk-circuits_amd — MI355X (gfx950) backend for the qp-wormhole proving hot path.
+
+The product is libqpgpu.so (hand-written HIP kernels behind the C ABI of include/qpgpu.h).
+This Python package is only the ctypes harness used by tests/ and bench.py; it never falls back
+to a CPU implementation: if the shared library or a GPU is missing, calls raise.
+
+The directory name carries a hyphen (it mirrors the reference repository's name), so it is
+imported through `__graft_entry__.load_package()` under the module name `qp_zk_circuits_amd`.
+"""
+from .binding import QpGpu, QpGpuError, lib_path, load_library, P, MULT_GEN  # noqa: F401

@@ -1,0 +1,159 @@
+"""ctypes binding of include/qpgpu.h. Thin: argument marshalling and error mapping only."""
+import ctypes
+import os
+
+import numpy as np
+
+P = 0xFFFFFFFF00000001
+MULT_GEN = 14293326489335486720
+
+NTT_FORWARD = 0
+NTT_INVERSE = 1
+NTT_OUT_BITREV = 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libqpgpu.so")
+
+
+class QpGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"qpgpu error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Load libqpgpu.so. Raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(path)
+    c = ctypes
+    vp, u64p = c.c_void_p, c.c_void_p
+    sigs = {
+        "qpgpu_version": (c.c_char_p, []),
+        "qpgpu_ctx_create": (c.c_int, [c.c_int, c.POINTER(vp)]),
+        "qpgpu_ctx_destroy": (None, [vp]),
+        "qpgpu_last_error": (c.c_char_p, [vp]),
+        "qpgpu_ctx_set_stream": (c.c_int, [vp, vp]),
+        "qpgpu_sync": (c.c_int, [vp]),
+        "qpgpu_malloc": (c.c_int, [vp, c.c_size_t, c.POINTER(vp)]),
+        "qpgpu_free": (c.c_int, [vp, vp]),
+        "qpgpu_memcpy_h2d": (c.c_int, [vp, vp, vp, c.c_size_t]),
+        "qpgpu_memcpy_d2h": (c.c_int, [vp, vp, vp, c.c_size_t]),
+        "qpgpu_ntt_batch": (c.c_int, [vp, u64p, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
+        "qpgpu_ntt_batch_dev": (c.c_int, [vp, u64p, u64p, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
+        "qpgpu_lde_batch_dev": (c.c_int, [vp, u64p, u64p, c.c_uint, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names include/qpgpu.h declares; tests check each resolves in the built library."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "qpgpu.h")
+    text = open(hdr).read()
+    return sorted(set(re.findall(r"\b(qpgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+class DeviceBuffer:
+    """Device allocation owned through the C ABI (hipMalloc underneath)."""
+
+    def __init__(self, gpu, nbytes):
+        self.gpu, self.nbytes = gpu, nbytes
+        p = ctypes.c_void_p()
+        gpu._check(gpu.lib.qpgpu_malloc(gpu.ctx, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.gpu._check(self.gpu.lib.qpgpu_memcpy_h2d(self.gpu.ctx, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, count=None, dtype=np.uint64):
+        n = self.nbytes // np.dtype(dtype).itemsize if count is None else count
+        out = np.empty(n, dtype=dtype)
+        self.gpu._check(self.gpu.lib.qpgpu_memcpy_d2h(self.gpu.ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.gpu.lib.qpgpu_free(self.gpu.ctx, self.ptr)
+            self.ptr = None
+
+
+class QpGpu:
+    """One context = one GPU + one HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        ctx = ctypes.c_void_p()
+        rc = self.lib.qpgpu_ctx_create(device, ctypes.byref(ctx))
+        if rc != 0:
+            raise QpGpuError(rc, "qpgpu_ctx_create failed (no gfx950 device visible?)")
+        self.ctx = ctx
+        if stream is not None:
+            self._check(self.lib.qpgpu_ctx_set_stream(self.ctx, ctypes.c_void_p(stream)))
+
+    def close(self):
+        if self.ctx:
+            self.lib.qpgpu_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise QpGpuError(rc, self.lib.qpgpu_last_error(self.ctx).decode())
+
+    def sync(self):
+        self._check(self.lib.qpgpu_sync(self.ctx))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, arr.nbytes).upload(arr)
+
+    # ---- stage s2 ----
+    def ntt_host(self, data, log_n, inverse=False, coset_shift=0, bitrev=False):
+        """plonky2 fft / ifft / coset_fft on a host array [batch, 2^log_n]; returns a new array."""
+        a = np.array(data, dtype=np.uint64, copy=True).reshape(-1, 1 << log_n)
+        flags = (NTT_INVERSE if inverse else 0) | (NTT_OUT_BITREV if bitrev else 0)
+        self._check(self.lib.qpgpu_ntt_batch(self.ctx, a.ctypes.data, log_n, a.shape[0], flags, coset_shift))
+        return a
+
+    def ntt_dev(self, d_in, d_out, log_n, batch, inverse=False, coset_shift=0, bitrev=False):
+        flags = (NTT_INVERSE if inverse else 0) | (NTT_OUT_BITREV if bitrev else 0)
+        self._check(self.lib.qpgpu_ntt_batch_dev(self.ctx, _ptr(d_in), _ptr(d_out), log_n, batch, flags, coset_shift))
+
+    def lde_dev(self, d_coeffs, d_out, log_n, rate_bits, batch, coset_shift=MULT_GEN, bitrev=False):
+        flags = NTT_OUT_BITREV if bitrev else 0
+        self._check(self.lib.qpgpu_lde_batch_dev(self.ctx, _ptr(d_coeffs), _ptr(d_out), log_n, rate_bits, batch, flags, coset_shift))
+
+
+def _ptr(x):
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):  # torch tensor living in HBM
+        return x.data_ptr()
+    return int(x)

@@ -1,0 +1,36 @@
+// ctx.hpp — library context: one GPU, one stream, cached plans and scratch.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/qpgpu.h"
+
+struct NttTables;  // ntt_plan.cpp
+
+struct qpgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // scratch buffer reused by multi-pass transforms
+    uint64_t *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::map<std::string, std::shared_ptr<NttTables>> ntt_tables;
+    std::vector<void *> owned;  // table allocations freed at destroy
+
+    int fail(int code, const std::string &msg) { err = msg; return code; }
+    int hip_fail(hipError_t e, const char *what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return QPGPU_EDEVICE;
+    }
+    int ensure_scratch(size_t bytes);
+    int upload(const std::vector<uint64_t> &host, uint64_t **dptr);
+};
+
+#define QP_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->hip_fail(_e, #call); } while (0)
+
+int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
+            size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift);

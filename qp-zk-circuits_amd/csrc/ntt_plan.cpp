@@ -1,0 +1,194 @@
+// ntt_plan.cpp — host-side planning for the NTT passes: pass split, twiddle tables, launches.
+// Replaces the root-table / dispatch logic of plonky2::field::fft (fft_root_table, fft_dispatch).
+#include <hip/hip_runtime.h>
+#include <string>
+#include "ctx.hpp"
+#include "gl64.hpp"
+#include "ntt_pass.hpp"
+
+using gl::u64;
+
+struct NttTables {
+    uint64_t *d = nullptr;  // device table
+};
+
+int qpgpu_ctx::ensure_scratch(size_t bytes) {
+    if (bytes <= scratch_bytes) return QPGPU_OK;
+    if (scratch) { QP_HIP(this, hipStreamSynchronize(stream)); QP_HIP(this, hipFree(scratch)); scratch = nullptr; scratch_bytes = 0; }
+    QP_HIP(this, hipMalloc((void **)&scratch, bytes));
+    scratch_bytes = bytes;
+    return QPGPU_OK;
+}
+
+int qpgpu_ctx::upload(const std::vector<uint64_t> &host, uint64_t **dptr) {
+    void *p = nullptr;
+    QP_HIP(this, hipMalloc(&p, host.size() * sizeof(uint64_t)));
+    owned.push_back(p);
+    // tables are tiny; a synchronous copy from pageable memory keeps lifetime simple
+    QP_HIP(this, hipMemcpy(p, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    *dptr = (uint64_t *)p;
+    return QPGPU_OK;
+}
+
+namespace {
+
+// powers table: out[i] = base^(i*stride_exp) for i < count
+std::vector<uint64_t> powers(u64 base, u64 count) {
+    std::vector<uint64_t> t(count);
+    u64 acc = 1;
+    for (u64 i = 0; i < count; i++) { t[i] = gl::canon(acc); acc = gl::mul(acc, base); }
+    return t;
+}
+
+int cached(qpgpu_ctx *ctx, const std::string &key, u64 base, u64 count, uint64_t **out) {
+    auto it = ctx->ntt_tables.find(key);
+    if (it != ctx->ntt_tables.end()) { *out = it->second->d; return QPGPU_OK; }
+    auto t = std::make_shared<NttTables>();
+    int rc = ctx->upload(powers(base, count), &t->d);
+    if (rc) return rc;
+    ctx->ntt_tables[key] = t;
+    *out = t->d;
+    return QPGPU_OK;
+}
+
+struct Split { int ka, kb; };
+Split split_round(int l) { Split s; s.ka = (l + 1) / 2; s.kb = l / 2; if (l == 1) { s.ka = 1; s.kb = 0; } return s; }
+
+int pick_log_t(int ka, int kb, u64 lanes_total) {
+    int log_t = 8 - ka;  // 256 threads per workgroup
+    if (log_t < 3) log_t = 3;
+    // keep LDS under ~72 KB so two workgroups share a CU
+    while (log_t > 0 && ntt_pass_lds_bytes(ka, kb, log_t) > 72 * 1024) log_t--;
+    (void)lanes_total;
+    return log_t;
+}
+
+}  // namespace
+
+// Forward / inverse / coset-LDE transform. log_n_in <= log_n_out; inputs beyond 2^log_n_in are zero.
+int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
+            size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift) {
+    if (log_n_out > 20) return ctx->fail(QPGPU_EINVAL, "ntt: log_n > 20 not supported yet");
+    if (log_n_in > log_n_out) return ctx->fail(QPGPU_EINVAL, "ntt: log_n_in > log_n_out");
+    if (batch == 0) return QPGPU_OK;
+    const unsigned L = log_n_out;
+    const u64 N = 1ull << L, n_in = 1ull << log_n_in;
+    const bool coset = coset_shift > 1;
+    if (coset && inverse) return ctx->fail(QPGPU_EINVAL, "ntt: coset inverse is ifft + scale; not a single call");
+    if (L == 0) {
+        if (d_in != d_out) QP_HIP(ctx, hipMemcpyAsync(d_out, d_in, batch * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        return QPGPU_OK;
+    }
+    static bool inited = false;
+    if (!inited) { QP_HIP(ctx, ntt_pass_init()); inited = true; }
+
+    const std::string dir = inverse ? "i" : "f";
+    const u64 wN = inverse ? gl::inv(gl::root_of_unity(L)) : gl::root_of_unity(L);
+    u64 out_scale = 1;
+    if (inverse) out_scale = gl::inv(gl::canon(N % gl::P));
+
+    const int n_pass = (L <= 10) ? 1 : 2;
+    const int L1 = (n_pass == 1) ? (int)L : (int)(L + 1) / 2;
+    const int L2 = (int)L - L1;
+
+    NttPassArgs a{};
+    a.inverse = inverse ? 1 : 0;
+
+    if (n_pass == 1) {
+        Split s = split_round(L1);
+        a.ka = s.ka; a.kb = s.kb;
+        a.in = d_in; a.out = d_out;
+        a.in_col_stride = 0; a.out_col_stride = 0;
+        a.log_m = 0; a.lanes_total = batch;  // every polynomial is one row = one lane
+        a.in_row_stride = n_in; a.in_l_stride = 0; a.in_p_stride = 1;
+        a.out_row_stride = N; a.out_l_stride = 0; a.out_p_stride = 1;
+        a.log_t = pick_log_t(s.ka, s.kb, batch);
+        a.p_valid = (uint32_t)n_in;
+        a.load_lane_fast = 0; a.store_lane_fast = 0;
+        a.out_bitrev = out_bitrev ? 1 : 0;
+        a.has_out_scale = inverse ? 1 : 0; a.out_scale = out_scale;
+        if (s.kb > 0) {
+            u64 wR = wN;  // R == N
+            int rc = cached(ctx, "in" + dir + std::to_string(L1), wR, 1ull << L1, (uint64_t **)&a.tw_inner);
+            if (rc) return rc;
+        }
+        if (coset) {
+            int rc = cached(ctx, "csA" + std::to_string(coset_shift) + "_1_" + std::to_string(log_n_in), coset_shift, n_in, (uint64_t **)&a.in_scale_a);
+            if (rc) return rc;
+            rc = cached(ctx, "one", 1, 1, (uint64_t **)&a.in_scale_b);
+            if (rc) return rc;
+        }
+        // when in == out and the row strides differ (LDE in place) the caller must not alias; same size is safe
+        // because a workgroup reads its whole tile before writing it.
+        u64 tiles = (batch + (1ull << a.log_t) - 1) >> a.log_t;
+        QP_HIP(ctx, ntt_pass_launch(a, tiles, 1, ctx->stream));
+        return QPGPU_OK;
+    }
+
+    // ---- two passes: N = R1 * M1, pass 1 over the top L1 bits (stride M1), pass 2 on contiguous rows ----
+    const u64 R1 = 1ull << L1, M1 = 1ull << L2;
+    uint64_t *mid = d_out;
+    if (!out_bitrev) {
+        int rc = ctx->ensure_scratch(batch * N * sizeof(u64));
+        if (rc) return rc;
+        mid = ctx->scratch;
+    }
+    {
+        Split s = split_round(L1);
+        NttPassArgs p = a;
+        p.ka = s.ka; p.kb = s.kb;
+        p.in = d_in; p.out = mid;
+        p.in_col_stride = n_in; p.out_col_stride = N;
+        p.log_m = L2; p.lanes_total = M1;
+        p.in_row_stride = 0; p.in_l_stride = 1; p.in_p_stride = M1;
+        p.out_row_stride = 0; p.out_l_stride = 1; p.out_p_stride = M1;
+        p.log_t = pick_log_t(s.ka, s.kb, M1);
+        if ((1ull << p.log_t) > M1) p.log_t = L2;
+        // zero padding: coefficient index n = p*M1 + mm < n_in  <=>  p < n_in / M1 (n_in >= M1 required)
+        if (n_in < M1) return ctx->fail(QPGPU_EINVAL, "lde: input shorter than one pass-1 row is not supported");
+        p.p_valid = (uint32_t)(n_in / M1);
+        p.load_lane_fast = 1; p.store_lane_fast = 1;
+        p.out_bitrev = out_bitrev ? 1 : 0;  // natural mode: row k1 in natural order so pass-2 lanes are adjacent k1
+        p.has_out_scale = 0;
+        int rc = cached(ctx, "in" + dir + std::to_string(L1), gl::pow(wN, M1), R1, (uint64_t **)&p.tw_inner);
+        if (rc) return rc;
+        // inter-pass twiddle w_N^(mm*k): e < N, split at lo_bits
+        p.tw_lo_bits = (L + 1) / 2;
+        rc = cached(ctx, "lo" + dir + std::to_string(L), wN, 1ull << p.tw_lo_bits, (uint64_t **)&p.tw_lo);
+        if (rc) return rc;
+        rc = cached(ctx, "hi" + dir + std::to_string(L), gl::pow(wN, 1ull << p.tw_lo_bits), 1ull << (L - p.tw_lo_bits), (uint64_t **)&p.tw_hi);
+        if (rc) return rc;
+        if (coset) {
+            const std::string k = std::to_string(coset_shift) + "_" + std::to_string(L2);
+            rc = cached(ctx, "csA" + k + "_" + std::to_string(p.p_valid), gl::pow(coset_shift, M1), p.p_valid, (uint64_t **)&p.in_scale_a);
+            if (rc) return rc;
+            rc = cached(ctx, "csB" + k, coset_shift, M1, (uint64_t **)&p.in_scale_b);
+            if (rc) return rc;
+        }
+        u64 tiles = (M1 + (1ull << p.log_t) - 1) >> p.log_t;
+        QP_HIP(ctx, ntt_pass_launch(p, tiles, batch, ctx->stream));
+    }
+    {
+        Split s = split_round(L2);
+        NttPassArgs p = a;
+        p.ka = s.ka; p.kb = s.kb;
+        p.in = mid; p.out = d_out;
+        p.in_col_stride = N; p.out_col_stride = N;
+        p.log_m = 0; p.lanes_total = R1;
+        p.in_row_stride = M1; p.in_l_stride = 0; p.in_p_stride = 1;
+        p.log_t = pick_log_t(s.ka, s.kb, R1);
+        p.p_valid = (uint32_t)M1;
+        p.load_lane_fast = 0;
+        if (out_bitrev) { p.out_row_stride = M1; p.out_p_stride = 1; p.store_lane_fast = 0; p.out_bitrev = 1; }
+        else { p.out_row_stride = 1; p.out_p_stride = R1; p.store_lane_fast = 1; p.out_bitrev = 0; }
+        p.out_l_stride = 0;
+        p.has_out_scale = inverse ? 1 : 0; p.out_scale = out_scale;
+        if (s.kb > 0) {
+            int rc = cached(ctx, "in" + dir + std::to_string(L2), gl::pow(wN, R1), M1, (uint64_t **)&p.tw_inner);
+            if (rc) return rc;
+        }
+        u64 tiles = (R1 + (1ull << p.log_t) - 1) >> p.log_t;
+        QP_HIP(ctx, ntt_pass_launch(p, tiles, batch, ctx->stream));
+    }
+    return QPGPU_OK;
+}

@@ -1,0 +1,127 @@
+"""ctypes view of oracle/liboracle.so — the CPU restatement used as the parity checker.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+P = 0xFFFFFFFF00000001
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Oracle:
+    def __init__(self):
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["make", "-C", ORACLE_DIR])
+        self.lib = L = ctypes.CDLL(so)
+        u64 = ctypes.c_uint64
+        for name in ("orc_gl_mul", "orc_gl_add", "orc_gl_sub", "orc_gl_pow"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [u64, u64]
+        L.orc_gl_inv.restype = u64; L.orc_gl_inv.argtypes = [u64]
+        L.orc_gl_root.restype = u64; L.orc_gl_root.argtypes = [ctypes.c_uint]
+        L.orc_fft.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.orc_ifft.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.orc_coset_fft.argtypes = [ctypes.c_void_p, ctypes.c_uint, u64]
+        L.orc_coset_ifft.argtypes = [ctypes.c_void_p, ctypes.c_uint, u64]
+        L.orc_dft_naive.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        L.orc_fft_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_size_t, ctypes.c_int]
+        L.orc_lde_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_size_t, u64,
+                                    ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_poseidon_permute.argtypes = [ctypes.c_void_p]
+        L.orc_poseidon_round_constants.argtypes = [ctypes.c_void_p]
+        L.orc_hash_n_to_m_no_pad.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        L.orc_hash_or_noop.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_two_to_one.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_merkle_build.restype = ctypes.c_size_t
+        L.orc_merkle_build.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint,
+                                       ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_merkle_path.restype = ctypes.c_size_t
+        L.orc_merkle_path.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_challenger_size.restype = ctypes.c_size_t
+        L.orc_challenger_init.argtypes = [ctypes.c_void_p]
+        L.orc_challenger_observe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.orc_challenger_get.restype = u64; L.orc_challenger_get.argtypes = [ctypes.c_void_p]
+        L.orc_challenger_pow_response.restype = u64
+        L.orc_challenger_pow_response.argtypes = [ctypes.c_void_p, u64]
+        L.orc_p2_params_size.restype = ctypes.c_size_t
+        L.orc_p2_permute.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_p2_hash_pad10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_bytes_to_u64s.restype = ctypes.c_size_t
+        L.orc_bytes_to_u64s.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_bytes_to_digest.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+        L.orc_digest_to_bytes.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+
+    # ---- field ----
+    def mul(self, a, b): return self.lib.orc_gl_mul(a, b)
+    def add(self, a, b): return self.lib.orc_gl_add(a, b)
+    def sub(self, a, b): return self.lib.orc_gl_sub(a, b)
+    def inv(self, a): return self.lib.orc_gl_inv(a)
+    def pow(self, a, e): return self.lib.orc_gl_pow(a, e)
+    def root(self, log_n): return self.lib.orc_gl_root(log_n)
+
+    # ---- transforms (return new arrays) ----
+    def fft(self, a, log_n):
+        x = np.array(a, dtype=np.uint64, copy=True); self.lib.orc_fft(_vp(x), log_n); return x
+    def ifft(self, a, log_n):
+        x = np.array(a, dtype=np.uint64, copy=True); self.lib.orc_ifft(_vp(x), log_n); return x
+    def coset_fft(self, a, log_n, shift):
+        x = np.array(a, dtype=np.uint64, copy=True); self.lib.orc_coset_fft(_vp(x), log_n, shift); return x
+    def coset_ifft(self, a, log_n, shift):
+        x = np.array(a, dtype=np.uint64, copy=True); self.lib.orc_coset_ifft(_vp(x), log_n, shift); return x
+    def dft_naive(self, a, log_n):
+        x = np.ascontiguousarray(a, dtype=np.uint64); out = np.empty_like(x)
+        self.lib.orc_dft_naive(_vp(x), _vp(out), log_n); return out
+    def fft_batch(self, a, log_n, inverse=False):
+        x = np.array(a, dtype=np.uint64, copy=True).reshape(-1, 1 << log_n)
+        self.lib.orc_fft_batch(_vp(x), log_n, x.shape[0], 1 if inverse else 0); return x
+    def lde_batch(self, values, log_n, rate_bits, shift):
+        v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 1 << log_n)
+        coeffs = np.empty_like(v); out = np.empty((v.shape[0], 1 << (log_n + rate_bits)), dtype=np.uint64)
+        self.lib.orc_lde_batch(_vp(v), log_n, rate_bits, v.shape[0], shift, _vp(coeffs), _vp(out))
+        return coeffs, out
+
+    # ---- hashing ----
+    def poseidon(self, state):
+        s = np.array(state, dtype=np.uint64, copy=True); assert s.size == 12
+        self.lib.orc_poseidon_permute(_vp(s)); return s
+    def round_constants(self):
+        rc = np.empty(360, dtype=np.uint64); self.lib.orc_poseidon_round_constants(_vp(rc)); return rc
+    def hash_n_to_m(self, inp, m):
+        x = np.ascontiguousarray(inp, dtype=np.uint64); out = np.empty(m, dtype=np.uint64)
+        self.lib.orc_hash_n_to_m_no_pad(_vp(x), x.size, _vp(out), m); return out
+    def hash_or_noop(self, inp):
+        x = np.ascontiguousarray(inp, dtype=np.uint64); out = np.empty(4, dtype=np.uint64)
+        self.lib.orc_hash_or_noop(_vp(x), x.size, _vp(out)); return out
+    def two_to_one(self, l, r):
+        l = np.ascontiguousarray(l, dtype=np.uint64); r = np.ascontiguousarray(r, dtype=np.uint64)
+        out = np.empty(4, dtype=np.uint64); self.lib.orc_two_to_one(_vp(l), _vp(r), _vp(out)); return out
+    def merkle(self, leaves, cap_height):
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64); n, w = lv.shape
+        dig = np.empty((2 * n, 4), dtype=np.uint64); cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        tot = self.lib.orc_merkle_build(_vp(lv), n, w, cap_height, _vp(dig), _vp(cap))
+        return dig[:tot].copy(), cap
+    def merkle_path(self, digests, n_leaves, cap_height, index):
+        d = np.ascontiguousarray(digests, dtype=np.uint64); out = np.empty((64, 4), dtype=np.uint64)
+        ln = self.lib.orc_merkle_path(_vp(d), n_leaves, cap_height, index, _vp(out)); return out[:ln].copy()
+
+
+class Challenger:
+    def __init__(self, orc):
+        self.orc = orc
+        self.buf = ctypes.create_string_buffer(orc.lib.orc_challenger_size())
+        orc.lib.orc_challenger_init(self.buf)
+    def observe(self, xs):
+        x = np.ascontiguousarray(xs, dtype=np.uint64).ravel()
+        self.orc.lib.orc_challenger_observe(self.buf, _vp(x), x.size)
+    def get(self): return self.orc.lib.orc_challenger_get(self.buf)
+    def get_n(self, n): return [self.get() for _ in range(n)]
+    def pow_response(self, nonce): return self.orc.lib.orc_challenger_pow_response(self.buf, nonce)

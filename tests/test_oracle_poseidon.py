@@ -1,0 +1,139 @@
+"""Pins the oracle's Poseidon-v1 permutation, sponge, Merkle tree and challenger; exercises the
+Poseidon2 plug and the byte<->felt codecs against the reference's own anchors."""
+import ctypes
+import json
+import os
+
+import numpy as np
+
+from oracle_binding import Challenger
+
+P = 0xFFFFFFFF00000001
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+V1 = json.load(open(os.path.join(GOLD, "poseidon_v1.json")))
+KATS = json.load(open(os.path.join(GOLD, "poseidon2_kats.json")))
+
+
+def test_round_constants_anchor(orc):
+    rc = orc.round_constants()
+    assert [int(x) for x in rc[:12]] == [int(h, 16) for h in V1["round_constants_first12"]]
+    assert int(rc.max()) < int(V1["round_constant_bound"], 16)  # upstream's AVX2 precondition
+    assert len(set(rc.tolist())) == 360
+
+
+def test_permutation_vectors(orc):
+    for v in V1["vectors"]:
+        out = orc.poseidon(np.array(v["input"], dtype=np.uint64))
+        assert [int(x) for x in out] == [int(h, 16) for h in v["output"]]
+
+
+def test_sponge_shapes(orc):
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, P, 20, dtype=np.uint64)
+    # overwrite-mode absorption: first block then permute, compare with a manual walk
+    st = np.zeros(12, dtype=np.uint64); st[:8] = x[:8]; st = orc.poseidon(st)
+    st[:8] = x[8:16]; st = orc.poseidon(st)
+    st[:4] = x[16:20]; st = orc.poseidon(st)
+    assert np.array_equal(orc.hash_n_to_m(x, 4), st[:4])
+    # squeezing more than one block permutes in between
+    out = orc.hash_n_to_m(x, 11)
+    assert np.array_equal(out[:8], st[:8]) and np.array_equal(out[8:], orc.poseidon(st)[:3])
+    # hash_or_noop copies short rows
+    assert orc.hash_or_noop(x[:3]).tolist() == x[:3].tolist() + [0]
+    assert np.array_equal(orc.hash_or_noop(x[:5]), orc.hash_n_to_m(x[:5], 4))
+    # two_to_one
+    st = np.zeros(12, dtype=np.uint64); st[:8] = x[:8]
+    assert np.array_equal(orc.two_to_one(x[:4], x[4:8]), orc.poseidon(st)[:4])
+
+
+def test_merkle_and_paths(orc):
+    rng = np.random.default_rng(4)
+    leaves = rng.integers(0, P, (64, 7), dtype=np.uint64)
+    for cap_h in (0, 2, 4, 6):
+        dig, cap = orc.merkle(leaves, cap_h)
+        assert cap.shape == (1 << cap_h, 4)
+        for idx in (0, 1, 37, 63):
+            path = orc.merkle_path(dig, 64, cap_h, idx)
+            assert len(path) == 6 - cap_h
+            cur, i = orc.hash_or_noop(leaves[idx]), idx
+            for sib in path:
+                cur = orc.two_to_one(cur, sib) if i % 2 == 0 else orc.two_to_one(sib, cur)
+                i >>= 1
+            assert np.array_equal(cur, cap[idx >> (6 - cap_h)])
+
+
+def test_challenger_duplex(orc):
+    ch = Challenger(orc)
+    ch.observe([1, 2, 3])
+    a = ch.get()
+    st = np.zeros(12, dtype=np.uint64); st[:3] = [1, 2, 3]; st = orc.poseidon(st)
+    assert a == int(st[7])               # pops from the end of the rate block
+    assert ch.get() == int(st[6])
+    ch.observe([9])                      # observing clears the output buffer
+    st[0] = 9; st2 = orc.poseidon(st)
+    assert ch.get() == int(st2[7])
+    # 8 observations trigger a duplex immediately
+    ch2 = Challenger(orc); ch2.observe(list(range(8)))
+    s = np.zeros(12, dtype=np.uint64); s[:8] = range(8); s = orc.poseidon(s)
+    assert ch2.get() == int(s[7])
+    # proof-of-work response equals what observing the nonce then squeezing yields
+    ch3 = Challenger(orc); ch3.observe([5, 6, 7, 8, 9])
+    r = ch3.pow_response(123456)
+    ch3.observe([123456])
+    assert ch3.get() == r
+
+
+def test_codecs_against_reference_anchors(orc):
+    a = KATS["encoding_anchors"]
+    d = np.empty(4, dtype=np.uint64)
+    orc.lib.orc_bytes_to_digest(bytes([0xAB] * 32), d.ctypes.data_as(ctypes.c_void_p))
+    assert int(d[0]) == a["felt_of_ab_x8"]
+    orc.lib.orc_bytes_to_digest(bytes([0xCD] * 32), d.ctypes.data_as(ctypes.c_void_p))
+    assert int(d[0]) == a["felt_of_cd_x8"]
+    out = np.empty(64, dtype=np.uint64)
+    n = orc.lib.orc_bytes_to_u64s(KATS["salt"].encode(), len(KATS["salt"]), out.ctypes.data_as(ctypes.c_void_p))
+    assert n == a["salt_felts"] and out[:3].tolist() == [int.from_bytes(b"worm", "little"), int.from_bytes(b"hole", "little"), 1]
+    digest = bytes.fromhex(KATS["digest_hex_head"]) + bytes(KATS["digest_zero_run"]) + bytes.fromhex(KATS["digest_hex_tail"])
+    assert len(digest) == a["digest_bytes"]
+    n = orc.lib.orc_bytes_to_u64s(digest, len(digest), out.ctypes.data_as(ctypes.c_void_p))
+    assert n == a["digest_felts"]
+
+
+def _p2_params(orc, rc_ext, rc_int, diag, m4, absorb_add=0):
+    buf = np.zeros(orc.lib.orc_p2_params_size() // 8, dtype=np.uint64)
+    flat = list(np.array(rc_ext, dtype=np.uint64).ravel()) + list(rc_int) + list(diag) + list(np.array(m4, dtype=np.uint64).ravel())
+    buf[:len(flat)] = flat
+    buf[len(flat)] = absorb_add  # int in the low half of the next word (little endian)
+    return buf
+
+
+def p2_address(orc, params, secret_hex):
+    out = np.empty(64, dtype=np.uint64)
+    n = orc.lib.orc_bytes_to_u64s(b"wormhole", 8, out.ctypes.data_as(ctypes.c_void_p))
+    sec = np.empty(4, dtype=np.uint64)
+    orc.lib.orc_bytes_to_digest(bytes.fromhex(secret_hex), sec.ctypes.data_as(ctypes.c_void_p))
+    pre = np.concatenate([out[:n], sec])
+    h1 = np.empty(4, dtype=np.uint64); h2 = np.empty(4, dtype=np.uint64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    orc.lib.orc_p2_hash_pad10(vp(params), vp(pre), pre.size, vp(h1))
+    orc.lib.orc_p2_hash_pad10(vp(params), vp(h1), 4, vp(h2))
+    b = ctypes.create_string_buffer(32)
+    orc.lib.orc_digest_to_bytes(vp(h2), b)
+    return b.raw.hex()
+
+
+def test_poseidon2_plug_is_kat_gated(orc):
+    """qp-poseidon-core's constants are not available offline. The plug must run, be
+    deterministic, and the acceptance gate must reject a set that does not reproduce the reference KATs.
+    The candidate below is the public HorizenLabs Grain-LFSR schedule shape with placeholder values."""
+    rng = np.random.default_rng(5)
+    rc_ext = rng.integers(0, P, (8, 12), dtype=np.uint64)
+    rc_int = rng.integers(0, P, 22, dtype=np.uint64)
+    diag = rng.integers(0, P, 12, dtype=np.uint64)
+    m4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]
+    params = _p2_params(orc, rc_ext, rc_int, diag, m4)
+    kat = KATS["address_kats"][0]
+    got = p2_address(orc, params, kat["secret"])
+    assert got == p2_address(orc, params, kat["secret"])
+    accepted = all(p2_address(orc, params, k["secret"]) == k["address"] for k in KATS["address_kats"])
+    assert not accepted, "random constants cannot satisfy the reference KATs"
