@@ -46,6 +46,11 @@ int qpgpu_ctx_set_stream(qpgpu_ctx *ctx, void *hip_stream);
 int qpgpu_sync(qpgpu_ctx *ctx);
 const char *qpgpu_version(void);
 
+/* ---- measurement: per-kernel HIP-event timing on the ctx stream (off by default) ---- */
+int qpgpu_profile_enable(qpgpu_ctx *ctx, int on);   /* on: clears the counters */
+/* kernel: "ntt_pass_strided", "ntt_pass_rows", "ntt_pass_single", ... ; sums since enable */
+int qpgpu_profile_read(qpgpu_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
+
 /* ---- device memory plumbing ---- */
 int qpgpu_malloc(qpgpu_ctx *ctx, size_t bytes, void **dptr);
 int qpgpu_free(qpgpu_ctx *ctx, void *dptr);

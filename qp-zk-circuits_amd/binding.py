@@ -45,6 +45,8 @@ def load_library():
         "qpgpu_last_error": (c.c_char_p, [vp]),
         "qpgpu_ctx_set_stream": (c.c_int, [vp, vp]),
         "qpgpu_sync": (c.c_int, [vp]),
+        "qpgpu_profile_enable": (c.c_int, [vp, c.c_int]),
+        "qpgpu_profile_read": (c.c_int, [vp, c.c_char_p, c.POINTER(c.c_double), c.POINTER(c.c_uint64)]),
         "qpgpu_malloc": (c.c_int, [vp, c.c_size_t, c.POINTER(vp)]),
         "qpgpu_free": (c.c_int, [vp, vp]),
         "qpgpu_memcpy_h2d": (c.c_int, [vp, vp, vp, c.c_size_t]),
@@ -126,6 +128,14 @@ class QpGpu:
 
     def sync(self):
         self._check(self.lib.qpgpu_sync(self.ctx))
+
+    def profile(self, on=True):
+        self._check(self.lib.qpgpu_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_read(self, kernel):
+        ms, n = ctypes.c_double(), ctypes.c_uint64()
+        self._check(self.lib.qpgpu_profile_read(self.ctx, kernel.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

@@ -21,6 +21,16 @@ struct qpgpu_ctx {
     std::map<std::string, std::shared_ptr<NttTables>> ntt_tables;
     std::vector<void *> owned;  // table allocations freed at destroy
 
+    // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)
+    struct KStat { double ms = 0; uint64_t launches = 0; };
+    struct Pending { std::string name; hipEvent_t e0, e1; };
+    bool profiling = false;
+    std::map<std::string, KStat> kstats;
+    std::vector<Pending> pending;
+    void prof_begin(const char *name);
+    void prof_end();
+    int prof_collect();
+
     int fail(int code, const std::string &msg) { err = msg; return code; }
     int hip_fail(hipError_t e, const char *what) {
         err = std::string(what) + ": " + hipGetErrorString(e);

@@ -121,7 +121,10 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
         // when in == out and the row strides differ (LDE in place) the caller must not alias; same size is safe
         // because a workgroup reads its whole tile before writing it.
         u64 tiles = (batch + (1ull << a.log_t) - 1) >> a.log_t;
-        QP_HIP(ctx, ntt_pass_launch(a, tiles, 1, ctx->stream));
+        ctx->prof_begin("ntt_pass_single");
+        hipError_t le = ntt_pass_launch(a, tiles, 1, ctx->stream);
+        ctx->prof_end();
+        QP_HIP(ctx, le);
         return QPGPU_OK;
     }
 
@@ -166,7 +169,10 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
             if (rc) return rc;
         }
         u64 tiles = (M1 + (1ull << p.log_t) - 1) >> p.log_t;
-        QP_HIP(ctx, ntt_pass_launch(p, tiles, batch, ctx->stream));
+        ctx->prof_begin("ntt_pass_strided");
+        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream);
+        ctx->prof_end();
+        QP_HIP(ctx, le);
     }
     {
         Split s = split_round(L2);
@@ -188,7 +194,10 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
             if (rc) return rc;
         }
         u64 tiles = (R1 + (1ull << p.log_t) - 1) >> p.log_t;
-        QP_HIP(ctx, ntt_pass_launch(p, tiles, batch, ctx->stream));
+        ctx->prof_begin("ntt_pass_rows");
+        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream);
+        ctx->prof_end();
+        QP_HIP(ctx, le);
     }
     return QPGPU_OK;
 }

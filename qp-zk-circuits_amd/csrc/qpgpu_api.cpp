@@ -4,7 +4,46 @@
 #include "ctx.hpp"
 #include "gl64.hpp"
 
+void qpgpu_ctx::prof_begin(const char *name) {
+    if (!profiling) return;
+    Pending p; p.name = name;
+    if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
+    (void)hipEventRecord(p.e0, stream);
+    pending.push_back(p);
+}
+void qpgpu_ctx::prof_end() {
+    if (!profiling || pending.empty()) return;
+    (void)hipEventRecord(pending.back().e1, stream);
+}
+int qpgpu_ctx::prof_collect() {
+    QP_HIP(this, hipStreamSynchronize(stream));
+    for (auto &p : pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { kstats[p.name].ms += ms; kstats[p.name].launches++; }
+        (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+    }
+    pending.clear();
+    return QPGPU_OK;
+}
+
 extern "C" {
+
+int qpgpu_profile_enable(qpgpu_ctx *ctx, int on) {
+    if (!ctx) return QPGPU_EINVAL;
+    int rc = ctx->prof_collect();
+    ctx->profiling = on != 0;
+    if (on) ctx->kstats.clear();
+    return rc;
+}
+int qpgpu_profile_read(qpgpu_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
+    if (!ctx || !kernel) return QPGPU_EINVAL;
+    int rc = ctx->prof_collect();
+    if (rc) return rc;
+    auto it = ctx->kstats.find(kernel);
+    if (total_ms) *total_ms = it == ctx->kstats.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->kstats.end() ? 0 : it->second.launches;
+    return QPGPU_OK;
+}
 
 const char *qpgpu_version(void) { return "qpgpu 0.1 (gfx950)"; }
 

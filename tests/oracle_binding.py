@@ -60,6 +60,9 @@ class Oracle:
         L.orc_bytes_to_digest.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
         L.orc_digest_to_bytes.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
 
+    def set_threads(self, n): self.lib.orc_set_threads(int(n))
+    def max_threads(self): return int(self.lib.orc_max_threads())
+
     # ---- field ----
     def mul(self, a, b): return self.lib.orc_gl_mul(a, b)
     def add(self, a, b): return self.lib.orc_gl_add(a, b)
