@@ -27,53 +27,121 @@ constexpr u64 ROOT_2_32 = 7277203076849721926ULL;
 
 GL_HD u64 canon(u64 x) { return x >= P ? x - P : x; }
 
-// loose add: inputs any u64, at least one of them < 2^64 - 2^32 (true for canonical or reduce output
-// minus the top sliver); result loose. Two carry folds keep it exact for all inputs.
-GL_HD u64 add(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 device primitives: 32-bit carry chains (v_add_co/v_addc_co), no 64-bit compares ----
+// All take any u64 ("loose") and return loose values; exact for every input.
+__device__ __forceinline__ u64 add(u64 a, u64 b) {
+    // v_lshl_add_u64 + 64-bit compare measured faster than a v_add_co/v_addc_co chain (tools/valu_rates.hip)
     u64 s = a + b;
     u64 c = s < a ? EPS : 0;
     u64 t = s + c;
     t += (t < c) ? EPS : 0;
     return t;
 }
-GL_HD u64 sub(u64 a, u64 b) {
+__device__ __forceinline__ u64 sub(u64 a, u64 b) {
+    u32 lo, hi, t;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\t"      // borrow -> - (2^32-1)
+        "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\t"      // rare second borrow
+        "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(lo), "=&v"(hi), "=&v"(t)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 neg(u64 a) { return sub(0, a); }
+
+// (hi:lo) 128-bit -> loose u64:  lo - hi_hi + hi_lo*(2^32-1), with the borrow / carry folds
+__device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
+    u32 r0, r1, t, u0, u1;
+    asm("v_sub_co_u32 %0, vcc, %5, %8\n\t"          // t = lo - hi_hi
+        "v_subbrev_co_u32 %1, vcc, 0, %6, vcc\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\t"          // borrow -> - (2^32-1)
+        "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_sub_co_u32 %3, vcc, 0, %7\n\t"           // u = hi_lo*(2^32-1) = (hi_lo<<32) - hi_lo
+        "v_subbrev_co_u32 %4, vcc, 0, %7, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %3\n\t"          // r = t + u
+        "v_addc_co_u32 %1, vcc, %1, %4, vcc\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\t"          // carry -> + (2^32-1)
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(t), "=&v"(u0), "=&v"(u1)
+        : "v"((u32)lo), "v"((u32)(lo >> 32)), "v"((u32)hi), "v"((u32)(hi >> 32))
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+}
+// a * (2^32 - 1) for a 32-bit a, as two 32-bit ops (the compiler would pick an 8-cycle v_mad_u64_u32)
+__device__ __forceinline__ u64 mul_eps(u32 a) {
+    u32 r0, r1;
+    asm("v_sub_co_u32 %0, vcc, 0, %2\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %2, vcc"
+        : "=&v"(r0), "=&v"(r1) : "v"(a) : "vcc");
+    return ((u64)r1 << 32) | r0;
+}
+// lo + hi*2^64 with hi < 2^32
+__device__ __forceinline__ u64 reduce96(u64 lo, u32 hi) {
+    u32 r0, r1, t, u0, u1;
+    asm("v_sub_co_u32 %3, vcc, 0, %7\n\t"           // u = hi*(2^32-1)
+        "v_subbrev_co_u32 %4, vcc, 0, %7, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %5, %3\n\t"
+        "v_addc_co_u32 %1, vcc, %6, %4, vcc\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(t), "=&v"(u0), "=&v"(u1)
+        : "v"((u32)lo), "v"((u32)(lo >> 32)), "v"(hi)
+        : "vcc");
+    return ((u64)r1 << 32) | r0;
+}
+#else
+// host versions (plan building, table generation)
+inline u64 add(u64 a, u64 b) {
+    u64 s = a + b;
+    u64 c = s < a ? EPS : 0;
+    u64 t = s + c;
+    t += (t < c) ? EPS : 0;
+    return t;
+}
+inline u64 sub(u64 a, u64 b) {
     u64 d = a - b;
     u64 c = a < b ? EPS : 0;
     u64 t = d - c;
     t -= (d < c) ? EPS : 0;
     return t;
 }
-GL_HD u64 neg(u64 a) { return sub(0, a); }
-
-// (hi:lo) 128-bit -> loose u64
-GL_HD u64 reduce128(u64 lo, u64 hi) {
+inline u64 neg(u64 a) { return sub(0, a); }
+inline u64 reduce128(u64 lo, u64 hi) {
     u64 hh = hi >> 32, hl = hi & EPS;
     u64 t0 = lo - hh;
     if (lo < hh) t0 -= EPS;
-    u64 t1 = (hl << 32) - hl;  // hl * (2^32-1)
+    u64 t1 = (hl << 32) - hl;
     u64 t2 = t0 + t1;
     if (t2 < t1) t2 += EPS;
     return t2;
 }
-// lo + hi*2^64 with hi < 2^32
-GL_HD u64 reduce96(u64 lo, u32 hi) {
+inline u64 mul_eps(u32 a) { return ((u64)a << 32) - a; }
+inline u64 reduce96(u64 lo, u32 hi) {
     u64 t1 = ((u64)hi << 32) - hi;
     u64 t2 = lo + t1;
     if (t2 < t1) t2 += EPS;
     return t2;
 }
+#endif
 
 GL_HD void mul64wide(u64 a, u64 b, u64 &lo, u64 &hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
-    u64 p01 = (u64)a0 * b1;
-    u64 p10 = (u64)a1 * b0;
-    u64 p11 = (u64)a1 * b1;
-    u64 mid = p01 + (p00 >> 32);          // no overflow: < 2^64
-    u64 mid2 = p10 + (u32)mid;            // no overflow
-    lo = (mid2 << 32) | (u32)p00;
-    hi = p11 + (mid >> 32) + (mid2 >> 32);
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);   // v_mad_u64_u32, no overflow
+    u64 p10 = (u64)a1 * b0 + (u32)p01;      // no overflow
+    u64 p11 = (u64)a1 * b1 + (p01 >> 32);   // no overflow: (2^32-1)^2 + 2^32-1 < 2^64
+    lo = (p10 << 32) | (u32)p00;
+    hi = p11 + (p10 >> 32);
 #else
     unsigned __int128 m = (unsigned __int128)a * b;
     lo = (u64)m; hi = (u64)(m >> 64);
@@ -101,14 +169,15 @@ GL_HD u64 mul_pow2(u64 x) {
     } else if constexpr (S < 64) {
         return reduce128(x << S, x >> (64 - S));
     } else if constexpr (S == 64) {
-        // x * 2^64 = x * (2^32 - 1)
-        u64 y = reduce96(x << 32, (u32)(x >> 32));
-        return sub(y, x);
+        // x*W^2 = x0*(W-1) - x1   (W = 2^32, W^2 = W - 1, W^3 = -1)
+        u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+        return sub(mul_eps(x0), (u64)x1);
     } else {
-        // 64 < S < 96: first x*2^(S-64) (< 2^96), then times 2^64 = 2^32 - 1
-        u64 y = reduce96(x << (S - 64), (u32)(x >> (128 - S)));
-        u64 z = reduce96(y << 32, (u32)(y >> 32));
-        return sub(z, y);
+        // 64 < S < 96: (a0,a1,a2) = x << (S-64) as three 32-bit limbs; x*2^S = a0*(W-1) - (a1 + a2*W)
+        constexpr int r = S - 64;
+        u32 a0 = (u32)x << r;
+        u64 top = x >> (32 - r);   // a1 + a2*W
+        return sub(mul_eps(a0), top);
     }
 }
 

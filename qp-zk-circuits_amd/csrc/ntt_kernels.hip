@@ -35,12 +35,13 @@ __device__ __forceinline__ u64 mul_pow2_dyn(u64 x, int s) {
             return gl::reduce128(x << s, x >> (64 - s));
         case 2: {
             if (s == 64) {
-                u64 y = gl::reduce96(x << 32, (u32)(x >> 32));
-                return gl::sub(y, x);
+                u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+                return gl::sub(gl::mul_eps(x0), (u64)x1);
             }
-            u64 y = gl::reduce96(x << (s - 64), (u32)(x >> (128 - s)));
-            u64 z = gl::reduce96(y << 32, (u32)(y >> 32));
-            return gl::sub(z, y);
+            const int r = s - 64;
+            u32 a0 = (u32)x << r;
+            u64 top = x >> (32 - r);
+            return gl::sub(gl::mul_eps(a0), top);
         }
     }
 }
