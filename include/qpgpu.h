@@ -82,6 +82,24 @@ int qpgpu_ntt_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, u
 int qpgpu_lde_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_out, unsigned log_n,
                         unsigned rate_bits, size_t batch, int flags, uint64_t coset_shift);
 
+/* ---- stage s3: plonky2::hash::{poseidon, merkle_tree} ---- */
+/* Poseidon permutation (width 12) on n states of 12 elements each, in place. */
+int qpgpu_poseidon_permute_dev(qpgpu_ctx *ctx, uint64_t *d_states, size_t n);
+/* Digests stored by a tree: level 0 (2^log_leaves leaf digests), then each parent level down to the
+ * cap level (2^cap_height digests), concatenated; 4 elements per digest. */
+size_t qpgpu_merkle_digest_count(unsigned log_leaves, unsigned cap_height);
+/*
+ * MerkleTree::new(leaves, cap_height) for leaves given column-major and already in leaf order:
+ * leaf j = (d_cols[c*col_stride + j])_{c < n_cols}; leaf digest = hash_or_noop (rows of <= 4 elements
+ * are copied, longer rows go through the overwrite-mode sponge, rate 8); node = two_to_one.
+ * d_digests receives qpgpu_merkle_digest_count() digests; h_cap_out (host, optional) the cap.
+ */
+int qpgpu_merkle_build_dev(qpgpu_ctx *ctx, const uint64_t *d_cols, uint64_t col_stride, uint32_t n_cols,
+                           unsigned log_leaves, unsigned cap_height, uint64_t *d_digests, uint64_t *h_cap_out);
+/* Same for row-major leaves of `width` contiguous elements (FRI round trees). */
+int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t width, unsigned log_leaves,
+                                unsigned cap_height, uint64_t *d_digests, uint64_t *h_cap_out);
+
 #ifdef __cplusplus
 }
 #endif

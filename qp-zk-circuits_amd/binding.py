@@ -54,6 +54,10 @@ def load_library():
         "qpgpu_ntt_batch": (c.c_int, [vp, u64p, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
         "qpgpu_ntt_batch_dev": (c.c_int, [vp, u64p, u64p, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
         "qpgpu_lde_batch_dev": (c.c_int, [vp, u64p, u64p, c.c_uint, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
+        "qpgpu_poseidon_permute_dev": (c.c_int, [vp, u64p, c.c_size_t]),
+        "qpgpu_merkle_digest_count": (c.c_size_t, [c.c_uint, c.c_uint]),
+        "qpgpu_merkle_build_dev": (c.c_int, [vp, u64p, c.c_uint64, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
+        "qpgpu_merkle_build_rows_dev": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -98,7 +102,34 @@ class DeviceBuffer:
             self.ptr = None
 
 
-class QpGpu:
+class _Stage3:
+    """mixin: stage s3 wrappers"""
+
+    def poseidon_permute(self, states):
+        st = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 12)
+        d = self.to_device(st)
+        self._check(self.lib.qpgpu_poseidon_permute_dev(self.ctx, d.ptr, st.shape[0]))
+        out = d.download().reshape(-1, 12)
+        d.free()
+        return out
+
+    def merkle_digest_count(self, log_leaves, cap_height):
+        return self.lib.qpgpu_merkle_digest_count(log_leaves, cap_height)
+
+    def merkle_build_dev(self, d_cols, col_stride, n_cols, log_leaves, cap_height, d_digests):
+        cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        self._check(self.lib.qpgpu_merkle_build_dev(self.ctx, _ptr(d_cols), col_stride, n_cols, log_leaves,
+                                                    cap_height, _ptr(d_digests), cap.ctypes.data))
+        return cap
+
+    def merkle_build_rows_dev(self, d_rows, width, log_leaves, cap_height, d_digests):
+        cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        self._check(self.lib.qpgpu_merkle_build_rows_dev(self.ctx, _ptr(d_rows), width, log_leaves, cap_height,
+                                                         _ptr(d_digests), cap.ctypes.data))
+        return cap
+
+
+class QpGpu(_Stage3):
     """One context = one GPU + one HIP stream."""
 
     def __init__(self, device=0, stream=None):

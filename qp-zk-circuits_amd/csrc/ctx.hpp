@@ -20,6 +20,7 @@ struct qpgpu_ctx {
     size_t scratch_bytes = 0;
     std::map<std::string, std::shared_ptr<NttTables>> ntt_tables;
     std::vector<void *> owned;  // table allocations freed at destroy
+    bool poseidon_ready = false;  // round constants uploaded to __constant__ memory
 
     // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)
     struct KStat { double ms = 0; uint64_t launches = 0; };
@@ -42,5 +43,8 @@ struct qpgpu_ctx {
 
 #define QP_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->hip_fail(_e, #call); } while (0)
 
+struct MerkleLeafArgs;
+int merkle_ensure_constants(qpgpu_ctx *ctx);
+int merkle_build(qpgpu_ctx *ctx, const MerkleLeafArgs &leaf, unsigned log_leaves, unsigned cap_height, uint64_t *d_digests);
 int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
             size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift);

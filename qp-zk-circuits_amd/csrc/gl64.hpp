@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define GL_HD __host__ __device__ __forceinline__
 #else
 #define GL_HD inline

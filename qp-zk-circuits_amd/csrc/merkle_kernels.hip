@@ -1,0 +1,135 @@
+// merkle_kernels.hip — Poseidon leaf hashing and Merkle reduction for gfx950.
+//
+// Replaces plonky2::hash::merkle_tree::MerkleTree::new and hash::hashing::{hash_n_to_hash_no_pad,
+// hash_or_noop, two_to_one} (stage s3 of SURVEY.md §8a; reached from PolynomialBatch::from_coeffs inside
+// prove, reference call site wormhole/prover/src/lib.rs:171-175).
+//
+// Layout: the LDE is column-major and already in leaf order (bit-reversed slots), so thread j reads
+// slot j of each column: a wave reads 512 contiguous bytes per column, no transpose in HBM.
+// One thread = one sponge (state in 24 VGPRs). Integer-ALU-bound: ceil(W/8) permutations per leaf.
+#include <hip/hip_runtime.h>
+#include "merkle.hpp"
+#include "poseidon.hpp"
+
+using gl::u32;
+using gl::u64;
+
+__constant__ u64 c_poseidon_rc[poseidon::ROUNDS * poseidon::WIDTH];
+
+hipError_t merkle_upload_constants(const u64 *rc360) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
+}
+
+namespace {
+
+struct PoseidonV1 {
+    static __device__ __forceinline__ void permute(u64 (&s)[12]) { poseidon::permute(s, c_poseidon_rc); }
+};
+
+// leaf j = [src0 cols..., src1 cols...] at slot j (each source column-major with its own stride).
+template <class Perm>
+__global__ void __launch_bounds__(256) leaf_hash_kernel(MerkleLeafArgs a) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= a.n_leaves) return;
+    const u32 W = a.ncols0 + a.ncols1;
+    u64 *out = a.digests + j * 4;
+    auto elem = [&](u32 c) -> u64 {
+        return c < a.ncols0 ? a.src0[(u64)c * a.stride0 + j] : a.src1[(u64)(c - a.ncols0) * a.stride1 + j];
+    };
+    if (W <= 4) {  // hash_or_noop: short rows are copied
+        for (u32 c = 0; c < 4; c++) out[c] = c < W ? gl::canon(elem(c)) : 0;
+        return;
+    }
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    for (u32 c = 0; c < W; c += 8) {
+        // overwrite-mode absorption of up to 8 elements
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (c + i < W) s[i] = elem(c + i);
+        Perm::permute(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = s[i];
+}
+
+// row-major leaves (FRI round trees: leaf = 2^arity ext values = contiguous felts)
+template <class Perm>
+__global__ void __launch_bounds__(256) leaf_hash_rows_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= n_leaves) return;
+    const u64 *row = rows + j * width;
+    u64 *out = digests + j * 4;
+    if (width <= 4) {
+        for (u32 c = 0; c < 4; c++) out[c] = c < width ? gl::canon(row[c]) : 0;
+        return;
+    }
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    for (u32 c = 0; c < width; c += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (c + i < width) s[i] = row[c + i];
+        Perm::permute(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = s[i];
+}
+
+// one level: out[i] = two_to_one(in[2i], in[2i+1])
+template <class Perm>
+__global__ void __launch_bounds__(256) node_kernel(const u64 *in, u64 *out, u64 n_out) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    u64 s[12];
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(in + i * 8);
+    ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
+    s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = c.x; s[5] = c.y; s[6] = d.x; s[7] = d.y;
+    s[8] = s[9] = s[10] = s[11] = 0;
+    Perm::permute(s);
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + i * 4);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+template <class Perm>
+__global__ void permute_kernel(u64 *states, u64 n) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = gl::canon(states[i * 12 + k]);
+    Perm::permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; k++) states[i * 12 + k] = s[k];
+}
+
+}  // namespace
+
+hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, hipStream_t st) {
+    if (a.n_leaves == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((a.n_leaves + 255) / 256));
+    hipLaunchKernelGGL((leaf_hash_kernel<PoseidonV1>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, hipStream_t st) {
+    if (n_leaves == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_leaves + 255) / 256));
+    hipLaunchKernelGGL((leaf_hash_rows_kernel<PoseidonV1>), grid, block, 0, st, rows, n_leaves, width, digests);
+    return hipGetLastError();
+}
+hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, hipStream_t st) {
+    if (n_out == 0) return hipSuccess;
+    unsigned threads = n_out >= 256 ? 256 : 64;
+    dim3 block(threads), grid((unsigned)((n_out + threads - 1) / threads));
+    hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out);
+    return hipGetLastError();
+}
+hipError_t poseidon_permute_batch(u64 *states, u64 n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL((permute_kernel<PoseidonV1>), grid, block, 0, st, states, n);
+    return hipGetLastError();
+}
