@@ -100,6 +100,18 @@ int qpgpu_merkle_build_dev(qpgpu_ctx *ctx, const uint64_t *d_cols, uint64_t col_
 int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t width, unsigned log_leaves,
                                 unsigned cap_height, uint64_t *d_digests, uint64_t *h_cap_out);
 
+/* ---- synthetic circuits (stand-in for reference rows a1/a6 while no Rust exporter exists) ---- */
+/*
+ * Builds a satisfied plonky2-shaped circuit (PublicInput / Constant / Arithmetic / Noop gates wired by copy
+ * constraints, standard_recursion_config parameters) and its witness. pack_out receives the circuit pack
+ * ("QPCP1", see qp-zk-circuits_amd/csrc/circuit.hpp); wires_out num_wires x 2^degree_bits column-major;
+ * pis_out num_public_inputs elements. Host-only; no GPU needed.
+ */
+size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed);
+int qpgpu_synth_circuit(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
+                        uint64_t seed, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,
+                        uint64_t *wires_out, uint64_t *pis_out);
+
 #ifdef __cplusplus
 }
 #endif

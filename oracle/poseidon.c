@@ -16,6 +16,7 @@
  * Sponge / Merkle / challenger conventions: SURVEY.md Appendix A.3.
  */
 #include "gl.h"
+#include "challenger.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -171,11 +172,6 @@ size_t orc_merkle_path(const gl_t *digests, size_t n_leaves, unsigned cap_height
 }
 
 /* ---- Challenger (duplex sponge) ---- */
-typedef struct {
-    gl_t state[12];
-    gl_t in[SPONGE_RATE]; int n_in;
-    gl_t out[SPONGE_RATE]; int n_out;
-} orc_challenger;
 size_t orc_challenger_size(void) { return sizeof(orc_challenger); }
 void orc_challenger_init(orc_challenger *c) { memset(c, 0, sizeof *c); }
 static void duplex(orc_challenger *c) {

@@ -1,0 +1,516 @@
+/*
+ * oracle/prove.c — CPU restatement of qp-plonky2 `plonk::prover::prove` + `fri::prover` (stages s4..s12).
+ * See oracle/plonk.h. TEST INFRASTRUCTURE ONLY.
+ *
+ * Stage order and transcript order follow SURVEY.md Appendix A.3-A.5:
+ *   wires commit -> betas, gammas -> partial products / Z commit -> alphas -> quotient commit -> zeta ->
+ *   openings -> FRI (alpha, per-round cap + beta, final poly, proof of work, query indices).
+ */
+#include "plonk.h"
+#include "challenger.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define QPCP_MAGIC 0x0000003150435051ULL
+#define MAXC 4
+
+/* ------------------------------------------------------------------ trace */
+typedef struct { char name[32]; uint64_t *data; size_t len; } trace_item;
+static trace_item g_trace[64];
+static int g_ntrace = 0;
+static void trace_clear(void) { for (int i = 0; i < g_ntrace; i++) free(g_trace[i].data); g_ntrace = 0; }
+static void trace_put(const char *name, const void *data, size_t words) {
+    if (g_ntrace >= 64) return;
+    trace_item *t = &g_trace[g_ntrace++];
+    snprintf(t->name, sizeof t->name, "%s", name);
+    t->data = (uint64_t *)malloc(words * 8 + 8); t->len = words;
+    memcpy(t->data, data, words * 8);
+}
+size_t orc_trace_len(const char *name) { for (int i = 0; i < g_ntrace; i++) if (!strcmp(g_trace[i].name, name)) return g_trace[i].len; return 0; }
+int orc_trace_get(const char *name, uint64_t *out) {
+    for (int i = 0; i < g_ntrace; i++) if (!strcmp(g_trace[i].name, name)) { memcpy(out, g_trace[i].data, g_trace[i].len * 8); return 0; }
+    return -1;
+}
+
+/* ------------------------------------------------------------------ batches */
+static void batch_free(orc_batch *b) { free(b->coeffs); free(b->leaves); free(b->digests); free(b->cap); memset(b, 0, sizeof *b); }
+
+/* PolynomialBatch::from_coeffs (no blinding): LDE each column on the coset g<w>, transpose, bit-reverse rows, Merkle */
+static void batch_from_coeffs(orc_batch *b, gl_t *coeffs /* owned */, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height) {
+    memset(b, 0, sizeof *b);
+    b->ncols = ncols; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->n = (size_t)1 << log_n; b->lde_n = b->n << rate_bits;
+    b->coeffs = coeffs;
+    unsigned L = log_n + rate_bits;
+    gl_t *lde = (gl_t *)malloc(sizeof(gl_t) * ncols * b->lde_n);
+#pragma omp parallel for schedule(dynamic)
+    for (long c = 0; c < (long)ncols; c++) {
+        gl_t *col = lde + (size_t)c * b->lde_n;
+        memcpy(col, coeffs + (size_t)c * b->n, b->n * sizeof(gl_t));
+        memset(col + b->n, 0, (b->lde_n - b->n) * sizeof(gl_t));
+        orc_coset_fft(col, L, GL_MULT_GEN);
+    }
+    b->leaves = (gl_t *)malloc(sizeof(gl_t) * ncols * b->lde_n);
+#pragma omp parallel for schedule(static)
+    for (long j = 0; j < (long)b->lde_n; j++) {
+        size_t src = bitrev32((uint32_t)j, L);
+        for (size_t c = 0; c < ncols; c++) b->leaves[(size_t)j * ncols + c] = lde[c * b->lde_n + src];
+    }
+    free(lde);
+    b->digests = (gl_t *)malloc(sizeof(gl_t) * 4 * 2 * b->lde_n);
+    b->cap = (gl_t *)malloc(sizeof(gl_t) * 4 * ((size_t)1 << cap_height));
+    orc_merkle_build(b->leaves, b->lde_n, ncols, cap_height, b->digests, b->cap);
+}
+/* PolynomialBatch::from_values: ifft then from_coeffs. values is copied. */
+static void batch_from_values(orc_batch *b, const gl_t *values, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height) {
+    size_t n = (size_t)1 << log_n;
+    gl_t *coeffs = (gl_t *)malloc(sizeof(gl_t) * ncols * n);
+    memcpy(coeffs, values, sizeof(gl_t) * ncols * n);
+#pragma omp parallel for schedule(dynamic)
+    for (long c = 0; c < (long)ncols; c++) orc_ifft(coeffs + (size_t)c * n, log_n);
+    batch_from_coeffs(b, coeffs, ncols, log_n, rate_bits, cap_height);
+}
+/* row of the LDE at natural point index i (plonky2 get_lde_values) */
+static const gl_t *batch_lde_row(const orc_batch *b, size_t i) { return b->leaves + (size_t)bitrev32((uint32_t)i, b->log_n + b->rate_bits) * b->ncols; }
+
+/* ------------------------------------------------------------------ circuit */
+orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
+    if (nw < 18 || w[0] != QPCP_MAGIC) return NULL;
+    orc_circuit *c = (orc_circuit *)calloc(1, sizeof *c);
+    size_t p = 1;
+    c->degree_bits = w[p++]; c->num_wires = w[p++]; c->num_routed = w[p++]; c->num_constants = w[p++];
+    c->num_selectors = w[p++]; c->num_challenges = w[p++]; c->qdf = w[p++]; c->num_pp = w[p++]; c->num_pis = w[p++];
+    c->rate_bits = w[p++]; c->cap_height = w[p++]; c->pow_bits = w[p++]; c->num_queries = w[p++]; c->zk = w[p++];
+    c->num_gate_constraints = w[p++]; c->n_gates = w[p++]; c->n_arity = w[p++];
+    if (c->n_arity > 16 || c->num_challenges > MAXC || c->zk) { free(c); return NULL; }
+    for (size_t i = 0; i < c->n_arity; i++) c->arity[i] = w[p++];
+    c->gates = (orc_gate *)malloc(sizeof(orc_gate) * c->n_gates);
+    memcpy(c->gates, w + p, sizeof(orc_gate) * c->n_gates); p += 8 * c->n_gates;
+    c->k_is = (gl_t *)malloc(sizeof(gl_t) * c->num_routed);
+    memcpy(c->k_is, w + p, sizeof(gl_t) * c->num_routed); p += c->num_routed;
+    memcpy(c->digest, w + p, 32); p += 4;
+    size_t n = (size_t)1 << c->degree_bits, ncs = c->num_selectors + c->num_constants + c->num_routed;
+    if (p + ncs * n != nw) { free(c->gates); free(c->k_is); free(c); return NULL; }
+    c->cs_values = (gl_t *)malloc(sizeof(gl_t) * ncs * n);
+    memcpy(c->cs_values, w + p, sizeof(gl_t) * ncs * n);
+    batch_from_values(&c->cs, c->cs_values, ncs, (unsigned)c->degree_bits, (unsigned)c->rate_bits, (unsigned)c->cap_height);
+    return c;
+}
+void orc_circuit_free(orc_circuit *c) {
+    if (!c) return;
+    batch_free(&c->cs); free(c->cs_values); free(c->gates); free(c->k_is); free(c);
+}
+
+/* ------------------------------------------------------------------ gate constraints (base field, one point) */
+/* compute_filter: prod_{j in group, j != row} (j - s) [* (UNUSED - s) when several selectors] */
+static gl_t gate_filter(const orc_circuit *c, size_t gi, gl_t s) {
+    const orc_gate *g = &c->gates[gi];
+    gl_t f = 1;
+    for (uint64_t j = g->group_start; j < g->group_end; j++) if (j != gi) f = gl_mul(f, gl_sub(j, s));
+    if (c->num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFULL, s));
+    return f;
+}
+/* adds filter * constraint_k into acc[k]. consts = local constants after the selector prefix. */
+static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t *wires, const gl_t pih[4], gl_t *acc) {
+    const gl_t *consts = cs_row + c->num_selectors;
+    for (size_t gi = 0; gi < c->n_gates; gi++) {
+        const orc_gate *g = &c->gates[gi];
+        if (g->num_constraints == 0) continue;
+        gl_t f = gate_filter(c, gi, cs_row[g->selector_index]);
+        switch (g->type) {
+        case OG_CONSTANT:
+            for (uint64_t i = 0; i < g->param0; i++) acc[i] = gl_add(acc[i], gl_mul(f, gl_sub(consts[i], wires[i])));
+            break;
+        case OG_PUBLIC_INPUT:
+            for (int i = 0; i < 4; i++) acc[i] = gl_add(acc[i], gl_mul(f, gl_sub(wires[i], pih[i])));
+            break;
+        case OG_ARITHMETIC:
+            for (uint64_t i = 0; i < g->param0; i++) {
+                gl_t m0 = wires[4 * i], m1 = wires[4 * i + 1], ad = wires[4 * i + 2], out = wires[4 * i + 3];
+                gl_t computed = gl_add(gl_mul(gl_mul(m0, m1), consts[0]), gl_mul(ad, consts[1]));
+                acc[i] = gl_add(acc[i], gl_mul(f, gl_sub(out, computed)));
+            }
+            break;
+        default: break;
+        }
+    }
+}
+/* same over the extension (verifier side, at zeta) */
+static gl2_t gate_filter_ext(const orc_circuit *c, size_t gi, gl2_t s) {
+    const orc_gate *g = &c->gates[gi];
+    gl2_t f = gl2_from(1);
+    for (uint64_t j = g->group_start; j < g->group_end; j++) if (j != gi) f = gl2_mul(f, gl2_sub(gl2_from(j), s));
+    if (c->num_selectors > 1) f = gl2_mul(f, gl2_sub(gl2_from(0xFFFFFFFFULL), s));
+    return f;
+}
+void orc_eval_gates_ext(const orc_circuit *c, const gl2_t *cs_row, const gl2_t *wires, const gl_t pih[4], gl2_t *acc) {
+    const gl2_t *consts = cs_row + c->num_selectors;
+    for (size_t gi = 0; gi < c->n_gates; gi++) {
+        const orc_gate *g = &c->gates[gi];
+        if (g->num_constraints == 0) continue;
+        gl2_t f = gate_filter_ext(c, gi, cs_row[g->selector_index]);
+        switch (g->type) {
+        case OG_CONSTANT:
+            for (uint64_t i = 0; i < g->param0; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, gl2_sub(consts[i], wires[i])));
+            break;
+        case OG_PUBLIC_INPUT:
+            for (int i = 0; i < 4; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, gl2_sub(wires[i], gl2_from(pih[i]))));
+            break;
+        case OG_ARITHMETIC:
+            for (uint64_t i = 0; i < g->param0; i++) {
+                gl2_t computed = gl2_add(gl2_mul(gl2_mul(wires[4 * i], wires[4 * i + 1]), consts[0]), gl2_mul(wires[4 * i + 2], consts[1]));
+                acc[i] = gl2_add(acc[i], gl2_mul(f, gl2_sub(wires[4 * i + 3], computed)));
+            }
+            break;
+        default: break;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ helpers */
+static void batch_inverse(gl_t *x, size_t n, gl_t *scratch) {
+    gl_t acc = 1;
+    for (size_t i = 0; i < n; i++) { scratch[i] = acc; acc = gl_mul(acc, x[i]); }
+    gl_t inv = gl_inv(acc);
+    for (size_t i = n; i-- > 0;) { gl_t t = gl_mul(inv, scratch[i]); inv = gl_mul(inv, x[i]); x[i] = t; }
+}
+static gl2_t challenger_get_ext(orc_challenger *ch) { gl_t a = orc_challenger_get(ch), b = orc_challenger_get(ch); return gl2_make(a, b); }
+static gl2_t eval_poly_ext(const gl_t *coeffs, size_t n, gl2_t z) {
+    gl2_t acc = gl2_from(0);
+    for (size_t i = n; i-- > 0;) acc = gl2_add(gl2_mul(acc, z), gl2_from(coeffs[i]));
+    return acc;
+}
+
+typedef struct { uint8_t *p; size_t cap, len; int overflow; } wbuf;
+static void w_u64(wbuf *b, uint64_t v) { if (b->len + 8 > b->cap) { b->overflow = 1; b->len += 8; return; } for (int k = 0; k < 8; k++) b->p[b->len + k] = (uint8_t)(v >> (8 * k)); b->len += 8; }
+static void w_u8(wbuf *b, uint8_t v) { if (b->len + 1 > b->cap) { b->overflow = 1; b->len += 1; return; } b->p[b->len++] = v; }
+static void w_vec(wbuf *b, const gl_t *v, size_t n) { for (size_t i = 0; i < n; i++) w_u64(b, v[i]); }
+static void w_ext(wbuf *b, gl2_t v) { w_u64(b, v.c[0]); w_u64(b, v.c[1]); }
+static void w_path(wbuf *b, const gl_t *digests, size_t n_leaves, unsigned cap_h, size_t idx) {
+    gl_t path[64 * 4];
+    size_t len = orc_merkle_path(digests, n_leaves, cap_h, idx, path);
+    w_u8(b, (uint8_t)len);
+    w_vec(b, path, len * 4);
+}
+
+size_t orc_proof_size(const orc_circuit *c) {
+    size_t n_cs = c->num_selectors + c->num_constants + c->num_routed, nch = c->num_challenges;
+    size_t cap = ((size_t)1 << c->cap_height) * 4 * 8;
+    size_t openings = (n_cs + c->num_wires + nch * 2 + nch * c->num_pp + nch * c->qdf) * 16;
+    size_t L = c->degree_bits + c->rate_bits, sz = 3 * cap + openings;
+    size_t widths[4] = {n_cs, c->num_wires, nch * (1 + c->num_pp), nch * c->qdf};
+    size_t q = 0;
+    for (int o = 0; o < 4; o++) q += widths[o] * 8 + 1 + (L - c->cap_height) * 32;
+    size_t lvl = L, fin = c->degree_bits;
+    for (size_t r = 0; r < c->n_arity; r++) {
+        sz += cap; lvl -= c->arity[r]; fin -= c->arity[r];
+        q += ((size_t)1 << c->arity[r]) * 16 + 1 + (lvl - c->cap_height) * 32;
+    }
+    sz += c->num_queries * q + ((size_t)1 << fin) * 16 + 8 + c->num_pis * 8;
+    return sz;
+}
+
+/* ------------------------------------------------------------------ prove */
+int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len) {
+    trace_clear();
+    const unsigned d = (unsigned)c->degree_bits, rb = (unsigned)c->rate_bits, ch_h = (unsigned)c->cap_height, L = d + rb;
+    const size_t n = (size_t)1 << d, lde_n = n << rb, R = c->num_routed, NW = c->num_wires, nch = c->num_challenges;
+    const size_t npp = c->num_pp, nchunks = npp + 1, chunk = c->qdf, ncs = c->num_selectors + c->num_constants + R;
+    const size_t sig0 = c->num_selectors + c->num_constants, cap_words = ((size_t)1 << ch_h) * 4;
+
+    gl_t pih[4];
+    orc_hash_no_pad(public_inputs, c->num_pis, pih);
+    trace_put("pi_hash", pih, 4);
+
+    /* s2/s3: wires commitment */
+    orc_batch wb;
+    batch_from_values(&wb, wires, NW, d, rb, ch_h);
+    trace_put("wires_cap", wb.cap, cap_words);
+
+    orc_challenger ch;
+    orc_challenger_init(&ch);
+    orc_challenger_observe(&ch, c->digest, 4);
+    orc_challenger_observe(&ch, pih, 4);
+    orc_challenger_observe(&ch, wb.cap, cap_words);
+    gl_t betas[MAXC], gammas[MAXC], alphas[MAXC];
+    orc_challenger_get_n(&ch, betas, nch);
+    orc_challenger_get_n(&ch, gammas, nch);
+    trace_put("betas", betas, nch); trace_put("gammas", gammas, nch);
+
+    /* s5: partial products and Z. zs_pp columns: [Z_0..Z_{nch-1}, pp_0_*, pp_1_*, ...] */
+    const size_t nzp = nch * (1 + npp);
+    gl_t *zs_pp = (gl_t *)malloc(sizeof(gl_t) * nzp * n);
+    gl_t *omega = (gl_t *)malloc(sizeof(gl_t) * n);
+    { gl_t w = gl_root_of_unity(d), a = 1; for (size_t i = 0; i < n; i++) { omega[i] = a; a = gl_mul(a, w); } }
+    for (size_t k = 0; k < nch; k++) {
+        gl_t *qcp = (gl_t *)malloc(sizeof(gl_t) * n * nchunks);  /* quotient chunk products per row */
+#pragma omp parallel
+        {
+            gl_t *den = (gl_t *)malloc(sizeof(gl_t) * R), *num = (gl_t *)malloc(sizeof(gl_t) * R), *scr = (gl_t *)malloc(sizeof(gl_t) * R);
+#pragma omp for schedule(static)
+            for (long i = 0; i < (long)n; i++) {
+                gl_t x = omega[i];
+                for (size_t j = 0; j < R; j++) {
+                    gl_t wv = wires[j * n + i];
+                    num[j] = gl_add(gl_add(wv, gl_mul(betas[k], gl_mul(c->k_is[j], x))), gammas[k]);
+                    den[j] = gl_add(gl_add(wv, gl_mul(betas[k], c->cs_values[(sig0 + j) * n + i])), gammas[k]);
+                }
+                batch_inverse(den, R, scr);
+                for (size_t cc = 0; cc < nchunks; cc++) {
+                    gl_t p = 1;
+                    for (size_t j = cc * chunk; j < (cc + 1) * chunk && j < R; j++) p = gl_mul(p, gl_mul(num[j], den[j]));
+                    qcp[(size_t)i * nchunks + cc] = p;
+                }
+            }
+            free(den); free(num); free(scr);
+        }
+        gl_t z = 1;
+        for (size_t i = 0; i < n; i++) {
+            zs_pp[k * n + i] = z;   /* Z(x_i) */
+            gl_t acc = z;
+            for (size_t cc = 0; cc < nchunks; cc++) {
+                acc = gl_mul(acc, qcp[i * nchunks + cc]);
+                if (cc < npp) zs_pp[(nch + k * npp + cc) * n + i] = acc;
+            }
+            z = acc;                /* Z(g x_i) */
+        }
+        free(qcp);
+    }
+    trace_put("zs_pp_values", zs_pp, nzp * n);
+    orc_batch zb;
+    batch_from_values(&zb, zs_pp, nzp, d, rb, ch_h);
+    free(zs_pp);
+    trace_put("zs_pp_cap", zb.cap, cap_words);
+    orc_challenger_observe(&ch, zb.cap, cap_words);
+    orc_challenger_get_n(&ch, alphas, nch);
+    trace_put("alphas", alphas, nch);
+
+    /* s6: quotient polynomials on the coset g<w_{8n}> */
+    gl_t *quot = (gl_t *)malloc(sizeof(gl_t) * nch * lde_n);
+    {
+        gl_t zh_inv[64];
+        gl_t gn = gl_pow(GL_MULT_GEN, n), wr = gl_root_of_unity(rb);
+        size_t rate = (size_t)1 << rb;
+        gl_t zh[64];
+        for (size_t i = 0; i < rate; i++) { zh[i] = gl_sub(gl_mul(gn, gl_pow(wr, i)), 1); zh_inv[i] = gl_inv(zh[i]); }
+        gl_t wl = gl_root_of_unity(L), n_f = (gl_t)n;
+        const size_t nterms = nch + nch * nchunks + c->num_gate_constraints;
+#pragma omp parallel
+        {
+            gl_t *terms = (gl_t *)malloc(sizeof(gl_t) * nterms), *num = (gl_t *)malloc(sizeof(gl_t) * R), *den = (gl_t *)malloc(sizeof(gl_t) * R);
+#pragma omp for schedule(static)
+            for (long i = 0; i < (long)lde_n; i++) {
+                gl_t x = gl_mul(GL_MULT_GEN, gl_pow(wl, (uint64_t)i));
+                const gl_t *w_row = batch_lde_row(&wb, i), *cs_row = batch_lde_row(&c->cs, i), *z_row = batch_lde_row(&zb, i);
+                const gl_t *z_next = batch_lde_row(&zb, (i + rate) % lde_n);
+                gl_t l0 = gl_mul(zh[i % rate], gl_inv(gl_mul(n_f, gl_sub(x, 1))));
+                size_t t = 0;
+                for (size_t k = 0; k < nch; k++) terms[t++] = gl_mul(l0, gl_sub(z_row[k], 1));
+                for (size_t k = 0; k < nch; k++) {
+                    for (size_t j = 0; j < R; j++) {
+                        num[j] = gl_add(gl_add(w_row[j], gl_mul(betas[k], gl_mul(c->k_is[j], x))), gammas[k]);
+                        den[j] = gl_add(gl_add(w_row[j], gl_mul(betas[k], cs_row[sig0 + j])), gammas[k]);
+                    }
+                    for (size_t cc = 0; cc < nchunks; cc++) {
+                        gl_t prev = cc == 0 ? z_row[k] : z_row[nch + k * npp + cc - 1];
+                        gl_t next = cc == nchunks - 1 ? z_next[k] : z_row[nch + k * npp + cc];
+                        gl_t pn = 1, pd = 1;
+                        for (size_t j = cc * chunk; j < (cc + 1) * chunk && j < R; j++) { pn = gl_mul(pn, num[j]); pd = gl_mul(pd, den[j]); }
+                        terms[t++] = gl_sub(gl_mul(prev, pn), gl_mul(next, pd));
+                    }
+                }
+                for (size_t g = 0; g < c->num_gate_constraints; g++) terms[t + g] = 0;
+                eval_gates_base(c, cs_row, w_row, pih, terms + t);
+                for (size_t k = 0; k < nch; k++) {
+                    gl_t acc = 0;   /* reduce_with_powers: sum terms[j] * alpha^j */
+                    for (size_t j = nterms; j-- > 0;) acc = gl_add(gl_mul(acc, alphas[k]), terms[j]);
+                    quot[k * lde_n + i] = gl_mul(acc, zh_inv[i % rate]);
+                }
+            }
+            free(terms); free(num); free(den);
+        }
+    }
+    trace_put("quotient_values", quot, nch * lde_n);
+#pragma omp parallel for
+    for (long k = 0; k < (long)nch; k++) orc_coset_ifft(quot + (size_t)k * lde_n, L, GL_MULT_GEN);
+    /* each quotient poly (8n coefficients) is split into qdf chunks of n: contiguous => nch*qdf columns of n */
+    const size_t nq = nch * c->qdf;
+    orc_batch qb;
+    batch_from_coeffs(&qb, quot, nq, d, rb, ch_h);   /* quot now owned by qb.coeffs */
+    trace_put("quotient_chunk_coeffs", qb.coeffs, nq * n);
+    trace_put("quotient_cap", qb.cap, cap_words);
+    orc_challenger_observe(&ch, qb.cap, cap_words);
+    gl2_t zeta = challenger_get_ext(&ch);
+    trace_put("zeta", zeta.c, 2);
+
+    /* s7: openings */
+    gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(d));
+    const orc_batch *oracles[4] = {&c->cs, &wb, &zb, &qb};
+    const size_t n_open = ncs + NW + nzp + nq;
+    gl2_t *open_zeta = (gl2_t *)malloc(sizeof(gl2_t) * n_open), *open_next = (gl2_t *)malloc(sizeof(gl2_t) * nch);
+    {
+        size_t off = 0;
+        for (int o = 0; o < 4; o++) {
+            const orc_batch *b = oracles[o];
+#pragma omp parallel for schedule(dynamic)
+            for (long p = 0; p < (long)b->ncols; p++) open_zeta[off + p] = eval_poly_ext(b->coeffs + (size_t)p * n, n, zeta);
+            off += b->ncols;
+        }
+        for (size_t k = 0; k < nch; k++) open_next[k] = eval_poly_ext(zb.coeffs + k * n, n, g_zeta);
+    }
+    /* OpeningSet field order: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys */
+    const gl2_t *o_consts = open_zeta, *o_wires = open_zeta + ncs, *o_zs = o_wires + NW, *o_pp = o_zs + nch, *o_q = o_pp + nch * npp;
+    trace_put("openings_zeta", open_zeta, n_open * 2); trace_put("openings_zeta_next", open_next, nch * 2);
+    /* observe_openings(to_fri_openings): batch 0 = everything at zeta in oracle order, batch 1 = zs_next */
+    orc_challenger_observe(&ch, (const gl_t *)open_zeta, n_open * 2);
+    orc_challenger_observe(&ch, (const gl_t *)open_next, nch * 2);
+
+    /* s8: batched opening polynomial */
+    gl2_t fri_alpha = challenger_get_ext(&ch);
+    trace_put("fri_alpha", fri_alpha.c, 2);
+    gl2_t *final_poly = (gl2_t *)calloc(lde_n, sizeof(gl2_t));   /* zero padded to 8n (the LDE of step s8) */
+    {
+        /* batch 0: all polynomials of all oracles at zeta; batch 1: Z polynomials at g*zeta */
+        gl2_t *comp = (gl2_t *)malloc(sizeof(gl2_t) * n), *q0 = (gl2_t *)malloc(sizeof(gl2_t) * n);
+        for (int batch = 0; batch < 2; batch++) {
+            for (size_t i = 0; i < n; i++) comp[i] = gl2_from(0);
+            gl2_t apow = gl2_from(1);
+            size_t count = 0;
+            if (batch == 0) {
+                for (int o = 0; o < 4; o++) for (size_t p = 0; p < oracles[o]->ncols; p++) {
+                    const gl_t *f = oracles[o]->coeffs + p * n;
+                    for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(apow, f[i]));
+                    apow = gl2_mul(apow, fri_alpha); count++;
+                }
+            } else {
+                for (size_t p = 0; p < nch; p++) {
+                    const gl_t *f = zb.coeffs + p * n;
+                    for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(apow, f[i]));
+                    apow = gl2_mul(apow, fri_alpha); count++;
+                }
+            }
+            gl2_t z = batch == 0 ? zeta : g_zeta;
+            /* divide_by_linear: synthetic division, quotient has n-1 coefficients, padded with a zero */
+            gl2_t acc = gl2_from(0);
+            for (size_t i = n; i-- > 0;) { acc = gl2_add(gl2_mul(acc, z), comp[i]); if (i > 0) q0[i - 1] = acc; }
+            q0[n - 1] = gl2_from(0);
+            /* alpha.shift_poly(final_poly): multiply by alpha^count, then add the quotient */
+            gl2_t shift = gl2_pow(fri_alpha, count);
+            for (size_t i = 0; i < n; i++) final_poly[i] = gl2_add(gl2_mul(final_poly[i], shift), q0[i]);
+        }
+        free(comp); free(q0);
+    }
+    trace_put("final_poly_coeffs", final_poly, n * 2);
+
+    /* s9: FRI commit phase */
+    wbuf fri_caps = {(uint8_t *)malloc(cap_words * 8 * (c->n_arity + 1)), cap_words * 8 * (c->n_arity + 1), 0, 0};
+    size_t cur_len = lde_n;                 /* coefficient vector length (zero padded) */
+    gl2_t *coeffs = final_poly;
+    gl_t shift = GL_MULT_GEN;
+    gl_t **tree_digests = (gl_t **)calloc(c->n_arity + 1, sizeof(gl_t *));
+    gl_t **tree_leaves = (gl_t **)calloc(c->n_arity + 1, sizeof(gl_t *));
+    size_t tree_nleaves[17];
+    gl2_t *values = (gl2_t *)malloc(sizeof(gl2_t) * lde_n);
+    {   /* values = coset_fft(coeffs, g) componentwise */
+        gl_t *a = (gl_t *)malloc(sizeof(gl_t) * lde_n), *b = (gl_t *)malloc(sizeof(gl_t) * lde_n);
+        for (size_t i = 0; i < lde_n; i++) { a[i] = coeffs[i].c[0]; b[i] = coeffs[i].c[1]; }
+        orc_coset_fft(a, L, shift); orc_coset_fft(b, L, shift);
+        for (size_t i = 0; i < lde_n; i++) values[i] = gl2_make(a[i], b[i]);
+        free(a); free(b);
+    }
+    trace_put("fri_values0", values, lde_n * 2);
+    for (size_t r = 0; r < c->n_arity; r++) {
+        unsigned ab = (unsigned)c->arity[r], logc = 0;
+        size_t arity = (size_t)1 << ab;
+        while (((size_t)1 << logc) < cur_len) logc++;
+        /* reverse_index_bits, chunk into leaves of `arity` extension values */
+        size_t nl = cur_len >> ab;
+        gl_t *leaves = (gl_t *)malloc(sizeof(gl_t) * cur_len * 2);
+        for (size_t j = 0; j < cur_len; j++) { gl2_t v = values[bitrev32((uint32_t)j, logc)]; leaves[2 * j] = v.c[0]; leaves[2 * j + 1] = v.c[1]; }
+        gl_t *dig = (gl_t *)malloc(sizeof(gl_t) * 4 * 2 * nl), capv[64 * 4];
+        orc_merkle_build(leaves, nl, 2 * arity, ch_h, dig, capv);
+        tree_digests[r] = dig; tree_leaves[r] = leaves; tree_nleaves[r] = nl;
+        w_vec(&fri_caps, capv, cap_words);
+        orc_challenger_observe(&ch, capv, cap_words);
+        gl2_t beta = challenger_get_ext(&ch);
+        { char nm[32]; snprintf(nm, sizeof nm, "fri_beta%zu", r); trace_put(nm, beta.c, 2); snprintf(nm, sizeof nm, "fri_cap%zu", r); trace_put(nm, capv, cap_words); }
+        /* fold coefficients: new[i] = sum_k beta^k * coeffs[arity*i + k] */
+        size_t new_len = cur_len >> ab;
+        for (size_t i = 0; i < new_len; i++) {
+            gl2_t acc = gl2_from(0);
+            for (size_t k = arity; k-- > 0;) acc = gl2_add(gl2_mul(acc, beta), coeffs[arity * i + k]);
+            coeffs[i] = acc;
+        }
+        cur_len = new_len;
+        shift = gl_pow(shift, arity);
+        unsigned logn2 = logc - ab;
+        gl_t *a = (gl_t *)malloc(sizeof(gl_t) * cur_len), *b = (gl_t *)malloc(sizeof(gl_t) * cur_len);
+        for (size_t i = 0; i < cur_len; i++) { a[i] = coeffs[i].c[0]; b[i] = coeffs[i].c[1]; }
+        orc_coset_fft(a, logn2, shift); orc_coset_fft(b, logn2, shift);
+        for (size_t i = 0; i < cur_len; i++) values[i] = gl2_make(a[i], b[i]);
+        free(a); free(b);
+    }
+    size_t final_len = cur_len >> rb;   /* coeffs.truncate(len >> rate_bits) */
+    orc_challenger_observe(&ch, (const gl_t *)coeffs, final_len * 2);
+    trace_put("fri_final_poly", coeffs, final_len * 2);
+
+    /* s10: proof of work, minimum nonce */
+    gl_t pow_witness = 0;
+    {
+        unsigned min_lz = (unsigned)c->pow_bits;
+        for (gl_t cand = 0;; cand++) {
+            gl_t resp = orc_challenger_pow_response(&ch, cand);
+            if (min_lz == 0 || (resp >> (64 - min_lz)) == 0) { pow_witness = cand; break; }
+        }
+        orc_challenger_observe(&ch, &pow_witness, 1);
+        gl_t resp = orc_challenger_get(&ch);
+        (void)resp;
+    }
+    trace_put("pow_witness", &pow_witness, 1);
+
+    /* s12 (first part): serialise */
+    wbuf o = {out, cap, 0, 0};
+    w_vec(&o, wb.cap, cap_words); w_vec(&o, zb.cap, cap_words); w_vec(&o, qb.cap, cap_words);
+    for (size_t i = 0; i < ncs; i++) w_ext(&o, o_consts[i]);           /* constants then plonk_sigmas */
+    for (size_t i = 0; i < NW; i++) w_ext(&o, o_wires[i]);
+    for (size_t i = 0; i < nch; i++) w_ext(&o, o_zs[i]);
+    for (size_t i = 0; i < nch; i++) w_ext(&o, open_next[i]);
+    for (size_t i = 0; i < nch * npp; i++) w_ext(&o, o_pp[i]);
+    for (size_t i = 0; i < nq; i++) w_ext(&o, o_q[i]);
+    /* lookup_zs, lookup_zs_next: empty */
+    for (size_t i = 0; i < fri_caps.len && !o.overflow; i++) w_u8(&o, fri_caps.p[i]);
+    if (o.overflow) o.len += 0;
+
+    /* s11: query rounds */
+    uint64_t *qidx = (uint64_t *)malloc(8 * c->num_queries);
+    for (size_t q = 0; q < c->num_queries; q++) {
+        gl_t xch = orc_challenger_get(&ch);
+        size_t x_index = (size_t)(xch % lde_n);
+        qidx[q] = x_index;
+        for (int oi = 0; oi < 4; oi++) {
+            const orc_batch *b = oracles[oi];
+            w_vec(&o, b->leaves + x_index * b->ncols, b->ncols);
+            w_path(&o, b->digests, b->lde_n, ch_h, x_index);
+        }
+        for (size_t r = 0; r < c->n_arity; r++) {
+            unsigned ab = (unsigned)c->arity[r];
+            size_t arity = (size_t)1 << ab, leaf = x_index >> ab;
+            w_vec(&o, tree_leaves[r] + leaf * 2 * arity, 2 * arity);
+            w_path(&o, tree_digests[r], tree_nleaves[r], ch_h, leaf);
+            x_index = leaf;
+        }
+    }
+    trace_put("query_indices", qidx, c->num_queries);
+    free(qidx);
+    for (size_t i = 0; i < final_len; i++) w_ext(&o, coeffs[i]);
+    w_u64(&o, pow_witness);
+    w_vec(&o, public_inputs, c->num_pis);
+    *len = o.len;
+
+    for (size_t r = 0; r < c->n_arity; r++) { free(tree_digests[r]); free(tree_leaves[r]); }
+    free(tree_digests); free(tree_leaves); free(values); free(final_poly); free(fri_caps.p);
+    free(open_zeta); free(open_next); free(omega);
+    batch_free(&wb); batch_free(&zb); batch_free(&qb);
+    return o.overflow ? -1 : 0;
+}

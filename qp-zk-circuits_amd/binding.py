@@ -58,6 +58,9 @@ def load_library():
         "qpgpu_merkle_digest_count": (c.c_size_t, [c.c_uint, c.c_uint]),
         "qpgpu_merkle_build_dev": (c.c_int, [vp, u64p, c.c_uint64, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
         "qpgpu_merkle_build_rows_dev": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
+        "qpgpu_synth_pack_words": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint]),
+        "qpgpu_synth_circuit": (c.c_int, [c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, u64p, c.c_size_t,
+                                          c.POINTER(c.c_size_t), u64p, u64p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -73,6 +76,21 @@ def exported_symbols():
     hdr = os.path.join(os.path.dirname(_HERE), "include", "qpgpu.h")
     text = open(hdr).read()
     return sorted(set(re.findall(r"\b(qpgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=21, seed=1):
+    """Synthetic satisfied circuit: returns (pack_words, wires[num_wires, n], public_inputs). Host only."""
+    lib = load_library()
+    words = lib.qpgpu_synth_pack_words(degree_bits, num_wires, num_routed)
+    pack = np.empty(words, dtype=np.uint64)
+    wires = np.empty((num_wires, 1 << degree_bits), dtype=np.uint64)
+    pis = np.empty(num_public_inputs, dtype=np.uint64)
+    got = ctypes.c_size_t()
+    rc = lib.qpgpu_synth_circuit(degree_bits, num_wires, num_routed, num_public_inputs, seed, pack.ctypes.data, words,
+                                 ctypes.byref(got), wires.ctypes.data, pis.ctypes.data)
+    if rc != 0 or got.value != words:
+        raise QpGpuError(rc, f"synth_circuit failed (words {got.value} vs {words})")
+    return pack, wires, pis
 
 
 class DeviceBuffer:

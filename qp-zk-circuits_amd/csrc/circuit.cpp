@@ -1,0 +1,89 @@
+// circuit.cpp — circuit pack (de)serialisation and validation. See circuit.hpp for the format.
+#include "circuit.hpp"
+
+std::vector<uint64_t> CircuitPack::serialize() const {
+    std::vector<uint64_t> w;
+    w.push_back(QPCP_MAGIC);
+    const uint64_t hdr[] = {degree_bits, num_wires, num_routed_wires, num_constants, num_selectors, num_challenges,
+                            quotient_degree_factor, num_partial_products, num_public_inputs, rate_bits, cap_height,
+                            proof_of_work_bits, num_query_rounds, zero_knowledge, num_gate_constraints,
+                            (uint64_t)gates.size(), (uint64_t)arity_bits.size()};
+    w.insert(w.end(), hdr, hdr + 17);
+    w.insert(w.end(), arity_bits.begin(), arity_bits.end());
+    for (const auto &g : gates) {
+        const uint64_t gw[] = {g.type, g.param0, g.param1, g.selector_index, g.group_start, g.group_end, g.num_constraints, g.reserved};
+        w.insert(w.end(), gw, gw + 8);
+    }
+    w.insert(w.end(), k_is.begin(), k_is.end());
+    w.insert(w.end(), circuit_digest, circuit_digest + 4);
+    w.insert(w.end(), constants_sigmas.begin(), constants_sigmas.end());
+    return w;
+}
+
+std::string CircuitPack::parse(const uint64_t *words, size_t n_words) {
+    size_t pos = 0;
+    auto need = [&](size_t k) { return pos + k <= n_words; };
+    if (!need(18) || words[0] != QPCP_MAGIC) return "bad magic or truncated header";
+    pos = 1;
+    uint64_t *fields[] = {&degree_bits, &num_wires, &num_routed_wires, &num_constants, &num_selectors, &num_challenges,
+                          &quotient_degree_factor, &num_partial_products, &num_public_inputs, &rate_bits, &cap_height,
+                          &proof_of_work_bits, &num_query_rounds, &zero_knowledge, &num_gate_constraints};
+    for (auto f : fields) *f = words[pos++];
+    uint64_t ng = words[pos++], na = words[pos++];
+    if (degree_bits > 24 || ng > 4096 || na > 16 || num_routed_wires > 4096 || num_wires > 4096) return "header field out of range";
+    if (!need(na)) return "truncated arity list";
+    arity_bits.assign(words + pos, words + pos + na); pos += na;
+    if (!need(ng * 8)) return "truncated gate list";
+    gates.resize(ng);
+    for (auto &g : gates) {
+        g.type = words[pos]; g.param0 = words[pos + 1]; g.param1 = words[pos + 2]; g.selector_index = words[pos + 3];
+        g.group_start = words[pos + 4]; g.group_end = words[pos + 5]; g.num_constraints = words[pos + 6]; g.reserved = words[pos + 7];
+        pos += 8;
+    }
+    if (!need(num_routed_wires + 4)) return "truncated k_is";
+    k_is.assign(words + pos, words + pos + num_routed_wires); pos += num_routed_wires;
+    for (int i = 0; i < 4; i++) circuit_digest[i] = words[pos++];
+    const size_t cs = (size_t)num_cs_cols() << degree_bits;
+    if (!need(cs)) return "truncated constants_sigmas";
+    constants_sigmas.assign(words + pos, words + pos + cs); pos += cs;
+    if (pos != n_words) return "trailing data";
+    return validate();
+}
+
+std::string CircuitPack::validate() const {
+    if (num_routed_wires > num_wires) return "num_routed_wires > num_wires";
+    if (num_challenges == 0 || num_challenges > 4) return "unsupported num_challenges";
+    if (quotient_degree_factor == 0 || (quotient_degree_factor & (quotient_degree_factor - 1))) return "quotient_degree_factor must be a power of two";
+    if ((1ull << rate_bits) != quotient_degree_factor) return "this backend requires quotient_degree_factor == 2^rate_bits";
+    if (num_partial_products + 1 != (num_routed_wires + quotient_degree_factor - 1) / quotient_degree_factor) return "num_partial_products inconsistent";
+    if (cap_height > degree_bits + rate_bits) return "cap_height above tree height";
+    if (zero_knowledge) return "zero_knowledge packs are not supported yet";
+    uint64_t sum = 0;
+    for (auto a : arity_bits) { if (a == 0 || a > 4) return "unsupported FRI arity"; sum += a; }
+    if (sum > degree_bits) return "FRI reductions exceed degree";
+    for (const auto &g : gates) {
+        if (g.type > GATE_POSEIDON) return "unknown gate type";
+        if (g.selector_index >= num_selectors) return "gate selector index out of range";
+        if (g.group_end > gates.size() || g.group_start >= g.group_end) return "gate group out of range";
+        if (g.num_constraints > num_gate_constraints) return "gate constraint count exceeds num_gate_constraints";
+        if (g.type == GATE_ARITHMETIC && (g.param0 * 4 > num_routed_wires || g.num_constraints != g.param0 || num_constants < 2)) return "bad arithmetic gate";
+        if (g.type == GATE_CONSTANT && (g.param0 > num_constants || g.param0 > num_wires || g.num_constraints != g.param0)) return "bad constant gate";
+        if (g.type == GATE_PUBLIC_INPUT && (num_wires < 4 || g.num_constraints != 4)) return "bad public input gate";
+        if (g.type == GATE_POSEIDON) return "poseidon gate not supported yet";
+    }
+    return "";
+}
+
+std::vector<uint64_t> fri_reduction_arity_bits(uint64_t degree_bits, uint64_t rate_bits, uint64_t cap_height,
+                                               uint64_t arity_bits, uint64_t final_poly_bits) {
+    // FriReductionStrategy::ConstantArityBits: reduce while the polynomial is longer than 2^final_poly_bits and the
+    // next tree still has at least 2^cap_height leaves.
+    std::vector<uint64_t> out;
+    uint64_t d = degree_bits;
+    while (d > final_poly_bits && d + rate_bits >= cap_height + arity_bits) {
+        out.push_back(arity_bits);
+        if (d < arity_bits) { out.pop_back(); break; }
+        d -= arity_bits;
+    }
+    return out;
+}

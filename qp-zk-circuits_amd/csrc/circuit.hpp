@@ -1,0 +1,57 @@
+// circuit.hpp — the "circuit pack": everything the prover needs that the Rust CircuitBuilder produces
+// (SURVEY.md §8f-1). It is the serialised form of plonky2's CommonCircuitData + ProverOnlyCircuitData
+// restricted to what `prove` reads after witness generation: sizes and FRI parameters, the gate list with
+// selector groups, k_is, circuit_digest, and the constants/sigmas polynomials in value form.
+//
+// Format "QPCP1": little-endian u64 words.
+//   [0]  magic 0x0000003150435051 ("QPCP1")
+//   [1..17] degree_bits, num_wires, num_routed_wires, num_constants, num_selectors, num_challenges,
+//           quotient_degree_factor, num_partial_products, num_public_inputs, rate_bits, cap_height,
+//           proof_of_work_bits, num_query_rounds, zero_knowledge, num_gate_constraints, num_gates,
+//           num_arity_rounds
+//   arity_bits[num_arity_rounds]
+//   gates[num_gates] x 8 words: type, param0, param1, selector_index, group_start, group_end,
+//           num_constraints, reserved
+//   k_is[num_routed_wires]; circuit_digest[4]
+//   constants_sigmas values: (num_selectors + num_constants + num_routed_wires) columns x 2^degree_bits,
+//           column-major, natural subgroup order (column order = plonky2's constants_sigmas oracle:
+//           selectors, constants, sigmas)
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+enum GateType : uint64_t { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4 };
+
+struct GateInfo {
+    uint64_t type, param0, param1, selector_index, group_start, group_end, num_constraints, reserved;
+};
+
+struct CircuitPack {
+    uint64_t degree_bits = 0, num_wires = 0, num_routed_wires = 0, num_constants = 0, num_selectors = 0,
+             num_challenges = 0, quotient_degree_factor = 0, num_partial_products = 0, num_public_inputs = 0,
+             rate_bits = 0, cap_height = 0, proof_of_work_bits = 0, num_query_rounds = 0, zero_knowledge = 0,
+             num_gate_constraints = 0;
+    std::vector<uint64_t> arity_bits;
+    std::vector<GateInfo> gates;
+    std::vector<uint64_t> k_is;
+    uint64_t circuit_digest[4] = {0, 0, 0, 0};
+    std::vector<uint64_t> constants_sigmas;  // column-major values
+
+    uint64_t n() const { return 1ull << degree_bits; }
+    uint64_t num_cs_cols() const { return num_selectors + num_constants + num_routed_wires; }
+    uint64_t num_chunks() const { return num_partial_products + 1; }
+    uint64_t num_zs_pp_cols() const { return num_challenges * (1 + num_partial_products); }
+    uint64_t num_quotient_cols() const { return num_challenges * quotient_degree_factor; }
+
+    std::vector<uint64_t> serialize() const;
+    // returns empty string on success, otherwise the reason
+    std::string parse(const uint64_t *words, size_t n_words);
+    std::string validate() const;
+};
+
+constexpr uint64_t QPCP_MAGIC = 0x0000003150435051ull;
+
+// FriParams::reduction_arity_bits for ConstantArityBits(arity_bits, final_poly_bits)
+std::vector<uint64_t> fri_reduction_arity_bits(uint64_t degree_bits, uint64_t rate_bits, uint64_t cap_height,
+                                               uint64_t arity_bits, uint64_t final_poly_bits);

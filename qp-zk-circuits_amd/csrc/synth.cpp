@@ -1,0 +1,144 @@
+// synth.cpp — synthetic, satisfied plonky2-shaped circuits for tests and bench ("shape-equivalent
+// synthetic"): the Rust CircuitBuilder that would export the real Wormhole circuit pack
+// cannot run in this image, so this generator produces a circuit with the same shape parameters
+// (135 wires, 80 routed, 2 constants, standard_recursion_config FRI) and a witness that satisfies it:
+// PublicInputGate row, ConstantGate rows, ArithmeticGate rows wired together by copy constraints,
+// NoopGate padding. It plays the role of reference rows a1/a6 (witness + circuit shape providers).
+#include <algorithm>
+#include <numeric>
+#include "circuit.hpp"
+#include "ctx.hpp"
+#include "gl64.hpp"
+#include "poseidon.hpp"
+
+using gl::u64;
+
+namespace {
+struct SplitMix {
+    u64 s;
+    u64 next() { u64 z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    u64 felt() { for (;;) { u64 v = next(); if (v < gl::P) return v; } }
+    u64 below(u64 n) { return next() % n; }
+};
+void host_hash_no_pad(const u64 *in, size_t n, u64 out[4]) {
+    u64 st[12] = {0};
+    for (size_t i = 0; i < n; i += 8) {
+        size_t len = std::min<size_t>(8, n - i);
+        for (size_t k = 0; k < len; k++) st[k] = gl::canon(in[i + k]);
+        poseidon::permute(st, poseidon::host_round_constants());
+    }
+    for (int i = 0; i < 4; i++) out[i] = st[i];
+}
+}  // namespace
+
+void synth_public_inputs_hash(const u64 *pis, size_t n, u64 out[4]) { host_hash_no_pad(pis, n, out); }
+
+// Builds the pack and the witness. wires: num_wires x n column-major. Returns "" or an error.
+std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
+                        u64 seed, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
+    if (degree_bits < 3 || degree_bits > 20) return "degree_bits out of range";
+    if (num_routed < 8 || num_routed > num_wires || num_routed % 4) return "num_routed_wires must be a multiple of 4, >= 8";
+    SplitMix rng{seed ^ 0x5EED5EED5EEDull};
+    const u64 n = 1ull << degree_bits;
+    pack = CircuitPack();
+    pack.degree_bits = degree_bits; pack.num_wires = num_wires; pack.num_routed_wires = num_routed;
+    pack.num_constants = 2; pack.num_selectors = 1; pack.num_challenges = 2; pack.quotient_degree_factor = 8;
+    pack.num_partial_products = (num_routed + 7) / 8 - 1; pack.num_public_inputs = num_public_inputs;
+    pack.rate_bits = 3; pack.cap_height = 4; pack.proof_of_work_bits = 16; pack.num_query_rounds = 28;
+    pack.zero_knowledge = 0;
+    pack.arity_bits = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5);
+    const u64 num_ops = num_routed / 4;
+    pack.num_gate_constraints = std::max<u64>(num_ops, 4);
+    // gates sorted by (degree, id) as the builder does: Noop, Constant, PublicInput, Arithmetic; one selector group
+    pack.gates = {
+        {GATE_NOOP, 0, 0, 0, 0, 4, 0, 0},
+        {GATE_CONSTANT, 2, 0, 0, 0, 4, 2, 0},
+        {GATE_PUBLIC_INPUT, 0, 0, 0, 0, 4, 4, 0},
+        {GATE_ARITHMETIC, num_ops, 0, 0, 0, 4, num_ops, 0},
+    };
+    pack.k_is.resize(num_routed);
+    { u64 k = 1; for (unsigned j = 0; j < num_routed; j++) { pack.k_is[j] = gl::canon(k); k = gl::mul(k, gl::MULT_GEN); } }
+
+    pis.resize(num_public_inputs);
+    for (auto &v : pis) v = rng.felt();
+    u64 pih[4];
+    host_hash_no_pad(pis.data(), pis.size(), pih);
+
+    // row layout
+    const u64 n_const_rows = 2, n_noop = std::max<u64>(1, n / 16);
+    std::vector<uint8_t> row_gate(n, 3);
+    row_gate[0] = 2;
+    for (u64 r = 1; r <= n_const_rows; r++) row_gate[r] = 1;
+    for (u64 r = n - n_noop; r < n; r++) row_gate[r] = 0;
+
+    wires.assign((size_t)num_wires * n, 0);
+    auto W = [&](u64 row, u64 col) -> u64 & { return wires[col * n + row]; };
+    for (u64 c = 0; c < num_wires; c++) for (u64 r = 0; r < n; r++) W(r, c) = rng.felt();  // unconstrained cells
+
+    const u64 ncs = pack.num_cs_cols();
+    pack.constants_sigmas.assign(ncs * n, 0);
+    auto CS = [&](u64 row, u64 col) -> u64 & { return pack.constants_sigmas[col * n + row]; };
+
+    // union-find over routed cells for copy constraints
+    std::vector<uint32_t> parent((size_t)n * num_routed);
+    std::iota(parent.begin(), parent.end(), 0u);
+    auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    auto cell = [&](u64 row, u64 col) { return (uint32_t)(row * num_routed + col); };
+    std::vector<uint32_t> pool;  // cells whose value may be copied
+
+    for (u64 r = 0; r < n; r++) {
+        CS(r, 0) = row_gate[r];  // selector value = gate index
+        if (row_gate[r] == 2) {
+            for (int i = 0; i < 4; i++) W(r, i) = pih[i];
+        } else if (row_gate[r] == 1) {
+            for (int i = 0; i < 2; i++) { u64 c = rng.felt(); CS(r, 1 + i) = c; W(r, i) = c; pool.push_back(cell(r, i)); }
+        } else if (row_gate[r] == 3) {
+            u64 c0 = (r & 1) ? rng.felt() : 1, c1 = (r & 2) ? rng.felt() : 1;
+            CS(r, 1) = c0; CS(r, 2) = c1;
+            for (u64 op = 0; op < num_ops; op++) {
+                u64 in[3];
+                for (int k = 0; k < 3; k++) {
+                    const u64 col = 4 * op + k;
+                    if (!pool.empty() && rng.below(10) < 7) {
+                        uint32_t src = pool[rng.below(pool.size())];
+                        in[k] = wires[(size_t)(src % num_routed) * n + src / num_routed];
+                        W(r, col) = in[k];
+                        uint32_t a = find(src), b = find(cell(r, col));
+                        if (a != b) parent[b] = a;
+                    } else {
+                        in[k] = W(r, col);
+                    }
+                }
+                u64 out = gl::canon(gl::add(gl::mul(gl::mul(in[0], in[1]), c0), gl::mul(in[2], c1)));
+                W(r, 4 * op + 3) = out;
+                pool.push_back(cell(r, 4 * op + 3));
+                if (pool.size() > 4096) pool.erase(pool.begin(), pool.begin() + 2048);
+            }
+        }
+    }
+    // sigma: cycle through each copy class
+    std::vector<uint32_t> order(parent.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::vector<uint32_t> root(parent.size());
+    for (uint32_t i = 0; i < parent.size(); i++) root[i] = find(i);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return root[a] < root[b]; });
+    std::vector<uint32_t> next(parent.size());
+    for (size_t s = 0; s < order.size();) {
+        size_t e = s;
+        while (e < order.size() && root[order[e]] == root[order[s]]) e++;
+        for (size_t k = s; k < e; k++) next[order[k]] = order[k + 1 < e ? k + 1 : s];
+        s = e;
+    }
+    std::vector<u64> omega_pow(n);
+    { u64 w = gl::root_of_unity(degree_bits), a = 1; for (u64 i = 0; i < n; i++) { omega_pow[i] = gl::canon(a); a = gl::mul(a, w); } }
+    const u64 sig0 = pack.num_selectors + pack.num_constants;
+    for (u64 r = 0; r < n; r++)
+        for (u64 c = 0; c < num_routed; c++) {
+            uint32_t t = next[cell(r, c)];
+            CS(r, sig0 + c) = gl::canon(gl::mul(pack.k_is[t % num_routed], omega_pow[t / num_routed]));
+        }
+    // circuit_digest: any 4 elements bound to the shape (the real one comes from the builder)
+    u64 shape[6] = {degree_bits, num_wires, num_routed, num_public_inputs, seed % gl::P, 0x51504350};
+    host_hash_no_pad(shape, 6, pack.circuit_digest);
+    return pack.validate();
+}

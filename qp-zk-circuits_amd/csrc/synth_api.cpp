@@ -1,0 +1,37 @@
+// synth_api.cpp — C ABI of the synthetic circuit generator (host only; no GPU needed).
+#include <cstring>
+#include "circuit.hpp"
+#include "ctx.hpp"
+
+std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
+                        uint64_t seed, CircuitPack &pack, std::vector<uint64_t> &wires, std::vector<uint64_t> &pis);
+
+extern "C" {
+
+size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed) {
+    (void)num_wires;
+    CircuitPack p;
+    p.degree_bits = degree_bits; p.num_routed_wires = num_routed; p.num_selectors = 1; p.num_constants = 2;
+    size_t arity = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5).size();
+    return 18 + arity + 4 * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits);
+}
+
+int qpgpu_synth_circuit(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
+                        uint64_t seed, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,
+                        uint64_t *wires_out, uint64_t *pis_out) {
+    CircuitPack pack;
+    std::vector<uint64_t> wires, pis;
+    std::string err = synth_build(degree_bits, num_wires, num_routed, num_public_inputs, seed, pack, wires, pis);
+    if (!err.empty()) return QPGPU_EINVAL;
+    std::vector<uint64_t> words = pack.serialize();
+    if (pack_words) *pack_words = words.size();
+    if (pack_out) {
+        if (pack_cap_words < words.size()) return QPGPU_EBUFSIZE;
+        std::memcpy(pack_out, words.data(), words.size() * 8);
+    }
+    if (wires_out) std::memcpy(wires_out, wires.data(), wires.size() * 8);
+    if (pis_out) std::memcpy(pis_out, pis.data(), pis.size() * 8);
+    return QPGPU_OK;
+}
+
+}  // extern "C"

@@ -52,6 +52,15 @@ class Oracle:
         L.orc_challenger_get.restype = u64; L.orc_challenger_get.argtypes = [ctypes.c_void_p]
         L.orc_challenger_pow_response.restype = u64
         L.orc_challenger_pow_response.argtypes = [ctypes.c_void_p, u64]
+        L.orc_circuit_load.restype = ctypes.c_void_p
+        L.orc_circuit_load.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.orc_circuit_free.argtypes = [ctypes.c_void_p]
+        L.orc_proof_size.restype = ctypes.c_size_t; L.orc_proof_size.argtypes = [ctypes.c_void_p]
+        L.orc_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                ctypes.POINTER(ctypes.c_size_t)]
+        L.orc_verify.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.orc_trace_len.restype = ctypes.c_size_t; L.orc_trace_len.argtypes = [ctypes.c_char_p]
+        L.orc_trace_get.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
         L.orc_p2_params_size.restype = ctypes.c_size_t
         L.orc_p2_permute.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_p2_hash_pad10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -128,3 +137,31 @@ class Challenger:
     def get(self): return self.orc.lib.orc_challenger_get(self.buf)
     def get_n(self, n): return [self.get() for _ in range(n)]
     def pow_response(self, nonce): return self.orc.lib.orc_challenger_pow_response(self.buf, nonce)
+
+
+class OracleCircuit:
+    """A loaded circuit pack on the oracle side: prove / verify / stage trace."""
+    def __init__(self, orc, pack_words):
+        self.orc = orc
+        pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
+        self.h = orc.lib.orc_circuit_load(_vp(pw), pw.size)
+        if not self.h:
+            raise ValueError("oracle rejected the circuit pack")
+    def close(self):
+        if self.h:
+            self.orc.lib.orc_circuit_free(self.h); self.h = None
+    def proof_size(self): return self.orc.lib.orc_proof_size(self.h)
+    def prove(self, wires, pis):
+        w = np.ascontiguousarray(wires, dtype=np.uint64); p = np.ascontiguousarray(pis, dtype=np.uint64)
+        out = np.empty(self.proof_size(), dtype=np.uint8); ln = ctypes.c_size_t()
+        rc = self.orc.lib.orc_prove(self.h, _vp(w), _vp(p), _vp(out), out.size, ctypes.byref(ln))
+        assert rc == 0 and ln.value == out.size, (rc, ln.value, out.size)
+        return out.tobytes()
+    def verify(self, proof_bytes):
+        b = np.frombuffer(proof_bytes, dtype=np.uint8)
+        return self.orc.lib.orc_verify(self.h, _vp(b), b.size)
+    def trace(self, name):
+        n = self.orc.lib.orc_trace_len(name.encode())
+        out = np.empty(n, dtype=np.uint64)
+        if n: self.orc.lib.orc_trace_get(name.encode(), _vp(out))
+        return out

@@ -1,0 +1,55 @@
+"""The oracle's full prover (stages s4..s12) and verifier on synthetic circuit packs: the proof verifies,
+every tampering is rejected, and the byte layout has the stated size."""
+import numpy as np
+import pytest
+
+from oracle_binding import OracleCircuit
+
+
+@pytest.fixture(scope="module")
+def small(pkg, orc):
+    pack, wires, pis = pkg.synth_circuit(6, num_wires=24, num_routed=16, num_public_inputs=5, seed=3)
+    oc = OracleCircuit(orc, pack)
+    proof = oc.prove(wires, pis)
+    yield oc, pack, wires, pis, proof
+    oc.close()
+
+
+def test_proof_verifies(small):
+    oc, pack, wires, pis, proof = small
+    assert len(proof) == oc.proof_size()
+    assert oc.verify(proof) == 0
+    assert oc.prove(wires, pis) == proof           # deterministic (non-ZK, minimum PoW nonce)
+
+
+def test_tampering_is_rejected(small):
+    oc, pack, wires, pis, proof = small
+    rng = np.random.default_rng(9)
+    bad_codes = set()
+    for pos in list(rng.integers(0, len(proof), 40)) + [0, len(proof) - 1, len(proof) - 8 * len(pis)]:
+        b = bytearray(proof); b[pos] ^= 0x01
+        code = oc.verify(bytes(b))
+        assert code != 0, f"flipping byte {pos} was accepted"
+        bad_codes.add(code)
+    assert len(bad_codes) >= 2
+    assert oc.verify(proof[:-1]) == 1
+
+
+def test_unsatisfied_witness_fails_verification(small, orc):
+    oc, pack, wires, pis, proof = small
+    w = wires.copy()
+    w[3, 10] = (int(w[3, 10]) + 1) % 0xFFFFFFFF00000001   # break an arithmetic output
+    assert oc.verify(oc.prove(w, pis)) != 0
+    p = pis.copy(); p[0] = (int(p[0]) + 1) % 0xFFFFFFFF00000001   # public inputs no longer match the PI gate
+    assert oc.verify(oc.prove(wires, p)) != 0
+
+
+def test_standard_shape_proof(pkg, orc):
+    """standard_recursion_config shape: 135 wires, 80 routed, degree 2^9 keeps the CPU suite fast."""
+    pack, wires, pis = pkg.synth_circuit(9, seed=5)
+    oc = OracleCircuit(orc, pack)
+    proof = oc.prove(wires, pis)
+    assert oc.verify(proof) == 0
+    assert len(oc.trace("query_indices")) == 28
+    assert int(oc.trace("pow_witness")[0]) < 2**24
+    oc.close()
