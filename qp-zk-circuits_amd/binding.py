@@ -58,6 +58,12 @@ def load_library():
         "qpgpu_merkle_digest_count": (c.c_size_t, [c.c_uint, c.c_uint]),
         "qpgpu_merkle_build_dev": (c.c_int, [vp, u64p, c.c_uint64, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
         "qpgpu_merkle_build_rows_dev": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
+        "qpgpu_circuit_load": (c.c_int, [vp, u64p, c.c_size_t, c.POINTER(vp)]),
+        "qpgpu_circuit_free": (None, [vp]),
+        "qpgpu_circuit_constants_sigmas_cap": (c.c_int, [vp, u64p, c.c_size_t]),
+        "qpgpu_proof_size": (c.c_size_t, [vp]),
+        "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
+        "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_synth_pack_words": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint]),
         "qpgpu_synth_circuit": (c.c_int, [c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, u64p, c.c_size_t,
                                           c.POINTER(c.c_size_t), u64p, u64p]),
@@ -118,6 +124,48 @@ class DeviceBuffer:
         if self.ptr:
             self.gpu.lib.qpgpu_free(self.gpu.ctx, self.ptr)
             self.ptr = None
+
+
+class Circuit:
+    """A circuit pack loaded on the GPU (constants/sigmas committed, workspace allocated)."""
+
+    def __init__(self, gpu, pack_words):
+        self.gpu = gpu
+        pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
+        h = ctypes.c_void_p()
+        gpu._check(gpu.lib.qpgpu_circuit_load(gpu.ctx, pw.ctypes.data, pw.size, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.gpu.lib.qpgpu_circuit_free(self.h)
+            self.h = None
+
+    def proof_size(self):
+        return self.gpu.lib.qpgpu_proof_size(self.h)
+
+    def constants_sigmas_cap(self, cap_height=4):
+        out = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_circuit_constants_sigmas_cap(self.h, out.ctypes.data, out.size))
+        return out
+
+    def prove(self, wires, public_inputs):
+        """wires: host array [num_wires, n]; returns proof bytes."""
+        w = np.ascontiguousarray(wires, dtype=np.uint64)
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        out = np.empty(self.proof_size(), dtype=np.uint8)
+        ln = ctypes.c_size_t()
+        self.gpu._check(self.gpu.lib.qpgpu_prove(self.h, w.ctypes.data, p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(ln)))
+        return out[:ln.value].tobytes()
+
+    def prove_dev(self, d_wires, public_inputs, out=None):
+        """wires resident in HBM (DeviceBuffer / torch tensor / raw pointer)."""
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        if out is None:
+            out = np.empty(self.proof_size(), dtype=np.uint8)
+        ln = ctypes.c_size_t()
+        self.gpu._check(self.gpu.lib.qpgpu_prove_dev(self.h, _ptr(d_wires), p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(ln)))
+        return out[:ln.value].tobytes()
 
 
 class _Stage3:

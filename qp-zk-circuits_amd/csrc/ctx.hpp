@@ -28,6 +28,7 @@ struct qpgpu_ctx {
     bool profiling = false;
     std::map<std::string, KStat> kstats;
     std::vector<Pending> pending;
+    std::vector<size_t> prof_stack;   // indices into pending: begin/end pairs may nest
     void prof_begin(const char *name);
     void prof_end();
     int prof_collect();

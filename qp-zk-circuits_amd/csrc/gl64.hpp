@@ -194,4 +194,31 @@ GL_HD u64 root_of_unity(unsigned log_n) {
     return canon(r);
 }
 
+
+// ---- quadratic extension F[x]/(x^2 - 7): serialised [a, b] = a + b x ----
+struct e2 { u64 a, b; };
+GL_HD e2 e2_make(u64 a, u64 b) { e2 r; r.a = a; r.b = b; return r; }
+GL_HD e2 e2_from(u64 a) { return e2_make(a, 0); }
+GL_HD e2 e2_add(e2 x, e2 y) { return e2_make(add(x.a, y.a), add(x.b, y.b)); }
+GL_HD e2 e2_sub(e2 x, e2 y) { return e2_make(sub(x.a, y.a), sub(x.b, y.b)); }
+GL_HD u64 mul7(u64 x) { return sub(mul_pow2<3>(x), x); }
+GL_HD e2 e2_mul(e2 x, e2 y) {
+    // Karatsuba: 3 base products
+    u64 t0 = mul(x.a, y.a), t1 = mul(x.b, y.b);
+    u64 t2 = mul(add(x.a, x.b), add(y.a, y.b));
+    return e2_make(add(t0, mul7(t1)), sub(sub(t2, t0), t1));
+}
+GL_HD e2 e2_scale(e2 x, u64 s) { return e2_make(mul(x.a, s), mul(x.b, s)); }
+GL_HD e2 e2_canon(e2 x) { return e2_make(canon(x.a), canon(x.b)); }
+GL_HD e2 e2_pow(e2 b, u64 e) {
+    e2 r = e2_from(1);
+    while (e) { if (e & 1) r = e2_mul(r, b); b = e2_mul(b, b); e >>= 1; }
+    return e2_canon(r);
+}
+GL_HD e2 e2_inv(e2 x) {
+    u64 nrm = sub(sqr(x.a), mul7(sqr(x.b)));
+    u64 ni = inv(nrm);
+    return e2_canon(e2_make(mul(x.a, ni), mul(neg(x.b), ni)));
+}
+
 }  // namespace gl

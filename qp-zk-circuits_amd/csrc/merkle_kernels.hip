@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include "merkle.hpp"
 #include "poseidon.hpp"
+#include "prover_kernels.hpp"
 
 using gl::u32;
 using gl::u64;
@@ -106,7 +107,27 @@ __global__ void permute_kernel(u64 *states, u64 n) {
     for (int k = 0; k < 12; k++) states[i * 12 + k] = s[k];
 }
 
+// s10 fri_proof_of_work: candidate nonce at `pos` of the pre-absorbed duplex state; accept when the last rate
+// element has >= pow_bits leading zeros; result = minimum accepted nonce in [base, base + count).
+__global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
+    const u64 idx = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (idx >= a.count) return;
+    const u64 nonce = a.base + idx;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = (i == (int)a.pos) ? nonce : a.state[i];
+    poseidon::permute(s, c_poseidon_rc);
+    if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin((unsigned long long *)a.result, (unsigned long long)nonce);
+}
+
 }  // namespace
+
+hipError_t pk_pow(const PowArgs &a, hipStream_t st) {
+    if (a.count == 0) return hipSuccess;
+    dim3 b(256), g((unsigned)((a.count + 255) / 256));
+    hipLaunchKernelGGL(pow_kernel, g, b, 0, st, a);
+    return hipGetLastError();
+}
 
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, hipStream_t st) {
     if (a.n_leaves == 0) return hipSuccess;

@@ -1,0 +1,383 @@
+// prover_kernels.hip — stages s5..s11 of plonky2's prove() as gfx950 kernels.
+//
+// Replaces, inside qp-plonky2 1.5.5 `plonk::prover::prove` (reference call site
+// wormhole/prover/src/lib.rs:171-175):
+//   s5  all_wires_permutation_partial_products   -> pp_rows_kernel, pp_scan_kernel, pp_finish_kernel
+//   s6  compute_quotient_polys                   -> quotient_kernel
+//   s7  OpeningSet::new (poly evaluation at zeta) -> poly_eval_kernel
+//   s8  prove_openings (batch reduce, /(X - z))  -> reduce_polys_kernel, divide_linear_kernel
+//   s9  fri_committed_trees (fold)               -> fri_fold_kernel, interleave_ext_kernel
+//   s10 fri_proof_of_work                        -> pow_kernel
+//   s11 fri_prover_query_rounds (gathers)        -> gather kernels
+// Layout: polynomial batches column-major; LDEs in leaf order (slot j = point bitrev(j)), so every
+// per-point kernel reads one slot of every column with unit-stride across the wave.
+#include <hip/hip_runtime.h>
+#include "gl64.hpp"
+#include "prover_kernels.hpp"
+
+using gl::e2;
+using gl::u32;
+using gl::u64;
+
+namespace {
+
+__device__ __forceinline__ u32 brev32(u32 x, u32 bits) { return bits ? __brev(x) >> (32 - bits) : 0; }
+
+// ---------------------------------------------------------------- s5
+// Row i: quotient chunk products prod_{j in chunk} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma).
+// qcp layout: [challenge][chunk][row]; rowprod: [challenge][row].
+__global__ void __launch_bounds__(256) pp_rows_kernel(PpArgs a) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const u32 k = blockIdx.y;
+    const u64 beta = a.betas[k], gamma = a.gammas[k];
+    const u64 x = a.omega_pows[i];
+    const u32 R = a.num_routed, chunk = a.chunk, nchunks = a.nchunks;
+    u64 nums[16], dens[16], pref[16];   // nchunks <= 16
+    for (u32 cc = 0; cc < nchunks; cc++) {
+        u64 pn = 1, pd = 1;
+        for (u32 j = cc * chunk; j < (cc + 1) * chunk && j < R; j++) {
+            const u64 w = a.wires[(u64)j * a.n + i];
+            const u64 sid = gl::mul(a.beta_k_is[k * R + j], x);          // beta * k_j * x
+            const u64 ssg = gl::mul(beta, a.sigmas[(u64)j * a.n + i]);   // beta * sigma_j(x)
+            pn = gl::mul(pn, gl::add(gl::add(w, sid), gamma));
+            pd = gl::mul(pd, gl::add(gl::add(w, ssg), gamma));
+        }
+        nums[cc] = pn; dens[cc] = pd;
+    }
+    // Montgomery batch inversion of the chunk denominators
+    u64 acc = 1;
+    for (u32 cc = 0; cc < nchunks; cc++) { pref[cc] = acc; acc = gl::mul(acc, dens[cc]); }
+    u64 inv = gl::inv(acc);
+    u64 rowp = 1;
+    for (u32 cc = nchunks; cc-- > 0;) {
+        const u64 dinv = gl::mul(inv, pref[cc]);
+        inv = gl::mul(inv, dens[cc]);
+        nums[cc] = gl::mul(nums[cc], dinv);
+    }
+    for (u32 cc = 0; cc < nchunks; cc++) {
+        rowp = gl::mul(rowp, nums[cc]);
+        a.qcp[((u64)k * nchunks + cc) * a.n + i] = gl::canon(nums[cc]);
+    }
+    a.rowprod[(u64)k * a.n + i] = gl::canon(rowp);
+}
+
+// Exclusive prefix product over rows (Z(x_0) = 1). One workgroup of 1024 threads per challenge.
+__global__ void __launch_bounds__(1024) pp_scan_kernel(const u64 *rowprod, u64 *z_out, u64 n) {
+    __shared__ u64 part[1024];
+    const u32 t = threadIdx.x, T = blockDim.x;
+    const u64 *rp = rowprod + (u64)blockIdx.x * n;
+    u64 *z = z_out + (u64)blockIdx.x * n;
+    const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = lo + per < n ? lo + per : n;
+    u64 acc = 1;
+    for (u64 i = lo; i < hi; i++) acc = gl::mul(acc, rp[i]);
+    part[t] = acc;
+    __syncthreads();
+    for (u32 off = 1; off < T; off <<= 1) {   // inclusive Hillis-Steele scan of the partial products
+        u64 v = part[t];
+        if (t >= off) v = gl::mul(v, part[t - off]);
+        __syncthreads();
+        part[t] = v;
+        __syncthreads();
+    }
+    acc = t == 0 ? 1 : part[t - 1];
+    for (u64 i = lo; i < hi; i++) { z[i] = gl::canon(acc); acc = gl::mul(acc, rp[i]); }
+}
+
+// zs_pp columns: [Z_0..Z_{nch-1}, pp_{0,*}, pp_{1,*}, ...]; pp_{k,c}(x_i) = Z_k(x_i) * prod_{c' <= c} qcp
+__global__ void __launch_bounds__(256) pp_finish_kernel(PpArgs a, const u64 *z, u64 *zs_pp) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const u32 k = blockIdx.y, npp = a.nchunks - 1;
+    u64 acc = z[(u64)k * a.n + i];
+    zs_pp[(u64)k * a.n + i] = acc;
+    for (u32 cc = 0; cc < npp; cc++) {
+        acc = gl::mul(acc, a.qcp[((u64)k * a.nchunks + cc) * a.n + i]);
+        zs_pp[((u64)a.nch + (u64)k * npp + cc) * a.n + i] = gl::canon(acc);
+    }
+}
+
+// ---------------------------------------------------------------- s6
+__device__ __forceinline__ u64 gate_filter(const QuotientArgs &a, u32 gi, u64 s) {
+    const GateDev g = a.gates[gi];
+    u64 f = 1;
+    for (u32 j = g.group_start; j < g.group_end; j++)
+        if (j != gi) f = gl::mul(f, gl::sub((u64)j, s));
+    if (a.num_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFull, s));
+    return f;
+}
+
+// One thread per LDE slot j (point index i = bitrev(j), x = g w^i). Writes quotient values in natural order.
+__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= a.lde_n) return;
+    const u32 logL = a.log_lde, nch = a.nch, R = a.num_routed, chunk = a.chunk, nchunks = a.nchunks, npp = nchunks - 1;
+    const u64 i = brev32((u32)j, logL);
+    const u64 jn = brev32((u32)((i + a.rate) & (a.lde_n - 1)), logL);   // slot of the next row g*x
+    const u64 x = a.x_coset[j];
+    const u64 l0 = a.l0_coset[j];
+    const u64 S = a.lde_n;   // column stride
+    u64 acc[4] = {0, 0, 0, 0};
+    u32 t = 0;
+    // L_0(x) (Z(x) - 1)
+    for (u32 k = 0; k < nch; k++, t++) {
+        const u64 term = gl::mul(l0, gl::sub(a.zs_pp[(u64)k * S + j], 1));
+        for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(term, a.alpha_pows[(u64)c * a.nterms + t]));
+    }
+    // partial product checks
+    for (u32 k = 0; k < nch; k++) {
+        const u64 beta = a.betas[k], gamma = a.gammas[k];
+        for (u32 cc = 0; cc < nchunks; cc++, t++) {
+            u64 pn = 1, pd = 1;
+            for (u32 r = cc * chunk; r < (cc + 1) * chunk && r < R; r++) {
+                const u64 w = a.wires[(u64)r * S + j];
+                const u64 sid = gl::mul(a.beta_k_is[k * R + r], x);
+                const u64 ssg = gl::mul(beta, a.cs[(u64)(a.sig0 + r) * S + j]);
+                pn = gl::mul(pn, gl::add(gl::add(w, sid), gamma));
+                pd = gl::mul(pd, gl::add(gl::add(w, ssg), gamma));
+            }
+            const u64 prev = cc == 0 ? a.zs_pp[(u64)k * S + j] : a.zs_pp[((u64)nch + (u64)k * npp + cc - 1) * S + j];
+            const u64 next = cc == nchunks - 1 ? a.zs_pp[(u64)k * S + jn] : a.zs_pp[((u64)nch + (u64)k * npp + cc) * S + j];
+            const u64 term = gl::sub(gl::mul(prev, pn), gl::mul(next, pd));
+            for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(term, a.alpha_pows[(u64)c * a.nterms + t]));
+        }
+    }
+    // gate constraints (constraint index g of every gate shares alpha^(t+g))
+    const u64 *consts_base = a.cs + (u64)a.num_selectors * S + j;
+    for (u32 gi = 0; gi < a.num_gates; gi++) {
+        const GateDev g = a.gates[gi];
+        if (g.num_constraints == 0) continue;
+        const u64 f = gate_filter(a, gi, a.cs[(u64)g.selector_index * S + j]);
+        if (f == 0) continue;   // canonical zero: this row is not of this gate type
+        if (g.type == 1) {            // ConstantGate: const_i - wire_i
+            for (u32 q = 0; q < g.param0; q++) {
+                const u64 cst = gl::mul(f, gl::sub(consts_base[(u64)q * S], a.wires[(u64)q * S + j]));
+                for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
+            }
+        } else if (g.type == 2) {     // PublicInputGate: wire_i - pi_hash_i
+            for (u32 q = 0; q < 4; q++) {
+                const u64 cst = gl::mul(f, gl::sub(a.wires[(u64)q * S + j], a.pi_hash[q]));
+                for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
+            }
+        } else if (g.type == 3) {     // ArithmeticGate: out - (c0 m0 m1 + c1 addend)
+            const u64 c0 = consts_base[0], c1 = consts_base[S];
+            for (u32 q = 0; q < g.param0; q++) {
+                const u64 m0 = a.wires[(u64)(4 * q) * S + j], m1 = a.wires[(u64)(4 * q + 1) * S + j];
+                const u64 ad = a.wires[(u64)(4 * q + 2) * S + j], out = a.wires[(u64)(4 * q + 3) * S + j];
+                const u64 computed = gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1));
+                const u64 cst = gl::mul(f, gl::sub(out, computed));
+                for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
+            }
+        }
+    }
+    const u64 zi = a.zh_inv[i & (a.rate - 1)];
+    for (u32 c = 0; c < nch; c++) a.out[(u64)c * S + i] = gl::canon(gl::mul(acc[c], zi));
+}
+
+// out[i] = in[i] * shift_inv^i (coset_ifft tail), two-level power table
+__global__ void __launch_bounds__(256) scale_powers_kernel(u64 *data, u64 n, u64 ncols, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 s = gl::mul(pw_hi[i >> lo_bits], pw_lo[i & ((1u << lo_bits) - 1)]);
+    for (u64 c = 0; c < ncols; c++) data[c * n + i] = gl::canon(gl::mul(data[c * n + i], s));
+}
+
+// ---------------------------------------------------------------- s7
+// Evaluate polynomial p (n base-field coefficients) at an extension point. One workgroup per (poly, point).
+__global__ void __launch_bounds__(256) poly_eval_kernel(const u64 *coeffs, u64 n, const e2 *points, const u64 *poly_index, e2 *out) {
+    __shared__ e2 part[256];
+    const u32 t = threadIdx.x, T = blockDim.x;
+    const u64 p = poly_index ? poly_index[blockIdx.x] : blockIdx.x;
+    const e2 z = points[blockIdx.y];
+    const u64 *f = coeffs + p * n;
+    const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = lo + per < n ? lo + per : n;
+    e2 acc = gl::e2_from(0);
+    for (u64 i = hi; i-- > lo;) acc = gl::e2_add(gl::e2_mul(acc, z), gl::e2_from(f[i]));   // Horner on the slice
+    // slice value * z^lo
+    if (lo < n) acc = gl::e2_mul(acc, gl::e2_pow(z, lo)); else acc = gl::e2_from(0);
+    part[t] = acc;
+    __syncthreads();
+    for (u32 off = T >> 1; off > 0; off >>= 1) {
+        if (t < off) part[t] = gl::e2_add(part[t], part[t + off]);
+        __syncthreads();
+    }
+    if (t == 0) out[(u64)blockIdx.y * gridDim.x + blockIdx.x] = gl::e2_canon(part[0]);
+}
+
+// ---------------------------------------------------------------- s8
+// comp[i] = sum_p alpha^p f_p[i] over the listed polynomials (several source batches)
+__global__ void __launch_bounds__(256) reduce_polys_kernel(ReduceArgs a) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    e2 acc = gl::e2_from(0);
+    u32 p = 0;
+    for (u32 s = 0; s < a.nsrc; s++) {
+        const u64 *base = a.src[s];
+        for (u32 c = 0; c < a.ncols[s]; c++, p++) acc = gl::e2_add(acc, gl::e2_scale(a.alpha_pows[p], base[(u64)c * a.n + i]));
+    }
+    a.comp_a[i] = gl::canon(acc.a);
+    a.comp_b[i] = gl::canon(acc.b);
+}
+
+// q = comp / (X - z) by synthetic division: b_{i-1} = b_i z + comp_i (from the top), quotient coefficient
+// q_{i-1} = b_i ... one workgroup, blocked linear-recurrence scan. final += handled by the caller's mode:
+// mode 0: final = q ; mode 1: final = final * shift + q.
+__global__ void __launch_bounds__(1024) divide_linear_kernel(const u64 *comp_a, const u64 *comp_b, u64 n, e2 z, e2 shift, int mode, u64 *fin_a, u64 *fin_b) {
+    __shared__ e2 carry[1024];
+    const u32 t = threadIdx.x, T = blockDim.x;
+    const u64 per = (n + T - 1) / T;
+    // thread t owns indices [lo, hi) counted from the TOP: index i = n-1-r
+    const u64 rlo = (u64)t * per, rhi = rlo + per < n ? rlo + per : n;
+    // local Horner with zero incoming carry
+    e2 acc = gl::e2_from(0);
+    for (u64 r = rlo; r < rhi; r++) { const u64 i = n - 1 - r; acc = gl::e2_add(gl::e2_mul(acc, z), gl::e2_make(comp_a[i], comp_b[i])); }
+    const e2 zper = gl::e2_pow(z, rhi > rlo ? rhi - rlo : 0);
+    // sequential-in-log combine: carry_in(t) = value of the recurrence after all elements owned by threads < t
+    carry[t] = acc;
+    __syncthreads();
+    // Hillis-Steele over the affine maps (acc, zper): combined(t) = carry[t - off] * zpow[t] + carry[t]
+    __shared__ e2 zp[1024];
+    zp[t] = zper;
+    __syncthreads();
+    for (u32 off = 1; off < T; off <<= 1) {
+        e2 c = carry[t], m = zp[t];
+        if (t >= off) { c = gl::e2_add(gl::e2_mul(carry[t - off], zp[t]), carry[t]); m = gl::e2_mul(zp[t - off], zp[t]); }
+        __syncthreads();
+        carry[t] = c; zp[t] = m;
+        __syncthreads();
+    }
+    e2 cin = t == 0 ? gl::e2_from(0) : carry[t - 1];
+    // replay with the true incoming value: b after consuming index i is the quotient coefficient q_{i-1}
+    acc = cin;
+    for (u64 r = rlo; r < rhi; r++) {
+        const u64 i = n - 1 - r;
+        acc = gl::e2_add(gl::e2_mul(acc, z), gl::e2_make(comp_a[i], comp_b[i]));
+        if (i > 0) {
+            e2 q = acc;
+            if (mode) q = gl::e2_add(gl::e2_mul(gl::e2_make(fin_a[i - 1], fin_b[i - 1]), shift), q);
+            fin_a[i - 1] = gl::canon(q.a); fin_b[i - 1] = gl::canon(q.b);
+        }
+    }
+    if (t == 0) {   // the padded top coefficient q_{n-1} = 0
+        e2 q = gl::e2_from(0);
+        if (mode) q = gl::e2_mul(gl::e2_make(fin_a[n - 1], fin_b[n - 1]), shift);
+        fin_a[n - 1] = gl::canon(q.a); fin_b[n - 1] = gl::canon(q.b);
+    }
+}
+
+// ---------------------------------------------------------------- s9
+// rows[j] = (va[j], vb[j]) interleaved: extension values in leaf order -> row-major leaves of 2*arity felts
+__global__ void __launch_bounds__(256) interleave_ext_kernel(const u64 *va, const u64 *vb, u64 n, u64 *rows) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    reinterpret_cast<ulonglong2 *>(rows)[i] = make_ulonglong2(va[i], vb[i]);
+}
+// new[i] = sum_{k < arity} beta^k coeffs[arity*i + k]   (in place is safe: i <= arity*i; done out of place here)
+__global__ void __launch_bounds__(256) fri_fold_kernel(const u64 *ca, const u64 *cb, u64 new_n, u32 arity, e2 beta, u64 *oa, u64 *ob) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= new_n) return;
+    e2 acc = gl::e2_from(0);
+    for (u32 k = arity; k-- > 0;) acc = gl::e2_add(gl::e2_mul(acc, beta), gl::e2_make(ca[(u64)arity * i + k], cb[(u64)arity * i + k]));
+    oa[i] = gl::canon(acc.a); ob[i] = gl::canon(acc.b);
+}
+
+// ---------------------------------------------------------------- s11
+// out[q][c] = cols[c*stride + idx[q]]
+__global__ void gather_rows_kernel(const u64 *cols, u64 stride, u32 ncols, const u64 *idx, u32 nq, u64 *out) {
+    const u32 q = blockIdx.x;
+    for (u32 c = threadIdx.x; c < ncols; c += blockDim.x) out[(u64)q * ncols + c] = cols[(u64)c * stride + idx[q]];
+}
+// Merkle authentication paths: out[q][lvl] = digests[level lvl][ (idx[q] >> lvl) ^ 1 ]
+__global__ void gather_paths_kernel(const u64 *digests, u64 n_leaves, u32 path_len, const u64 *idx, u32 shift, u64 *out) {
+    const u32 q = blockIdx.x, t = threadIdx.x;
+    if (t >= path_len * 4) return;
+    const u32 lvl = t >> 2, e = t & 3;
+    u64 off = 0, cnt = n_leaves;
+    for (u32 l = 0; l < lvl; l++) { off += cnt; cnt >>= 1; }
+    const u64 node = ((idx[q] >> shift) >> lvl) ^ 1;
+    out[((u64)q * path_len + lvl) * 4 + e] = digests[(off + node) * 4 + e];
+}
+// out[q][e] = rows[(idx[q] >> shift) * width + e]
+__global__ void gather_leaf_rows_kernel(const u64 *rows, u32 width, const u64 *idx, u32 shift, u64 *out) {
+    const u32 q = blockIdx.x;
+    for (u32 e = threadIdx.x; e < width; e += blockDim.x) out[(u64)q * width + e] = rows[(idx[q] >> shift) * width + e];
+}
+
+// x_coset[j] = g * w^bitrev(j), l0_coset[j] = zh(i) / (n (x - 1))
+__global__ void __launch_bounds__(256) coset_tables_kernel(u64 lde_n, u32 log_lde, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits,
+                                                             const u64 *zh, u32 rate, u64 n_field, u64 *x_coset, u64 *l0_coset) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= lde_n) return;
+    const u64 i = brev32((u32)j, log_lde);
+    const u64 x = gl::canon(gl::mul(gl::MULT_GEN, gl::mul(pw_hi[i >> lo_bits], pw_lo[i & ((1u << lo_bits) - 1)])));
+    x_coset[j] = x;
+    l0_coset[j] = gl::canon(gl::mul(zh[i & (rate - 1)], gl::inv(gl::mul(n_field, gl::sub(x, 1)))));
+}
+
+}  // namespace
+
+#define LAUNCH_1D(kern, count, threads, st, ...) \
+    do { if ((count) > 0) { dim3 b(threads), g((unsigned)(((count) + (threads)-1) / (threads))); hipLaunchKernelGGL(kern, g, b, 0, st, __VA_ARGS__); } } while (0)
+
+hipError_t pk_pp_rows(const PpArgs &a, hipStream_t st) {
+    dim3 b(256), g((unsigned)((a.n + 255) / 256), a.nch);
+    hipLaunchKernelGGL(pp_rows_kernel, g, b, 0, st, a);
+    return hipGetLastError();
+}
+hipError_t pk_pp_scan(const u64 *rowprod, u64 *z, u64 n, u32 nch, hipStream_t st) {
+    hipLaunchKernelGGL(pp_scan_kernel, dim3(nch), dim3(1024), 0, st, rowprod, z, n);
+    return hipGetLastError();
+}
+hipError_t pk_pp_finish(const PpArgs &a, const u64 *z, u64 *zs_pp, hipStream_t st) {
+    dim3 b(256), g((unsigned)((a.n + 255) / 256), a.nch);
+    hipLaunchKernelGGL(pp_finish_kernel, g, b, 0, st, a, z, zs_pp);
+    return hipGetLastError();
+}
+hipError_t pk_quotient(const QuotientArgs &a, hipStream_t st) {
+    LAUNCH_1D(quotient_kernel, a.lde_n, 256, st, a);
+    return hipGetLastError();
+}
+hipError_t pk_scale_powers(u64 *data, u64 n, u64 ncols, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits, hipStream_t st) {
+    LAUNCH_1D(scale_powers_kernel, n, 256, st, data, n, ncols, pw_lo, pw_hi, lo_bits);
+    return hipGetLastError();
+}
+hipError_t pk_poly_eval(const u64 *coeffs, u64 n, u32 npolys, const e2 *points, u32 npoints, const u64 *poly_index, e2 *out, hipStream_t st) {
+    if (npolys == 0) return hipSuccess;
+    hipLaunchKernelGGL(poly_eval_kernel, dim3(npolys, npoints), dim3(256), 0, st, coeffs, n, points, poly_index, out);
+    return hipGetLastError();
+}
+hipError_t pk_reduce_polys(const ReduceArgs &a, hipStream_t st) {
+    LAUNCH_1D(reduce_polys_kernel, a.n, 256, st, a);
+    return hipGetLastError();
+}
+hipError_t pk_divide_linear(const u64 *comp_a, const u64 *comp_b, u64 n, e2 z, e2 shift, int mode, u64 *fin_a, u64 *fin_b, hipStream_t st) {
+    unsigned threads = n >= 1024 ? 1024 : (n >= 64 ? (unsigned)n : 64);
+    hipLaunchKernelGGL(divide_linear_kernel, dim3(1), dim3(threads), 0, st, comp_a, comp_b, n, z, shift, mode, fin_a, fin_b);
+    return hipGetLastError();
+}
+hipError_t pk_interleave_ext(const u64 *va, const u64 *vb, u64 n, u64 *rows, hipStream_t st) {
+    LAUNCH_1D(interleave_ext_kernel, n, 256, st, va, vb, n, rows);
+    return hipGetLastError();
+}
+hipError_t pk_fri_fold(const u64 *ca, const u64 *cb, u64 new_n, u32 arity, e2 beta, u64 *oa, u64 *ob, hipStream_t st) {
+    LAUNCH_1D(fri_fold_kernel, new_n, 256, st, ca, cb, new_n, arity, beta, oa, ob);
+    return hipGetLastError();
+}
+hipError_t pk_gather_rows(const u64 *cols, u64 stride, u32 ncols, const u64 *idx, u32 nq, u64 *out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nq), dim3(128), 0, st, cols, stride, ncols, idx, nq, out);
+    return hipGetLastError();
+}
+hipError_t pk_gather_paths(const u64 *digests, u64 n_leaves, u32 path_len, const u64 *idx, u32 shift, u32 nq, u64 *out, hipStream_t st) {
+    if (path_len == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_paths_kernel, dim3(nq), dim3(256), 0, st, digests, n_leaves, path_len, idx, shift, out);
+    return hipGetLastError();
+}
+hipError_t pk_gather_leaf_rows(const u64 *rows, u32 width, const u64 *idx, u32 shift, u32 nq, u64 *out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_leaf_rows_kernel, dim3(nq), dim3(64), 0, st, rows, width, idx, shift, out);
+    return hipGetLastError();
+}
+hipError_t pk_coset_tables(u64 lde_n, u32 log_lde, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits, const u64 *zh, u32 rate,
+                           u64 n_field, u64 *x_coset, u64 *l0_coset, hipStream_t st) {
+    LAUNCH_1D(coset_tables_kernel, lde_n, 256, st, lde_n, log_lde, pw_lo, pw_hi, lo_bits, zh, rate, n_field, x_coset, l0_coset);
+    return hipGetLastError();
+}

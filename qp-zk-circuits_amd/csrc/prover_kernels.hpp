@@ -1,0 +1,64 @@
+// prover_kernels.hpp — argument blocks and launchers of prover_kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "gl64.hpp"
+
+struct GateDev { uint32_t type, param0, param1, selector_index, group_start, group_end, num_constraints, pad; };
+
+struct PpArgs {
+    const uint64_t *wires;      // [num_wires][n] values, natural order
+    const uint64_t *sigmas;     // [num_routed][n] sigma values
+    const uint64_t *omega_pows; // [n]
+    const uint64_t *beta_k_is;  // [nch][num_routed] beta_k * k_j
+    const uint64_t *betas, *gammas;
+    uint64_t *qcp;              // [nch][nchunks][n]
+    uint64_t *rowprod;          // [nch][n]
+    uint64_t n;
+    uint32_t num_routed, chunk, nchunks, nch;
+};
+
+struct QuotientArgs {
+    const uint64_t *wires, *cs, *zs_pp;   // LDE, column-major, leaf order, stride lde_n
+    const uint64_t *x_coset, *l0_coset;   // [lde_n] slot order
+    const uint64_t *zh_inv;               // [rate]
+    const uint64_t *alpha_pows;           // [nch][nterms]
+    const uint64_t *beta_k_is, *betas, *gammas, *pi_hash;
+    const GateDev *gates;
+    uint64_t *out;                        // [nch][lde_n] natural order
+    uint64_t lde_n;
+    uint32_t log_lde, rate, nch, num_routed, chunk, nchunks, sig0, num_selectors, num_gates, nterms;
+};
+
+struct ReduceArgs {
+    const uint64_t *src[4];
+    uint32_t ncols[4];
+    uint32_t nsrc;
+    const gl::e2 *alpha_pows;
+    uint64_t *comp_a, *comp_b;
+    uint64_t n;
+};
+
+struct PowArgs {
+    uint64_t state[12];
+    uint32_t pos, pow_bits;
+    uint64_t base, count;
+    uint64_t *result;
+};
+
+hipError_t pk_pp_rows(const PpArgs &a, hipStream_t st);
+hipError_t pk_pp_scan(const uint64_t *rowprod, uint64_t *z, uint64_t n, uint32_t nch, hipStream_t st);
+hipError_t pk_pp_finish(const PpArgs &a, const uint64_t *z, uint64_t *zs_pp, hipStream_t st);
+hipError_t pk_quotient(const QuotientArgs &a, hipStream_t st);
+hipError_t pk_scale_powers(uint64_t *data, uint64_t n, uint64_t ncols, const uint64_t *pw_lo, const uint64_t *pw_hi, uint32_t lo_bits, hipStream_t st);
+hipError_t pk_poly_eval(const uint64_t *coeffs, uint64_t n, uint32_t npolys, const gl::e2 *points, uint32_t npoints, const uint64_t *poly_index, gl::e2 *out, hipStream_t st);
+hipError_t pk_reduce_polys(const ReduceArgs &a, hipStream_t st);
+hipError_t pk_divide_linear(const uint64_t *comp_a, const uint64_t *comp_b, uint64_t n, gl::e2 z, gl::e2 shift, int mode, uint64_t *fin_a, uint64_t *fin_b, hipStream_t st);
+hipError_t pk_interleave_ext(const uint64_t *va, const uint64_t *vb, uint64_t n, uint64_t *rows, hipStream_t st);
+hipError_t pk_fri_fold(const uint64_t *ca, const uint64_t *cb, uint64_t new_n, uint32_t arity, gl::e2 beta, uint64_t *oa, uint64_t *ob, hipStream_t st);
+hipError_t pk_pow(const PowArgs &a, hipStream_t st);   // defined next to the Poseidon constants (merkle_kernels.hip)
+hipError_t pk_gather_rows(const uint64_t *cols, uint64_t stride, uint32_t ncols, const uint64_t *idx, uint32_t nq, uint64_t *out, hipStream_t st);
+hipError_t pk_gather_paths(const uint64_t *digests, uint64_t n_leaves, uint32_t path_len, const uint64_t *idx, uint32_t shift, uint32_t nq, uint64_t *out, hipStream_t st);
+hipError_t pk_gather_leaf_rows(const uint64_t *rows, uint32_t width, const uint64_t *idx, uint32_t shift, uint32_t nq, uint64_t *out, hipStream_t st);
+hipError_t pk_coset_tables(uint64_t lde_n, uint32_t log_lde, const uint64_t *pw_lo, const uint64_t *pw_hi, uint32_t lo_bits, const uint64_t *zh,
+                           uint32_t rate, uint64_t n_field, uint64_t *x_coset, uint64_t *l0_coset, hipStream_t st);

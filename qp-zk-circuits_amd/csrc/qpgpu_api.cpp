@@ -9,11 +9,13 @@ void qpgpu_ctx::prof_begin(const char *name) {
     Pending p; p.name = name;
     if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
     (void)hipEventRecord(p.e0, stream);
+    prof_stack.push_back(pending.size());
     pending.push_back(p);
 }
 void qpgpu_ctx::prof_end() {
-    if (!profiling || pending.empty()) return;
-    (void)hipEventRecord(pending.back().e1, stream);
+    if (!profiling || prof_stack.empty()) return;
+    (void)hipEventRecord(pending[prof_stack.back()].e1, stream);
+    prof_stack.pop_back();
 }
 int qpgpu_ctx::prof_collect() {
     QP_HIP(this, hipStreamSynchronize(stream));
@@ -23,6 +25,7 @@ int qpgpu_ctx::prof_collect() {
         (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
     }
     pending.clear();
+    prof_stack.clear();
     return QPGPU_OK;
 }
 

@@ -1,0 +1,75 @@
+"""GPU parity for the whole hot path (stages s2..s12): the proof bytes produced through the C ABI are
+identical to the CPU oracle's for the same circuit pack, witness and public inputs, and the oracle's
+verifier (the reference's own acceptance criterion) accepts them."""
+import numpy as np
+import pytest
+
+from oracle_binding import OracleCircuit
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed):
+    pack, wires, pis = pkg.synth_circuit(degree_bits, num_wires=num_wires, num_routed=num_routed, num_public_inputs=npis, seed=seed)
+    oc = OracleCircuit(orc, pack)
+    want = oc.prove(wires, pis)
+    circ = pkg.Circuit(gpu, pack)
+    try:
+        assert circ.proof_size() == oc.proof_size()
+        got = circ.prove(wires, pis)
+        # stage-level diagnostics before the byte comparison
+        cap_words = 16 * 4 * 8
+        assert got[:cap_words] == want[:cap_words], "wires cap differs"
+        assert got[cap_words:2 * cap_words] == want[cap_words:2 * cap_words], "Z/partial-products cap differs"
+        assert got[2 * cap_words:3 * cap_words] == want[2 * cap_words:3 * cap_words], "quotient cap differs"
+        assert len(got) == len(want)
+        if got != want:
+            first = next(i for i in range(len(got)) if got[i] != want[i])
+            raise AssertionError(f"proof bytes differ from the oracle at byte {first} of {len(got)}")
+        assert oc.verify(got) == 0
+        # device-resident witness entry gives the same bytes and leaves the witness untouched
+        d_w = gpu.to_device(wires)
+        assert circ.prove_dev(d_w, pis) == want
+        assert np.array_equal(d_w.download().reshape(wires.shape), wires)
+        d_w.free()
+    finally:
+        circ.close(); oc.close()
+
+
+@pytest.mark.parametrize("degree_bits,num_wires,num_routed,npis,seed", [
+    (6, 24, 16, 5, 3),        # tiny, one FRI round
+    (8, 40, 24, 3, 4),
+    (10, 135, 80, 21, 5),     # standard_recursion_config shape
+    (12, 135, 80, 21, 6),     # leaf-sized trace (degree_bits >= 12, reference common/src/circuit.rs:464-467)
+])
+def test_proof_bytes_match_oracle(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed):
+    run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed)
+
+
+def test_constants_sigmas_cap_matches_oracle(pkg, gpu, orc):
+    pack, wires, pis = pkg.synth_circuit(7, num_wires=24, num_routed=16, num_public_inputs=2, seed=8)
+    circ = pkg.Circuit(gpu, pack)
+    oc = OracleCircuit(orc, pack)
+    # the oracle's proof opens the constants_sigmas oracle against its own cap; equal proofs imply equal caps,
+    # but check the setup commitment directly as well through a proof round trip
+    assert circ.prove(wires, pis) == oc.prove(wires, pis)
+    circ.close(); oc.close()
+
+
+def test_unsatisfied_witness_is_not_accepted(pkg, gpu, orc):
+    pack, wires, pis = pkg.synth_circuit(6, num_wires=24, num_routed=16, num_public_inputs=5, seed=3)
+    circ = pkg.Circuit(gpu, pack); oc = OracleCircuit(orc, pack)
+    w = wires.copy(); w[3, 10] = (int(w[3, 10]) + 1) % 0xFFFFFFFF00000001
+    bad = circ.prove(w, pis)
+    assert bad == oc.prove(w, pis)          # still bit-identical to the CPU path
+    assert oc.verify(bad) != 0              # and rejected, as the reference's verifier would
+    circ.close(); oc.close()
+
+
+def test_bad_pack_is_a_loud_error(pkg, gpu):
+    pack, _, _ = pkg.synth_circuit(6, num_wires=24, num_routed=16, num_public_inputs=1, seed=1)
+    broken = pack.copy(); broken[0] ^= 1
+    with pytest.raises(pkg.QpGpuError):
+        pkg.Circuit(gpu, broken)
+    with pytest.raises(pkg.QpGpuError):
+        pkg.Circuit(gpu, pack[:-3])
