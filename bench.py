@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — headline measurement for the MI355X wormhole-prover backend.
 
-Workload (BASELINE.json configs[1]): batched 2^20-point Goldilocks NTT + inverse on one MI355X,
-column-major batch resident in HBM, bit-exact vs plonky2::field::fft conventions (the parity tests
-prove that; here one column is re-checked against the CPU oracle after the timed region).
+BASELINE.json metric: "Wormhole proofs/sec + ms/proof at 1/2/4/8 GPUs; NTT HBM GB/s vs peak".
 
-A "step" = forward NTT then inverse NTT over the whole batch (B columns x 2^20 points).
-Algorithmic bytes: 16*N*B per direction => 32*N*B per step.
+Headline workload (BASELINE configs[2], "Full Wormhole proof (LDE + Poseidon Merkle commit + FRI) on 1
+MI355X"): one proof per step per GPU of a shape-equivalent synthetic leaf circuit (the real circuit pack needs
+a Rust exporter): 2^13 rows, 135 wires, 80 routed, standard_recursion_config FRI (rate
+1/8, cap height 4, 28 queries, 16 PoW bits, arity 16). The witness is resident in HBM when the timed region
+starts; a step ends when the proof bytes are in host memory. value = proofs/s over all ranks.
 
-N ranks: independent batches, one per GPU, no data-path collective (the path shards by column);
-rank 0 prints one JSON line. value = whole-job algorithmic GB/s.
+N ranks (BASELINE configs[3]): independent proofs, one stream per GPU, then an RCCL all_gather of the padded
+proof bytes (what the aggregation level consumes) inside the timed region. No other data-path collective.
+
+Also reported (BASELINE configs[1], "NTT HBM GB/s vs peak"): the 2^20-point Goldilocks NTT + inverse over 128
+columns; `roofline` is for that kernel pair, measured with HIP events on the launch stream by the library.
 """
 import argparse
 import json
@@ -23,8 +27,51 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-LOG_N = 20
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable copy)
+STAGES = ["prove_commit_wires", "prove_partial_products", "prove_commit_zs", "prove_quotient", "prove_commit_quotient",
+          "prove_openings", "prove_fri_batch", "prove_fri_commit", "prove_pow", "prove_queries"]
+
+
+def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
+    """BASELINE configs[1]: fwd + inverse NTT over `batch` columns of 2^log_n. Returns (GB/s, roofline dict, ok)."""
+    n = 1 << log_n
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    hi = torch.randint(0, 0xFFFFFFFF, (batch, n), dtype=torch.int64, device=dev, generator=g)
+    lo = torch.randint(0, 1 << 32, (batch, n), dtype=torch.int64, device=dev, generator=g)
+    x = (hi << 32) | lo
+    del hi, lo
+    y = torch.empty_like(x); z = torch.empty_like(x)
+
+    def step():
+        gpu.ntt_dev(x, y, log_n, batch)
+        gpu.ntt_dev(y, z, log_n, batch, inverse=True)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    gbs = 32.0 * n * batch * steps / dt / 1e9
+    gpu.profile(True)
+    for _ in range(5):
+        step()
+    ms_s, n_s = gpu.profile_read("ntt_pass_strided")
+    ms_r, n_r = gpu.profile_read("ntt_pass_rows")
+    gpu.profile(False)
+    per_transform_ms = ms_s / max(n_s, 1) + ms_r / max(n_r, 1)
+    achieved = 16.0 * n * batch / (per_transform_ms * 1e-3) / 1e9
+    roof = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": "ntt_pass_kernel<5,5,*> (one strided launch + one rows launch = one 2^20 transform; each launch is credited half of the transform's 16*N*B algorithmic bytes)",
+        "avg_ms": {"ntt_pass_strided": round(ms_s / max(n_s, 1), 4), "ntt_pass_rows": round(ms_r / max(n_r, 1), 4)},
+        "algorithmic_bytes_per_transform": 16 * n * batch, "workload": f"2^{log_n} points x {batch} columns",
+    }
+    ok = bool(torch.equal(z, x))
+    return gbs, roof, ok, x[0].cpu().numpy().view(np.uint64), y[0].cpu().numpy().view(np.uint64)
 
 
 def main():
@@ -32,8 +79,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="columns per GPU")
+    ap.add_argument("--degree-bits", type=int, default=13)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -42,35 +90,37 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
 
     import __graft_entry__ as ge
     pkg = ge.load_package()
-
-    n = 1 << LOG_N
-    B = args.batch
     stream = torch.cuda.current_stream(dev)
     gpu = pkg.QpGpu(local_rank, stream=stream.cuda_stream)
 
-    # synthetic input already resident in HBM: random canonical field elements
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    hi = torch.randint(0, 0xFFFFFFFF, (B, n), dtype=torch.int64, device=dev, generator=g)  # < 2^32 - 1
-    lo = torch.randint(0, 1 << 32, (B, n), dtype=torch.int64, device=dev, generator=g)
-    x = (hi << 32) | lo          # hi < 0xFFFFFFFF => value < p; int64 holds the u64 bit pattern
-    del hi, lo
-    y = torch.empty_like(x)
-    z = torch.empty_like(x)
+    # ---- synthetic leaf-shaped circuit + witness (setup, untimed: reference builds the circuit in the bench's
+    # setup closure too, wormhole/prover/benches/prover.rs:35-37) ----
+    d = args.degree_bits
+    pack, wires, pis = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000 + rank)
+    circ = pkg.Circuit(gpu, pack)
+    w_t = torch.from_numpy(wires.view(np.int64)).to(dev)       # witness resident in HBM
+    proof_len = circ.proof_size()
+    out = np.empty(proof_len, dtype=np.uint8)
+    pad = (proof_len + 255) // 256 * 256
+    send = torch.zeros(pad, dtype=torch.uint8, device=dev)
+    recv = [torch.empty(pad, dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 else None
 
     def step():
-        gpu.ntt_dev(x, y, LOG_N, B)                 # forward, natural -> natural
-        gpu.ntt_dev(y, z, LOG_N, B, inverse=True)   # inverse (1/n included)
+        proof = circ.prove_dev(w_t, pis, out=out)
+        if world > 1:   # aggregation step's input: every rank's proof bytes gathered over xGMI (RCCL)
+            send[:proof_len].copy_(torch.from_numpy(out), non_blocking=False)
+            dist.all_gather(recv, send)
+        return proof
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -79,81 +129,89 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step()
+        proof = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        proof = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if rank == 0:   # the gathered bytes of rank 0 must be its own proof
+            assert bytes(recv[0][:proof_len].cpu().numpy().tobytes()) == proof
+    value = args.steps * world / dt
 
-    ok = bool(torch.equal(z, x))  # round trip must be the identity, on every rank
-    alg_bytes_step = 32.0 * n * B
-    value = alg_bytes_step * args.steps * world / dt / 1e9
-
-    roofline = None
-    cpu_baseline = None
+    extra = {}
+    ok = True
     if rank == 0:
-        # roofline leg: per-kernel HIP-event timing on the same stream (separate from the timed region)
+        # per-stage breakdown (HIP events recorded by the library on the launch stream; separate leg)
         gpu.profile(True)
-        for _ in range(max(3, min(args.steps, 10))):
+        for _ in range(5):
             step()
-        ms_s, n_s = gpu.profile_read("ntt_pass_strided")
-        ms_r, n_r = gpu.profile_read("ntt_pass_rows")
+        stages = {}
+        for s in STAGES:
+            ms, cnt = gpu.profile_read(s)
+            stages[s] = round(ms / max(cnt, 1), 4)
+        leaf_ms, leaf_n = gpu.profile_read("merkle_leaf_hash")
         gpu.profile(False)
-        # one transform = one strided launch + one rows launch; each launch is credited half of the
-        # transform's 16*N*B algorithmic bytes (DESIGN.md "roofline accounting")
-        per_transform_ms = ms_s / max(n_s, 1) + ms_r / max(n_r, 1)
-        achieved = 16.0 * n * B / (per_transform_ms * 1e-3) / 1e9
-        roofline = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "ntt_pass_kernel<5,5> (strided launch + rows launch = one 2^20 transform)",
-            "avg_ms": {"ntt_pass_strided": round(ms_s / max(n_s, 1), 4), "ntt_pass_rows": round(ms_r / max(n_r, 1), 4)},
-            "algorithmic_bytes_per_transform": 16 * n * B,
-        }
-        # correctness spot check against the CPU oracle (checker only; not in any timed region)
+        extra["proof_stage_ms"] = stages
+        extra["merkle_leaf_hash_avg_ms"] = round(leaf_ms / max(leaf_n, 1), 4)
+
+        # checker (not timed): the oracle verifies the GPU proof and reproduces its bytes
         import oracle_binding
         orc = oracle_binding.Oracle()
-        col = x[0].cpu().numpy().view(np.uint64)
-        ok = ok and bool(np.array_equal(y[0].cpu().numpy().view(np.uint64), orc.fft(col, LOG_N)))
+        oc = oracle_binding.OracleCircuit(orc, pack)
+        ok = oc.verify(proof) == 0
+        cpu_baseline = None
         if not args.no_cpu_baseline:
             threads = max(1, min(len(os.sched_getaffinity(0)), 16))
             orc.set_threads(threads)
-            sample_cols = 2 * threads
-            s = x[:sample_cols].cpu().numpy().view(np.uint64).copy()
             reps = 0
             t1 = time.perf_counter()
             while True:
-                f = orc.fft_batch(s, LOG_N)
-                orc.fft_batch(f, LOG_N, inverse=True)
+                cpu_proof = oc.prove(wires, pis)
                 reps += 1
-                if time.perf_counter() - t1 > 10.0 or reps >= 50:
+                if time.perf_counter() - t1 > 12.0 or reps >= 30:
                     break
             cdt = time.perf_counter() - t1
+            ok = ok and cpu_proof == proof
             cpu_baseline = {
-                "value": round(32.0 * n * sample_cols * reps / cdt / 1e9, 3), "unit": "GB/s",
-                "cores": threads, "kind": "port",
-                "sample": f"{reps} x (fwd+inv) over {sample_cols} columns of 2^20, oracle/fft.c, one column per OpenMP thread",
+                "value": round(reps / cdt, 4), "unit": "proofs/s", "cores": threads, "kind": "port",
+                "sample": f"{reps} proofs of the same circuit and witness with oracle/prove.c (OpenMP, {threads} threads); "
+                          "the reference's Rayon prover cannot be built here (no Rust toolchain)",
             }
+        extra["cpu_baseline"] = cpu_baseline
+        oc.close()
+        if not args.no_ntt:
+            gbs, roof, ntt_ok, col_in, col_out = ntt_leg(torch, pkg, gpu, dev, 20, 128, 10)
+            ok = ok and ntt_ok and bool(np.array_equal(col_out, orc.fft(col_in, 20)))
+            extra["roofline"] = roof
+            extra["ntt_2p20_fwd_inv_GBps"] = round(gbs, 1)
+    circ.close()
     gpu.close()
     if not ok:
-        raise SystemExit("bench.py: NTT round trip / oracle check FAILED")
+        raise SystemExit("bench.py: correctness check FAILED (oracle verify / byte parity / NTT round trip)")
     if rank == 0:
-        print(json.dumps({
-            "metric": "NTT HBM GB/s vs peak (2^20-point Goldilocks NTT + inverse)", "value": round(value, 1), "unit": "GB/s",
+        line = {
+            "metric": "Wormhole proofs/sec", "value": round(value, 3), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 2^20-point Goldilocks NTT + inverse, column-major batch in HBM",
-                       "log_n": LOG_N, "columns_per_gpu": B, "step": "fft then ifft over the batch",
-                       "algorithmic_bytes_per_step": int(alg_bytes_step)},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
-        }))
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_proof": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]/[3]: full proof (LDE + Poseidon Merkle commit + quotient + FRI) of a "
+                                   "shape-equivalent synthetic leaf circuit, one proof per GPU per step, witness resident in HBM",
+                       "degree_bits": d, "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
+                       "num_query_rounds": 28, "proof_of_work_bits": 16, "fri_arity_bits": 4, "proof_bytes": proof_len,
+                       "multi_gpu": "independent proofs per rank + RCCL all_gather of proof bytes" if world > 1 else "single GPU"},
+        }
+        line.update(extra)
+        if "roofline" not in line:
+            line["roofline"] = None
+        if "cpu_baseline" not in line:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 

@@ -55,6 +55,88 @@ __global__ void __launch_bounds__(256) leaf_hash_kernel(MerkleLeafArgs a) {
     for (int i = 0; i < 4; i++) out[i] = s[i];
 }
 
+// ---- lane-cooperative permutation: one state spread over 16 lanes (element g in lane g, 12 used), four states
+// per wave. The S-box layer runs on all elements at once and the MDS layer gathers the other eleven elements with
+// wave shuffles (ds_bpermute), so one permutation has ~1/5 of the single-thread latency. Total work is ~3x higher
+// (partial rounds keep 11 lanes idle), so it is used only where a tree level is latency-bound: few nodes.
+__device__ __forceinline__ u64 coop_permute(u64 s, const int g, const int lane_base) {
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    int src[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { int e = g + i; e -= e >= 12 ? 12 : 0; src[i] = lane_base + (g < 12 ? e : i); }
+#pragma unroll 1
+    for (int r = 0; r < poseidon::ROUNDS; r++) {
+        const u64 rc = g < 12 ? c_poseidon_rc[r * 12 + g] : 0;
+        s = gl::add(s, rc);
+        const bool full = r < poseidon::HALF_FULL || r >= poseidon::HALF_FULL + poseidon::PARTIAL;
+        const u64 sb = poseidon::sbox7(s);
+        s = (full || g == 0) ? sb : s;
+        const u32 lo = (u32)s, hi = (u32)(s >> 32);
+        u64 al = 0, ah = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const u32 l = (u32)__shfl((int)lo, src[i], 64), h = (u32)__shfl((int)hi, src[i], 64);
+            al += (u64)l * C[i];
+            ah += (u64)h * C[i];
+        }
+        if (g == 0) { al += (u64)lo * 8u; ah += (u64)hi * 8u; }
+        const u64 low = al + (ah << 32);
+        const u32 top = (u32)(ah >> 32) + (low < al ? 1u : 0u);
+        s = gl::reduce96(low, top);
+    }
+    return gl::canon(s);
+}
+
+// one 16-lane group per node: out[i] = two_to_one(in[2i], in[2i+1])
+__global__ void __launch_bounds__(256) node_coop_kernel(const u64 *in, u64 *out, u64 n_out) {
+    const u64 grp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
+    const int lane = threadIdx.x & 63, g = lane & 15, base = lane & 48;
+    const bool live = grp < n_out;
+    u64 s = (live && g < 8) ? in[grp * 8 + g] : 0;
+    s = coop_permute(s, g, base);
+    if (live && g < 4) out[grp * 4 + g] = s;
+}
+
+// one 16-lane group per row-major leaf
+__global__ void __launch_bounds__(256) leaf_rows_coop_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests) {
+    const u64 grp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
+    const int lane = threadIdx.x & 63, g = lane & 15, base = lane & 48;
+    const bool live = grp < n_leaves;
+    const u64 *row = rows + (live ? grp : 0) * width;
+    if (width <= 4) {
+        if (live && g < 4) digests[grp * 4 + g] = g < (int)width ? gl::canon(row[g]) : 0;
+        return;
+    }
+    u64 s = 0;
+    for (u32 c = 0; c < width; c += 8) {
+        if (g < 8 && c + g < width) s = row[c + g];
+        s = coop_permute(s, g, base);
+    }
+    if (live && g < 4) digests[grp * 4 + g] = s;
+}
+
+// one 16-lane group per column-major leaf (small LDEs)
+__global__ void __launch_bounds__(256) leaf_cols_coop_kernel(MerkleLeafArgs a) {
+    const u64 grp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
+    const int lane = threadIdx.x & 63, g = lane & 15, base = lane & 48;
+    const bool live = grp < a.n_leaves;
+    const u64 j = live ? grp : 0;
+    const u32 W = a.ncols0 + a.ncols1;
+    auto elem = [&](u32 c) -> u64 {
+        return c < a.ncols0 ? a.src0[(u64)c * a.stride0 + j] : a.src1[(u64)(c - a.ncols0) * a.stride1 + j];
+    };
+    if (W <= 4) {
+        if (live && g < 4) a.digests[j * 4 + g] = g < (int)W ? gl::canon(elem(g)) : 0;
+        return;
+    }
+    u64 s = 0;
+    for (u32 c = 0; c < W; c += 8) {
+        if (g < 8 && c + g < W) s = elem(c + g);
+        s = coop_permute(s, g, base);
+    }
+    if (live && g < 4) a.digests[j * 4 + g] = s;
+}
+
 // row-major leaves (FRI round trees: leaf = 2^arity ext values = contiguous felts)
 template <class Perm>
 __global__ void __launch_bounds__(256) leaf_hash_rows_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests) {
@@ -129,20 +211,38 @@ hipError_t pk_pow(const PowArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// below this many independent hashes a level is latency-bound and the lane-cooperative form wins
+static const u64 COOP_MAX = 16384;
+
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, hipStream_t st) {
     if (a.n_leaves == 0) return hipSuccess;
+    if (a.n_leaves <= COOP_MAX / 2) {
+        dim3 block(256), grid((unsigned)((a.n_leaves * 16 + 255) / 256));
+        hipLaunchKernelGGL(leaf_cols_coop_kernel, grid, block, 0, st, a);
+        return hipGetLastError();
+    }
     dim3 block(256), grid((unsigned)((a.n_leaves + 255) / 256));
     hipLaunchKernelGGL((leaf_hash_kernel<PoseidonV1>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, hipStream_t st) {
     if (n_leaves == 0) return hipSuccess;
+    if (n_leaves <= COOP_MAX) {
+        dim3 block(256), grid((unsigned)((n_leaves * 16 + 255) / 256));
+        hipLaunchKernelGGL(leaf_rows_coop_kernel, grid, block, 0, st, rows, n_leaves, width, digests);
+        return hipGetLastError();
+    }
     dim3 block(256), grid((unsigned)((n_leaves + 255) / 256));
     hipLaunchKernelGGL((leaf_hash_rows_kernel<PoseidonV1>), grid, block, 0, st, rows, n_leaves, width, digests);
     return hipGetLastError();
 }
 hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, hipStream_t st) {
     if (n_out == 0) return hipSuccess;
+    if (n_out <= COOP_MAX) {
+        dim3 block(256), grid((unsigned)((n_out * 16 + 255) / 256));
+        hipLaunchKernelGGL(node_coop_kernel, grid, block, 0, st, in, out, n_out);
+        return hipGetLastError();
+    }
     unsigned threads = n_out >= 256 ? 256 : 64;
     dim3 block(threads), grid((unsigned)((n_out + threads - 1) / threads));
     hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out);
