@@ -1,6 +1,7 @@
 // ntt_plan.cpp — host-side planning for the NTT passes: pass split, twiddle tables, launches.
 // Replaces the root-table / dispatch logic of plonky2::field::fft (fft_root_table, fft_dispatch).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string>
 #include "ctx.hpp"
 #include "gl64.hpp"
@@ -79,8 +80,12 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
         if (d_in != d_out) QP_HIP(ctx, hipMemcpyAsync(d_out, d_in, batch * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         return QPGPU_OK;
     }
-    static bool inited = false;
-    if (!inited) { QP_HIP(ctx, ntt_pass_init()); inited = true; }
+    {   // one-time kernel attribute setup, safe when several proving threads start together
+        static std::once_flag once;
+        static hipError_t init_err = hipSuccess;
+        std::call_once(once, [] { init_err = ntt_pass_init(); });
+        QP_HIP(ctx, init_err);
+    }
 
     const std::string dir = inverse ? "i" : "f";
     const u64 wN = inverse ? gl::inv(gl::root_of_unity(L)) : gl::root_of_unity(L);

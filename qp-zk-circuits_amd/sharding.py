@@ -1,0 +1,62 @@
+"""Multi-GPU sharding of independent proofs.
+
+The path shards across proofs: leaf proofs are independent (each is build_fresh().commit().prove(),
+reference wormhole/aggregator/benches/aggregator.rs:45-49); private batches are independent of each other;
+only the single public-batch proof is a join. One process per GPU; the only exchange is a gather of proof
+bytes (about 130 KB per leaf proof) to the rank that proves the next level, an all_gather over RCCL/xGMI on
+GPUs (gloo in the CPU tests). Nothing else crosses ranks.
+"""
+import numpy as np
+
+
+def shard_range(num_items, world, rank):
+    """Contiguous block partition: rank r gets items [lo, hi). BASELINE config 5: 64 leaves -> 8 per GPU."""
+    base, rem = divmod(num_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def aggregation_schedule(num_leaves=64, leaves_per_private_batch=8, world=8):
+    """Who proves what in the recursive tree (reference call stack SURVEY 3.4: 64 leaf proofs ->
+    num_leaves/N private batches of N -> one public batch). Returns a dict rank -> {"leaves", "private_batches"}
+    plus "root" (the rank that proves the public batch after the second gather)."""
+    if num_leaves % leaves_per_private_batch:
+        raise ValueError("num_leaves must be a multiple of leaves_per_private_batch")
+    n_batches = num_leaves // leaves_per_private_batch
+    plan = {"root": 0, "ranks": {}}
+    for r in range(world):
+        blo, bhi = shard_range(n_batches, world, r)
+        leaves = list(range(blo * leaves_per_private_batch, bhi * leaves_per_private_batch))
+        plan["ranks"][r] = {"leaves": leaves, "private_batches": list(range(blo, bhi))}
+    return plan
+
+
+def gather_proof_bytes(proofs, dist=None, device=None):
+    """All ranks contribute a list of proofs (bytes); every rank receives the list of all ranks' lists, in rank
+    order. Fixed-size padded uint8 buffers + a length vector, one all_gather each (payload is latency-bound)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [list(proofs)]
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    lens = torch.tensor([len(p) for p in proofs], dtype=torch.int64, device=dev)
+    count = torch.tensor([len(proofs)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    max_count = max(int(c.item()) for c in counts)
+    lens_pad = torch.zeros(max_count, dtype=torch.int64, device=dev)
+    lens_pad[:len(proofs)] = lens
+    all_lens = [torch.zeros_like(lens_pad) for _ in range(world)]
+    dist.all_gather(all_lens, lens_pad)
+    max_len = max(int(l.max().item()) if l.numel() else 0 for l in all_lens)
+    payload = torch.zeros(max_count * max_len, dtype=torch.uint8, device=dev)
+    for i, p in enumerate(proofs):
+        payload[i * max_len:i * max_len + len(p)] = torch.from_numpy(np.frombuffer(p, dtype=np.uint8).copy()).to(dev)
+    recv = [torch.zeros_like(payload) for _ in range(world)]
+    dist.all_gather(recv, payload)
+    out = []
+    for r in range(world):
+        buf = recv[r].cpu().numpy()
+        cnt = int(counts[r].item())
+        out.append([buf[i * max_len:i * max_len + int(all_lens[r][i].item())].tobytes() for i in range(cnt)])
+    return out

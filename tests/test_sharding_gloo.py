@@ -1,0 +1,58 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard a set of proofs, gather the proof bytes the way
+bench.py --gpus N does (same function), and agree on the aggregation-tree schedule."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import __graft_entry__ as ge
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    sh = pkg.sharding
+    lo, hi = sh.shard_range(5, world, rank)                 # 5 proofs over 2 ranks: 3 + 2
+    rng = np.random.default_rng(100)
+    all_proofs = [rng.integers(0, 256, 1000 + 37 * i, dtype=np.uint8).tobytes() for i in range(5)]
+    mine = all_proofs[lo:hi]
+    gathered = sh.gather_proof_bytes(mine, dist)
+    flat = [p for r in gathered for p in r]
+    ok = flat == all_proofs and [len(r) for r in gathered] == [3, 2]
+    # a rank with nothing to contribute still takes part
+    g2 = sh.gather_proof_bytes(mine if rank == 0 else [], dist)
+    ok = ok and g2 == [all_proofs[0:3], []] if rank == 0 else ok and g2[1] == []
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_two_ranks_gloo():
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0] and ret[1]
+
+
+def test_schedule_and_shards(pkg):
+    sh = pkg.sharding
+    assert [sh.shard_range(64, 8, r) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
+    assert [sh.shard_range(5, 2, r) for r in range(2)] == [(0, 3), (3, 5)]
+    assert sh.shard_range(3, 8, 7) == (3, 3)
+    plan = sh.aggregation_schedule(64, 8, 8)              # BASELINE config 5
+    assert plan["root"] == 0
+    leaves = sorted(l for r in plan["ranks"].values() for l in r["leaves"])
+    assert leaves == list(range(64))
+    assert all(len(r["leaves"]) == 8 and len(r["private_batches"]) == 1 for r in plan["ranks"].values())
+    plan2 = sh.aggregation_schedule(64, 8, 2)
+    assert [len(plan2["ranks"][r]["private_batches"]) for r in range(2)] == [4, 4]
+    # single process: gather is the identity
+    assert sh.gather_proof_bytes([b"ab", b"c"]) == [[b"ab", b"c"]]
