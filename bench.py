@@ -70,6 +70,17 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
         "avg_ms": {"ntt_pass_strided": round(ms_s / max(n_s, 1), 4), "ntt_pass_rows": round(ms_r / max(n_r, 1), 4)},
         "algorithmic_bytes_per_transform": 16 * n * batch, "workload": f"2^{log_n} points x {batch} columns",
     }
+    # HBM traffic from the PMC counters cannot be collected inside this process; it is read from the committed
+    # rocprofv3 --pmc summary of the same kernels on the same workload (profiles/*ntt_pmc_summary.json)
+    try:
+        import glob
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*ntt_pmc_summary.json")))[-1]
+        pm = json.load(open(latest))
+        if pm.get("algorithmic_bytes_per_transform") == 16 * n * batch:
+            roof["traffic"] = pm["hbm_bytes_per_transform"]
+            roof["traffic_source"] = os.path.relpath(latest, ROOT)
+    except Exception:
+        pass
     ok = bool(torch.equal(z, x))
     return gbs, roof, ok, x[0].cpu().numpy().view(np.uint64), y[0].cpu().numpy().view(np.uint64)
 
