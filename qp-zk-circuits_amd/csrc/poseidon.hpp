@@ -20,9 +20,9 @@ GL_HD u64 sbox7(u64 x) {
     return gl::mul(x3, x4);
 }
 
-// s <- MDS * s. Works on the 32-bit halves with 64-bit accumulators (constants < 2^6, 13 terms),
-// then one 96-bit fold per output.
-GL_HD void mds_layer(u64 (&s)[WIDTH]) {
+// Reference form of the MDS layer (circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag(8,0,...)):
+// 32-bit halves, 64-bit accumulators, one 96-bit fold per output. Kept for the self-check in tests.
+GL_HD void mds_layer_naive(u64 (&s)[WIDTH]) {
     constexpr u32 C[WIDTH] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u32 lo[WIDTH], hi[WIDTH];
 #pragma unroll
@@ -37,9 +37,56 @@ GL_HD void mds_layer(u64 (&s)[WIDTH]) {
             ah += (u64)hi[j] * C[i];
         }
         if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
-        // value = al + ah * 2^32, al, ah < 2^42
         u64 low = al + (ah << 32);
         u32 top = (u32)(ah >> 32) + (low < al ? 1u : 0u);
+        s[r] = gl::reduce96(low, top);
+    }
+}
+
+// The circulant part on one vector of 32-bit halves, without multiplications: reduce the length-12 cyclic
+// convolution modulo x^3 - w for w in {1, -1, i} (4-point real FFT over the stride-3 subsequences), where the
+// kernel's images are powers of two: 64*(1,2,1), 4*(-1,-8,2), 2*(2+i, -4-i, 16-i); three 3-term twisted
+// convolutions with shifts only; inverse FFT. All in signed 64-bit integers (|values| < 2^42).
+typedef long long i64;
+GL_HD void mds_circulant_half(const i64 (&x)[WIDTH], i64 (&o)[WIDTH]) {
+    i64 U1[3], Um[3], F[3], H[3];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const i64 e = x[b] + x[b + 6], f = x[b] - x[b + 6], g = x[b + 3] + x[b + 9], h = x[b + 3] - x[b + 9];
+        U1[b] = e + g; Um[b] = e - g; F[b] = f; H[b] = h;
+    }
+    const i64 T = U1[0] + U1[1] + U1[2];
+    const i64 A[3] = {T + U1[2], T + U1[0], T + U1[1]};                       // V_1 / 64
+    const i64 B[3] = {(Um[2] << 3) - Um[0] - (Um[1] << 1),                    // V_-1 / 4
+                      -((Um[0] << 3) + Um[1] + (Um[2] << 1)),
+                      (Um[0] << 1) - (Um[1] << 3) - Um[2]};
+    const i64 f0 = F[0], f1 = F[1], f2 = F[2], h0 = H[0], h1 = H[1], h2 = H[2];
+    const i64 R[3] = {(f0 << 1) - h0 + f1 - (h1 << 4) + f2 + (h2 << 2),       // Re(V_i / 2)
+                      -(f0 << 2) + h0 + (f1 << 1) - h1 + f2 - (h2 << 4),
+                      (f0 << 4) + h0 - (f1 << 2) + h1 + (f2 << 1) - h2};
+    const i64 I[3] = {f0 + (h0 << 1) + (f1 << 4) + h1 - (f2 << 2) + h2,       // Im(V_i / 2)
+                      -f0 - (h0 << 2) + f1 + (h1 << 1) + (f2 << 4) + h2,
+                      -f0 + (h0 << 4) - f1 - (h1 << 2) + f2 + (h2 << 1)};
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const i64 a16 = A[b] << 4, p = a16 + B[b], q = a16 - B[b];
+        o[b] = p + R[b]; o[b + 3] = q + I[b]; o[b + 6] = p - R[b]; o[b + 9] = q - I[b];
+    }
+}
+
+// s <- MDS * s
+GL_HD void mds_layer(u64 (&s)[WIDTH]) {
+    i64 lo[WIDTH], hi[WIDTH], ol[WIDTH], oh[WIDTH];
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) { lo[i] = (i64)(u32)s[i]; hi[i] = (i64)(s[i] >> 32); }
+    mds_circulant_half(lo, ol);
+    mds_circulant_half(hi, oh);
+    ol[0] += lo[0] << 3; oh[0] += hi[0] << 3;   // the diagonal term 8 * s[0]
+#pragma unroll
+    for (int r = 0; r < WIDTH; r++) {
+        const u64 al = (u64)ol[r], ah = (u64)oh[r];   // both in [0, 2^42)
+        const u64 low = al + (ah << 32);
+        const u32 top = (u32)(ah >> 32) + (low < al ? 1u : 0u);
         s[r] = gl::reduce96(low, top);
     }
 }
