@@ -112,6 +112,11 @@ int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t
 int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_words, qpgpu_circuit **out);
 void qpgpu_circuit_free(qpgpu_circuit *c);
 int qpgpu_circuit_constants_sigmas_cap(const qpgpu_circuit *c, uint64_t *out, size_t out_words);
+/* Zero-knowledge packs (standard_recursion_zk_config, reference common/src/circuit.rs:396-402): the wires,
+ * Z/partial-products and quotient oracles carry 4 salt columns per leaf. By default they are drawn from the OS
+ * entropy source per proof (the reference uses thread_rng); a seed set here applies to the NEXT prove call only and
+ * makes its bytes reproducible. */
+int qpgpu_circuit_set_blinding_seed(qpgpu_circuit *c, uint64_t seed);
 size_t qpgpu_proof_size(const qpgpu_circuit *c);   /* bytes written by qpgpu_prove for this circuit */
 /*
  * prove(): wires = the full witness matrix (num_wires x 2^degree_bits, column-major, as

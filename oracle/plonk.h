@@ -18,6 +18,7 @@ typedef struct { uint64_t type, param0, param1, selector_index, group_start, gro
 
 typedef struct {
     size_t ncols, n, lde_n;      /* polynomials, degree, lde size */
+    size_t width;                /* leaf width = ncols + salt columns (4 when blinding) */
     unsigned log_n, rate_bits, cap_height;
     gl_t *coeffs;                /* [ncols][n] */
     gl_t *leaves;                /* [lde_n][ncols] leaf order (leaf j = point bitrev(j)) */
@@ -39,6 +40,9 @@ orc_circuit *orc_circuit_load(const uint64_t *words, size_t n_words);
 void orc_circuit_free(orc_circuit *c);
 /* returns 0 and writes proof bytes (ProofWithPublicInputs::to_bytes order); -1 buffer too small */
 int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len);
+/* zero-knowledge circuits: salts are drawn from a counter-mode generator keyed by `seed` (the reference uses thread_rng) */
+int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint64_t seed, uint8_t *out, size_t cap, size_t *len);
+gl_t orc_salt_value(uint64_t seed, unsigned oracle_index, unsigned column, uint64_t leaf);
 /* 0 = accepted; otherwise a positive stage code saying what failed */
 int orc_verify(const orc_circuit *c, const uint8_t *proof, size_t len);
 size_t orc_proof_size(const orc_circuit *c);

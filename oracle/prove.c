@@ -37,6 +37,17 @@ int orc_trace_get(const char *name, uint64_t *out) {
 static void batch_free(orc_batch *b) { free(b->coeffs); free(b->leaves); free(b->digests); free(b->cap); memset(b, 0, sizeof *b); }
 
 /* PolynomialBatch::from_coeffs (no blinding): LDE each column on the coset g<w>, transpose, bit-reverse rows, Merkle */
+/* salt for leaf `leaf` of a blinded oracle: splitmix64 in counter mode, reduced into the field */
+gl_t orc_salt_value(uint64_t seed, unsigned oracle_index, unsigned column, uint64_t leaf) {
+    uint64_t ctr = ((uint64_t)(oracle_index * 4 + column) << 40) | leaf;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (ctr + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+    return z >= GL_P ? z - GL_P : z;
+}
+static uint64_t g_seed = 0;
+static int g_blind = 0;
+static unsigned g_oracle_index = 0;
+
 static void batch_from_coeffs(orc_batch *b, gl_t *coeffs /* owned */, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height) {
     memset(b, 0, sizeof *b);
     b->ncols = ncols; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
@@ -51,16 +62,20 @@ static void batch_from_coeffs(orc_batch *b, gl_t *coeffs /* owned */, size_t nco
         memset(col + b->n, 0, (b->lde_n - b->n) * sizeof(gl_t));
         orc_coset_fft(col, L, GL_MULT_GEN);
     }
-    b->leaves = (gl_t *)malloc(sizeof(gl_t) * ncols * b->lde_n);
+    const size_t salt = g_blind ? 4 : 0, W = ncols + salt;
+    const unsigned oi = g_oracle_index;
+    b->width = W;
+    b->leaves = (gl_t *)malloc(sizeof(gl_t) * W * b->lde_n);
 #pragma omp parallel for schedule(static)
     for (long j = 0; j < (long)b->lde_n; j++) {
         size_t src = bitrev32((uint32_t)j, L);
-        for (size_t c = 0; c < ncols; c++) b->leaves[(size_t)j * ncols + c] = lde[c * b->lde_n + src];
+        for (size_t c = 0; c < ncols; c++) b->leaves[(size_t)j * W + c] = lde[c * b->lde_n + src];
+        for (size_t c = 0; c < salt; c++) b->leaves[(size_t)j * W + ncols + c] = orc_salt_value(g_seed, oi, (unsigned)c, (uint64_t)j);
     }
     free(lde);
     b->digests = (gl_t *)malloc(sizeof(gl_t) * 4 * 2 * b->lde_n);
     b->cap = (gl_t *)malloc(sizeof(gl_t) * 4 * ((size_t)1 << cap_height));
-    orc_merkle_build(b->leaves, b->lde_n, ncols, cap_height, b->digests, b->cap);
+    orc_merkle_build(b->leaves, b->lde_n, W, cap_height, b->digests, b->cap);
 }
 /* PolynomialBatch::from_values: ifft then from_coeffs. values is copied. */
 static void batch_from_values(orc_batch *b, const gl_t *values, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height) {
@@ -72,7 +87,7 @@ static void batch_from_values(orc_batch *b, const gl_t *values, size_t ncols, un
     batch_from_coeffs(b, coeffs, ncols, log_n, rate_bits, cap_height);
 }
 /* row of the LDE at natural point index i (plonky2 get_lde_values) */
-static const gl_t *batch_lde_row(const orc_batch *b, size_t i) { return b->leaves + (size_t)bitrev32((uint32_t)i, b->log_n + b->rate_bits) * b->ncols; }
+static const gl_t *batch_lde_row(const orc_batch *b, size_t i) { return b->leaves + (size_t)bitrev32((uint32_t)i, b->log_n + b->rate_bits) * b->width; }
 
 /* ------------------------------------------------------------------ circuit */
 orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
@@ -83,7 +98,7 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
     c->num_selectors = w[p++]; c->num_challenges = w[p++]; c->qdf = w[p++]; c->num_pp = w[p++]; c->num_pis = w[p++];
     c->rate_bits = w[p++]; c->cap_height = w[p++]; c->pow_bits = w[p++]; c->num_queries = w[p++]; c->zk = w[p++];
     c->num_gate_constraints = w[p++]; c->n_gates = w[p++]; c->n_arity = w[p++];
-    if (c->n_arity > 16 || c->num_challenges > MAXC || c->zk) { free(c); return NULL; }
+    if (c->n_arity > 16 || c->num_challenges > MAXC) { free(c); return NULL; }
     for (size_t i = 0; i < c->n_arity; i++) c->arity[i] = w[p++];
     c->gates = (orc_gate *)malloc(sizeof(orc_gate) * c->n_gates);
     memcpy(c->gates, w + p, sizeof(orc_gate) * c->n_gates); p += 8 * c->n_gates;
@@ -94,6 +109,7 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
     if (p + ncs * n != nw) { free(c->gates); free(c->k_is); free(c); return NULL; }
     c->cs_values = (gl_t *)malloc(sizeof(gl_t) * ncs * n);
     memcpy(c->cs_values, w + p, sizeof(gl_t) * ncs * n);
+    g_blind = 0;
     batch_from_values(&c->cs, c->cs_values, ncs, (unsigned)c->degree_bits, (unsigned)c->rate_bits, (unsigned)c->cap_height);
     return c;
 }
@@ -199,7 +215,8 @@ size_t orc_proof_size(const orc_circuit *c) {
     size_t cap = ((size_t)1 << c->cap_height) * 4 * 8;
     size_t openings = (n_cs + c->num_wires + nch * 2 + nch * c->num_pp + nch * c->qdf) * 16;
     size_t L = c->degree_bits + c->rate_bits, sz = 3 * cap + openings;
-    size_t widths[4] = {n_cs, c->num_wires, nch * (1 + c->num_pp), nch * c->qdf};
+    size_t salt = c->zk ? 4 : 0;
+    size_t widths[4] = {n_cs, c->num_wires + salt, nch * (1 + c->num_pp) + salt, nch * c->qdf + salt};
     size_t q = 0;
     for (int o = 0; o < 4; o++) q += widths[o] * 8 + 1 + (L - c->cap_height) * 32;
     size_t lvl = L, fin = c->degree_bits;
@@ -213,7 +230,11 @@ size_t orc_proof_size(const orc_circuit *c) {
 
 /* ------------------------------------------------------------------ prove */
 int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len) {
+    return orc_prove_seeded(c, wires, public_inputs, 0, out, cap, len);
+}
+int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint64_t seed, uint8_t *out, size_t cap, size_t *len) {
     trace_clear();
+    g_seed = seed;
     const unsigned d = (unsigned)c->degree_bits, rb = (unsigned)c->rate_bits, ch_h = (unsigned)c->cap_height, L = d + rb;
     const size_t n = (size_t)1 << d, lde_n = n << rb, R = c->num_routed, NW = c->num_wires, nch = c->num_challenges;
     const size_t npp = c->num_pp, nchunks = npp + 1, chunk = c->qdf, ncs = c->num_selectors + c->num_constants + R;
@@ -225,6 +246,7 @@ int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs
 
     /* s2/s3: wires commitment */
     orc_batch wb;
+    g_blind = c->zk ? 1 : 0; g_oracle_index = 1;
     batch_from_values(&wb, wires, NW, d, rb, ch_h);
     trace_put("wires_cap", wb.cap, cap_words);
 
@@ -279,6 +301,7 @@ int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs
     }
     trace_put("zs_pp_values", zs_pp, nzp * n);
     orc_batch zb;
+    g_oracle_index = 2;
     batch_from_values(&zb, zs_pp, nzp, d, rb, ch_h);
     free(zs_pp);
     trace_put("zs_pp_cap", zb.cap, cap_words);
@@ -337,6 +360,7 @@ int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs
     /* each quotient poly (8n coefficients) is split into qdf chunks of n: contiguous => nch*qdf columns of n */
     const size_t nq = nch * c->qdf;
     orc_batch qb;
+    g_oracle_index = 3;
     batch_from_coeffs(&qb, quot, nq, d, rb, ch_h);   /* quot now owned by qb.coeffs */
     trace_put("quotient_chunk_coeffs", qb.coeffs, nq * n);
     trace_put("quotient_cap", qb.cap, cap_words);
@@ -490,7 +514,7 @@ int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs
         qidx[q] = x_index;
         for (int oi = 0; oi < 4; oi++) {
             const orc_batch *b = oracles[oi];
-            w_vec(&o, b->leaves + x_index * b->ncols, b->ncols);
+            w_vec(&o, b->leaves + x_index * b->width, b->width);
             w_path(&o, b->digests, b->lde_n, ch_h, x_index);
         }
         for (size_t r = 0; r < c->n_arity; r++) {

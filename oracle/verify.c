@@ -54,7 +54,9 @@ int orc_verify(const orc_circuit *c, const uint8_t *proof, size_t len) {
     for (size_t r = 0; r < c->n_arity; r++) r_vec(&b, fri_caps + r * cap_words, cap_words);
     size_t queries_pos = b.pos;
     /* skip the query rounds to reach final_poly / pow / public inputs */
-    size_t widths[4] = {ncs, NW, nch * (1 + npp), nq};
+    const size_t salt = c->zk ? 4 : 0;
+    size_t widths[4] = {ncs, NW + salt, nch * (1 + npp) + salt, nq + salt};
+    const size_t polys[4] = {ncs, NW, nch * (1 + npp), nq};
     {
         size_t q = 0, lvl = L;
         for (int o = 0; o < 4; o++) q += widths[o] * 8 + 1 + (L - ch_h) * 32;
@@ -142,7 +144,7 @@ int orc_verify(const orc_circuit *c, const uint8_t *proof, size_t len) {
         gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(d));
         const gl_t *caps0[4] = {c->cs.cap, wires_cap, zs_cap, q_cap};
         rbuf q = {proof, len, queries_pos, 0};
-        gl_t *row = malloc(8 * (n0 + 64)), path[64 * 4];
+        gl_t *row = malloc(8 * (n0 + 64 + 16)), path[64 * 4];
         for (size_t qi = 0; qi < c->num_queries && !rc; qi++) {
             size_t x_index = (size_t)(orc_challenger_get(&ch) % lde_n);
             /* initial trees */
@@ -157,7 +159,8 @@ int orc_verify(const orc_circuit *c, const uint8_t *proof, size_t len) {
             gl_t subgroup_x = gl_mul(GL_MULT_GEN, gl_pow(gl_root_of_unity(L), bitrev32((uint32_t)x_index, L)));
             /* fri_combine_initial */
             gl2_t e0 = gl2_from(0), e1 = gl2_from(0);
-            for (size_t j = n0; j-- > 0;) e0 = gl2_add(gl2_mul(e0, fri_alpha), gl2_from(row[j]));
+            /* unsalted evaluations, oracle by oracle in reverse (Horner in alpha) */
+            for (int o = 3; o >= 0; o--) for (size_t j = polys[o]; j-- > 0;) e0 = gl2_add(gl2_mul(e0, fri_alpha), gl2_from(rows[o][j]));
             for (size_t j = nch; j-- > 0;) e1 = gl2_add(gl2_mul(e1, fri_alpha), gl2_from(rows[2][j]));
             gl2_t sx = gl2_from(subgroup_x);
             gl2_t sum = gl2_mul(gl2_sub(e0, red0), gl2_inv(gl2_sub(sx, zeta)));

@@ -62,6 +62,7 @@ def load_library():
         "qpgpu_circuit_free": (None, [vp]),
         "qpgpu_circuit_constants_sigmas_cap": (c.c_int, [vp, u64p, c.c_size_t]),
         "qpgpu_proof_size": (c.c_size_t, [vp]),
+        "qpgpu_circuit_set_blinding_seed": (c.c_int, [vp, c.c_uint64]),
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_synth_pack_words": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint]),
@@ -143,6 +144,10 @@ class Circuit:
 
     def proof_size(self):
         return self.gpu.lib.qpgpu_proof_size(self.h)
+
+    def set_blinding_seed(self, seed):
+        """Zero-knowledge packs: fixes the salts of the next proof (reproducible bytes)."""
+        self.gpu._check(self.gpu.lib.qpgpu_circuit_set_blinding_seed(self.h, seed))
 
     def constants_sigmas_cap(self, cap_height=4):
         out = np.empty((1 << cap_height, 4), dtype=np.uint64)

@@ -57,7 +57,7 @@ std::string CircuitPack::validate() const {
     if ((1ull << rate_bits) != quotient_degree_factor) return "this backend requires quotient_degree_factor == 2^rate_bits";
     if (num_partial_products + 1 != (num_routed_wires + quotient_degree_factor - 1) / quotient_degree_factor) return "num_partial_products inconsistent";
     if (cap_height > degree_bits + rate_bits) return "cap_height above tree height";
-    if (zero_knowledge) return "zero_knowledge packs are not supported yet";
+    if (zero_knowledge > 1) return "zero_knowledge must be 0 or 1";
     uint64_t sum = 0;
     for (auto a : arity_bits) { if (a == 0 || a > 4) return "unsupported FRI arity"; sum += a; }
     if (sum > degree_bits) return "FRI reductions exceed degree";

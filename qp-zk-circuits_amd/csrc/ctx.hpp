@@ -42,6 +42,8 @@ struct qpgpu_ctx {
     int upload(const std::vector<uint64_t> &host, uint64_t **dptr);
 };
 
+// HIP's current device is per host thread: every entry point selects the ctx's GPU first
+#define QP_DEV(ctx) do { hipError_t _e = hipSetDevice((ctx)->device); if (_e != hipSuccess) return (ctx)->hip_fail(_e, "hipSetDevice"); } while (0)
 #define QP_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->hip_fail(_e, #call); } while (0)
 
 struct MerkleLeafArgs;

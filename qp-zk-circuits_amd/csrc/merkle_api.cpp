@@ -45,6 +45,7 @@ size_t qpgpu_merkle_digest_count(unsigned log_leaves, unsigned cap_height) {
 int qpgpu_merkle_build_dev(qpgpu_ctx *ctx, const uint64_t *d_cols, uint64_t col_stride, uint32_t n_cols,
                            unsigned log_leaves, unsigned cap_height, uint64_t *d_digests, uint64_t *h_cap_out) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     if (!d_cols || !d_digests || n_cols == 0) return ctx->fail(QPGPU_EINVAL, "merkle: null buffer or no columns");
     if (log_leaves > 40) return ctx->fail(QPGPU_EINVAL, "merkle: log_leaves out of range");
     MerkleLeafArgs a{};
@@ -63,6 +64,7 @@ int qpgpu_merkle_build_dev(qpgpu_ctx *ctx, const uint64_t *d_cols, uint64_t col_
 int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t width, unsigned log_leaves,
                                 unsigned cap_height, uint64_t *d_digests, uint64_t *h_cap_out) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     if (!d_rows || !d_digests || width == 0) return ctx->fail(QPGPU_EINVAL, "merkle: null buffer or zero width");
     if (cap_height > log_leaves) return ctx->fail(QPGPU_EINVAL, "merkle: cap_height exceeds tree height");
     int rc = merkle_ensure_constants(ctx);
@@ -85,6 +87,7 @@ int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t
 
 int qpgpu_poseidon_permute_dev(qpgpu_ctx *ctx, uint64_t *d_states, size_t n) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     if (!d_states && n) return ctx->fail(QPGPU_EINVAL, "poseidon: null buffer");
     int rc = merkle_ensure_constants(ctx);
     if (rc) return rc;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
 #include "circuit.hpp"
@@ -63,6 +64,8 @@ struct DevBatch {
     uint32_t ncols = 0;
     unsigned log_n = 0;
     u64 *coeffs = nullptr, *lde = nullptr, *digests = nullptr;
+    u64 *salt = nullptr;            // [4][lde_n] when the oracle is blinded
+    uint32_t oracle_index = 0;
     std::vector<u64> cap;
 };
 
@@ -89,6 +92,8 @@ struct qpgpu_circuit {
     std::vector<u64 *> d_fri_digests, d_fri_leafrows;
     u64 *d_pow = nullptr, *d_qidx = nullptr, *d_gather = nullptr;
     size_t gather_words = 0;
+    bool seed_set = false;
+    u64 blinding_seed = 0;
 
     template <class T> int alloc(T **p, size_t count) {
         void *v = nullptr;
@@ -106,7 +111,9 @@ size_t digest_words(unsigned log_leaves, unsigned cap_h) { return ((2ull << log_
 
 #define QP_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-int alloc_batch(qpgpu_circuit *c, DevBatch &b, uint32_t ncols, bool need_coeffs = true) {
+int alloc_batch(qpgpu_circuit *c, DevBatch &b, uint32_t ncols, bool need_coeffs = true, uint32_t oracle_index = 0) {
+    b.oracle_index = oracle_index;
+    if (oracle_index > 0 && c->pack.zero_knowledge) QP_TRY(c->alloc(&b.salt, (size_t)4 << (c->pack.degree_bits + c->pack.rate_bits)));
     const CircuitPack &p = c->pack;
     const u64 n = p.n(), lde_n = n << p.rate_bits;
     b.ncols = ncols; b.log_n = (unsigned)p.degree_bits;
@@ -125,6 +132,10 @@ int commit_coeffs(qpgpu_circuit *c, DevBatch &b) {
     QP_TRY(ntt_run(ctx, b.coeffs, b.lde, b.log_n, L, b.ncols, false, true, gl::MULT_GEN));
     MerkleLeafArgs a{};
     a.src0 = b.lde; a.stride0 = 1ull << L; a.ncols0 = b.ncols; a.n_leaves = 1ull << L; a.digests = b.digests;
+    if (b.salt) {
+        QP_HIP(ctx, pk_salt(c->blinding_seed, b.oracle_index, 1ull << L, b.salt, ctx->stream));
+        a.src1 = b.salt; a.stride1 = 1ull << L; a.ncols1 = 4;
+    }
     QP_TRY(merkle_build(ctx, a, L, (unsigned)p.cap_height, b.digests));
     const size_t total = digest_words(L, (unsigned)p.cap_height);
     QP_HIP(ctx, hipMemcpyAsync(b.cap.data(), b.digests + total - b.cap.size(), b.cap.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -161,7 +172,8 @@ size_t qpgpu_proof_size(const qpgpu_circuit *c) {
     const size_t ncs = p.num_cs_cols(), nch = p.num_challenges, cap = (1ull << p.cap_height) * 32;
     const size_t L = p.degree_bits + p.rate_bits;
     size_t sz = 3 * cap + (ncs + p.num_wires + nch * 2 + nch * p.num_partial_products + p.num_quotient_cols()) * 16;
-    const size_t widths[4] = {ncs, (size_t)p.num_wires, (size_t)p.num_zs_pp_cols(), (size_t)p.num_quotient_cols()};
+    const size_t salt = p.zero_knowledge ? 4 : 0;
+    const size_t widths[4] = {ncs, (size_t)p.num_wires + salt, (size_t)p.num_zs_pp_cols() + salt, (size_t)p.num_quotient_cols() + salt};
     size_t q = 0, lvl = L, fin = p.degree_bits;
     for (size_t w : widths) q += w * 8 + 1 + (L - p.cap_height) * 32;
     for (u64 a : p.arity_bits) { sz += cap; lvl -= a; fin -= a; q += (16ull << a) + 1 + (lvl - p.cap_height) * 32; }
@@ -177,6 +189,7 @@ void qpgpu_circuit_free(qpgpu_circuit *c) {
 
 int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_words, qpgpu_circuit **out) {
     if (!ctx || !out) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     *out = nullptr;
     if (!pack_words) return ctx->fail(QPGPU_EINVAL, "circuit_load: null pack");
     qpgpu_circuit *c = new qpgpu_circuit();
@@ -234,9 +247,9 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     }
     // per-proof workspace
     CK(c->alloc(&c->d_wires_vals, (size_t)p.num_wires * n));
-    CK(alloc_batch(c, c->wires, (uint32_t)p.num_wires));
-    CK(alloc_batch(c, c->zs, (uint32_t)p.num_zs_pp_cols()));
-    CK(alloc_batch(c, c->quot, (uint32_t)p.num_quotient_cols(), false));
+    CK(alloc_batch(c, c->wires, (uint32_t)p.num_wires, true, 1));
+    CK(alloc_batch(c, c->zs, (uint32_t)p.num_zs_pp_cols(), true, 2));
+    CK(alloc_batch(c, c->quot, (uint32_t)p.num_quotient_cols(), false, 3));
     CK(c->alloc(&c->quot.coeffs, (size_t)nch * lde_n));       // quotient values -> coefficients, = nq chunks of n
     CK(c->alloc(&c->d_qcp, (size_t)nch * p.num_chunks() * n));
     CK(c->alloc(&c->d_rowprod, (size_t)nch * n));
@@ -256,7 +269,8 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     {
         unsigned lvl = L;
         size_t gw = 0;
-        const size_t widths[4] = {(size_t)p.num_cs_cols(), (size_t)p.num_wires, (size_t)p.num_zs_pp_cols(), (size_t)p.num_quotient_cols()};
+        const size_t salt = p.zero_knowledge ? 4 : 0;
+        const size_t widths[4] = {(size_t)p.num_cs_cols(), (size_t)p.num_wires + salt, (size_t)p.num_zs_pp_cols() + salt, (size_t)p.num_quotient_cols() + salt};
         for (size_t w : widths) gw += w + (L - p.cap_height) * 4;
         for (u64 a : p.arity_bits) {
             lvl -= (unsigned)a;
@@ -274,6 +288,12 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #undef CK
     *out = c;
+    return QPGPU_OK;
+}
+
+int qpgpu_circuit_set_blinding_seed(qpgpu_circuit *c, uint64_t seed) {
+    if (!c) return QPGPU_EINVAL;
+    c->blinding_seed = seed; c->seed_set = true;
     return QPGPU_OK;
 }
 
@@ -296,6 +316,11 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
 
     u64 pih[4];
     host_hash_no_pad(public_inputs, p.num_public_inputs, pih);
+    if (p.zero_knowledge && !c->seed_set) {   // fresh randomness per proof unless the caller injected a seed
+        std::random_device rd;
+        c->blinding_seed = ((u64)rd() << 32) ^ (u64)rd() ^ ((u64)rd() << 17);
+    }
+    c->seed_set = false;
 
     // ---- s2/s3 wires ----
     ctx->prof_begin("prove_commit_wires");
@@ -486,16 +511,20 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     for (auto &x : qidx) x = ch.get() % lde_n;
     QP_HIP(ctx, hipMemcpyAsync(c->d_qidx, qidx.data(), nqr * 8, hipMemcpyHostToDevice, st));
     // gather layout (per section, all queries contiguous): for each oracle rows then paths; for each FRI round evals then paths
-    struct Sec { size_t off, words; };
+    struct Sec { size_t off, words; bool is_path; };
     std::vector<Sec> secs;
     size_t goff = 0;
     const DevBatch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
     const uint32_t plen0 = L - cap_h;
     for (const DevBatch *b : bs) {
         QP_HIP(ctx, pk_gather_rows(b->lde, lde_n, b->ncols, c->d_qidx, nqr, c->d_gather + goff, st));
-        secs.push_back({goff, b->ncols}); goff += (size_t)b->ncols * nqr;
+        secs.push_back({goff, b->ncols, false}); goff += (size_t)b->ncols * nqr;
+        if (b->salt) {
+            QP_HIP(ctx, pk_gather_rows(b->salt, lde_n, 4, c->d_qidx, nqr, c->d_gather + goff, st));
+            secs.push_back({goff, 4, false}); goff += (size_t)4 * nqr;
+        }
         QP_HIP(ctx, pk_gather_paths(b->digests, lde_n, plen0, c->d_qidx, 0, nqr, c->d_gather + goff, st));
-        secs.push_back({goff, (size_t)plen0 * 4}); goff += (size_t)plen0 * 4 * nqr;
+        secs.push_back({goff, (size_t)plen0 * 4, true}); goff += (size_t)plen0 * 4 * nqr;
     }
     {
         uint32_t sh = 0;
@@ -503,9 +532,9 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
             const uint32_t ab = (uint32_t)p.arity_bits[r], width = 2u << ab, pl = tree_log_leaves[r] - cap_h;
             sh += ab;
             QP_HIP(ctx, pk_gather_leaf_rows(c->d_fri_leafrows[r], width, c->d_qidx, sh, nqr, c->d_gather + goff, st));
-            secs.push_back({goff, width}); goff += (size_t)width * nqr;
+            secs.push_back({goff, width, false}); goff += (size_t)width * nqr;
             QP_HIP(ctx, pk_gather_paths(c->d_fri_digests[r], 1ull << tree_log_leaves[r], pl, c->d_qidx, sh, nqr, c->d_gather + goff, st));
-            secs.push_back({goff, (size_t)pl * 4}); goff += (size_t)pl * 4 * nqr;
+            secs.push_back({goff, (size_t)pl * 4, true}); goff += (size_t)pl * 4 * nqr;
         }
     }
     if (goff != c->gather_words) return ctx->fail(QPGPU_EDEVICE, "prove: internal gather size mismatch");
@@ -526,11 +555,9 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     for (size_t i = 0; i < nq; i++) w.ext(o_q[i]);            // quotient_polys (lookup vectors are empty)
     for (auto &cp : fri_caps) w.vec(cp.data(), cap_words);
     for (uint32_t q = 0; q < nqr; q++) {
-        for (size_t s = 0; s < secs.size(); s += 2) {
-            w.vec(gathered.data() + secs[s].off + (size_t)q * secs[s].words, secs[s].words);
-            const size_t pw = secs[s + 1].words;
-            w.u8((uint8_t)(pw / 4));
-            w.vec(gathered.data() + secs[s + 1].off + (size_t)q * pw, pw);
+        for (const Sec &sc : secs) {
+            if (sc.is_path) w.u8((uint8_t)(sc.words / 4));   // write_merkle_proof: one-byte sibling count
+            w.vec(gathered.data() + sc.off + (size_t)q * sc.words, sc.words);
         }
     }
     for (u64 i = 0; i < valid; i++) w.ext(final_poly[i]);
@@ -543,12 +570,14 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
 
 int qpgpu_prove_dev(qpgpu_circuit *c, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len) {
     if (!c) return QPGPU_EINVAL;
+    QP_DEV(c->ctx);
     if (!d_wires || (!public_inputs && c->pack.num_public_inputs) || !out) return c->ctx->fail(QPGPU_EINVAL, "prove: null argument");
     return prove_impl(c, d_wires, public_inputs, out, out_cap, out_len);
 }
 
 int qpgpu_prove(qpgpu_circuit *c, const uint64_t *wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len) {
     if (!c) return QPGPU_EINVAL;
+    QP_DEV(c->ctx);
     if (!wires || (!public_inputs && c->pack.num_public_inputs) || !out) return c->ctx->fail(QPGPU_EINVAL, "prove: null argument");
     const size_t bytes = (size_t)c->pack.num_wires * c->pack.n() * 8;
     QP_TRY(h2d(c->ctx, c->d_wires_vals, wires, bytes));

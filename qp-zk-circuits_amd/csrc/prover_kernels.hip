@@ -303,6 +303,20 @@ __global__ void gather_leaf_rows_kernel(const u64 *rows, u32 width, const u64 *i
     for (u32 e = threadIdx.x; e < width; e += blockDim.x) out[(u64)q * width + e] = rows[(idx[q] >> shift) * width + e];
 }
 
+// salt columns of a blinded oracle (PolynomialBatch::from_coeffs with blinding: SALT_SIZE = 4 random columns in
+// every leaf). The reference draws them from thread_rng; here a counter-mode splitmix64 keyed by the caller's seed,
+// so a proof is reproducible under an injected seed.
+__global__ void __launch_bounds__(256) salt_kernel(u64 seed, u32 oracle_index, u64 lde_n, u64 *out) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= lde_n) return;
+    for (u32 c = 0; c < 4; c++) {
+        const u64 ctr = ((u64)(oracle_index * 4 + c) << 40) | j;
+        u64 z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        out[(u64)c * lde_n + j] = gl::canon(z);
+    }
+}
+
 // x_coset[j] = g * w^bitrev(j), l0_coset[j] = zh(i) / (n (x - 1))
 __global__ void __launch_bounds__(256) coset_tables_kernel(u64 lde_n, u32 log_lde, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits,
                                                              const u64 *zh, u32 rate, u64 n_field, u64 *x_coset, u64 *l0_coset) {
@@ -374,6 +388,10 @@ hipError_t pk_gather_paths(const u64 *digests, u64 n_leaves, u32 path_len, const
 }
 hipError_t pk_gather_leaf_rows(const u64 *rows, u32 width, const u64 *idx, u32 shift, u32 nq, u64 *out, hipStream_t st) {
     hipLaunchKernelGGL(gather_leaf_rows_kernel, dim3(nq), dim3(64), 0, st, rows, width, idx, shift, out);
+    return hipGetLastError();
+}
+hipError_t pk_salt(u64 seed, u32 oracle_index, u64 lde_n, u64 *out, hipStream_t st) {
+    LAUNCH_1D(salt_kernel, lde_n, 256, st, seed, oracle_index, lde_n, out);
     return hipGetLastError();
 }
 hipError_t pk_coset_tables(u64 lde_n, u32 log_lde, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits, const u64 *zh, u32 rate,

@@ -60,5 +60,6 @@ hipError_t pk_pow(const PowArgs &a, hipStream_t st);   // defined next to the Po
 hipError_t pk_gather_rows(const uint64_t *cols, uint64_t stride, uint32_t ncols, const uint64_t *idx, uint32_t nq, uint64_t *out, hipStream_t st);
 hipError_t pk_gather_paths(const uint64_t *digests, uint64_t n_leaves, uint32_t path_len, const uint64_t *idx, uint32_t shift, uint32_t nq, uint64_t *out, hipStream_t st);
 hipError_t pk_gather_leaf_rows(const uint64_t *rows, uint32_t width, const uint64_t *idx, uint32_t shift, uint32_t nq, uint64_t *out, hipStream_t st);
+hipError_t pk_salt(uint64_t seed, uint32_t oracle_index, uint64_t lde_n, uint64_t *out, hipStream_t st);
 hipError_t pk_coset_tables(uint64_t lde_n, uint32_t log_lde, const uint64_t *pw_lo, const uint64_t *pw_hi, uint32_t lo_bits, const uint64_t *zh,
                            uint32_t rate, uint64_t n_field, uint64_t *x_coset, uint64_t *l0_coset, hipStream_t st);

@@ -33,6 +33,7 @@ extern "C" {
 
 int qpgpu_profile_enable(qpgpu_ctx *ctx, int on) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     int rc = ctx->prof_collect();
     ctx->profiling = on != 0;
     if (on) ctx->kstats.clear();
@@ -40,6 +41,7 @@ int qpgpu_profile_enable(qpgpu_ctx *ctx, int on) {
 }
 int qpgpu_profile_read(qpgpu_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
     if (!ctx || !kernel) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     int rc = ctx->prof_collect();
     if (rc) return rc;
     auto it = ctx->kstats.find(kernel);
@@ -79,6 +81,7 @@ const char *qpgpu_last_error(const qpgpu_ctx *ctx) { return ctx ? ctx->err.c_str
 
 int qpgpu_ctx_set_stream(qpgpu_ctx *ctx, void *hip_stream) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) { QP_HIP(ctx, hipStreamDestroy(ctx->stream)); ctx->own_stream = false; }
     if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
@@ -88,6 +91,7 @@ int qpgpu_ctx_set_stream(qpgpu_ctx *ctx, void *hip_stream) {
 
 int qpgpu_sync(qpgpu_ctx *ctx) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return QPGPU_OK;
 }
@@ -102,18 +106,21 @@ int qpgpu_malloc(qpgpu_ctx *ctx, size_t bytes, void **dptr) {
 }
 int qpgpu_free(qpgpu_ctx *ctx, void *dptr) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     QP_HIP(ctx, hipFree(dptr));
     return QPGPU_OK;
 }
 int qpgpu_memcpy_h2d(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx || (!dst && bytes) || (!src && bytes)) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     QP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return QPGPU_OK;
 }
 int qpgpu_memcpy_d2h(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx || (!dst && bytes) || (!src && bytes)) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     QP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return QPGPU_OK;
@@ -122,6 +129,7 @@ int qpgpu_memcpy_d2h(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
 int qpgpu_ntt_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, size_t batch,
                         int flags, uint64_t coset_shift) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     if ((!d_in || !d_out) && batch) return ctx->fail(QPGPU_EINVAL, "ntt: null buffer");
     if (flags & ~3) return ctx->fail(QPGPU_EINVAL, "ntt: unknown flag");
     return ntt_run(ctx, d_in, d_out, log_n, log_n, batch, (flags & QPGPU_NTT_INVERSE) != 0,
@@ -131,6 +139,7 @@ int qpgpu_ntt_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, u
 int qpgpu_lde_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_out, unsigned log_n,
                         unsigned rate_bits, size_t batch, int flags, uint64_t coset_shift) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     if ((!d_coeffs || !d_out) && batch) return ctx->fail(QPGPU_EINVAL, "lde: null buffer");
     if (flags & ~QPGPU_NTT_OUT_BITREV) return ctx->fail(QPGPU_EINVAL, "lde: unknown flag");
     if (d_coeffs == d_out && rate_bits) return ctx->fail(QPGPU_EINVAL, "lde: in-place extension is not possible");
@@ -140,6 +149,7 @@ int qpgpu_lde_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_ou
 
 int qpgpu_ntt_batch(qpgpu_ctx *ctx, uint64_t *data, unsigned log_n, size_t batch, int flags, uint64_t coset_shift) {
     if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
     if (!data && batch) return ctx->fail(QPGPU_EINVAL, "ntt: null buffer");
     if (log_n > 40) return ctx->fail(QPGPU_EINVAL, "ntt: log_n out of range");
     size_t bytes = (batch << log_n) * sizeof(uint64_t);

@@ -58,6 +58,8 @@ class Oracle:
         L.orc_proof_size.restype = ctypes.c_size_t; L.orc_proof_size.argtypes = [ctypes.c_void_p]
         L.orc_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                 ctypes.POINTER(ctypes.c_size_t)]
+        L.orc_prove_seeded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                       ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.orc_verify.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         L.orc_trace_len.restype = ctypes.c_size_t; L.orc_trace_len.argtypes = [ctypes.c_char_p]
         L.orc_trace_get.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
@@ -151,10 +153,10 @@ class OracleCircuit:
         if self.h:
             self.orc.lib.orc_circuit_free(self.h); self.h = None
     def proof_size(self): return self.orc.lib.orc_proof_size(self.h)
-    def prove(self, wires, pis):
+    def prove(self, wires, pis, seed=0):
         w = np.ascontiguousarray(wires, dtype=np.uint64); p = np.ascontiguousarray(pis, dtype=np.uint64)
         out = np.empty(self.proof_size(), dtype=np.uint8); ln = ctypes.c_size_t()
-        rc = self.orc.lib.orc_prove(self.h, _vp(w), _vp(p), _vp(out), out.size, ctypes.byref(ln))
+        rc = self.orc.lib.orc_prove_seeded(self.h, _vp(w), _vp(p), seed, _vp(out), out.size, ctypes.byref(ln))
         assert rc == 0 and ln.value == out.size, (rc, ln.value, out.size)
         return out.tobytes()
     def verify(self, proof_bytes):

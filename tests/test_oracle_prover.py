@@ -53,3 +53,19 @@ def test_standard_shape_proof(pkg, orc):
     assert len(oc.trace("query_indices")) == 28
     assert int(oc.trace("pow_witness")[0]) < 2**24
     oc.close()
+
+
+def test_zero_knowledge_salts(pkg, orc):
+    """Blinded oracles (private-batch config): 4 salt columns per leaf; reproducible under an injected seed,
+    different under another seed, and the verifier strips the salts from the FRI combination."""
+    pack, wires, pis = pkg.synth_circuit(6, num_wires=24, num_routed=16, num_public_inputs=5, seed=3)
+    zk = pack.copy(); zk[14] = 1                      # header word 14 = zero_knowledge
+    oc = OracleCircuit(orc, zk)
+    plain = OracleCircuit(orc, pack)
+    assert oc.proof_size() == plain.proof_size() + 28 * 3 * 4 * 8
+    a = oc.prove(wires, pis, seed=11); b = oc.prove(wires, pis, seed=11); c = oc.prove(wires, pis, seed=12)
+    assert a == b and a != c
+    assert oc.verify(a) == 0 and oc.verify(c) == 0
+    cap = 16 * 4 * 8
+    assert a[:cap] != plain.prove(wires, pis)[:cap]    # salts change every commitment
+    oc.close(); plain.close()

@@ -73,3 +73,18 @@ def test_bad_pack_is_a_loud_error(pkg, gpu):
         pkg.Circuit(gpu, broken)
     with pytest.raises(pkg.QpGpuError):
         pkg.Circuit(gpu, pack[:-3])
+
+
+def test_zero_knowledge_proof_matches_oracle_under_seed(pkg, gpu, orc):
+    pack, wires, pis = pkg.synth_circuit(9, num_wires=135, num_routed=80, num_public_inputs=21, seed=9)
+    zk = pack.copy(); zk[14] = 1
+    circ = pkg.Circuit(gpu, zk); oc = OracleCircuit(orc, zk)
+    assert circ.proof_size() == oc.proof_size()
+    circ.set_blinding_seed(0xC0FFEE)
+    got = circ.prove(wires, pis)
+    assert got == oc.prove(wires, pis, seed=0xC0FFEE)
+    assert oc.verify(got) == 0
+    # without an injected seed every proof is freshly randomized, still valid
+    p1, p2 = circ.prove(wires, pis), circ.prove(wires, pis)
+    assert p1 != p2 and oc.verify(p1) == 0 and oc.verify(p2) == 0
+    circ.close(); oc.close()
