@@ -137,6 +137,12 @@ int qpgpu_prove_dev(qpgpu_circuit *c, const uint64_t *d_wires, const uint64_t *p
  * pis_out num_public_inputs elements. Host-only; no GPU needed.
  */
 size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed);
+/* flags bit 0: every 8th row is a PoseidonGate row (135 wires, 123 constraints of degree 7, its own selector group),
+ * the gate that dominates the recursive (aggregator) circuits. */
+size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags);
+int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
+                           uint64_t seed, unsigned flags, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,
+                           uint64_t *wires_out, uint64_t *pis_out);
 int qpgpu_synth_circuit(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         uint64_t seed, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,
                         uint64_t *wires_out, uint64_t *pis_out);

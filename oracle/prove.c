@@ -127,6 +127,92 @@ static gl_t gate_filter(const orc_circuit *c, size_t gi, gl_t s) {
     if (c->num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFULL, s));
     return f;
 }
+/*
+ * PoseidonGate (plonky2::gates::poseidon): wires 0..11 input, 12..23 output, 24 swap, 25..28 delta, 29..64 S-box inputs
+ * of full rounds 1..3, 65..86 S-box inputs of the 22 partial rounds, 87..134 S-box inputs of the last 4 full rounds;
+ * 123 constraints of degree 7. Deviation kept explicit: partial rounds are evaluated in textbook form (constant layer,
+ * S-box on element 0, dense MDS), not in upstream's fast-partial basis, because FAST_PARTIAL_* tables are not derivable
+ * here; wire layout, constraint count and degree are upstream's.
+ */
+void orc_poseidon_round_constants(gl_t *out);
+static gl_t PRC[360]; static int prc_ready = 0;
+static const gl_t PMDS[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+static void pg_mds(gl_t s[12]) {
+    gl_t o[12];
+    for (int r = 0; r < 12; r++) {
+        u128 acc = 0;
+        for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * PMDS[i];
+        if (r == 0) acc += (u128)s[0] * 8;
+        o[r] = gl_reduce128(acc);
+    }
+    memcpy(s, o, sizeof o);
+}
+static inline gl_t pg_sbox(gl_t x) { gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2); return gl_mul(gl_mul(x, x2), x4); }
+/* emits the 123 constraints into out[] */
+static void poseidon_gate_base(const gl_t *w, gl_t *out) {
+    if (!prc_ready) { orc_poseidon_round_constants(PRC); prc_ready = 1; }
+    size_t k = 0;
+    gl_t swap = w[24], st[12];
+    out[k++] = gl_mul(swap, gl_sub(swap, 1));
+    for (int i = 0; i < 4; i++) out[k++] = gl_sub(gl_mul(swap, gl_sub(w[i + 4], w[i])), w[25 + i]);
+    for (int i = 0; i < 4; i++) { st[i] = gl_add(w[i], w[25 + i]); st[i + 4] = gl_sub(w[i + 4], w[25 + i]); }
+    for (int i = 8; i < 12; i++) st[i] = w[i];
+    int rc = 0;
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], PRC[rc * 12 + i]);
+        if (r) for (int i = 0; i < 12; i++) { gl_t in = w[29 + 12 * (r - 1) + i]; out[k++] = gl_sub(st[i], in); st[i] = in; }
+        for (int i = 0; i < 12; i++) st[i] = pg_sbox(st[i]);
+        pg_mds(st);
+    }
+    for (int r = 0; r < 22; r++, rc++) {
+        for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], PRC[rc * 12 + i]);
+        gl_t in = w[65 + r]; out[k++] = gl_sub(st[0], in); st[0] = pg_sbox(in);
+        pg_mds(st);
+    }
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], PRC[rc * 12 + i]);
+        for (int i = 0; i < 12; i++) { gl_t in = w[87 + 12 * r + i]; out[k++] = gl_sub(st[i], in); st[i] = in; }
+        for (int i = 0; i < 12; i++) st[i] = pg_sbox(st[i]);
+        pg_mds(st);
+    }
+    for (int i = 0; i < 12; i++) out[k++] = gl_sub(st[i], w[12 + i]);
+}
+static void pg_mds_ext(gl2_t s[12]) {
+    gl_t a[12], b[12];
+    for (int i = 0; i < 12; i++) { a[i] = s[i].c[0]; b[i] = s[i].c[1]; }
+    pg_mds(a); pg_mds(b);
+    for (int i = 0; i < 12; i++) s[i] = gl2_make(a[i], b[i]);
+}
+static inline gl2_t pg_sbox_ext(gl2_t x) { gl2_t x2 = gl2_mul(x, x), x4 = gl2_mul(x2, x2); return gl2_mul(gl2_mul(x, x2), x4); }
+static void poseidon_gate_ext(const gl2_t *w, gl2_t *out) {
+    if (!prc_ready) { orc_poseidon_round_constants(PRC); prc_ready = 1; }
+    size_t k = 0;
+    gl2_t swap = w[24], st[12];
+    out[k++] = gl2_mul(swap, gl2_sub(swap, gl2_from(1)));
+    for (int i = 0; i < 4; i++) out[k++] = gl2_sub(gl2_mul(swap, gl2_sub(w[i + 4], w[i])), w[25 + i]);
+    for (int i = 0; i < 4; i++) { st[i] = gl2_add(w[i], w[25 + i]); st[i + 4] = gl2_sub(w[i + 4], w[25 + i]); }
+    for (int i = 8; i < 12; i++) st[i] = w[i];
+    int rc = 0;
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from(PRC[rc * 12 + i]));
+        if (r) for (int i = 0; i < 12; i++) { gl2_t in = w[29 + 12 * (r - 1) + i]; out[k++] = gl2_sub(st[i], in); st[i] = in; }
+        for (int i = 0; i < 12; i++) st[i] = pg_sbox_ext(st[i]);
+        pg_mds_ext(st);
+    }
+    for (int r = 0; r < 22; r++, rc++) {
+        for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from(PRC[rc * 12 + i]));
+        gl2_t in = w[65 + r]; out[k++] = gl2_sub(st[0], in); st[0] = pg_sbox_ext(in);
+        pg_mds_ext(st);
+    }
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from(PRC[rc * 12 + i]));
+        for (int i = 0; i < 12; i++) { gl2_t in = w[87 + 12 * r + i]; out[k++] = gl2_sub(st[i], in); st[i] = in; }
+        for (int i = 0; i < 12; i++) st[i] = pg_sbox_ext(st[i]);
+        pg_mds_ext(st);
+    }
+    for (int i = 0; i < 12; i++) out[k++] = gl2_sub(st[i], w[12 + i]);
+}
+
 /* adds filter * constraint_k into acc[k]. consts = local constants after the selector prefix. */
 static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t *wires, const gl_t pih[4], gl_t *acc) {
     const gl_t *consts = cs_row + c->num_selectors;
@@ -148,6 +234,12 @@ static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t
                 acc[i] = gl_add(acc[i], gl_mul(f, gl_sub(out, computed)));
             }
             break;
+        case OG_POSEIDON: {
+            gl_t cst[123];
+            poseidon_gate_base(wires, cst);
+            for (int i = 0; i < 123; i++) acc[i] = gl_add(acc[i], gl_mul(f, cst[i]));
+            break;
+        }
         default: break;
         }
     }
@@ -179,6 +271,12 @@ void orc_eval_gates_ext(const orc_circuit *c, const gl2_t *cs_row, const gl2_t *
                 acc[i] = gl2_add(acc[i], gl2_mul(f, gl2_sub(wires[4 * i + 3], computed)));
             }
             break;
+        case OG_POSEIDON: {
+            gl2_t cst[123];
+            poseidon_gate_ext(wires, cst);
+            for (int i = 0; i < 123; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, cst[i]));
+            break;
+        }
         default: break;
         }
     }

@@ -66,6 +66,9 @@ def load_library():
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_synth_pack_words": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint]),
+        "qpgpu_synth_pack_words_ex": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint, c.c_uint]),
+        "qpgpu_synth_circuit_ex": (c.c_int, [c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint, u64p, c.c_size_t,
+                                             c.POINTER(c.c_size_t), u64p, u64p]),
         "qpgpu_synth_circuit": (c.c_int, [c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, u64p, c.c_size_t,
                                           c.POINTER(c.c_size_t), u64p, u64p]),
     }
@@ -85,16 +88,18 @@ def exported_symbols():
     return sorted(set(re.findall(r"\b(qpgpu_[a-z0-9_]+)\s*\(", text)))
 
 
-def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=21, seed=1):
-    """Synthetic satisfied circuit: returns (pack_words, wires[num_wires, n], public_inputs). Host only."""
+def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=21, seed=1, poseidon=False):
+    """Synthetic satisfied circuit: returns (pack_words, wires[num_wires, n], public_inputs). Host only.
+    poseidon=True adds PoseidonGate rows (needs 135 wires)."""
     lib = load_library()
-    words = lib.qpgpu_synth_pack_words(degree_bits, num_wires, num_routed)
+    flags = 1 if poseidon else 0
+    words = lib.qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, flags)
     pack = np.empty(words, dtype=np.uint64)
     wires = np.empty((num_wires, 1 << degree_bits), dtype=np.uint64)
     pis = np.empty(num_public_inputs, dtype=np.uint64)
     got = ctypes.c_size_t()
-    rc = lib.qpgpu_synth_circuit(degree_bits, num_wires, num_routed, num_public_inputs, seed, pack.ctypes.data, words,
-                                 ctypes.byref(got), wires.ctypes.data, pis.ctypes.data)
+    rc = lib.qpgpu_synth_circuit_ex(degree_bits, num_wires, num_routed, num_public_inputs, seed, flags, pack.ctypes.data,
+                                    words, ctypes.byref(got), wires.ctypes.data, pis.ctypes.data)
     if rc != 0 or got.value != words:
         raise QpGpuError(rc, f"synth_circuit failed (words {got.value} vs {words})")
     return pack, wires, pis

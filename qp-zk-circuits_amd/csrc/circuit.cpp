@@ -69,7 +69,7 @@ std::string CircuitPack::validate() const {
         if (g.type == GATE_ARITHMETIC && (g.param0 * 4 > num_routed_wires || g.num_constraints != g.param0 || num_constants < 2)) return "bad arithmetic gate";
         if (g.type == GATE_CONSTANT && (g.param0 > num_constants || g.param0 > num_wires || g.num_constraints != g.param0)) return "bad constant gate";
         if (g.type == GATE_PUBLIC_INPUT && (num_wires < 4 || g.num_constraints != 4)) return "bad public input gate";
-        if (g.type == GATE_POSEIDON) return "poseidon gate not supported yet";
+        if (g.type == GATE_POSEIDON && (num_wires < 135 || num_routed_wires < 25 || g.num_constraints != 123)) return "bad poseidon gate";
     }
     return "";
 }

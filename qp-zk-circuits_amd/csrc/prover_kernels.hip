@@ -13,6 +13,7 @@
 // per-point kernel reads one slot of every column with unit-stride across the wave.
 #include <hip/hip_runtime.h>
 #include "gl64.hpp"
+#include "poseidon.hpp"
 #include "prover_kernels.hpp"
 
 using gl::e2;
@@ -107,6 +108,62 @@ __device__ __forceinline__ u64 gate_filter(const QuotientArgs &a, u32 gi, u64 s)
     return f;
 }
 
+// PoseidonGate (plonky2::gates::poseidon) at one point: wires 0..11 input, 12..23 output, 24 swap, 25..28 delta,
+// 29..64 / 65..86 / 87..134 S-box inputs of the full / partial / full rounds; 123 constraints. Each constraint q is
+// weighted by alpha_c^(t+q) on the fly. Partial rounds in textbook form (see oracle/prove.c for the stated deviation).
+__device__ __noinline__ void poseidon_gate_point(const QuotientArgs &a, u64 j, u32 t, u64 (&sum)[4]) {
+    const u64 S = a.lde_n;
+    const u32 nch = a.nch;
+    auto W = [&](u32 i) -> u64 { return a.wires[(u64)i * S + j]; };
+    u32 q = 0;
+    auto emit = [&](u64 cst) {
+        for (u32 c = 0; c < nch; c++) sum[c] = gl::add(sum[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
+        q++;
+    };
+    const u64 swap = W(24);
+    emit(gl::mul(swap, gl::sub(swap, 1)));
+    u64 st[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 lhs = W(i), rhs = W(i + 4), delta = W(25 + i);
+        emit(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+        st[i] = gl::add(lhs, delta); st[i + 4] = gl::sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) st[i] = W(i);
+    int rc = 0;
+    for (int r = 0; r < 4; r++, rc++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);
+        if (r) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const u64 in = W(29 + 12 * (r - 1) + i); emit(gl::sub(st[i], in)); st[i] = in; }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+        poseidon::mds_layer(st);
+    }
+    for (int r = 0; r < 22; r++, rc++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);
+        const u64 in = W(65 + r);
+        emit(gl::sub(st[0], in));
+        st[0] = poseidon::sbox7(in);
+        poseidon::mds_layer(st);
+    }
+    for (int r = 0; r < 4; r++, rc++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);
+#pragma unroll
+        for (int i = 0; i < 12; i++) { const u64 in = W(87 + 12 * r + i); emit(gl::sub(st[i], in)); st[i] = in; }
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+        poseidon::mds_layer(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) emit(gl::sub(st[i], W(12 + i)));
+}
+
 // One thread per LDE slot j (point index i = bitrev(j), x = g w^i). Writes quotient values in natural order.
 __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -168,6 +225,10 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
                 const u64 cst = gl::mul(f, gl::sub(out, computed));
                 for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
             }
+        } else if (g.type == 4) {     // PoseidonGate
+            u64 sum[4] = {0, 0, 0, 0};
+            poseidon_gate_point(a, j, t, sum);
+            for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(f, sum[c]));
         }
     }
     const u64 zi = a.zh_inv[i & (a.rate - 1)];

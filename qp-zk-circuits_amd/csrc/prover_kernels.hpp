@@ -25,6 +25,7 @@ struct QuotientArgs {
     const uint64_t *alpha_pows;           // [nch][nterms]
     const uint64_t *beta_k_is, *betas, *gammas, *pi_hash;
     const GateDev *gates;
+    const uint64_t *poseidon_rc;          // 360 round constants (PoseidonGate)
     uint64_t *out;                        // [nch][lde_n] natural order
     uint64_t lde_n;
     uint32_t log_lde, rate, nch, num_routed, chunk, nchunks, sig0, num_selectors, num_gates, nterms;

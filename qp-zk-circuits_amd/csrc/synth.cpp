@@ -35,20 +35,22 @@ void synth_public_inputs_hash(const u64 *pis, size_t n, u64 out[4]) { host_hash_
 
 // Builds the pack and the witness. wires: num_wires x n column-major. Returns "" or an error.
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
-                        u64 seed, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
+                        u64 seed, unsigned flags, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
+    const bool with_poseidon = (flags & 1) != 0;
+    if (with_poseidon && (num_wires < 135 || num_routed < 28)) return "poseidon gates need 135 wires";
     if (degree_bits < 3 || degree_bits > 20) return "degree_bits out of range";
     if (num_routed < 8 || num_routed > num_wires || num_routed % 4) return "num_routed_wires must be a multiple of 4, >= 8";
     SplitMix rng{seed ^ 0x5EED5EED5EEDull};
     const u64 n = 1ull << degree_bits;
     pack = CircuitPack();
     pack.degree_bits = degree_bits; pack.num_wires = num_wires; pack.num_routed_wires = num_routed;
-    pack.num_constants = 2; pack.num_selectors = 1; pack.num_challenges = 2; pack.quotient_degree_factor = 8;
+    pack.num_constants = 2; pack.num_selectors = with_poseidon ? 2 : 1; pack.num_challenges = 2; pack.quotient_degree_factor = 8;
     pack.num_partial_products = (num_routed + 7) / 8 - 1; pack.num_public_inputs = num_public_inputs;
     pack.rate_bits = 3; pack.cap_height = 4; pack.proof_of_work_bits = 16; pack.num_query_rounds = 28;
     pack.zero_knowledge = 0;
     pack.arity_bits = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5);
     const u64 num_ops = num_routed / 4;
-    pack.num_gate_constraints = std::max<u64>(num_ops, 4);
+    pack.num_gate_constraints = std::max<u64>(std::max<u64>(num_ops, 4), with_poseidon ? 123 : 0);
     // gates sorted by (degree, id) as the builder does: Noop, Constant, PublicInput, Arithmetic; one selector group
     pack.gates = {
         {GATE_NOOP, 0, 0, 0, 0, 4, 0, 0},
@@ -56,6 +58,8 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
         {GATE_PUBLIC_INPUT, 0, 0, 0, 0, 4, 4, 0},
         {GATE_ARITHMETIC, num_ops, 0, 0, 0, 4, num_ops, 0},
     };
+    // PoseidonGate has degree 7: with 5 gates the builder's greedy grouping puts it in a selector group of its own
+    if (with_poseidon) pack.gates.push_back({GATE_POSEIDON, 0, 0, 1, 4, 5, 123, 0});
     pack.k_is.resize(num_routed);
     { u64 k = 1; for (unsigned j = 0; j < num_routed; j++) { pack.k_is[j] = gl::canon(k); k = gl::mul(k, gl::MULT_GEN); } }
 
@@ -70,6 +74,7 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     row_gate[0] = 2;
     for (u64 r = 1; r <= n_const_rows; r++) row_gate[r] = 1;
     for (u64 r = n - n_noop; r < n; r++) row_gate[r] = 0;
+    if (with_poseidon) for (u64 r = 8; r + n_noop < n; r += 8) row_gate[r] = 4;   // every 8th row hashes
 
     wires.assign((size_t)num_wires * n, 0);
     auto W = [&](u64 row, u64 col) -> u64 & { return wires[col * n + row]; };
@@ -87,14 +92,16 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     std::vector<uint32_t> pool;  // cells whose value may be copied
 
     for (u64 r = 0; r < n; r++) {
-        CS(r, 0) = row_gate[r];  // selector value = gate index
+        const u64 sel_cols = pack.num_selectors, UNUSED = 0xFFFFFFFFull;
+        if (!with_poseidon) CS(r, 0) = row_gate[r];            // selector value = gate index
+        else { CS(r, 0) = row_gate[r] == 4 ? UNUSED : row_gate[r]; CS(r, 1) = row_gate[r] == 4 ? 4 : UNUSED; }
         if (row_gate[r] == 2) {
             for (int i = 0; i < 4; i++) W(r, i) = pih[i];
         } else if (row_gate[r] == 1) {
-            for (int i = 0; i < 2; i++) { u64 c = rng.felt(); CS(r, 1 + i) = c; W(r, i) = c; pool.push_back(cell(r, i)); }
+            for (int i = 0; i < 2; i++) { u64 c = rng.felt(); CS(r, sel_cols + i) = c; W(r, i) = c; pool.push_back(cell(r, i)); }
         } else if (row_gate[r] == 3) {
             u64 c0 = (r & 1) ? rng.felt() : 1, c1 = (r & 2) ? rng.felt() : 1;
-            CS(r, 1) = c0; CS(r, 2) = c1;
+            CS(r, sel_cols) = c0; CS(r, sel_cols + 1) = c1;
             for (u64 op = 0; op < num_ops; op++) {
                 u64 in[3];
                 for (int k = 0; k < 3; k++) {
@@ -114,6 +121,51 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
                 pool.push_back(cell(r, 4 * op + 3));
                 if (pool.size() > 4096) pool.erase(pool.begin(), pool.begin() + 2048);
             }
+        } else if (row_gate[r] == 4) {
+            // PoseidonGate row: inputs (some copied), swap bit, deltas, recorded S-box inputs, outputs
+            const u64 *rcs = poseidon::host_round_constants();
+            u64 in[12];
+            for (int k = 0; k < 12; k++) {
+                if (!pool.empty() && rng.below(10) < 7) {
+                    uint32_t src = pool[rng.below(pool.size())];
+                    in[k] = wires[(size_t)(src % num_routed) * n + src / num_routed];
+                    W(r, k) = in[k];
+                    uint32_t a = find(src), b = find(cell(r, k));
+                    if (a != b) parent[b] = a;
+                } else in[k] = W(r, k);
+            }
+            const u64 swap = rng.below(2);
+            W(r, 24) = swap;
+            u64 st[12];
+            for (int i = 0; i < 4; i++) {
+                u64 delta = swap ? gl::canon(gl::sub(in[i + 4], in[i])) : 0;
+                W(r, 25 + i) = delta;
+                st[i] = gl::canon(gl::add(in[i], delta)); st[i + 4] = gl::canon(gl::sub(in[i + 4], delta));
+            }
+            for (int i = 8; i < 12; i++) st[i] = in[i];
+            int rc = 0;
+            for (int rr = 0; rr < 4; rr++, rc++) {
+                for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
+                if (rr) for (int i = 0; i < 12; i++) W(r, 29 + 12 * (rr - 1) + i) = st[i];
+                for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+                poseidon::mds_layer(st);
+                for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+            }
+            for (int rr = 0; rr < 22; rr++, rc++) {
+                for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
+                W(r, 65 + rr) = st[0];
+                st[0] = poseidon::sbox7(st[0]);
+                poseidon::mds_layer(st);
+                for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+            }
+            for (int rr = 0; rr < 4; rr++, rc++) {
+                for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
+                for (int i = 0; i < 12; i++) W(r, 87 + 12 * rr + i) = st[i];
+                for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+                poseidon::mds_layer(st);
+                for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+            }
+            for (int i = 0; i < 12; i++) { W(r, 12 + i) = st[i]; pool.push_back(cell(r, 12 + i)); }
         }
     }
     // sigma: cycle through each copy class
@@ -138,7 +190,7 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
             CS(r, sig0 + c) = gl::canon(gl::mul(pack.k_is[t % num_routed], omega_pow[t / num_routed]));
         }
     // circuit_digest: any 4 elements bound to the shape (the real one comes from the builder)
-    u64 shape[6] = {degree_bits, num_wires, num_routed, num_public_inputs, seed % gl::P, 0x51504350};
+    u64 shape[6] = {degree_bits, num_wires, num_routed, num_public_inputs, seed % gl::P, 0x51504350ull + flags};
     host_hash_no_pad(shape, 6, pack.circuit_digest);
     return pack.validate();
 }

@@ -4,24 +4,37 @@
 #include "ctx.hpp"
 
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
-                        uint64_t seed, CircuitPack &pack, std::vector<uint64_t> &wires, std::vector<uint64_t> &pis);
+                        uint64_t seed, unsigned flags, CircuitPack &pack, std::vector<uint64_t> &wires, std::vector<uint64_t> &pis);
 
 extern "C" {
 
-size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed) {
+size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags) {
     (void)num_wires;
+    const bool pos = (flags & 1) != 0;
     CircuitPack p;
-    p.degree_bits = degree_bits; p.num_routed_wires = num_routed; p.num_selectors = 1; p.num_constants = 2;
+    p.degree_bits = degree_bits; p.num_routed_wires = num_routed; p.num_selectors = pos ? 2 : 1; p.num_constants = 2;
     size_t arity = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5).size();
-    return 18 + arity + 4 * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits);
+    return 18 + arity + (pos ? 5 : 4) * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits);
+}
+size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed) {
+    return qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, 0);
 }
 
+int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
+                           uint64_t seed, unsigned flags, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,
+                           uint64_t *wires_out, uint64_t *pis_out);
 int qpgpu_synth_circuit(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         uint64_t seed, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,
                         uint64_t *wires_out, uint64_t *pis_out) {
+    return qpgpu_synth_circuit_ex(degree_bits, num_wires, num_routed, num_public_inputs, seed, 0, pack_out, pack_cap_words,
+                                  pack_words, wires_out, pis_out);
+}
+int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
+                           uint64_t seed, unsigned flags, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,
+                           uint64_t *wires_out, uint64_t *pis_out) {
     CircuitPack pack;
     std::vector<uint64_t> wires, pis;
-    std::string err = synth_build(degree_bits, num_wires, num_routed, num_public_inputs, seed, pack, wires, pis);
+    std::string err = synth_build(degree_bits, num_wires, num_routed, num_public_inputs, seed, flags, pack, wires, pis);
     if (!err.empty()) return QPGPU_EINVAL;
     std::vector<uint64_t> words = pack.serialize();
     if (pack_words) *pack_words = words.size();

@@ -69,3 +69,17 @@ def test_zero_knowledge_salts(pkg, orc):
     cap = 16 * 4 * 8
     assert a[:cap] != plain.prove(wires, pis)[:cap]    # salts change every commitment
     oc.close(); plain.close()
+
+
+def test_poseidon_gate_circuit(pkg, orc):
+    """PoseidonGate rows (degree 7) force a second selector group; a wrong S-box wire breaks the quotient identity."""
+    pack, wires, pis = pkg.synth_circuit(7, seed=5, poseidon=True)
+    assert int(pack[5]) == 2                          # num_selectors
+    oc = OracleCircuit(orc, pack)
+    proof = oc.prove(wires, pis)
+    assert oc.verify(proof) == 0
+    w = wires.copy(); w[70, 8] = (int(w[70, 8]) + 1) % 0xFFFFFFFF00000001    # partial-round S-box input, row 8
+    assert oc.verify(oc.prove(w, pis)) == 3
+    w = wires.copy(); w[24, 8] = 2                                            # swap must be binary
+    assert oc.verify(oc.prove(w, pis)) == 3
+    oc.close()

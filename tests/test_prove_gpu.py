@@ -9,8 +9,9 @@ from oracle_binding import OracleCircuit
 pytestmark = pytest.mark.gpu
 
 
-def run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed):
-    pack, wires, pis = pkg.synth_circuit(degree_bits, num_wires=num_wires, num_routed=num_routed, num_public_inputs=npis, seed=seed)
+def run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed, poseidon=False):
+    pack, wires, pis = pkg.synth_circuit(degree_bits, num_wires=num_wires, num_routed=num_routed, num_public_inputs=npis, seed=seed,
+                                         poseidon=poseidon)
     oc = OracleCircuit(orc, pack)
     want = oc.prove(wires, pis)
     circ = pkg.Circuit(gpu, pack)
@@ -44,6 +45,12 @@ def run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed):
 ])
 def test_proof_bytes_match_oracle(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed):
     run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed)
+
+
+@pytest.mark.parametrize("degree_bits,seed", [(7, 21), (11, 22)])
+def test_poseidon_gate_circuits(pkg, gpu, orc, degree_bits, seed):
+    """PoseidonGate rows: 123 constraints of degree 7, two selector groups (the multi-selector filter path)."""
+    run_case(pkg, gpu, orc, degree_bits, 135, 80, 21, seed, poseidon=True)
 
 
 def test_constants_sigmas_cap_matches_oracle(pkg, gpu, orc):
