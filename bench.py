@@ -184,7 +184,7 @@ def main():
         oc = oracle_binding.OracleCircuit(orc, pack)
         ok = oc.verify(proof) == 0
         cpu_baseline = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             threads = max(1, min(len(os.sched_getaffinity(0)), 16))
             orc.set_threads(threads)
             reps = 0
