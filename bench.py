@@ -104,11 +104,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # rehearsal on a one-GPU box: QPGPU_BENCH_BACKEND=gloo puts every rank on the visible GPUs round-robin and does
+    # the gather on host tensors; the driver's multi-GPU runs use the default (nccl = RCCL over xGMI)
+    backend = os.environ.get("QPGPU_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import __graft_entry__ as ge
     pkg = ge.load_package()
@@ -136,7 +144,7 @@ def main():
         proofs = [f.result() for f in futs]
         if world > 1:   # aggregation step's input: every rank's proof bytes gathered over xGMI (RCCL)
             nonlocal gathered
-            gathered = pkg.sharding.gather_proof_bytes(proofs, dist, dev)
+            gathered = pkg.sharding.gather_proof_bytes(proofs, dist, coll_dev)
         return proofs[0]
 
     def barrier():
@@ -154,7 +162,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         if rank == 0:   # every rank's S proofs arrived; rank 0's own are unchanged

@@ -101,13 +101,16 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) {
         if (active) {
             u64 x[NA];
             // lane -> (outer row, inner lane) for strided passes: lane = row * M + mm
-            const u64 row = lane >> a.log_m, mm = lane & ((1ull << a.log_m) - 1);
-            const u64 base = row * a.in_row_stride + mm * a.in_l_stride;
+            // offsets inside one column fit 32 bits (N <= 2^30): 32-bit index arithmetic, one 64-bit add per access
+            const u32 row = (u32)(lane >> a.log_m), mm = (u32)lane & ((1u << a.log_m) - 1);
+            const u32 ips = (u32)a.in_p_stride;
+            const u32 base = row * (u32)a.in_row_stride + mm * (u32)a.in_l_stride + (u32)m * ips;
+            const u32 istep = (u32)NB * ips;
 #pragma unroll
             for (int i = 0; i < NA; i++) {
                 const u32 p = (u32)(i * NB + m);
                 u64 v = 0;
-                if (lane_ok && p < a.p_valid) v = in[base + (u64)p * a.in_p_stride];
+                if (lane_ok && p < a.p_valid) v = in[base + (u32)i * istep];
                 x[i] = v;
             }
             if (a.in_scale_a) {  // coset: x[p, lane] *= A[p] * B[mm]
@@ -134,13 +137,13 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) {
                     const u32 k = (u32)brev(j, KA);
                     u64 v = x[j];
                     if (a.tw_lo) {
-                        const u64 e = mm * k;
+                        const u32 e = mm * k;
                         if (e) v = gl::mul(v, gl::mul(a.tw_hi[e >> a.tw_lo_bits], a.tw_lo[e & ((1u << a.tw_lo_bits) - 1)]));
                     }
                     if (a.has_out_scale) v = gl::mul(v, a.out_scale);
                     v = gl::canon(v);
-                    const u64 pos = a.out_bitrev ? (u64)j : (u64)k;
-                    if (lane_ok) out[row * a.out_row_stride + mm * a.out_l_stride + pos * a.out_p_stride] = v;
+                    const u32 pos = a.out_bitrev ? (u32)j : k;
+                    if (lane_ok) out[row * (u32)a.out_row_stride + mm * (u32)a.out_l_stride + pos * (u32)a.out_p_stride] = v;
                 }
             }
         }
@@ -163,21 +166,22 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) {
                 y[i] = lds[l * RP + s + (s >> KB)];
             }
             dif_regs<KB, INV>(y);
-            const u64 row = lane >> a.log_m, mm = lane & ((1ull << a.log_m) - 1);
-            const u64 obase = row * a.out_row_stride + mm * a.out_l_stride;
+            const u32 row = (u32)(lane >> a.log_m), mm = (u32)lane & ((1u << a.log_m) - 1);
+            const u32 ops = (u32)a.out_p_stride;
+            const u32 obase = row * (u32)a.out_row_stride + mm * (u32)a.out_l_stride;
             const u32 ka = (u32)brev(j, KA);
 #pragma unroll
             for (int jb = 0; jb < NB; jb++) {
                 const u32 k = ka + ((u32)brev(jb, KB) << KA);
                 u64 v = y[jb];
                 if (a.tw_lo) {
-                    const u64 e = mm * k;
+                    const u32 e = mm * k;
                     if (e) v = gl::mul(v, gl::mul(a.tw_hi[e >> a.tw_lo_bits], a.tw_lo[e & ((1u << a.tw_lo_bits) - 1)]));
                 }
                 if (a.has_out_scale) v = gl::mul(v, a.out_scale);
                 v = gl::canon(v);
-                const u64 pos = a.out_bitrev ? (u64)(j * NB + jb) : (u64)k;
-                if (lane_ok) out[obase + pos * a.out_p_stride] = v;
+                const u32 pos = a.out_bitrev ? (u32)(j * NB + jb) : k;
+                if (lane_ok) out[obase + pos * ops] = v;
             }
         }
     }
