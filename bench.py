@@ -129,7 +129,7 @@ def main():
     # ---- synthetic leaf-shaped circuit + witness (setup, untimed: reference builds the circuit in the bench's
     # setup closure too, wormhole/prover/benches/prover.rs:35-37) ----
     d = args.degree_bits
-    pack, wires, pis = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000 + rank, poseidon=True)
+    pack, wires, pis = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000 + rank, poseidon=True, base_sum=True)
     circs = [pkg.Circuit(g, pack) for g in gpus]                    # per-stream workspace, no allocation while proving
     circ = circs[0]
     w_t = torch.from_numpy(wires.view(np.int64)).to(dev)            # witness resident in HBM
@@ -231,7 +231,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]/[3]: full proof (LDE + Poseidon Merkle commit + quotient + FRI) of a "
                                    "shape-equivalent synthetic leaf circuit, one proof per GPU per step, witness resident in HBM",
-                       "degree_bits": d, "gates": "PublicInput, Constant, Arithmetic(20 ops), Poseidon(123 constraints, every 8th row), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
+                       "degree_bits": d, "gates": "PublicInput, Constant, BaseSum<2>(63 limbs), Arithmetic(20 ops), Poseidon(123 constraints), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
                        "num_query_rounds": 28, "proof_of_work_bits": 16, "fri_arity_bits": 4, "proof_bytes": proof_len, "proofs_in_flight_per_gpu": S, "proofs_per_step_per_gpu": S,
                        "multi_gpu": "independent proofs per rank + RCCL all_gather of proof bytes" if world > 1 else "single GPU"},
         }

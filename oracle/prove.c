@@ -240,6 +240,13 @@ static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t
             for (int i = 0; i < 123; i++) acc[i] = gl_add(acc[i], gl_mul(f, cst[i]));
             break;
         }
+        case OG_BASE_SUM: {   /* BaseSumGate<2>: wire 0 = sum, wires 1..num_limbs = bits */
+            gl_t s2 = 0;
+            for (uint64_t i = g->param0; i-- > 0;) s2 = gl_add(gl_add(s2, s2), wires[1 + i]);
+            acc[0] = gl_add(acc[0], gl_mul(f, gl_sub(s2, wires[0])));
+            for (uint64_t i = 0; i < g->param0; i++) acc[1 + i] = gl_add(acc[1 + i], gl_mul(f, gl_mul(wires[1 + i], gl_sub(wires[1 + i], 1))));
+            break;
+        }
         default: break;
         }
     }
@@ -275,6 +282,13 @@ void orc_eval_gates_ext(const orc_circuit *c, const gl2_t *cs_row, const gl2_t *
             gl2_t cst[123];
             poseidon_gate_ext(wires, cst);
             for (int i = 0; i < 123; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, cst[i]));
+            break;
+        }
+        case OG_BASE_SUM: {
+            gl2_t s2 = gl2_from(0);
+            for (uint64_t i = g->param0; i-- > 0;) s2 = gl2_add(gl2_add(s2, s2), wires[1 + i]);
+            acc[0] = gl2_add(acc[0], gl2_mul(f, gl2_sub(s2, wires[0])));
+            for (uint64_t i = 0; i < g->param0; i++) acc[1 + i] = gl2_add(acc[1 + i], gl2_mul(f, gl2_mul(wires[1 + i], gl2_sub(wires[1 + i], gl2_from(1)))));
             break;
         }
         default: break;

@@ -225,6 +225,17 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
                 const u64 cst = gl::mul(f, gl::sub(out, computed));
                 for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
             }
+        } else if (g.type == 5) {     // BaseSumGate<2>: sum - sum_i 2^i limb_i, and limb_i (limb_i - 1)
+            u64 s2 = 0, wsum[4] = {0, 0, 0, 0};
+            for (u32 q = g.param0; q-- > 0;) s2 = gl::add(gl::add(s2, s2), a.wires[(u64)(1 + q) * S + j]);
+            const u64 c0 = gl::sub(s2, a.wires[j]);
+            for (u32 c = 0; c < nch; c++) wsum[c] = gl::mul(c0, a.alpha_pows[(u64)c * a.nterms + t]);
+            for (u32 q = 0; q < g.param0; q++) {
+                const u64 limb = a.wires[(u64)(1 + q) * S + j];
+                const u64 cst = gl::mul(limb, gl::sub(limb, 1));
+                for (u32 c = 0; c < nch; c++) wsum[c] = gl::add(wsum[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + 1 + q]));
+            }
+            for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(f, wsum[c]));
         } else if (g.type == 4) {     // PoseidonGate
             u64 sum[4] = {0, 0, 0, 0};
             poseidon_gate_point(a, j, t, sum);

@@ -36,7 +36,8 @@ void synth_public_inputs_hash(const u64 *pis, size_t n, u64 out[4]) { host_hash_
 // Builds the pack and the witness. wires: num_wires x n column-major. Returns "" or an error.
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         u64 seed, unsigned flags, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
-    const bool with_poseidon = (flags & 1) != 0;
+    const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0;
+    const u64 num_limbs = std::min<u64>(63, num_routed - 1);
     if (with_poseidon && (num_wires < 135 || num_routed < 28)) return "poseidon gates need 135 wires";
     if (degree_bits < 3 || degree_bits > 20) return "degree_bits out of range";
     if (num_routed < 8 || num_routed > num_wires || num_routed % 4) return "num_routed_wires must be a multiple of 4, >= 8";
@@ -51,15 +52,20 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     pack.arity_bits = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5);
     const u64 num_ops = num_routed / 4;
     pack.num_gate_constraints = std::max<u64>(std::max<u64>(num_ops, 4), with_poseidon ? 123 : 0);
-    // gates sorted by (degree, id) as the builder does: Noop, Constant, PublicInput, Arithmetic; one selector group
+    if (with_base_sum) pack.num_gate_constraints = std::max<u64>(pack.num_gate_constraints, num_limbs + 1);
+    // gates sorted by (degree, id) as the builder does: Noop(0), Constant(1), PublicInput(1), [BaseSum(2)], Arithmetic(3)
+    // share selector group 0; PoseidonGate (degree 7) does not fit (size + degree < 9) and gets a group of its own
+    const u64 g0 = with_base_sum ? 5 : 4;
     pack.gates = {
-        {GATE_NOOP, 0, 0, 0, 0, 4, 0, 0},
-        {GATE_CONSTANT, 2, 0, 0, 0, 4, 2, 0},
-        {GATE_PUBLIC_INPUT, 0, 0, 0, 0, 4, 4, 0},
-        {GATE_ARITHMETIC, num_ops, 0, 0, 0, 4, num_ops, 0},
+        {GATE_NOOP, 0, 0, 0, 0, g0, 0, 0},
+        {GATE_CONSTANT, 2, 0, 0, 0, g0, 2, 0},
+        {GATE_PUBLIC_INPUT, 0, 0, 0, 0, g0, 4, 0},
     };
-    // PoseidonGate has degree 7: with 5 gates the builder's greedy grouping puts it in a selector group of its own
-    if (with_poseidon) pack.gates.push_back({GATE_POSEIDON, 0, 0, 1, 4, 5, 123, 0});
+    if (with_base_sum) pack.gates.push_back({GATE_BASE_SUM, num_limbs, 2, 0, 0, g0, num_limbs + 1, 0});
+    pack.gates.push_back({GATE_ARITHMETIC, num_ops, 0, 0, 0, g0, num_ops, 0});
+    if (with_poseidon) pack.gates.push_back({GATE_POSEIDON, 0, 0, 1, g0, g0 + 1, 123, 0});
+    // row kinds below use: 0 noop, 1 constant, 2 public input, 3 arithmetic, 4 poseidon, 5 base sum; gate index in the list:
+    const u64 idx_arith = with_base_sum ? 4 : 3, idx_bs = 3, idx_pos = g0;
     pack.k_is.resize(num_routed);
     { u64 k = 1; for (unsigned j = 0; j < num_routed; j++) { pack.k_is[j] = gl::canon(k); k = gl::mul(k, gl::MULT_GEN); } }
 
@@ -75,6 +81,7 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     for (u64 r = 1; r <= n_const_rows; r++) row_gate[r] = 1;
     for (u64 r = n - n_noop; r < n; r++) row_gate[r] = 0;
     if (with_poseidon) for (u64 r = 8; r + n_noop < n; r += 8) row_gate[r] = 4;   // every 8th row hashes
+    if (with_base_sum) for (u64 r = 5; r + n_noop < n; r += 8) row_gate[r] = 5;   // every 8th row range-checks
 
     wires.assign((size_t)num_wires * n, 0);
     auto W = [&](u64 row, u64 col) -> u64 & { return wires[col * n + row]; };
@@ -93,8 +100,10 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
 
     for (u64 r = 0; r < n; r++) {
         const u64 sel_cols = pack.num_selectors, UNUSED = 0xFFFFFFFFull;
-        if (!with_poseidon) CS(r, 0) = row_gate[r];            // selector value = gate index
-        else { CS(r, 0) = row_gate[r] == 4 ? UNUSED : row_gate[r]; CS(r, 1) = row_gate[r] == 4 ? 4 : UNUSED; }
+        const u64 kind = row_gate[r];
+        const u64 gidx = kind == 3 ? idx_arith : kind == 5 ? idx_bs : kind == 4 ? idx_pos : kind;   // index in pack.gates
+        if (!with_poseidon) CS(r, 0) = gidx;                   // selector value = gate index
+        else { CS(r, 0) = kind == 4 ? UNUSED : gidx; CS(r, 1) = kind == 4 ? gidx : UNUSED; }
         if (row_gate[r] == 2) {
             for (int i = 0; i < 4; i++) W(r, i) = pih[i];
         } else if (row_gate[r] == 1) {
@@ -121,6 +130,11 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
                 pool.push_back(cell(r, 4 * op + 3));
                 if (pool.size() > 4096) pool.erase(pool.begin(), pool.begin() + 2048);
             }
+        } else if (row_gate[r] == 5) {
+            // BaseSumGate<2> row: a value below 2^num_limbs and its bits
+            u64 v = rng.next() & ((num_limbs >= 64 ? ~0ull : (1ull << num_limbs) - 1));
+            W(r, 0) = v; pool.push_back(cell(r, 0));
+            for (u64 i = 0; i < num_limbs; i++) W(r, 1 + i) = (v >> i) & 1;
         } else if (row_gate[r] == 4) {
             // PoseidonGate row: inputs (some copied), swap bit, deltas, recorded S-box inputs, outputs
             const u64 *rcs = poseidon::host_round_constants();

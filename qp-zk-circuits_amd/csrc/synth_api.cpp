@@ -10,11 +10,11 @@ extern "C" {
 
 size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags) {
     (void)num_wires;
-    const bool pos = (flags & 1) != 0;
+    const bool pos = (flags & 1) != 0, bs = (flags & 2) != 0;
     CircuitPack p;
     p.degree_bits = degree_bits; p.num_routed_wires = num_routed; p.num_selectors = pos ? 2 : 1; p.num_constants = 2;
     size_t arity = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5).size();
-    return 18 + arity + (pos ? 5 : 4) * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits);
+    return 18 + arity + (4 + (pos ? 1 : 0) + (bs ? 1 : 0)) * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits);
 }
 size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed) {
     return qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, 0);

@@ -83,3 +83,14 @@ def test_poseidon_gate_circuit(pkg, orc):
     w = wires.copy(); w[24, 8] = 2                                            # swap must be binary
     assert oc.verify(oc.prove(w, pis)) == 3
     oc.close()
+
+
+def test_base_sum_gate_circuit(pkg, orc):
+    pack, wires, pis = pkg.synth_circuit(7, seed=5, base_sum=True, poseidon=True)
+    oc = OracleCircuit(orc, pack)
+    assert oc.verify(oc.prove(wires, pis)) == 0
+    w = wires.copy(); w[3, 5] = 2                       # a limb that is not a bit (row 5 is a base-sum row)
+    assert oc.verify(oc.prove(w, pis)) == 3
+    w = wires.copy(); w[0, 5] = (int(w[0, 5]) + 1) % 0xFFFFFFFF00000001   # sum no longer matches its bits
+    assert oc.verify(oc.prove(w, pis)) == 3
+    oc.close()
