@@ -93,6 +93,8 @@ struct qpgpu_circuit {
     std::vector<u64 *> d_fri_digests, d_fri_leafrows;
     u64 *d_pow = nullptr, *d_qidx = nullptr, *d_gather = nullptr;
     size_t gather_words = 0;
+    u64 *h_stage = nullptr;          // pinned host staging for the small per-proof tables (no sync on upload)
+    size_t stage_words = 0, stage_pos = 0;
     bool seed_set = false;
     u64 blinding_seed = 0;
 
@@ -149,6 +151,22 @@ int commit_values(qpgpu_circuit *c, const u64 *d_values, DevBatch &b) {
     return commit_coeffs(c, b);
 }
 
+// Upload a small table through the circuit's pinned staging area: asynchronous, no stream sync. Each proof uses a
+// fresh region per table; regions are recycled at the start of the next proof (the previous one has completed).
+int h2d_staged(qpgpu_circuit *c, void *dst, const void *src, size_t bytes) {
+    const size_t words = (bytes + 7) / 8;
+    if (c->stage_pos + words > c->stage_words) {   // should not happen: sized at load time
+        QP_HIP(c->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->ctx->stream));
+        QP_HIP(c->ctx, hipStreamSynchronize(c->ctx->stream));
+        return QPGPU_OK;
+    }
+    u64 *slot = c->h_stage + c->stage_pos;
+    c->stage_pos += words;
+    std::memcpy(slot, src, bytes);
+    QP_HIP(c->ctx, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->ctx->stream));
+    return QPGPU_OK;
+}
+
 int h2d(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     QP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // source is pageable and may go out of scope
@@ -183,7 +201,9 @@ size_t qpgpu_proof_size(const qpgpu_circuit *c) {
 
 void qpgpu_circuit_free(qpgpu_circuit *c) {
     if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (void *p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -288,6 +308,13 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
         CK(c->alloc(&c->d_qidx, p.num_query_rounds));
         CK(c->alloc(&c->d_pow, 1));
     }
+    {
+        c->stage_words = 2 * nch + nch * R + nch * nterms + 4 + 4 + 2 * n_open + p.num_query_rounds + 64;
+        void *hp = nullptr;
+        hipError_t e = hipHostMalloc(&hp, c->stage_words * 8, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipHostMalloc(stage)"));
+        c->h_stage = (u64 *)hp;
+    }
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #undef CK
     *out = c;
@@ -317,6 +344,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     const size_t sig0 = p.num_selectors + p.num_constants, cap_words = (1ull << cap_h) * 4;
     const size_t nterms = nch + nch * nchunks + p.num_gate_constraints;
 
+    c->stage_pos = 0;
     u64 pih[4];
     host_hash_no_pad(public_inputs, p.num_public_inputs, pih);
     if (p.zero_knowledge && !c->seed_set) {   // fresh randomness per proof unless the caller injected a seed
@@ -341,7 +369,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     u64 *d_betas = c->d_small, *d_gammas = d_betas + nch, *d_bk = d_gammas + nch, *d_apow = d_bk + (size_t)nch * R, *d_pih = d_apow + (size_t)nch * nterms;
     std::vector<u64> small(2 * nch + (size_t)nch * R);
     for (uint32_t k = 0; k < nch; k++) { small[k] = betas[k]; small[nch + k] = gammas[k]; for (u64 j = 0; j < R; j++) small[2 * nch + k * R + j] = gl::canon(gl::mul(betas[k], p.k_is[j])); }
-    QP_TRY(h2d(ctx, c->d_small, small.data(), small.size() * 8));
+    QP_TRY(h2d_staged(c, c->d_small, small.data(), small.size() * 8));
 
     // ---- s5 partial products ----
     ctx->prof_begin("prove_partial_products");
@@ -364,7 +392,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
         std::vector<u64> ap((size_t)nch * nterms + 4);
         for (uint32_t k = 0; k < nch; k++) { u64 a = 1; for (size_t t = 0; t < nterms; t++) { ap[k * nterms + t] = gl::canon(a); a = gl::mul(a, alphas[k]); } }
         std::memcpy(ap.data() + (size_t)nch * nterms, pih, 32);
-        QP_TRY(h2d(ctx, d_apow, ap.data(), ap.size() * 8));
+        QP_TRY(h2d_staged(c, d_apow, ap.data(), ap.size() * 8));
     }
     ctx->prof_begin("prove_quotient");
     QuotientArgs qa{};
@@ -396,7 +424,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     const size_t n_open = ncs + NW + nzp + nq;
     {
         e2 pts[2] = {zeta, g_zeta};
-        QP_TRY(h2d(ctx, c->d_points, pts, sizeof pts));
+        QP_TRY(h2d_staged(c, c->d_points, pts, sizeof pts));
         const DevBatch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
         size_t off = 0;
         for (const DevBatch *b : bs) { QP_HIP(ctx, pk_poly_eval(b->coeffs, n, b->ncols, c->d_points, 1, nullptr, c->d_open + off, st)); off += b->ncols; }
@@ -416,7 +444,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
         std::vector<e2> apw(n_open);
         e2 a = gl::e2_from(1);
         for (size_t i = 0; i < n_open; i++) { apw[i] = gl::e2_canon(a); a = gl::e2_mul(a, fri_alpha); }
-        QP_TRY(h2d(ctx, c->d_alpha_ext, apw.data(), apw.size() * sizeof(e2)));
+        QP_TRY(h2d_staged(c, c->d_alpha_ext, apw.data(), apw.size() * sizeof(e2)));
         ReduceArgs ra{};
         ra.src[0] = c->cs.coeffs; ra.src[1] = c->wires.coeffs; ra.src[2] = c->zs.coeffs; ra.src[3] = c->quot.coeffs;
         ra.ncols[0] = (uint32_t)ncs; ra.ncols[1] = (uint32_t)NW; ra.ncols[2] = (uint32_t)nzp; ra.ncols[3] = (uint32_t)nq; ra.nsrc = 4;
@@ -512,7 +540,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     const uint32_t nqr = (uint32_t)p.num_query_rounds;
     std::vector<u64> qidx(nqr);
     for (auto &x : qidx) x = ch.get() % lde_n;
-    QP_HIP(ctx, hipMemcpyAsync(c->d_qidx, qidx.data(), nqr * 8, hipMemcpyHostToDevice, st));
+    QP_TRY(h2d_staged(c, c->d_qidx, qidx.data(), nqr * 8));
     // gather layout (per section, all queries contiguous): for each oracle rows then paths; for each FRI round evals then paths
     struct Sec { size_t off, words; bool is_path; };
     std::vector<Sec> secs;
