@@ -110,7 +110,7 @@ __device__ __forceinline__ u64 gate_filter(const QuotientArgs &a, u32 gi, u64 s)
 
 // PoseidonGate (plonky2::gates::poseidon) at one point: wires 0..11 input, 12..23 output, 24 swap, 25..28 delta,
 // 29..64 / 65..86 / 87..134 S-box inputs of the full / partial / full rounds; 123 constraints. Each constraint q is
-// weighted by alpha_c^(t+q) on the fly. Partial rounds in textbook form (see oracle/prove.c for the stated deviation).
+// weighted by alpha_c^(t+q) on the fly. Partial rounds in textbook form, not upstream's fast-partial basis.
 __device__ __noinline__ void poseidon_gate_point(const QuotientArgs &a, u64 j, u32 t, u64 (&sum)[4]) {
     const u64 S = a.lde_n;
     const u32 nch = a.nch;

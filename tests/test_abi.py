@@ -35,3 +35,14 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in text and "oracle/" not in text and "oracle_binding" not in text, f
+
+
+def test_c_example_compiles_against_the_header():
+    """examples/prove_example.c uses only include/qpgpu.h; it must compile and link with plain gcc."""
+    import subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tempfile.gettempdir(), "qpgpu_prove_example")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "prove_example.c"),
+                           "-L", os.path.join(root, "qp-zk-circuits_amd"), "-lqpgpu",
+                           "-Wl,-rpath," + os.path.join(root, "qp-zk-circuits_amd"), "-o", out])
+    assert os.path.exists(out)

@@ -117,3 +117,16 @@ def test_private_batch_sized_trace_verifies(pkg, gpu, orc):
     bad = bytearray(proof); bad[len(bad) // 2] ^= 4
     assert oc.verify(bytes(bad)) != 0
     oc.close()
+
+
+def test_c_example_runs(pkg):
+    """The same flow from plain C through the C ABI (no Python in the loop)."""
+    import os, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tempfile.gettempdir(), "qpgpu_prove_example_gpu")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "prove_example.c"),
+                           "-L", os.path.join(root, "qp-zk-circuits_amd"), "-lqpgpu",
+                           "-Wl,-rpath," + os.path.join(root, "qp-zk-circuits_amd"), "-o", out])
+    res = subprocess.run([out, "10"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.startswith("ok degree_bits=10")
