@@ -129,6 +129,11 @@ size_t qpgpu_proof_size(const qpgpu_circuit *c);   /* bytes written by qpgpu_pro
 int qpgpu_prove(qpgpu_circuit *c, const uint64_t *wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len);
 int qpgpu_prove_dev(qpgpu_circuit *c, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* Hash constants the library derives at start-up (host only, no GPU): the 360 Poseidon round constants and plonky2's
+ * FAST_PARTIAL_* tables flattened as FIRST[12] | RC[22] | VS[22][11] | W_HATS[22][11] | INIT[11][11] (row c of INIT
+ * produces element 1+c). Returns the number of words of the second table. */
+size_t qpgpu_poseidon_constants(uint64_t *round_constants_360, uint64_t *fast_partial, size_t fast_partial_cap);
+
 /* ---- synthetic circuits (stand-in for reference rows a1/a6 while no Rust exporter exists) ---- */
 /*
  * Builds a satisfied plonky2-shaped circuit (PublicInput / Constant / Arithmetic / Noop gates wired by copy

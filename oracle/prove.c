@@ -130,9 +130,9 @@ static gl_t gate_filter(const orc_circuit *c, size_t gi, gl_t s) {
 /*
  * PoseidonGate (plonky2::gates::poseidon): wires 0..11 input, 12..23 output, 24 swap, 25..28 delta, 29..64 S-box inputs
  * of full rounds 1..3, 65..86 S-box inputs of the 22 partial rounds, 87..134 S-box inputs of the last 4 full rounds;
- * 123 constraints of degree 7. Deviation kept explicit: partial rounds are evaluated in textbook form (constant layer,
- * S-box on element 0, dense MDS), not in upstream's fast-partial basis, because FAST_PARTIAL_* tables are not derivable
- * here; wire layout, constraint count and degree are upstream's.
+ * 123 constraints of degree 7. The partial rounds run in upstream's fast basis (partial_first_constant_layer,
+ * mds_partial_layer_init, mds_partial_layer_fast); its FAST_PARTIAL_* tables are re-derived below from the MDS matrix and
+ * the round constants (published HADES optimisation) and pinned by tests/golden/poseidon_fast_partial.json.
  */
 void orc_poseidon_round_constants(gl_t *out);
 static gl_t PRC[360]; static int prc_ready = 0;
@@ -147,10 +147,71 @@ static void pg_mds(gl_t s[12]) {
     }
     memcpy(s, o, sizeof o);
 }
+/* ---- FAST_PARTIAL tables: FIRST[12], RCP[22], VS[22][11], WH[22][11], INIT[11][11] (row c gives element 1+c) ---- */
+static gl_t FP_FIRST[12], FP_RC[22], FP_VS[22][11], FP_WH[22][11], FP_INIT[11][11];
+static void mat_inv(gl_t *a, gl_t *inv, int n) {          /* Gauss-Jordan, a destroyed */
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) inv[i * n + j] = i == j;
+    for (int c = 0; c < n; c++) {
+        int piv = c; while (a[piv * n + c] == 0) piv++;
+        for (int j = 0; j < n; j++) { gl_t t = a[c * n + j]; a[c * n + j] = a[piv * n + j]; a[piv * n + j] = t; t = inv[c * n + j]; inv[c * n + j] = inv[piv * n + j]; inv[piv * n + j] = t; }
+        gl_t f = gl_inv(a[c * n + c]);
+        for (int j = 0; j < n; j++) { a[c * n + j] = gl_mul(a[c * n + j], f); inv[c * n + j] = gl_mul(inv[c * n + j], f); }
+        for (int r = 0; r < n; r++) if (r != c && a[r * n + c]) {
+            gl_t g = a[r * n + c];
+            for (int j = 0; j < n; j++) { a[r * n + j] = gl_sub(a[r * n + j], gl_mul(g, a[c * n + j])); inv[r * n + j] = gl_sub(inv[r * n + j], gl_mul(g, inv[c * n + j])); }
+        }
+    }
+}
+static void derive_fast_partial(void) {
+    gl_t M[144], Mt[144], Minv[144], C[22][12];
+    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) M[r * 12 + c] = PMDS[(c - r + 12) % 12] + (r == 0 && c == 0 ? 8 : 0);
+    memcpy(Mt, M, sizeof M); mat_inv(Mt, Minv, 12);
+    for (int k = 0; k < 22; k++) memcpy(C[k], PRC + (4 + k) * 12, sizeof C[k]);
+    for (int k = 20; k >= 0; k--) {       /* constants of round k+1 move behind the S-box of round k */
+        gl_t w[12];
+        for (int i = 0; i < 12; i++) { gl_t acc = 0; for (int j = 0; j < 12; j++) acc = gl_add(acc, gl_mul(Minv[i * 12 + j], C[k + 1][j])); w[i] = acc; }
+        for (int i = 1; i < 12; i++) C[k][i] = gl_add(C[k][i], w[i]);
+        FP_RC[k] = w[0];
+    }
+    FP_RC[21] = 0;
+    memcpy(FP_FIRST, C[0], sizeof FP_FIRST);
+    gl_t Mmul[144]; memcpy(Mmul, M, sizeof M);
+    gl_t B[121], Bt[121], Binv[121];
+    for (int i = 21; i >= 0; i--) {       /* Mmul = M'' * diag(1, B) */
+        gl_t row[11];
+        for (int r = 0; r < 11; r++) { FP_VS[i][r] = Mmul[(r + 1) * 12]; row[r] = Mmul[r + 1]; for (int c = 0; c < 11; c++) B[r * 11 + c] = Mmul[(r + 1) * 12 + c + 1]; }
+        for (int r = 0; r < 11; r++) for (int c = 0; c < 11; c++) Bt[r * 11 + c] = B[c * 11 + r];
+        mat_inv(Bt, Binv, 11);
+        for (int r = 0; r < 11; r++) { gl_t acc = 0; for (int c = 0; c < 11; c++) acc = gl_add(acc, gl_mul(Binv[r * 11 + c], row[c])); FP_WH[i][r] = acc; }
+        /* previous round's matrix: diag(1, B) * M */
+        gl_t nm[144];
+        for (int c = 0; c < 12; c++) nm[c] = M[c];
+        for (int r = 0; r < 11; r++) for (int c = 0; c < 12; c++) { gl_t acc = 0; for (int k = 0; k < 11; k++) acc = gl_add(acc, gl_mul(B[r * 11 + k], M[(k + 1) * 12 + c])); nm[(r + 1) * 12 + c] = acc; }
+        memcpy(Mmul, nm, sizeof nm);
+    }
+    for (int c = 0; c < 11; c++) for (int r = 0; r < 11; r++) FP_INIT[c][r] = B[c * 11 + r];
+}
+static void pg_init(void) {
+    if (prc_ready) return;
+    orc_poseidon_round_constants(PRC);
+    derive_fast_partial();
+    prc_ready = 1;
+}
+/* exports for the tests: flattened like the product's table */
+size_t orc_poseidon_fast_partial(gl_t *out) {
+    pg_init();
+    size_t k = 0;
+    for (int i = 0; i < 12; i++) out[k++] = FP_FIRST[i];
+    for (int i = 0; i < 22; i++) out[k++] = FP_RC[i];
+    for (int i = 0; i < 22; i++) for (int j = 0; j < 11; j++) out[k++] = FP_VS[i][j];
+    for (int i = 0; i < 22; i++) for (int j = 0; j < 11; j++) out[k++] = FP_WH[i][j];
+    for (int i = 0; i < 11; i++) for (int j = 0; j < 11; j++) out[k++] = FP_INIT[i][j];
+    return k;
+}
 static inline gl_t pg_sbox(gl_t x) { gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2); return gl_mul(gl_mul(x, x2), x4); }
 /* emits the 123 constraints into out[] */
 static void poseidon_gate_base(const gl_t *w, gl_t *out) {
-    if (!prc_ready) { orc_poseidon_round_constants(PRC); prc_ready = 1; }
+    pg_init();
     size_t k = 0;
     gl_t swap = w[24], st[12];
     out[k++] = gl_mul(swap, gl_sub(swap, 1));
@@ -164,11 +225,18 @@ static void poseidon_gate_base(const gl_t *w, gl_t *out) {
         for (int i = 0; i < 12; i++) st[i] = pg_sbox(st[i]);
         pg_mds(st);
     }
-    for (int r = 0; r < 22; r++, rc++) {
-        for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], PRC[rc * 12 + i]);
-        gl_t in = w[65 + r]; out[k++] = gl_sub(st[0], in); st[0] = pg_sbox(in);
-        pg_mds(st);
+    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], FP_FIRST[i]);      /* partial_first_constant_layer */
+    { gl_t t[11]; for (int c = 0; c < 11; c++) { gl_t acc = 0; for (int r = 0; r < 11; r++) acc = gl_add(acc, gl_mul(FP_INIT[c][r], st[1 + r])); t[c] = acc; }
+      memcpy(st + 1, t, sizeof t); }                                       /* mds_partial_layer_init */
+    for (int r = 0; r < 22; r++) {
+        gl_t in = w[65 + r]; out[k++] = gl_sub(st[0], in);
+        gl_t s0 = gl_add(pg_sbox(in), FP_RC[r]);
+        gl_t d = gl_mul(s0, 25);
+        for (int i = 0; i < 11; i++) d = gl_add(d, gl_mul(FP_WH[r][i], st[1 + i]));
+        for (int i = 0; i < 11; i++) st[1 + i] = gl_add(st[1 + i], gl_mul(s0, FP_VS[r][i]));
+        st[0] = d;                                                         /* mds_partial_layer_fast */
     }
+    rc += 22;
     for (int r = 0; r < 4; r++, rc++) {
         for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], PRC[rc * 12 + i]);
         for (int i = 0; i < 12; i++) { gl_t in = w[87 + 12 * r + i]; out[k++] = gl_sub(st[i], in); st[i] = in; }
@@ -185,7 +253,7 @@ static void pg_mds_ext(gl2_t s[12]) {
 }
 static inline gl2_t pg_sbox_ext(gl2_t x) { gl2_t x2 = gl2_mul(x, x), x4 = gl2_mul(x2, x2); return gl2_mul(gl2_mul(x, x2), x4); }
 static void poseidon_gate_ext(const gl2_t *w, gl2_t *out) {
-    if (!prc_ready) { orc_poseidon_round_constants(PRC); prc_ready = 1; }
+    pg_init();
     size_t k = 0;
     gl2_t swap = w[24], st[12];
     out[k++] = gl2_mul(swap, gl2_sub(swap, gl2_from(1)));
@@ -199,11 +267,18 @@ static void poseidon_gate_ext(const gl2_t *w, gl2_t *out) {
         for (int i = 0; i < 12; i++) st[i] = pg_sbox_ext(st[i]);
         pg_mds_ext(st);
     }
-    for (int r = 0; r < 22; r++, rc++) {
-        for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from(PRC[rc * 12 + i]));
-        gl2_t in = w[65 + r]; out[k++] = gl2_sub(st[0], in); st[0] = pg_sbox_ext(in);
-        pg_mds_ext(st);
+    for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from(FP_FIRST[i]));
+    { gl2_t t[11]; for (int c = 0; c < 11; c++) { gl2_t acc = gl2_from(0); for (int r = 0; r < 11; r++) acc = gl2_add(acc, gl2_scale(st[1 + r], FP_INIT[c][r])); t[c] = acc; }
+      memcpy(st + 1, t, sizeof t); }
+    for (int r = 0; r < 22; r++) {
+        gl2_t in = w[65 + r]; out[k++] = gl2_sub(st[0], in);
+        gl2_t s0 = gl2_add(pg_sbox_ext(in), gl2_from(FP_RC[r]));
+        gl2_t d = gl2_scale(s0, 25);
+        for (int i = 0; i < 11; i++) d = gl2_add(d, gl2_scale(st[1 + i], FP_WH[r][i]));
+        for (int i = 0; i < 11; i++) st[1 + i] = gl2_add(st[1 + i], gl2_scale(s0, FP_VS[r][i]));
+        st[0] = d;
     }
+    rc += 22;
     for (int r = 0; r < 4; r++, rc++) {
         for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from(PRC[rc * 12 + i]));
         for (int i = 0; i < 12; i++) { gl2_t in = w[87 + 12 * r + i]; out[k++] = gl2_sub(st[i], in); st[i] = in; }

@@ -7,5 +7,5 @@ to a CPU implementation: if the shared library or a GPU is missing, calls raise.
 The directory name carries a hyphen (it mirrors the reference repository's name), so it is
 imported through `__graft_entry__.load_package()` under the module name `qp_zk_circuits_amd`.
 """
-from .binding import synth_circuit, Circuit, QpGpu, QpGpuError, lib_path, load_library, P, MULT_GEN  # noqa: F401
+from .binding import poseidon_constants, synth_circuit, Circuit, QpGpu, QpGpuError, lib_path, load_library, P, MULT_GEN  # noqa: F401
 from . import sharding  # noqa: F401,E402

@@ -65,6 +65,7 @@ def load_library():
         "qpgpu_circuit_set_blinding_seed": (c.c_int, [vp, c.c_uint64]),
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
+        "qpgpu_poseidon_constants": (c.c_size_t, [u64p, u64p, c.c_size_t]),
         "qpgpu_synth_pack_words": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint]),
         "qpgpu_synth_pack_words_ex": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint, c.c_uint]),
         "qpgpu_synth_circuit_ex": (c.c_int, [c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint, u64p, c.c_size_t,
@@ -86,6 +87,15 @@ def exported_symbols():
     hdr = os.path.join(os.path.dirname(_HERE), "include", "qpgpu.h")
     text = open(hdr).read()
     return sorted(set(re.findall(r"\b(qpgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def poseidon_constants():
+    """(round_constants[360], fast_partial[flat]) as derived by the library at start-up. Host only."""
+    lib = load_library()
+    n = lib.qpgpu_poseidon_constants(None, None, 0)
+    rc = np.empty(360, dtype=np.uint64); fp = np.empty(n, dtype=np.uint64)
+    lib.qpgpu_poseidon_constants(rc.ctypes.data, fp.ctypes.data, n)
+    return rc, fp
 
 
 def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=21, seed=1, poseidon=False, base_sum=False):

@@ -114,6 +114,33 @@ GL_HD void permute(u64 (&s)[WIDTH], const u64 *rc) {
     for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
 }
 
+// ---- plonky2's fast partial rounds (the basis the PoseidonGate's partial-round wires live in) ----
+// Flat table layout: FIRST[12] | RC[22] (last 0) | VS[22][11] | W_HATS[22][11] | INIT[11][11] (new[1+c] = sum_r INIT[c][r] s[1+r])
+constexpr int FP_FIRST = 0, FP_RC = 12, FP_VS = 34, FP_WHATS = FP_VS + 22 * 11, FP_INIT = FP_WHATS + 22 * 11, FP_WORDS = FP_INIT + 121;
+constexpr u64 MDS_00 = 25;   // MDS_MATRIX_CIRC[0] + MDS_MATRIX_DIAG[0]
+
+// partial_first_constant_layer + mds_partial_layer_init
+GL_HD void fast_partial_enter(u64 (&s)[WIDTH], const u64 *fp) {
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::add(s[i], fp[FP_FIRST + i]);
+    u64 t[11];
+    for (int c = 0; c < 11; c++) {
+        u64 acc = 0;
+        for (int r = 0; r < 11; r++) acc = gl::add(acc, gl::mul(fp[FP_INIT + c * 11 + r], s[1 + r]));
+        t[c] = acc;
+    }
+    for (int c = 0; c < 11; c++) s[1 + c] = t[c];
+}
+// after the S-box on s[0]: add the round constant (0 for the last round) and apply the sparse layer of round r
+GL_HD void fast_partial_linear(u64 (&s)[WIDTH], const u64 *fp, int r) {
+    const u64 s0 = gl::add(s[0], fp[FP_RC + r]);
+    u64 d = gl::mul(s0, MDS_00);
+    for (int i = 0; i < 11; i++) d = gl::add(d, gl::mul(fp[FP_WHATS + r * 11 + i], s[1 + i]));
+    for (int i = 0; i < 11; i++) s[1 + i] = gl::add(s[1 + i], gl::mul(s0, fp[FP_VS + r * 11 + i]));
+    s[0] = d;
+}
+const u64 *host_fast_partial();   // FP_WORDS entries, derived at start-up (poseidon_constants.cpp)
+
 // host: derive the 360 round constants (ChaCha8, seed 0, rand 0.8 gen_range(0..p))
 void derive_round_constants(u64 *out360);
 const u64 *host_round_constants();

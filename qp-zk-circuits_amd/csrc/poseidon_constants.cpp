@@ -3,6 +3,7 @@
 // Rng::gen_range(0..ORDER) (rand 0.8: widening multiply, reject when the low word exceeds the zone).
 #include <cstring>
 #include <mutex>
+#include <vector>
 #include "poseidon.hpp"
 
 namespace poseidon {
@@ -62,5 +63,85 @@ void derive_round_constants(u64 *out360) {
 const u64 *host_round_constants() {
     std::call_once(g_once, [] { derive_round_constants(g_rc); });
     return g_rc;
+}
+
+// ---- fast partial rounds: the published HADES optimisation, written for column vectors ----
+namespace {
+typedef std::vector<std::vector<u64>> Mat;
+Mat mat_mul(const Mat &a, const Mat &b) {
+    Mat c(a.size(), std::vector<u64>(b[0].size(), 0));
+    for (size_t i = 0; i < a.size(); i++)
+        for (size_t j = 0; j < b[0].size(); j++) {
+            u64 acc = 0;
+            for (size_t k = 0; k < b.size(); k++) acc = gl::add(acc, gl::mul(a[i][k], b[k][j]));
+            c[i][j] = gl::canon(acc);
+        }
+    return c;
+}
+std::vector<u64> mat_vec(const Mat &a, const std::vector<u64> &x) {
+    std::vector<u64> y(a.size());
+    for (size_t i = 0; i < a.size(); i++) { u64 acc = 0; for (size_t k = 0; k < x.size(); k++) acc = gl::add(acc, gl::mul(a[i][k], x[k])); y[i] = gl::canon(acc); }
+    return y;
+}
+Mat mat_transpose(const Mat &a) { Mat t(a[0].size(), std::vector<u64>(a.size())); for (size_t i = 0; i < a.size(); i++) for (size_t j = 0; j < a[0].size(); j++) t[j][i] = a[i][j]; return t; }
+Mat mat_inverse(Mat a) {   // Gauss-Jordan over the field
+    const size_t n = a.size();
+    Mat inv(n, std::vector<u64>(n, 0));
+    for (size_t i = 0; i < n; i++) inv[i][i] = 1;
+    for (size_t c = 0; c < n; c++) {
+        size_t piv = c;
+        while (gl::canon(a[piv][c]) == 0) piv++;
+        std::swap(a[c], a[piv]); std::swap(inv[c], inv[piv]);
+        const u64 f = gl::inv(a[c][c]);
+        for (size_t j = 0; j < n; j++) { a[c][j] = gl::canon(gl::mul(a[c][j], f)); inv[c][j] = gl::canon(gl::mul(inv[c][j], f)); }
+        for (size_t r = 0; r < n; r++) {
+            if (r == c || a[r][c] == 0) continue;
+            const u64 g = a[r][c];
+            for (size_t j = 0; j < n; j++) {
+                a[r][j] = gl::canon(gl::sub(a[r][j], gl::mul(g, a[c][j])));
+                inv[r][j] = gl::canon(gl::sub(inv[r][j], gl::mul(g, inv[c][j])));
+            }
+        }
+    }
+    return inv;
+}
+u64 g_fp[FP_WORDS];
+std::once_flag g_fp_once;
+void derive_fast_partial() {
+    const u64 *rc = host_round_constants();
+    const u64 CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    Mat M(12, std::vector<u64>(12));
+    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) M[r][c] = CIRC[(c - r + 12) % 12] + (r == 0 && c == 0 ? 8 : 0);
+    // constants: move the constants of partial round k+1 up behind the S-box of round k
+    const Mat Minv = mat_inverse(M);
+    std::vector<std::vector<u64>> C(22);
+    for (int k = 0; k < 22; k++) C[k].assign(rc + (4 + k) * 12, rc + (5 + k) * 12);
+    u64 post[22] = {0};
+    for (int k = 20; k >= 0; k--) {
+        const std::vector<u64> w = mat_vec(Minv, C[k + 1]);
+        for (int i = 1; i < 12; i++) C[k][i] = gl::canon(gl::add(C[k][i], w[i]));
+        post[k] = w[0];
+    }
+    for (int i = 0; i < 12; i++) g_fp[FP_FIRST + i] = C[0][i];
+    for (int k = 0; k < 22; k++) g_fp[FP_RC + k] = k < 21 ? post[k] : 0;
+    // matrices: Mmul = M'' * M', M' = diag(1, B) moves in front of the round's S-box (into the previous linear layer)
+    Mat Mmul = M, Mi;
+    for (int i = 21; i >= 0; i--) {
+        Mat B(11, std::vector<u64>(11));
+        std::vector<u64> col(11), row(11);
+        for (int r = 0; r < 11; r++) { col[r] = Mmul[r + 1][0]; row[r] = Mmul[0][r + 1]; for (int c = 0; c < 11; c++) B[r][c] = Mmul[r + 1][c + 1]; }
+        const std::vector<u64> what = mat_vec(mat_inverse(mat_transpose(B)), row);
+        for (int k = 0; k < 11; k++) { g_fp[FP_VS + i * 11 + k] = col[k]; g_fp[FP_WHATS + i * 11 + k] = what[k]; }
+        Mi.assign(12, std::vector<u64>(12, 0));
+        Mi[0][0] = 1;
+        for (int r = 0; r < 11; r++) for (int c = 0; c < 11; c++) Mi[r + 1][c + 1] = B[r][c];
+        Mmul = mat_mul(Mi, M);
+    }
+    for (int c = 0; c < 11; c++) for (int r = 0; r < 11; r++) g_fp[FP_INIT + c * 11 + r] = Mi[c + 1][r + 1];
+}
+}  // namespace
+const u64 *host_fast_partial() {
+    std::call_once(g_fp_once, derive_fast_partial);
+    return g_fp;
 }
 }  // namespace poseidon

@@ -79,7 +79,7 @@ struct qpgpu_circuit {
     u64 *d_cs_values = nullptr;
     DevBatch cs;
     GateDev *d_gates = nullptr;
-    u64 *d_poseidon_rc = nullptr;
+    u64 *d_poseidon_rc = nullptr, *d_poseidon_fast = nullptr;
     u64 *d_omega = nullptr, *d_x_coset = nullptr, *d_l0_coset = nullptr, *d_zh_inv = nullptr;
     u64 *d_ginv_lo = nullptr, *d_ginv_hi = nullptr; uint32_t ginv_lo_bits = 0;
     // per-proof workspace
@@ -242,6 +242,8 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     CK(h2d(ctx, c->d_gates, gd.data(), gd.size() * sizeof(GateDev)));
     CK(c->alloc(&c->d_poseidon_rc, 360));
     CK(h2d(ctx, c->d_poseidon_rc, poseidon::host_round_constants(), 360 * 8));
+    CK(c->alloc(&c->d_poseidon_fast, poseidon::FP_WORDS));
+    CK(h2d(ctx, c->d_poseidon_fast, poseidon::host_fast_partial(), poseidon::FP_WORDS * 8));
     // subgroup, coset and vanishing tables
     CK(c->alloc(&c->d_omega, n));
     { auto t = powers_table(gl::root_of_unity(d), n); CK(h2d(ctx, c->d_omega, t.data(), n * 8)); }
@@ -398,7 +400,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     QuotientArgs qa{};
     qa.wires = c->wires.lde; qa.cs = c->cs.lde; qa.zs_pp = c->zs.lde; qa.x_coset = c->d_x_coset; qa.l0_coset = c->d_l0_coset;
     qa.zh_inv = c->d_zh_inv; qa.alpha_pows = d_apow; qa.beta_k_is = d_bk; qa.betas = d_betas; qa.gammas = d_gammas; qa.pi_hash = d_pih;
-    qa.gates = c->d_gates; qa.poseidon_rc = c->d_poseidon_rc; qa.out = c->quot.coeffs; qa.lde_n = lde_n; qa.log_lde = L; qa.rate = 1u << p.rate_bits; qa.nch = nch;
+    qa.gates = c->d_gates; qa.poseidon_rc = c->d_poseidon_rc; qa.poseidon_fast = c->d_poseidon_fast; qa.out = c->quot.coeffs; qa.lde_n = lde_n; qa.log_lde = L; qa.rate = 1u << p.rate_bits; qa.nch = nch;
     qa.num_routed = (uint32_t)R; qa.chunk = (uint32_t)p.quotient_degree_factor; qa.nchunks = nchunks; qa.sig0 = (uint32_t)sig0;
     qa.num_selectors = (uint32_t)p.num_selectors; qa.num_gates = (uint32_t)p.gates.size(); qa.nterms = (uint32_t)nterms;
     QP_HIP(ctx, pk_quotient(qa, st));

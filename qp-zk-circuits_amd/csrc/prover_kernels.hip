@@ -110,7 +110,7 @@ __device__ __forceinline__ u64 gate_filter(const QuotientArgs &a, u32 gi, u64 s)
 
 // PoseidonGate (plonky2::gates::poseidon) at one point: wires 0..11 input, 12..23 output, 24 swap, 25..28 delta,
 // 29..64 / 65..86 / 87..134 S-box inputs of the full / partial / full rounds; 123 constraints. Each constraint q is
-// weighted by alpha_c^(t+q) on the fly. Partial rounds in textbook form, not upstream's fast-partial basis.
+// weighted by alpha_c^(t+q) on the fly. Partial rounds in upstream's fast-partial basis (tables derived at start-up).
 __device__ __noinline__ void poseidon_gate_point(const QuotientArgs &a, u64 j, u32 t, u64 (&sum)[4]) {
     const u64 S = a.lde_n;
     const u32 nch = a.nch;
@@ -143,14 +143,16 @@ __device__ __noinline__ void poseidon_gate_point(const QuotientArgs &a, u64 j, u
         for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
         poseidon::mds_layer(st);
     }
-    for (int r = 0; r < 22; r++, rc++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);
+    // partial rounds in plonky2's fast basis (partial_first_constant_layer, mds_partial_layer_init, then per round:
+    // S-box input wire, S-box, round constant, sparse linear layer)
+    poseidon::fast_partial_enter(st, a.poseidon_fast);
+    for (int r = 0; r < 22; r++) {
         const u64 in = W(65 + r);
         emit(gl::sub(st[0], in));
         st[0] = poseidon::sbox7(in);
-        poseidon::mds_layer(st);
+        poseidon::fast_partial_linear(st, a.poseidon_fast, r);
     }
+    rc += 22;
     for (int r = 0; r < 4; r++, rc++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);

@@ -26,6 +26,7 @@ struct QuotientArgs {
     const uint64_t *beta_k_is, *betas, *gammas, *pi_hash;
     const GateDev *gates;
     const uint64_t *poseidon_rc;          // 360 round constants (PoseidonGate)
+    const uint64_t *poseidon_fast;        // FAST_PARTIAL_* tables, poseidon::FP_WORDS entries
     uint64_t *out;                        // [nch][lde_n] natural order
     uint64_t lde_n;
     uint32_t log_lde, rate, nch, num_routed, chunk, nchunks, sig0, num_selectors, num_gates, nterms;

@@ -165,13 +165,17 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
                 poseidon::mds_layer(st);
                 for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
             }
-            for (int rr = 0; rr < 22; rr++, rc++) {
-                for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
+            // partial rounds in plonky2's fast basis: the S-box input wires are state[0] of that formulation
+            const u64 *fpt = poseidon::host_fast_partial();
+            poseidon::fast_partial_enter(st, fpt);
+            for (int rr = 0; rr < 22; rr++) {
+                st[0] = gl::canon(st[0]);
                 W(r, 65 + rr) = st[0];
                 st[0] = poseidon::sbox7(st[0]);
-                poseidon::mds_layer(st);
-                for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+                poseidon::fast_partial_linear(st, fpt, rr);
             }
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+            rc += 22;
             for (int rr = 0; rr < 4; rr++, rc++) {
                 for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
                 for (int i = 0; i < 12; i++) W(r, 87 + 12 * rr + i) = st[i];

@@ -2,11 +2,19 @@
 #include <cstring>
 #include "circuit.hpp"
 #include "ctx.hpp"
+#include "poseidon.hpp"
 
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         uint64_t seed, unsigned flags, CircuitPack &pack, std::vector<uint64_t> &wires, std::vector<uint64_t> &pis);
 
 extern "C" {
+
+// the hash constants the library derives at start-up (host only): 360 round constants, then the FAST_PARTIAL tables
+size_t qpgpu_poseidon_constants(uint64_t *round_constants_360, uint64_t *fast_partial, size_t fast_partial_cap) {
+    if (round_constants_360) std::memcpy(round_constants_360, poseidon::host_round_constants(), 360 * 8);
+    if (fast_partial && fast_partial_cap >= (size_t)poseidon::FP_WORDS) std::memcpy(fast_partial, poseidon::host_fast_partial(), poseidon::FP_WORDS * 8);
+    return poseidon::FP_WORDS;
+}
 
 size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags) {
     (void)num_wires;

@@ -63,6 +63,7 @@ class Oracle:
         L.orc_verify.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         L.orc_trace_len.restype = ctypes.c_size_t; L.orc_trace_len.argtypes = [ctypes.c_char_p]
         L.orc_trace_get.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+        L.orc_poseidon_fast_partial.restype = ctypes.c_size_t; L.orc_poseidon_fast_partial.argtypes = [ctypes.c_void_p]
         L.orc_p2_params_size.restype = ctypes.c_size_t
         L.orc_p2_permute.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_p2_hash_pad10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -109,6 +110,8 @@ class Oracle:
         self.lib.orc_poseidon_permute(_vp(s)); return s
     def round_constants(self):
         rc = np.empty(360, dtype=np.uint64); self.lib.orc_poseidon_round_constants(_vp(rc)); return rc
+    def fast_partial(self):
+        out = np.empty(1024, dtype=np.uint64); n = self.lib.orc_poseidon_fast_partial(_vp(out)); return out[:n].copy()
     def hash_n_to_m(self, inp, m):
         x = np.ascontiguousarray(inp, dtype=np.uint64); out = np.empty(m, dtype=np.uint64)
         self.lib.orc_hash_n_to_m_no_pad(_vp(x), x.size, _vp(out), m); return out

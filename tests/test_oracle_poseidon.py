@@ -137,3 +137,26 @@ def test_poseidon2_plug_is_kat_gated(orc):
     assert got == p2_address(orc, params, kat["secret"])
     accepted = all(p2_address(orc, params, k["secret"]) == k["address"] for k in KATS["address_kats"])
     assert not accepted, "random constants cannot satisfy the reference KATs"
+
+
+def test_fast_partial_tables(orc, pkg):
+    """plonky2's FAST_PARTIAL_* tables: the oracle's derivation, the product's derivation and the golden fixture agree,
+    and the fixture reproduces the recalled upstream anchors."""
+    G = json.load(open(os.path.join(GOLD, "poseidon_fast_partial.json")))
+    flat = G["first_round_constant"] + G["round_constants"] + [0]
+    for row in G["vs"]: flat += row
+    for row in G["w_hats"]: flat += row
+    init_t = G["initial_matrix_upstream_layout"]            # upstream stores the transpose of the column-vector matrix
+    for c in range(11): flat += [init_t[r][c] for r in range(11)]
+    want = np.array(flat, dtype=np.uint64)
+    assert np.array_equal(orc.fast_partial(), want)
+    rc, fp = pkg.poseidon_constants()
+    assert np.array_equal(fp, want)
+    assert np.array_equal(rc, orc.round_constants())
+    a = G["anchors"]
+    assert [hex(x) for x in G["first_round_constant"][:2]] == a["first_round_constant"]
+    assert [hex(x) for x in G["round_constants"][:2]] == a["round_constants"]
+    assert [hex(x) for x in G["vs"][0][:2]] == a["vs_0"] and [hex(x) for x in G["w_hats"][0][:2]] == a["w_hats_0"]
+    assert [hex(x) for x in init_t[0][:2]] == a["initial_matrix_row0"]
+    assert int(G["m00"]) == 25
+    assert [int(x) for x in orc.poseidon(np.array(G["check_vector"]["input"], dtype=np.uint64))] == G["check_vector"]["output"]
