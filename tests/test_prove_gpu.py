@@ -130,3 +130,29 @@ def test_c_example_runs(pkg):
     res = subprocess.run([out, "10"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     assert res.stdout.startswith("ok degree_bits=10")
+
+
+def test_shape_fuzz_against_oracle(pkg, gpu, orc):
+    """Seeded differential sweep over circuit shapes: short last permutation chunk (num_routed % 8 != 0), no public
+    inputs, tiny degrees with zero FRI reduction rounds, gate mixes, zero-knowledge on/off."""
+    rng = np.random.default_rng(2024)
+    cases = [(3, 16, 8, 0, False, False, False), (4, 20, 12, 1, False, True, False), (5, 30, 20, 7, False, True, True),
+             (5, 135, 80, 21, True, True, False), (6, 135, 36, 3, True, False, True), (7, 140, 84, 2, True, True, True),
+             (8, 48, 44, 0, False, True, False)]
+    for _ in range(5):
+        d = int(rng.integers(3, 9)); routed = int(rng.integers(2, 21)) * 4; wires = routed + int(rng.integers(0, 20))
+        cases.append((d, wires, max(routed, 8), int(rng.integers(0, 9)), False, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+    for i, (d, wires_n, routed, npis, pos, bs, zk) in enumerate(cases):
+        pack, wires, pis = pkg.synth_circuit(d, num_wires=wires_n, num_routed=routed, num_public_inputs=npis, seed=500 + i,
+                                             poseidon=pos, base_sum=bs)
+        if zk:
+            pack = pack.copy(); pack[14] = 1
+        oc = OracleCircuit(orc, pack); circ = pkg.Circuit(gpu, pack)
+        try:
+            circ.set_blinding_seed(99 + i)
+            got = circ.prove(wires, pis)
+            want = oc.prove(wires, pis, seed=99 + i)
+            assert got == want, f"case {i}: d={d} wires={wires_n} routed={routed} pis={npis} poseidon={pos} base_sum={bs} zk={zk}"
+            assert oc.verify(got) == 0, f"case {i} rejected"
+        finally:
+            circ.close(); oc.close()
