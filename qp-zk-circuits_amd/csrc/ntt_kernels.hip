@@ -1,239 +1,76 @@
-// ntt_kernels.hip — Goldilocks radix-2^k NTT pass kernels for gfx950 (CDNA4).
-//
-// Replaces plonky2::field::fft::{fft, ifft, coset_fft} as used by PolynomialBatch::from_values /
-// from_coeffs inside `prove` (reference call site wormhole/prover/src/lib.rs:171-175; stage s2 of
-// SURVEY.md §8a). Output values are the same canonical field elements the CPU transform produces.
-//
-// Structure (MI355X-first, not a translation of the CPU butterfly loop):
-//   * An N-point transform is 1..3 "passes"; a pass does a 2^(KA+KB)-point DIF transform on every
-//     lane of a tile of T lanes, entirely on chip: round A (2^KA points per thread, in registers),
-//     one padded LDS exchange, round B (2^KB points per thread, in registers).
-//   * The register rounds are twiddle-free: plonky2's primitive 64th root of unity is 8, so every
-//     twiddle inside a <=64-point block is a power of two and a multiplication is a shift plus the
-//     2^64 = 2^32-1 / 2^96 = -1 folding. Real 64x64 multiplications happen once per element per
-//     round boundary only.
-//   * HBM access is tile-shaped: T adjacent lanes (T*8 B segments) on strided passes, full rows on
-//     the contiguous pass; 64-bit loads/stores, no atomics, no inter-workgroup communication.
+// ntt_kernels.hip — dispatcher for the NTT pass kernels (template in ntt_kernel_impl.hpp, instances in ntt_inst_*.hip).
 #include <hip/hip_runtime.h>
-#include "gl64.hpp"
 #include "ntt_pass.hpp"
 
-using gl::u32;
-using gl::u64;
-
-namespace {
-
-__device__ __forceinline__ u64 mul_pow2_dyn(u64 x, int s) {
-    // s is a compile-time constant after unrolling; the chain folds to one arm.
-    switch (s >> 5) {
-        default:
-        case 0:
-            if (s == 0) return x;
-            return gl::reduce96(x << s, (u32)(x >> (64 - s)));
-        case 1:
-            if (s == 32) return gl::reduce96(x << 32, (u32)(x >> 32));
-            return gl::reduce128(x << s, x >> (64 - s));
-        case 2: {
-            if (s == 64) {
-                u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-                return gl::sub(gl::mul_eps(x0), (u64)x1);
-            }
-            const int r = s - 64;
-            u32 a0 = (u32)x << r;
-            u64 top = x >> (32 - r);
-            return gl::sub(gl::mul_eps(a0), top);
-        }
-    }
-}
-
-__device__ __forceinline__ constexpr int brev(int x, int bits) {
-    int r = 0;
-    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
-    return r;
-}
-
-// In-register decimation-in-frequency transform of 2^K points. On exit x[j] holds X[bitrev_K(j)].
-template <int K, bool INV>
-__device__ __forceinline__ void dif_regs(u64 (&x)[1 << K]) {
-    constexpr int N = 1 << K;
-#pragma unroll
-    for (int len = N; len >= 2; len >>= 1) {
-        const int half = len >> 1;
-        const int step = 192 / len;  // w_len = 2^(192/len), len <= 64
-#pragma unroll
-        for (int b = 0; b < N; b += len) {
-#pragma unroll
-            for (int j = 0; j < half; j++) {
-                u64 u = x[b + j], v = x[b + j + half];
-                int s = (INV ? ((len - j) % len) : j) * step;  // in [0,192)
-                x[b + j] = gl::add(u, v);
-                if (s >= 96) x[b + j + half] = mul_pow2_dyn(gl::sub(v, u), s - 96);
-                else x[b + j + half] = mul_pow2_dyn(gl::sub(u, v), s);
-            }
-        }
-    }
-}
-
-template <int KA, int KB, bool INV>
-__global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) {
-    constexpr int NA = 1 << KA, NB = 1 << KB, R = 1 << (KA + KB);
-    extern __shared__ __align__(16) u64 lds[];
-
-    const int T = 1 << a.log_t;
-    const int tid = threadIdx.x;
-    const int RP = R + NA + 1;  // odd row pitch (8-byte words): conflict-free in both mappings
-
-    // tile / lane geometry
-    const u64 tile = blockIdx.x;
-    const u64 lane0 = tile << a.log_t;          // first lane of this tile (global lane index)
-    const u64 col = blockIdx.y;
-    const u64 *in = a.in + col * a.in_col_stride;
-    u64 *out = a.out + col * a.out_col_stride;
-
-    // ---------------- round A ----------------
-    {
-        int m, l;
-        if (a.load_lane_fast) { l = tid & (T - 1); m = tid >> a.log_t; }
-        else { m = tid & (NB - 1); l = tid >> KB; }
-        const bool active = (tid < (NB << a.log_t));
-        const u64 lane = lane0 + l;
-        const bool lane_ok = lane < a.lanes_total;
-        if (active) {
-            u64 x[NA];
-            // lane -> (outer row, inner lane) for strided passes: lane = row * M + mm
-            // offsets inside one column fit 32 bits (N <= 2^30): 32-bit index arithmetic, one 64-bit add per access
-            const u32 row = (u32)(lane >> a.log_m), mm = (u32)lane & ((1u << a.log_m) - 1);
-            const u32 ips = (u32)a.in_p_stride;
-            const u32 base = row * (u32)a.in_row_stride + mm * (u32)a.in_l_stride + (u32)m * ips;
-            const u32 istep = (u32)NB * ips;
-#pragma unroll
-            for (int i = 0; i < NA; i++) {
-                const u32 p = (u32)(i * NB + m);
-                u64 v = 0;
-                if (lane_ok && p < a.p_valid) v = in[base + (u32)i * istep];
-                x[i] = v;
-            }
-            if (a.in_scale_a) {  // coset: x[p, lane] *= A[p] * B[mm]
-                const u64 sb = a.in_scale_b[mm];
-#pragma unroll
-                for (int i = 0; i < NA; i++) {
-                    const u32 p = (u32)(i * NB + m);
-                    if (p < a.p_valid) x[i] = gl::mul(x[i], gl::mul(a.in_scale_a[p], sb));
-                }
-            }
-            dif_regs<KA, INV>(x);
-            if constexpr (KB > 0) {
-#pragma unroll
-                for (int j = 0; j < NA; j++) {
-                    const int ka = brev(j, KA);
-                    if (ka != 0 && m != 0) x[j] = gl::mul(x[j], a.tw_inner[(u32)(m * ka)]);
-                    const int s = j * NB + m;
-                    lds[l * RP + s + (s >> KB)] = x[j];
-                }
-            } else {
-                // single-round pass: finish here
-#pragma unroll
-                for (int j = 0; j < NA; j++) {
-                    const u32 k = (u32)brev(j, KA);
-                    u64 v = x[j];
-                    if (a.tw_lo) {
-                        const u32 e = mm * k;
-                        if (e) v = gl::mul(v, gl::mul(a.tw_hi[e >> a.tw_lo_bits], a.tw_lo[e & ((1u << a.tw_lo_bits) - 1)]));
-                    }
-                    if (a.has_out_scale) v = gl::mul(v, a.out_scale);
-                    v = gl::canon(v);
-                    const u32 pos = a.out_bitrev ? (u32)j : k;
-                    if (lane_ok) out[row * (u32)a.out_row_stride + mm * (u32)a.out_l_stride + pos * (u32)a.out_p_stride] = v;
-                }
-            }
-        }
-    }
-    if constexpr (KB == 0) return;
-    __syncthreads();
-    // ---------------- round B ----------------
-    {
-        int j, l;
-        if (a.store_lane_fast) { l = tid & (T - 1); j = tid >> a.log_t; }
-        else { j = tid & (NA - 1); l = tid >> KA; }
-        const bool active = (tid < (NA << a.log_t));
-        const u64 lane = lane0 + l;
-        const bool lane_ok = lane < a.lanes_total;
-        if (active) {
-            u64 y[NB];
-#pragma unroll
-            for (int i = 0; i < NB; i++) {
-                const int s = j * NB + i;
-                y[i] = lds[l * RP + s + (s >> KB)];
-            }
-            dif_regs<KB, INV>(y);
-            const u32 row = (u32)(lane >> a.log_m), mm = (u32)lane & ((1u << a.log_m) - 1);
-            const u32 ops = (u32)a.out_p_stride;
-            const u32 obase = row * (u32)a.out_row_stride + mm * (u32)a.out_l_stride;
-            const u32 ka = (u32)brev(j, KA);
-#pragma unroll
-            for (int jb = 0; jb < NB; jb++) {
-                const u32 k = ka + ((u32)brev(jb, KB) << KA);
-                u64 v = y[jb];
-                if (a.tw_lo) {
-                    const u32 e = mm * k;
-                    if (e) v = gl::mul(v, gl::mul(a.tw_hi[e >> a.tw_lo_bits], a.tw_lo[e & ((1u << a.tw_lo_bits) - 1)]));
-                }
-                if (a.has_out_scale) v = gl::mul(v, a.out_scale);
-                v = gl::canon(v);
-                const u32 pos = a.out_bitrev ? (u32)(j * NB + jb) : k;
-                if (lane_ok) out[obase + pos * ops] = v;
-            }
-        }
-    }
-}
-
-template <int KA, int KB>
-hipError_t launch_dir(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (a.inverse) {
-        hipLaunchKernelGGL((ntt_pass_kernel<KA, KB, true>), grid, block, lds, st, a);
-    } else {
-        hipLaunchKernelGGL((ntt_pass_kernel<KA, KB, false>), grid, block, lds, st, a);
-    }
-    return hipGetLastError();
-}
-
-template <int KA, int KB>
-hipError_t set_lds_attr() {
-    hipError_t e = hipFuncSetAttribute((const void *)ntt_pass_kernel<KA, KB, false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)ntt_pass_kernel<KA, KB, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
-}  // namespace
+hipError_t ntt_launch_1_0(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_1_0();
+hipError_t ntt_launch_2_0(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_2_0();
+hipError_t ntt_launch_3_0(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_3_0();
+hipError_t ntt_launch_4_0(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_4_0();
+hipError_t ntt_launch_5_0(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_5_0();
+hipError_t ntt_launch_1_1(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_1_1();
+hipError_t ntt_launch_2_1(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_2_1();
+hipError_t ntt_launch_2_2(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_2_2();
+hipError_t ntt_launch_3_2(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_3_2();
+hipError_t ntt_launch_3_3(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_3_3();
+hipError_t ntt_launch_4_3(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_4_3();
+hipError_t ntt_launch_4_4(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_4_4();
+hipError_t ntt_launch_5_4(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_5_4();
+hipError_t ntt_launch_5_5(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t ntt_attr_5_5();
 
 size_t ntt_pass_lds_bytes(int ka, int kb, int log_t) {
     if (kb == 0) return 0;
     size_t rp = ((size_t)1 << (ka + kb)) + ((size_t)1 << ka) + 1;
-    return (rp << log_t) * sizeof(u64);
+    return (rp << log_t) * sizeof(uint64_t);
 }
 
 hipError_t ntt_pass_init() {
     hipError_t e;
-#define SETATTR(A, B) if ((e = set_lds_attr<A, B>()) != hipSuccess) return e;
-    SETATTR(1, 1) SETATTR(2, 1) SETATTR(2, 2) SETATTR(3, 2) SETATTR(3, 3)
-    SETATTR(4, 3) SETATTR(4, 4) SETATTR(5, 4) SETATTR(5, 5)
-#undef SETATTR
+    if ((e = ntt_attr_1_1()) != hipSuccess) return e;
+    if ((e = ntt_attr_2_1()) != hipSuccess) return e;
+    if ((e = ntt_attr_2_2()) != hipSuccess) return e;
+    if ((e = ntt_attr_3_2()) != hipSuccess) return e;
+    if ((e = ntt_attr_3_3()) != hipSuccess) return e;
+    if ((e = ntt_attr_4_3()) != hipSuccess) return e;
+    if ((e = ntt_attr_4_4()) != hipSuccess) return e;
+    if ((e = ntt_attr_5_4()) != hipSuccess) return e;
+    if ((e = ntt_attr_5_5()) != hipSuccess) return e;
     return hipSuccess;
 }
 
-hipError_t ntt_pass_launch(const NttPassArgs &a, u64 n_tiles, u64 n_cols, hipStream_t st) {
+hipError_t ntt_pass_launch(const NttPassArgs &a, uint64_t n_tiles, uint64_t n_cols, hipStream_t st) {
     const int ka = a.ka, kb = a.kb;
     dim3 grid((unsigned)n_tiles, (unsigned)n_cols, 1);
     dim3 block((unsigned)(1u << (ka + a.log_t)), 1, 1);
     if (kb == 0) block.x = 1u << a.log_t;
     if (block.x < 64) block.x = 64;
     size_t lds = ntt_pass_lds_bytes(ka, kb, a.log_t);
-#define CASE(A, B) if (ka == A && kb == B) return launch_dir<A, B>(a, grid, block, lds, st);
-    CASE(1, 0) CASE(2, 0) CASE(3, 0) CASE(4, 0) CASE(5, 0)
-    CASE(1, 1) CASE(2, 1) CASE(2, 2) CASE(3, 2) CASE(3, 3)
-    CASE(4, 3) CASE(4, 4) CASE(5, 4) CASE(5, 5)
-#undef CASE
+    if (ka == 1 && kb == 0) return ntt_launch_1_0(a, grid, block, lds, st);
+    if (ka == 2 && kb == 0) return ntt_launch_2_0(a, grid, block, lds, st);
+    if (ka == 3 && kb == 0) return ntt_launch_3_0(a, grid, block, lds, st);
+    if (ka == 4 && kb == 0) return ntt_launch_4_0(a, grid, block, lds, st);
+    if (ka == 5 && kb == 0) return ntt_launch_5_0(a, grid, block, lds, st);
+    if (ka == 1 && kb == 1) return ntt_launch_1_1(a, grid, block, lds, st);
+    if (ka == 2 && kb == 1) return ntt_launch_2_1(a, grid, block, lds, st);
+    if (ka == 2 && kb == 2) return ntt_launch_2_2(a, grid, block, lds, st);
+    if (ka == 3 && kb == 2) return ntt_launch_3_2(a, grid, block, lds, st);
+    if (ka == 3 && kb == 3) return ntt_launch_3_3(a, grid, block, lds, st);
+    if (ka == 4 && kb == 3) return ntt_launch_4_3(a, grid, block, lds, st);
+    if (ka == 4 && kb == 4) return ntt_launch_4_4(a, grid, block, lds, st);
+    if (ka == 5 && kb == 4) return ntt_launch_5_4(a, grid, block, lds, st);
+    if (ka == 5 && kb == 5) return ntt_launch_5_5(a, grid, block, lds, st);
     return hipErrorInvalidValue;
 }
