@@ -79,6 +79,8 @@ struct qpgpu_circuit {
     u64 *d_cs_values = nullptr;
     DevBatch cs;
     GateDev *d_gates = nullptr;
+    std::vector<GateDev> h_gates;
+    u64 *d_qacc = nullptr;
     u64 *d_poseidon_rc = nullptr, *d_poseidon_fast = nullptr;
     u64 *d_omega = nullptr, *d_x_coset = nullptr, *d_l0_coset = nullptr, *d_zh_inv = nullptr;
     u64 *d_ginv_lo = nullptr, *d_ginv_hi = nullptr; uint32_t ginv_lo_bits = 0;
@@ -238,6 +240,7 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
         gd[i] = {(uint32_t)g.type, (uint32_t)g.param0, (uint32_t)g.param1, (uint32_t)g.selector_index, (uint32_t)g.group_start,
                  (uint32_t)g.group_end, (uint32_t)g.num_constraints, 0};
     }
+    c->h_gates = gd;
     CK(c->alloc(&c->d_gates, gd.size()));
     CK(h2d(ctx, c->d_gates, gd.data(), gd.size() * sizeof(GateDev)));
     CK(c->alloc(&c->d_poseidon_rc, 360));
@@ -276,6 +279,7 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     CK(alloc_batch(c, c->zs, (uint32_t)p.num_zs_pp_cols(), true, 2));
     CK(alloc_batch(c, c->quot, (uint32_t)p.num_quotient_cols(), false, 3));
     CK(c->alloc(&c->quot.coeffs, (size_t)nch * lde_n));       // quotient values -> coefficients, = nq chunks of n
+    CK(c->alloc(&c->d_qacc, (size_t)nch * lde_n));
     CK(c->alloc(&c->d_qcp, (size_t)nch * p.num_chunks() * n));
     CK(c->alloc(&c->d_rowprod, (size_t)nch * n));
     CK(c->alloc(&c->d_z, (size_t)nch * n));
@@ -400,10 +404,10 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     QuotientArgs qa{};
     qa.wires = c->wires.lde; qa.cs = c->cs.lde; qa.zs_pp = c->zs.lde; qa.x_coset = c->d_x_coset; qa.l0_coset = c->d_l0_coset;
     qa.zh_inv = c->d_zh_inv; qa.alpha_pows = d_apow; qa.beta_k_is = d_bk; qa.betas = d_betas; qa.gammas = d_gammas; qa.pi_hash = d_pih;
-    qa.gates = c->d_gates; qa.poseidon_rc = c->d_poseidon_rc; qa.poseidon_fast = c->d_poseidon_fast; qa.out = c->quot.coeffs; qa.lde_n = lde_n; qa.log_lde = L; qa.rate = 1u << p.rate_bits; qa.nch = nch;
+    qa.gates = c->d_gates; qa.acc = c->d_qacc; qa.poseidon_rc = c->d_poseidon_rc; qa.poseidon_fast = c->d_poseidon_fast; qa.out = c->quot.coeffs; qa.lde_n = lde_n; qa.log_lde = L; qa.rate = 1u << p.rate_bits; qa.nch = nch;
     qa.num_routed = (uint32_t)R; qa.chunk = (uint32_t)p.quotient_degree_factor; qa.nchunks = nchunks; qa.sig0 = (uint32_t)sig0;
     qa.num_selectors = (uint32_t)p.num_selectors; qa.num_gates = (uint32_t)p.gates.size(); qa.nterms = (uint32_t)nterms;
-    QP_HIP(ctx, pk_quotient(qa, st));
+    QP_HIP(ctx, pk_quotient(qa, c->h_gates.data(), st));
     // coset_ifft(g): ifft then scale coefficient i by g^-i; the 8n coefficients are the qdf chunks of n, contiguous
     QP_TRY(ntt_run(ctx, c->quot.coeffs, c->quot.coeffs, L, L, nch, true, false, 0));
     QP_HIP(ctx, pk_scale_powers(c->quot.coeffs, lde_n, nch, c->d_ginv_lo, c->d_ginv_hi, c->ginv_lo_bits, st));

@@ -3,7 +3,7 @@
 // Replaces, inside qp-plonky2 1.5.5 `plonk::prover::prove` (reference call site
 // wormhole/prover/src/lib.rs:171-175):
 //   s5  all_wires_permutation_partial_products   -> pp_rows_kernel, pp_scan_kernel, pp_finish_kernel
-//   s6  compute_quotient_polys                   -> quotient_kernel
+//   s6  compute_quotient_polys                   -> quotient_perm_kernel, quotient_gates_kernel, quotient_poseidon_kernel
 //   s7  OpeningSet::new (poly evaluation at zeta) -> poly_eval_kernel
 //   s8  prove_openings (batch reduce, /(X - z))  -> reduce_polys_kernel, divide_linear_kernel
 //   s9  fri_committed_trees (fold)               -> fri_fold_kernel, interleave_ext_kernel
@@ -108,16 +108,127 @@ __device__ __forceinline__ u64 gate_filter(const QuotientArgs &a, u32 gi, u64 s)
     return f;
 }
 
-// PoseidonGate (plonky2::gates::poseidon) at one point: wires 0..11 input, 12..23 output, 24 swap, 25..28 delta,
-// 29..64 / 65..86 / 87..134 S-box inputs of the full / partial / full rounds; 123 constraints. Each constraint q is
-// weighted by alpha_c^(t+q) on the fly. Partial rounds in upstream's fast-partial basis (tables derived at start-up).
-__device__ __noinline__ void poseidon_gate_point(const QuotientArgs &a, u64 j, u32 t, u64 (&sum)[4]) {
+// ---- s6 is three kernels over the LDE slots (thread = slot j, point index i = bitrev(j)), each adding its
+// alpha-weighted terms into acc[c][j] (slot order, unit stride); the last one multiplies by 1/Z_H(x) and stores the
+// quotient values in natural order for the inverse NTT. NCH (number of challenges) is a compile-time constant so the
+// per-challenge accumulators live in registers.
+
+// (1) L_0(x)(Z(x) - 1) and the partial-product checks
+template <int NCH>
+__global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= a.lde_n) return;
+    const u32 logL = a.log_lde, R = a.num_routed, chunk = a.chunk, nchunks = a.nchunks, npp = nchunks - 1;
+    const u64 i = brev32((u32)j, logL);
+    const u64 jn = brev32((u32)((i + a.rate) & (a.lde_n - 1)), logL);   // slot of the next row g*x
+    const u64 x = a.x_coset[j], l0 = a.l0_coset[j], S = a.lde_n;
+    u64 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) acc[c] = 0;
+    u32 t = 0;
+#pragma unroll
+    for (int k = 0; k < NCH; k++, t++) {
+        const u64 term = gl::mul(l0, gl::sub(a.zs_pp[(u64)k * S + j], 1));
+#pragma unroll
+        for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(term, a.alpha_pows[(u64)c * a.nterms + t]));
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+        const u64 beta = a.betas[k], gamma = a.gammas[k];
+        u64 prev = a.zs_pp[(u64)k * S + j];
+        for (u32 cc = 0; cc < nchunks; cc++, t++) {
+            u64 pn = 1, pd = 1;
+            for (u32 r = cc * chunk; r < (cc + 1) * chunk && r < R; r++) {
+                const u64 w = a.wires[(u64)r * S + j];
+                const u64 sid = gl::mul(a.beta_k_is[k * R + r], x);
+                const u64 ssg = gl::mul(beta, a.cs[(u64)(a.sig0 + r) * S + j]);
+                pn = gl::mul(pn, gl::add(gl::add(w, sid), gamma));
+                pd = gl::mul(pd, gl::add(gl::add(w, ssg), gamma));
+            }
+            const u64 next = cc == nchunks - 1 ? a.zs_pp[(u64)k * S + jn] : a.zs_pp[((u64)NCH + (u64)k * npp + cc) * S + j];
+            const u64 term = gl::sub(gl::mul(prev, pn), gl::mul(next, pd));
+#pragma unroll
+            for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(term, a.alpha_pows[(u64)c * a.nterms + t]));
+            prev = next;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = acc[c];
+}
+
+// (2) the low-degree gates: Constant, PublicInput, BaseSum<2>, Arithmetic. t0 = index of the first gate constraint.
+template <int NCH>
+__global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32 t0, int finalize) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= a.lde_n) return;
     const u64 S = a.lde_n;
-    const u32 nch = a.nch;
+    u64 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) acc[c] = a.acc[(u64)c * S + j];
+    const u64 *consts_base = a.cs + (u64)a.num_selectors * S + j;
+    const u64 *ap = a.alpha_pows + t0;
+    for (u32 gi = 0; gi < a.num_gates; gi++) {
+        const GateDev g = a.gates[gi];
+        if (g.num_constraints == 0 || g.type == 4) continue;
+        const u64 f = gate_filter(a, gi, a.cs[(u64)g.selector_index * S + j]);
+        u64 sum[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) sum[c] = 0;
+        auto emit = [&](u32 q, u64 cst) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) sum[c] = gl::add(sum[c], gl::mul(cst, ap[(u64)c * a.nterms + q]));
+        };
+        if (g.type == 1) {            // ConstantGate: const_i - wire_i
+            for (u32 q = 0; q < g.param0; q++) emit(q, gl::sub(consts_base[(u64)q * S], a.wires[(u64)q * S + j]));
+        } else if (g.type == 2) {     // PublicInputGate: wire_i - pi_hash_i
+            for (u32 q = 0; q < 4; q++) emit(q, gl::sub(a.wires[(u64)q * S + j], a.pi_hash[q]));
+        } else if (g.type == 3) {     // ArithmeticGate: out - (c0 m0 m1 + c1 addend)
+            const u64 c0 = consts_base[0], c1 = consts_base[S];
+            for (u32 q = 0; q < g.param0; q++) {
+                const u64 m0 = a.wires[(u64)(4 * q) * S + j], m1 = a.wires[(u64)(4 * q + 1) * S + j];
+                const u64 ad = a.wires[(u64)(4 * q + 2) * S + j], out = a.wires[(u64)(4 * q + 3) * S + j];
+                emit(q, gl::sub(out, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
+            }
+        } else if (g.type == 5) {     // BaseSumGate<2>: sum - sum_i 2^i limb_i, and limb_i (limb_i - 1)
+            u64 s2 = 0;
+            for (u32 q = g.param0; q-- > 0;) s2 = gl::add(gl::add(s2, s2), a.wires[(u64)(1 + q) * S + j]);
+            emit(0, gl::sub(s2, a.wires[j]));
+            for (u32 q = 0; q < g.param0; q++) {
+                const u64 limb = a.wires[(u64)(1 + q) * S + j];
+                emit(1 + q, gl::mul(limb, gl::sub(limb, 1)));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(f, sum[c]));
+    }
+    if (finalize) {
+        const u64 i = brev32((u32)j, a.log_lde);
+        const u64 zi = a.zh_inv[i & (a.rate - 1)];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a.out[(u64)c * S + i] = gl::canon(gl::mul(acc[c], zi));
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = acc[c];
+    }
+}
+
+// (3) PoseidonGate (plonky2::gates::poseidon) at one point: wires 0..11 input, 12..23 output, 24 swap, 25..28 delta,
+// 29..64 / 65..86 / 87..134 S-box inputs of the full / partial / full rounds; 123 constraints, each weighted by
+// alpha_c^(t0+q) on the fly. Partial rounds in upstream's fast-partial basis (tables derived at start-up).
+template <int NCH>
+__global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, u32 gi, u32 t0, int finalize) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= a.lde_n) return;
+    const u64 S = a.lde_n;
+    const u64 *ap = a.alpha_pows + t0;
     auto W = [&](u32 i) -> u64 { return a.wires[(u64)i * S + j]; };
+    u64 sum[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) sum[c] = 0;
     u32 q = 0;
     auto emit = [&](u64 cst) {
-        for (u32 c = 0; c < nch; c++) sum[c] = gl::add(sum[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
+#pragma unroll
+        for (int c = 0; c < NCH; c++) sum[c] = gl::add(sum[c], gl::mul(cst, ap[(u64)c * a.nterms + q]));
         q++;
     };
     const u64 swap = W(24);
@@ -143,8 +254,6 @@ __device__ __noinline__ void poseidon_gate_point(const QuotientArgs &a, u64 j, u
         for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
         poseidon::mds_layer(st);
     }
-    // partial rounds in plonky2's fast basis (partial_first_constant_layer, mds_partial_layer_init, then per round:
-    // S-box input wire, S-box, round constant, sparse linear layer)
     poseidon::fast_partial_enter(st, a.poseidon_fast);
     for (int r = 0; r < 22; r++) {
         const u64 in = W(65 + r);
@@ -164,88 +273,16 @@ __device__ __noinline__ void poseidon_gate_point(const QuotientArgs &a, u64 j, u
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) emit(gl::sub(st[i], W(12 + i)));
-}
-
-// One thread per LDE slot j (point index i = bitrev(j), x = g w^i). Writes quotient values in natural order.
-__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs a) {
-    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (j >= a.lde_n) return;
-    const u32 logL = a.log_lde, nch = a.nch, R = a.num_routed, chunk = a.chunk, nchunks = a.nchunks, npp = nchunks - 1;
-    const u64 i = brev32((u32)j, logL);
-    const u64 jn = brev32((u32)((i + a.rate) & (a.lde_n - 1)), logL);   // slot of the next row g*x
-    const u64 x = a.x_coset[j];
-    const u64 l0 = a.l0_coset[j];
-    const u64 S = a.lde_n;   // column stride
-    u64 acc[4] = {0, 0, 0, 0};
-    u32 t = 0;
-    // L_0(x) (Z(x) - 1)
-    for (u32 k = 0; k < nch; k++, t++) {
-        const u64 term = gl::mul(l0, gl::sub(a.zs_pp[(u64)k * S + j], 1));
-        for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(term, a.alpha_pows[(u64)c * a.nterms + t]));
+    const u64 f = gate_filter(a, gi, a.cs[(u64)a.gates[gi].selector_index * S + j]);
+    if (finalize) {
+        const u64 i = brev32((u32)j, a.log_lde);
+        const u64 zi = a.zh_inv[i & (a.rate - 1)];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a.out[(u64)c * S + i] = gl::canon(gl::mul(gl::add(a.acc[(u64)c * S + j], gl::mul(f, sum[c])), zi));
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = gl::add(a.acc[(u64)c * S + j], gl::mul(f, sum[c]));
     }
-    // partial product checks
-    for (u32 k = 0; k < nch; k++) {
-        const u64 beta = a.betas[k], gamma = a.gammas[k];
-        for (u32 cc = 0; cc < nchunks; cc++, t++) {
-            u64 pn = 1, pd = 1;
-            for (u32 r = cc * chunk; r < (cc + 1) * chunk && r < R; r++) {
-                const u64 w = a.wires[(u64)r * S + j];
-                const u64 sid = gl::mul(a.beta_k_is[k * R + r], x);
-                const u64 ssg = gl::mul(beta, a.cs[(u64)(a.sig0 + r) * S + j]);
-                pn = gl::mul(pn, gl::add(gl::add(w, sid), gamma));
-                pd = gl::mul(pd, gl::add(gl::add(w, ssg), gamma));
-            }
-            const u64 prev = cc == 0 ? a.zs_pp[(u64)k * S + j] : a.zs_pp[((u64)nch + (u64)k * npp + cc - 1) * S + j];
-            const u64 next = cc == nchunks - 1 ? a.zs_pp[(u64)k * S + jn] : a.zs_pp[((u64)nch + (u64)k * npp + cc) * S + j];
-            const u64 term = gl::sub(gl::mul(prev, pn), gl::mul(next, pd));
-            for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(term, a.alpha_pows[(u64)c * a.nterms + t]));
-        }
-    }
-    // gate constraints (constraint index g of every gate shares alpha^(t+g))
-    const u64 *consts_base = a.cs + (u64)a.num_selectors * S + j;
-    for (u32 gi = 0; gi < a.num_gates; gi++) {
-        const GateDev g = a.gates[gi];
-        if (g.num_constraints == 0) continue;
-        const u64 f = gate_filter(a, gi, a.cs[(u64)g.selector_index * S + j]);
-        if (f == 0) continue;   // canonical zero: this row is not of this gate type
-        if (g.type == 1) {            // ConstantGate: const_i - wire_i
-            for (u32 q = 0; q < g.param0; q++) {
-                const u64 cst = gl::mul(f, gl::sub(consts_base[(u64)q * S], a.wires[(u64)q * S + j]));
-                for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
-            }
-        } else if (g.type == 2) {     // PublicInputGate: wire_i - pi_hash_i
-            for (u32 q = 0; q < 4; q++) {
-                const u64 cst = gl::mul(f, gl::sub(a.wires[(u64)q * S + j], a.pi_hash[q]));
-                for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
-            }
-        } else if (g.type == 3) {     // ArithmeticGate: out - (c0 m0 m1 + c1 addend)
-            const u64 c0 = consts_base[0], c1 = consts_base[S];
-            for (u32 q = 0; q < g.param0; q++) {
-                const u64 m0 = a.wires[(u64)(4 * q) * S + j], m1 = a.wires[(u64)(4 * q + 1) * S + j];
-                const u64 ad = a.wires[(u64)(4 * q + 2) * S + j], out = a.wires[(u64)(4 * q + 3) * S + j];
-                const u64 computed = gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1));
-                const u64 cst = gl::mul(f, gl::sub(out, computed));
-                for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + q]));
-            }
-        } else if (g.type == 5) {     // BaseSumGate<2>: sum - sum_i 2^i limb_i, and limb_i (limb_i - 1)
-            u64 s2 = 0, wsum[4] = {0, 0, 0, 0};
-            for (u32 q = g.param0; q-- > 0;) s2 = gl::add(gl::add(s2, s2), a.wires[(u64)(1 + q) * S + j]);
-            const u64 c0 = gl::sub(s2, a.wires[j]);
-            for (u32 c = 0; c < nch; c++) wsum[c] = gl::mul(c0, a.alpha_pows[(u64)c * a.nterms + t]);
-            for (u32 q = 0; q < g.param0; q++) {
-                const u64 limb = a.wires[(u64)(1 + q) * S + j];
-                const u64 cst = gl::mul(limb, gl::sub(limb, 1));
-                for (u32 c = 0; c < nch; c++) wsum[c] = gl::add(wsum[c], gl::mul(cst, a.alpha_pows[(u64)c * a.nterms + t + 1 + q]));
-            }
-            for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(f, wsum[c]));
-        } else if (g.type == 4) {     // PoseidonGate
-            u64 sum[4] = {0, 0, 0, 0};
-            poseidon_gate_point(a, j, t, sum);
-            for (u32 c = 0; c < nch; c++) acc[c] = gl::add(acc[c], gl::mul(f, sum[c]));
-        }
-    }
-    const u64 zi = a.zh_inv[i & (a.rate - 1)];
-    for (u32 c = 0; c < nch; c++) a.out[(u64)c * S + i] = gl::canon(gl::mul(acc[c], zi));
 }
 
 // out[i] = in[i] * shift_inv^i (coset_ifft tail), two-level power table
@@ -421,9 +458,32 @@ hipError_t pk_pp_finish(const PpArgs &a, const u64 *z, u64 *zs_pp, hipStream_t s
     hipLaunchKernelGGL(pp_finish_kernel, g, b, 0, st, a, z, zs_pp);
     return hipGetLastError();
 }
-hipError_t pk_quotient(const QuotientArgs &a, hipStream_t st) {
-    LAUNCH_1D(quotient_kernel, a.lde_n, 256, st, a);
+template <int NCH>
+static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
+    dim3 b(256), g((unsigned)((a.lde_n + 255) / 256));
+    const u32 t0 = a.nch + a.nch * a.nchunks;
+    // Poseidon gates (heavy, one launch each) come last; the final launch also applies 1/Z_H and stores
+    int n_pos = 0;
+    for (u32 i = 0; i < a.num_gates; i++) if (host_gates[i].type == 4 && host_gates[i].num_constraints) n_pos++;
+    hipLaunchKernelGGL((quotient_perm_kernel<NCH>), g, b, 0, st, a);
+    hipLaunchKernelGGL((quotient_gates_kernel<NCH>), g, b, 0, st, a, t0, n_pos == 0 ? 1 : 0);
+    int seen = 0;
+    for (u32 i = 0; i < a.num_gates; i++)
+        if (host_gates[i].type == 4 && host_gates[i].num_constraints) {
+            seen++;
+            hipLaunchKernelGGL((quotient_poseidon_kernel<NCH>), g, b, 0, st, a, i, t0, seen == n_pos ? 1 : 0);
+        }
     return hipGetLastError();
+}
+hipError_t pk_quotient(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
+    if (a.lde_n == 0) return hipSuccess;
+    switch (a.nch) {
+        case 1: return quotient_launch<1>(a, host_gates, st);
+        case 2: return quotient_launch<2>(a, host_gates, st);
+        case 3: return quotient_launch<3>(a, host_gates, st);
+        case 4: return quotient_launch<4>(a, host_gates, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 hipError_t pk_scale_powers(u64 *data, u64 n, u64 ncols, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits, hipStream_t st) {
     LAUNCH_1D(scale_powers_kernel, n, 256, st, data, n, ncols, pw_lo, pw_hi, lo_bits);

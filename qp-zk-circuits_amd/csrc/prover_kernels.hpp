@@ -27,6 +27,7 @@ struct QuotientArgs {
     const GateDev *gates;
     const uint64_t *poseidon_rc;          // 360 round constants (PoseidonGate)
     const uint64_t *poseidon_fast;        // FAST_PARTIAL_* tables, poseidon::FP_WORDS entries
+    uint64_t *acc;                        // [nch][lde_n] slot order: running alpha-weighted sums between the s6 kernels
     uint64_t *out;                        // [nch][lde_n] natural order
     uint64_t lde_n;
     uint32_t log_lde, rate, nch, num_routed, chunk, nchunks, sig0, num_selectors, num_gates, nterms;
@@ -51,7 +52,7 @@ struct PowArgs {
 hipError_t pk_pp_rows(const PpArgs &a, hipStream_t st);
 hipError_t pk_pp_scan(const uint64_t *rowprod, uint64_t *z, uint64_t n, uint32_t nch, hipStream_t st);
 hipError_t pk_pp_finish(const PpArgs &a, const uint64_t *z, uint64_t *zs_pp, hipStream_t st);
-hipError_t pk_quotient(const QuotientArgs &a, hipStream_t st);
+hipError_t pk_quotient(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st);
 hipError_t pk_scale_powers(uint64_t *data, uint64_t n, uint64_t ncols, const uint64_t *pw_lo, const uint64_t *pw_hi, uint32_t lo_bits, hipStream_t st);
 hipError_t pk_poly_eval(const uint64_t *coeffs, uint64_t n, uint32_t npolys, const gl::e2 *points, uint32_t npoints, const uint64_t *poly_index, gl::e2 *out, hipStream_t st);
 hipError_t pk_reduce_polys(const ReduceArgs &a, hipStream_t st);
