@@ -153,6 +153,11 @@ GL_HD u64 mul(u64 a, u64 b) {
     mul64wide(a, b, lo, hi);
     return reduce128(lo, hi);
 }
+// a + b for a canonical b (< p): one carry fold is exact (a + b - 2^64 < b <= p - 1, so adding 2^32 - 1 cannot wrap)
+GL_HD u64 add_canonical(u64 a, u64 b) {
+    const u64 s = a + b;
+    return s + (s < a ? EPS : 0);
+}
 GL_HD u64 sqr(u64 a) { return mul(a, a); }
 
 // x * 2^S mod p for a compile-time S in [0, 192). 2^96 = -1, 2^192 = 1.

@@ -96,18 +96,18 @@ GL_HD void permute(u64 (&s)[WIDTH], const u64 *rc) {
     int r = 0;
     for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
-        for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add(s[i], rc[r * WIDTH + i]));
+        for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add_canonical(s[i], rc[r * WIDTH + i]));
         mds_layer(s);
     }
     for (int k = 0; k < PARTIAL; k++, r++) {
 #pragma unroll
-        for (int i = 0; i < WIDTH; i++) s[i] = gl::add(s[i], rc[r * WIDTH + i]);
+        for (int i = 0; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
         s[0] = sbox7(s[0]);
         mds_layer(s);
     }
     for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
-        for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add(s[i], rc[r * WIDTH + i]));
+        for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add_canonical(s[i], rc[r * WIDTH + i]));
         mds_layer(s);
     }
 #pragma unroll
