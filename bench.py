@@ -7,10 +7,13 @@ Headline workload (BASELINE configs[2], "Full Wormhole proof (LDE + Poseidon Mer
 MI355X"): one proof per step per GPU of a shape-equivalent synthetic leaf circuit (the real circuit pack needs
 a Rust exporter): 2^13 rows, 135 wires, 80 routed, standard_recursion_config FRI (rate
 1/8, cap height 4, 28 queries, 16 PoW bits, arity 16). The witness is resident in HBM when the timed region
-starts; a step ends when the proof bytes are in host memory. value = proofs/s over all ranks.
+starts; a proof ends when its bytes are in host memory. A step = one proof on each of the S streams of every GPU
+(S = --streams, 4 by default: independent pipelines, one HIP stream + workspace + host thread each).
+value = proofs/s over all ranks.
 
-N ranks (BASELINE configs[3]): independent proofs, one stream per GPU, then an RCCL all_gather of the padded
-proof bytes (what the aggregation level consumes) inside the timed region. No other data-path collective.
+N ranks (BASELINE configs[3]): independent proofs per rank; every step's proof bytes are gathered over RCCL
+(all_gather of padded byte buffers, what the aggregation level consumes) inside the timed region, overlapped with the
+next step's proving. No other data-path collective.
 
 Also reported (BASELINE configs[1], "NTT HBM GB/s vs peak"): the 2^20-point Goldilocks NTT + inverse over 128
 columns; `roofline` is for that kernel pair, measured with HIP events on the launch stream by the library.
@@ -154,12 +157,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        proof = step()
+    import queue
+
+    def run_steps(k):
+        """k steps = k proofs on each of the S streams. The streams are independent pipelines: a worker never waits for
+        the others. The main thread closes step j when every stream has delivered its j-th proof and, with several
+        ranks, gathers that step's proof bytes over RCCL while the workers are already proving step j+1."""
+        qs = [queue.Queue() for _ in range(S)]
+
+        def worker(i):
+            for _ in range(k):
+                qs[i].put(circs[i].prove_dev(w_t, pis, outs[i]))
+        futs = [pool.submit(worker, i) for i in range(S)]
+        last = None
+        nonlocal gathered
+        for _ in range(k):
+            proofs = [q.get() for q in qs]
+            if world > 1:
+                gathered = pkg.sharding.gather_proof_bytes(proofs, dist, coll_dev)
+            last = proofs[0]
+        for f in futs:
+            f.result()
+        return last
+
+    proof = run_steps(args.warmup) if args.warmup > 0 else step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof = step()
+    proof = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
