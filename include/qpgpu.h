@@ -117,6 +117,12 @@ int qpgpu_circuit_constants_sigmas_cap(const qpgpu_circuit *c, uint64_t *out, si
  * entropy source per proof (the reference uses thread_rng); a seed set here applies to the NEXT prove call only and
  * makes its bytes reproducible. */
 int qpgpu_circuit_set_blinding_seed(qpgpu_circuit *c, uint64_t seed);
+/* Optional witness check (off by default): before the quotient stage, evaluate every filtered gate constraint on the
+ * trace rows and the closing of the permutation product; a violation makes qpgpu_prove* return QPGPU_EUNSAT with the
+ * offending row in qpgpu_last_error. plonky2 only finds an unsatisfied witness through debug assertions or a proof that
+ * fails to verify (reference tests catch the panic, wormhole/tests/src/circuit/nullifier_tests.rs:53-58). Costs one
+ * extra pass over the trace and one stream sync. */
+int qpgpu_circuit_set_witness_check(qpgpu_circuit *c, int on);
 size_t qpgpu_proof_size(const qpgpu_circuit *c);   /* bytes written by qpgpu_prove for this circuit */
 /*
  * prove(): wires = the full witness matrix (num_wires x 2^degree_bits, column-major, as

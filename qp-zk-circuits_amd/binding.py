@@ -63,6 +63,7 @@ def load_library():
         "qpgpu_circuit_constants_sigmas_cap": (c.c_int, [vp, u64p, c.c_size_t]),
         "qpgpu_proof_size": (c.c_size_t, [vp]),
         "qpgpu_circuit_set_blinding_seed": (c.c_int, [vp, c.c_uint64]),
+        "qpgpu_circuit_set_witness_check": (c.c_int, [vp, c.c_int]),
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_poseidon_constants": (c.c_size_t, [u64p, u64p, c.c_size_t]),
@@ -159,6 +160,10 @@ class Circuit:
 
     def proof_size(self):
         return self.gpu.lib.qpgpu_proof_size(self.h)
+
+    def set_witness_check(self, on=True):
+        """Make prove() return QPGPU_EUNSAT (-4) for a witness that violates a gate or copy constraint."""
+        self.gpu._check(self.gpu.lib.qpgpu_circuit_set_witness_check(self.h, 1 if on else 0))
 
     def set_blinding_seed(self, seed):
         """Zero-knowledge packs: fixes the salts of the next proof (reproducible bytes)."""

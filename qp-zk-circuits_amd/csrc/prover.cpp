@@ -98,6 +98,8 @@ struct qpgpu_circuit {
     u64 *h_stage = nullptr;          // pinned host staging for the small per-proof tables (no sync on upload)
     size_t stage_words = 0, stage_pos = 0;
     bool seed_set = false;
+    bool check_witness = false;
+    u64 *d_check = nullptr;          // [2]: first bad row, permutation flag
     u64 blinding_seed = 0;
 
     template <class T> int alloc(T **p, size_t count) {
@@ -313,9 +315,10 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
         CK(c->alloc(&c->d_gather, c->gather_words));
         CK(c->alloc(&c->d_qidx, p.num_query_rounds));
         CK(c->alloc(&c->d_pow, 1));
+        CK(c->alloc(&c->d_check, 2));
     }
     {
-        c->stage_words = 2 * nch + nch * R + nch * nterms + 4 + 4 + 2 * n_open + p.num_query_rounds + 64;
+        c->stage_words = 2 * nch + nch * R + nch * nterms + 4 + 4 + 2 * n_open + p.num_query_rounds + 64 + 8;
         void *hp = nullptr;
         hipError_t e = hipHostMalloc(&hp, c->stage_words * 8, hipHostMallocDefault);
         if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipHostMalloc(stage)"));
@@ -324,6 +327,12 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #undef CK
     *out = c;
+    return QPGPU_OK;
+}
+
+int qpgpu_circuit_set_witness_check(qpgpu_circuit *c, int on) {
+    if (!c) return QPGPU_EINVAL;
+    c->check_witness = on != 0;
     return QPGPU_OK;
 }
 
@@ -399,6 +408,26 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
         for (uint32_t k = 0; k < nch; k++) { u64 a = 1; for (size_t t = 0; t < nterms; t++) { ap[k * nterms + t] = gl::canon(a); a = gl::mul(a, alphas[k]); } }
         std::memcpy(ap.data() + (size_t)nch * nterms, pih, 32);
         QP_TRY(h2d_staged(c, d_apow, ap.data(), ap.size() * 8));
+    }
+    if (c->check_witness) {
+        // the analogue of plonky2's debug assertions: filtered gate constraints must vanish on every trace row and the
+        // permutation product must close; alpha-weighted sums are zero iff every constraint is (alpha is a transcript challenge)
+        QuotientArgs ta{};
+        ta.wires = d_wires; ta.cs = c->d_cs_values; ta.alpha_pows = d_apow; ta.pi_hash = d_pih; ta.gates = c->d_gates;
+        ta.acc = c->d_qacc; ta.out = c->d_qacc; ta.poseidon_rc = c->d_poseidon_rc; ta.poseidon_fast = c->d_poseidon_fast;
+        ta.zh_inv = c->d_zh_inv; ta.lde_n = n; ta.log_lde = d; ta.rate = 1; ta.nch = nch; ta.num_routed = (uint32_t)R;
+        ta.chunk = (uint32_t)p.quotient_degree_factor; ta.nchunks = nchunks; ta.sig0 = (uint32_t)sig0;
+        ta.num_selectors = (uint32_t)p.num_selectors; ta.num_gates = (uint32_t)p.gates.size(); ta.nterms = (uint32_t)nterms;
+        QP_HIP(ctx, hipMemsetAsync(c->d_qacc, 0, (size_t)nch * n * 8, st));
+        const u64 init[2] = {~0ull, 0};
+        QP_TRY(h2d_staged(c, c->d_check, init, sizeof init));
+        QP_HIP(ctx, pk_gate_sums(ta, c->h_gates.data(), st));
+        QP_HIP(ctx, pk_witness_check(c->d_qacc, n, nch, c->d_z, c->d_rowprod, c->d_check, st));
+        u64 res[2];
+        QP_HIP(ctx, hipMemcpyAsync(res, c->d_check, sizeof res, hipMemcpyDeviceToHost, st));
+        QP_HIP(ctx, hipStreamSynchronize(st));
+        if (res[0] != ~0ull) return ctx->fail(QPGPU_EUNSAT, "witness does not satisfy the circuit: gate constraints fail at row " + std::to_string(res[0]));
+        if (res[1]) return ctx->fail(QPGPU_EUNSAT, "witness does not satisfy the circuit: a copy constraint is violated (permutation product != 1)");
     }
     ctx->prof_begin("prove_quotient");
     QuotientArgs qa{};

@@ -285,6 +285,20 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
     }
 }
 
+// Witness check on the trace rows (optional): acc holds the alpha-weighted gate-constraint sums per row (the gate kernels
+// run on the value arrays, S = n). result[0] = smallest row with a non-zero sum, result[1] = 1 when a permutation
+// product does not close (Z(g x_{n-1}) != 1), i.e. a copy constraint is violated.
+__global__ void __launch_bounds__(256) witness_check_kernel(const u64 *acc, u64 n, u32 nch, const u64 *z, const u64 *rowprod, u64 *result) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool bad = false;
+    for (u32 c = 0; c < nch; c++) bad |= gl::canon(acc[(u64)c * n + i]) != 0;
+    if (bad) atomicMin((unsigned long long *)&result[0], (unsigned long long)i);
+    if (i == n - 1)
+        for (u32 c = 0; c < nch; c++)
+            if (gl::canon(gl::mul(z[(u64)c * n + i], rowprod[(u64)c * n + i])) != 1) atomicMax((unsigned long long *)&result[1], 1ull);
+}
+
 // out[i] = in[i] * shift_inv^i (coset_ifft tail), two-level power table
 __global__ void __launch_bounds__(256) scale_powers_kernel(u64 *data, u64 n, u64 ncols, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -473,6 +487,29 @@ static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gat
             seen++;
             hipLaunchKernelGGL((quotient_poseidon_kernel<NCH>), g, b, 0, st, a, i, t0, seen == n_pos ? 1 : 0);
         }
+    return hipGetLastError();
+}
+// gate kernels only (no permutation terms, no 1/Z_H): used by the witness check on the trace rows
+template <int NCH>
+static hipError_t gates_only_launch(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
+    dim3 b(256), g((unsigned)((a.lde_n + 255) / 256));
+    const u32 t0 = a.nch + a.nch * a.nchunks;
+    hipLaunchKernelGGL((quotient_gates_kernel<NCH>), g, b, 0, st, a, t0, 0);
+    for (u32 i = 0; i < a.num_gates; i++)
+        if (host_gates[i].type == 4 && host_gates[i].num_constraints) hipLaunchKernelGGL((quotient_poseidon_kernel<NCH>), g, b, 0, st, a, i, t0, 0);
+    return hipGetLastError();
+}
+hipError_t pk_gate_sums(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
+    switch (a.nch) {
+        case 1: return gates_only_launch<1>(a, host_gates, st);
+        case 2: return gates_only_launch<2>(a, host_gates, st);
+        case 3: return gates_only_launch<3>(a, host_gates, st);
+        case 4: return gates_only_launch<4>(a, host_gates, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t pk_witness_check(const u64 *acc, u64 n, u32 nch, const u64 *z, const u64 *rowprod, u64 *result, hipStream_t st) {
+    LAUNCH_1D(witness_check_kernel, n, 256, st, acc, n, nch, z, rowprod, result);
     return hipGetLastError();
 }
 hipError_t pk_quotient(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {

@@ -53,6 +53,8 @@ hipError_t pk_pp_rows(const PpArgs &a, hipStream_t st);
 hipError_t pk_pp_scan(const uint64_t *rowprod, uint64_t *z, uint64_t n, uint32_t nch, hipStream_t st);
 hipError_t pk_pp_finish(const PpArgs &a, const uint64_t *z, uint64_t *zs_pp, hipStream_t st);
 hipError_t pk_quotient(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st);
+hipError_t pk_gate_sums(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st);
+hipError_t pk_witness_check(const uint64_t *acc, uint64_t n, uint32_t nch, const uint64_t *z, const uint64_t *rowprod, uint64_t *result, hipStream_t st);
 hipError_t pk_scale_powers(uint64_t *data, uint64_t n, uint64_t ncols, const uint64_t *pw_lo, const uint64_t *pw_hi, uint32_t lo_bits, hipStream_t st);
 hipError_t pk_poly_eval(const uint64_t *coeffs, uint64_t n, uint32_t npolys, const gl::e2 *points, uint32_t npoints, const uint64_t *poly_index, gl::e2 *out, hipStream_t st);
 hipError_t pk_reduce_polys(const ReduceArgs &a, hipStream_t st);

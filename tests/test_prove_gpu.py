@@ -156,3 +156,45 @@ def test_shape_fuzz_against_oracle(pkg, gpu, orc):
             assert oc.verify(got) == 0, f"case {i} rejected"
         finally:
             circ.close(); oc.close()
+
+
+def pack_const(pack, row, k):
+    """constant k of `row` from a synthetic pack (2 selector columns when Poseidon gates are present)."""
+    d = int(pack[1]); n = 1 << d; nsel = int(pack[5]); routed = int(pack[3]); ngates = int(pack[16]); narity = int(pack[17])
+    off = 18 + narity + 8 * ngates + routed + 4
+    return pack[off + (nsel + k) * n + row]
+
+
+def test_witness_check_reports_unsat(pkg, gpu, orc):
+    """QPGPU_EUNSAT: with the optional check on, a witness that violates a gate constraint or a copy constraint is
+    refused with the offending row; a satisfied witness still proves to the same bytes."""
+    P = 0xFFFFFFFF00000001
+    pack, wires, pis = pkg.synth_circuit(8, seed=61, poseidon=True, base_sum=True)
+    circ = pkg.Circuit(gpu, pack); oc = OracleCircuit(orc, pack)
+    want = oc.prove(wires, pis)
+    circ.set_witness_check(True)
+    assert circ.prove(wires, pis) == want
+    w = wires.copy(); w[3, 20] = (int(w[3, 20]) + 1) % P           # arithmetic output of op 0 on row 20
+    with pytest.raises(pkg.QpGpuError) as e:
+        circ.prove(w, pis)
+    assert e.value.code == -4 and "row 20" in str(e.value)
+    w = wires.copy(); w[70, 8] = (int(w[70, 8]) + 1) % P           # Poseidon row 8: partial-round S-box wire
+    with pytest.raises(pkg.QpGpuError) as e:
+        circ.prove(w, pis)
+    assert e.value.code == -4 and "row 8" in str(e.value)
+    p2 = pis.copy(); p2[0] = (int(p2[0]) + 1) % P                  # public inputs vs the PublicInputGate wires: row 0
+    with pytest.raises(pkg.QpGpuError) as e:
+        circ.prove(wires, p2)
+    assert e.value.code == -4 and "row 0" in str(e.value)
+    # only the wiring wrong: change an arithmetic input on row 41 and recompute that row's output so its gate still holds
+    row = 41
+    c0, c1 = int(pack_const(pack, row, 0)), int(pack_const(pack, row, 1))
+    w = wires.copy()
+    w[0, row] = (int(w[0, row]) + 1) % P
+    w[3, row] = (int(w[0, row]) * int(w[1, row]) % P * c0 + int(w[2, row]) * c1) % P
+    with pytest.raises(pkg.QpGpuError) as e:
+        circ.prove(w, pis)
+    assert e.value.code == -4
+    circ.set_witness_check(False)
+    assert oc.verify(circ.prove(w, pis)) != 0     # without the check the proof is produced and simply does not verify
+    circ.close(); oc.close()
