@@ -150,7 +150,8 @@ size_t qpgpu_poseidon_constants(uint64_t *round_constants_360, uint64_t *fast_pa
 size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed);
 /* flags bit 0: every 8th row is a PoseidonGate row (135 wires, 123 constraints of degree 7, its own selector group),
  * the gate that dominates the recursive (aggregator) circuits. bit 1: every 8th row is a BaseSumGate<2> row (the leaf
- * circuit's range checks, reference wormhole/circuit/src/zk_merkle_proof.rs:486-504). */
+ * circuit's range checks, reference wormhole/circuit/src/zk_merkle_proof.rs:486-504). bit 2: every 8th row alternates
+ * ArithmeticExtensionGate / MulExtensionGate (quadratic-extension arithmetic of the recursive verifier circuits). */
 size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags);
 int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                            uint64_t seed, unsigned flags, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,

@@ -12,7 +12,7 @@
 #define ORACLE_PLONK_H
 #include "gl.h"
 
-enum { OG_NOOP = 0, OG_CONSTANT = 1, OG_PUBLIC_INPUT = 2, OG_ARITHMETIC = 3, OG_POSEIDON = 4, OG_BASE_SUM = 5 };
+enum { OG_NOOP = 0, OG_CONSTANT = 1, OG_PUBLIC_INPUT = 2, OG_ARITHMETIC = 3, OG_POSEIDON = 4, OG_BASE_SUM = 5, OG_ARITHMETIC_EXT = 6, OG_MUL_EXT = 7 };
 
 typedef struct { uint64_t type, param0, param1, selector_index, group_start, group_end, num_constraints, reserved; } orc_gate;
 

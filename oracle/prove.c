@@ -315,6 +315,21 @@ static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t
             for (int i = 0; i < 123; i++) acc[i] = gl_add(acc[i], gl_mul(f, cst[i]));
             break;
         }
+        case OG_ARITHMETIC_EXT:   /* ArithmeticExtensionGate<2>: out - (c0 m0 m1 + c1 addend) over F[x]/(x^2-7), 8 wires per op */
+            for (uint64_t i = 0; i < g->param0; i++) {
+                const gl_t *w = wires + 8 * i;
+                gl2_t m0 = gl2_make(w[0], w[1]), m1 = gl2_make(w[2], w[3]), ad = gl2_make(w[4], w[5]), out = gl2_make(w[6], w[7]);
+                gl2_t d = gl2_sub(out, gl2_add(gl2_scale(gl2_mul(m0, m1), consts[0]), gl2_scale(ad, consts[1])));
+                acc[2 * i] = gl_add(acc[2 * i], gl_mul(f, d.c[0])); acc[2 * i + 1] = gl_add(acc[2 * i + 1], gl_mul(f, d.c[1]));
+            }
+            break;
+        case OG_MUL_EXT:          /* MulExtensionGate<2>: out - c0 m0 m1, 6 wires per op */
+            for (uint64_t i = 0; i < g->param0; i++) {
+                const gl_t *w = wires + 6 * i;
+                gl2_t d = gl2_sub(gl2_make(w[4], w[5]), gl2_scale(gl2_mul(gl2_make(w[0], w[1]), gl2_make(w[2], w[3])), consts[0]));
+                acc[2 * i] = gl_add(acc[2 * i], gl_mul(f, d.c[0])); acc[2 * i + 1] = gl_add(acc[2 * i + 1], gl_mul(f, d.c[1]));
+            }
+            break;
         case OG_BASE_SUM: {   /* BaseSumGate<2>: wire 0 = sum, wires 1..num_limbs = bits */
             gl_t s2 = 0;
             for (uint64_t i = g->param0; i-- > 0;) s2 = gl_add(gl_add(s2, s2), wires[1 + i]);
@@ -359,6 +374,25 @@ void orc_eval_gates_ext(const orc_circuit *c, const gl2_t *cs_row, const gl2_t *
             for (int i = 0; i < 123; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, cst[i]));
             break;
         }
+        case OG_ARITHMETIC_EXT:   /* wires are extension values: the algebra F2[X]/(X^2-7) with coefficients in F2 */
+            for (uint64_t i = 0; i < g->param0; i++) {
+                const gl2_t *w = wires + 8 * i;
+                gl2_t p0 = gl2_add(gl2_mul(w[0], w[2]), gl2_scale(gl2_mul(w[1], w[3]), 7));
+                gl2_t p1 = gl2_add(gl2_mul(w[0], w[3]), gl2_mul(w[1], w[2]));
+                gl2_t d0 = gl2_sub(w[6], gl2_add(gl2_mul(p0, consts[0]), gl2_mul(w[4], consts[1])));
+                gl2_t d1 = gl2_sub(w[7], gl2_add(gl2_mul(p1, consts[0]), gl2_mul(w[5], consts[1])));
+                acc[2 * i] = gl2_add(acc[2 * i], gl2_mul(f, d0)); acc[2 * i + 1] = gl2_add(acc[2 * i + 1], gl2_mul(f, d1));
+            }
+            break;
+        case OG_MUL_EXT:
+            for (uint64_t i = 0; i < g->param0; i++) {
+                const gl2_t *w = wires + 6 * i;
+                gl2_t p0 = gl2_add(gl2_mul(w[0], w[2]), gl2_scale(gl2_mul(w[1], w[3]), 7));
+                gl2_t p1 = gl2_add(gl2_mul(w[0], w[3]), gl2_mul(w[1], w[2]));
+                gl2_t d0 = gl2_sub(w[4], gl2_mul(p0, consts[0])), d1 = gl2_sub(w[5], gl2_mul(p1, consts[0]));
+                acc[2 * i] = gl2_add(acc[2 * i], gl2_mul(f, d0)); acc[2 * i + 1] = gl2_add(acc[2 * i + 1], gl2_mul(f, d1));
+            }
+            break;
         case OG_BASE_SUM: {
             gl2_t s2 = gl2_from(0);
             for (uint64_t i = g->param0; i-- > 0;) s2 = gl2_add(gl2_add(s2, s2), wires[1 + i]);

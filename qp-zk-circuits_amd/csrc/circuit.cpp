@@ -62,13 +62,15 @@ std::string CircuitPack::validate() const {
     for (auto a : arity_bits) { if (a == 0 || a > 4) return "unsupported FRI arity"; sum += a; }
     if (sum > degree_bits) return "FRI reductions exceed degree";
     for (const auto &g : gates) {
-        if (g.type > GATE_BASE_SUM) return "unknown gate type";
+        if (g.type > GATE_MUL_EXT) return "unknown gate type";
         if (g.selector_index >= num_selectors) return "gate selector index out of range";
         if (g.group_end > gates.size() || g.group_start >= g.group_end) return "gate group out of range";
         if (g.num_constraints > num_gate_constraints) return "gate constraint count exceeds num_gate_constraints";
         if (g.type == GATE_ARITHMETIC && (g.param0 * 4 > num_routed_wires || g.num_constraints != g.param0 || num_constants < 2)) return "bad arithmetic gate";
         if (g.type == GATE_CONSTANT && (g.param0 > num_constants || g.param0 > num_wires || g.num_constraints != g.param0)) return "bad constant gate";
         if (g.type == GATE_PUBLIC_INPUT && (num_wires < 4 || g.num_constraints != 4)) return "bad public input gate";
+        if (g.type == GATE_ARITHMETIC_EXT && (g.param0 * 8 > num_routed_wires || g.num_constraints != 2 * g.param0 || num_constants < 2)) return "bad arithmetic-extension gate";
+        if (g.type == GATE_MUL_EXT && (g.param0 * 6 > num_routed_wires || g.num_constraints != 2 * g.param0 || num_constants < 1)) return "bad mul-extension gate";
         if (g.type == GATE_BASE_SUM && (g.param0 == 0 || g.param0 > 63 || g.param0 + 1 > num_routed_wires || g.num_constraints != g.param0 + 1)) return "bad base-sum gate";
         if (g.type == GATE_POSEIDON && (num_wires < 135 || num_routed_wires < 25 || g.num_constraints != 123)) return "bad poseidon gate";
     }

@@ -21,7 +21,7 @@
 #include <string>
 #include <vector>
 
-enum GateType : uint64_t { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4, GATE_BASE_SUM = 5 };
+enum GateType : uint64_t { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4, GATE_BASE_SUM = 5, GATE_ARITHMETIC_EXT = 6, GATE_MUL_EXT = 7 };
 
 struct GateInfo {
     uint64_t type, param0, param1, selector_index, group_start, group_end, num_constraints, reserved;

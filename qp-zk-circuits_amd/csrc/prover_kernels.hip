@@ -189,6 +189,23 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
                 const u64 ad = a.wires[(u64)(4 * q + 2) * S + j], out = a.wires[(u64)(4 * q + 3) * S + j];
                 emit(q, gl::sub(out, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
             }
+        } else if (g.type == 6) {     // ArithmeticExtensionGate<2>: out - (c0 m0 m1 + c1 addend) over F[x]/(x^2-7)
+            const u64 c0 = consts_base[0], c1 = consts_base[S];
+            for (u32 q = 0; q < g.param0; q++) {
+                const u64 *w = a.wires + (u64)(8 * q) * S + j;
+                const e2 m0 = gl::e2_make(w[0], w[S]), m1 = gl::e2_make(w[2 * S], w[3 * S]), ad = gl::e2_make(w[4 * S], w[5 * S]);
+                const e2 out = gl::e2_make(w[6 * S], w[7 * S]);
+                const e2 d = gl::e2_sub(out, gl::e2_add(gl::e2_scale(gl::e2_mul(m0, m1), c0), gl::e2_scale(ad, c1)));
+                emit(2 * q, d.a); emit(2 * q + 1, d.b);
+            }
+        } else if (g.type == 7) {     // MulExtensionGate<2>: out - c0 m0 m1
+            const u64 c0 = consts_base[0];
+            for (u32 q = 0; q < g.param0; q++) {
+                const u64 *w = a.wires + (u64)(6 * q) * S + j;
+                const e2 d = gl::e2_sub(gl::e2_make(w[4 * S], w[5 * S]),
+                                        gl::e2_scale(gl::e2_mul(gl::e2_make(w[0], w[S]), gl::e2_make(w[2 * S], w[3 * S])), c0));
+                emit(2 * q, d.a); emit(2 * q + 1, d.b);
+            }
         } else if (g.type == 5) {     // BaseSumGate<2>: sum - sum_i 2^i limb_i, and limb_i (limb_i - 1)
             u64 s2 = 0;
             for (u32 q = g.param0; q-- > 0;) s2 = gl::add(gl::add(s2, s2), a.wires[(u64)(1 + q) * S + j]);

@@ -2,15 +2,19 @@
 // synthetic"): the Rust CircuitBuilder that would export the real Wormhole circuit pack
 // cannot run in this image, so this generator produces a circuit with the same shape parameters
 // (135 wires, 80 routed, 2 constants, standard_recursion_config FRI) and a witness that satisfies it:
-// PublicInputGate row, ConstantGate rows, ArithmeticGate rows wired together by copy constraints,
-// NoopGate padding. It plays the role of reference rows a1/a6 (witness + circuit shape providers).
+// a PublicInputGate row, ConstantGate rows, ArithmeticGate rows wired together by copy constraints, optional
+// BaseSumGate<2> / PoseidonGate / ArithmeticExtensionGate / MulExtensionGate rows, NoopGate padding. Gates are sorted
+// and grouped into selector polynomials with the builder's own rule. It plays the role of reference rows a1/a6
+// (witness + circuit shape providers).
 #include <algorithm>
 #include <numeric>
+#include <string>
 #include "circuit.hpp"
 #include "ctx.hpp"
 #include "gl64.hpp"
 #include "poseidon.hpp"
 
+using gl::e2;
 using gl::u64;
 
 namespace {
@@ -29,43 +33,82 @@ void host_hash_no_pad(const u64 *in, size_t n, u64 out[4]) {
     }
     for (int i = 0; i < 4; i++) out[i] = st[i];
 }
+struct GateSpec { uint64_t type, p0, p1, degree, ncons; std::string id; };
 }  // namespace
+
+// Gate list of a synthetic circuit: sorted by (degree, id) and grouped into selector polynomials the way
+// CircuitBuilder::build does (a group holds gates while size + degree < max_degree; one group if everything fits).
+std::string synth_gate_layout(unsigned num_routed, unsigned flags, std::vector<GateInfo> &gates, u64 &num_selectors) {
+    const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0;
+    const u64 num_limbs = std::min<u64>(63, num_routed - 1), num_ops = num_routed / 4;
+    const u64 ext_ops = num_routed / 8, mul_ops = num_routed / 6;
+    std::vector<GateSpec> gs = {
+        {GATE_NOOP, 0, 0, 0, 0, "NoopGate"},
+        {GATE_CONSTANT, 2, 0, 1, 2, "ConstantGate { num_consts: 2 }"},
+        {GATE_PUBLIC_INPUT, 0, 0, 1, 4, "PublicInputGate"},
+        {GATE_ARITHMETIC, num_ops, 0, 3, num_ops, "ArithmeticGate { num_ops: " + std::to_string(num_ops) + " }"},
+    };
+    if (with_base_sum) gs.push_back({GATE_BASE_SUM, num_limbs, 2, 2, num_limbs + 1, "BaseSumGate { num_limbs: " + std::to_string(num_limbs) + " } + Base: 2"});
+    if (with_poseidon) gs.push_back({GATE_POSEIDON, 0, 0, 7, 123, "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"});
+    if (with_ext) {
+        gs.push_back({GATE_ARITHMETIC_EXT, ext_ops, 0, 3, 2 * ext_ops, "ArithmeticExtensionGate { num_ops: " + std::to_string(ext_ops) + " }"});
+        gs.push_back({GATE_MUL_EXT, mul_ops, 0, 3, 2 * mul_ops, "MulExtensionGate { num_ops: " + std::to_string(mul_ops) + " }"});
+    }
+    std::sort(gs.begin(), gs.end(), [](const GateSpec &a, const GateSpec &b) { return a.degree != b.degree ? a.degree < b.degree : a.id < b.id; });
+    const u64 max_degree = 9;   // quotient_degree_factor + 1
+    std::vector<std::pair<u64, u64>> groups;
+    if (gs.back().degree + gs.size() - 1 <= max_degree) groups.push_back({0, gs.size()});
+    else {
+        for (size_t start = 0; start < gs.size();) {
+            size_t size = 0;
+            while (start + size < gs.size() && size + gs[start + size].degree < max_degree) size++;
+            if (size == 0) return "gate degree too high for the quotient degree";
+            groups.push_back({start, start + size});
+            start += size;
+        }
+    }
+    gates.clear();
+    for (size_t i = 0; i < gs.size(); i++) {
+        size_t grp = 0;
+        while (!(groups[grp].first <= i && i < groups[grp].second)) grp++;
+        gates.push_back({gs[i].type, gs[i].p0, gs[i].p1, grp, groups[grp].first, groups[grp].second, gs[i].ncons, 0});
+    }
+    num_selectors = groups.size();
+    return "";
+}
 
 void synth_public_inputs_hash(const u64 *pis, size_t n, u64 out[4]) { host_hash_no_pad(pis, n, out); }
 
+// flags: bit 0 PoseidonGate rows, bit 1 BaseSumGate<2> rows, bit 2 ArithmeticExtension + MulExtension rows.
 // Builds the pack and the witness. wires: num_wires x n column-major. Returns "" or an error.
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         u64 seed, unsigned flags, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
-    const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0;
-    const u64 num_limbs = std::min<u64>(63, num_routed - 1);
-    if (with_poseidon && (num_wires < 135 || num_routed < 28)) return "poseidon gates need 135 wires";
+    const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0;
     if (degree_bits < 3 || degree_bits > 20) return "degree_bits out of range";
     if (num_routed < 8 || num_routed > num_wires || num_routed % 4) return "num_routed_wires must be a multiple of 4, >= 8";
+    if (with_poseidon && (num_wires < 135 || num_routed < 28)) return "poseidon gates need 135 wires";
     SplitMix rng{seed ^ 0x5EED5EED5EEDull};
     const u64 n = 1ull << degree_bits;
+    const u64 num_limbs = std::min<u64>(63, num_routed - 1), num_ops = num_routed / 4;
+    const u64 ext_ops = num_routed / 8, mul_ops = num_routed / 6;
+
+    std::vector<GateInfo> layout;
+    u64 n_groups = 0;
+    { std::string e = synth_gate_layout(num_routed, flags, layout, n_groups); if (!e.empty()) return e; }
     pack = CircuitPack();
     pack.degree_bits = degree_bits; pack.num_wires = num_wires; pack.num_routed_wires = num_routed;
-    pack.num_constants = 2; pack.num_selectors = with_poseidon ? 2 : 1; pack.num_challenges = 2; pack.quotient_degree_factor = 8;
+    pack.num_constants = 2; pack.num_selectors = n_groups; pack.num_challenges = 2; pack.quotient_degree_factor = 8;
     pack.num_partial_products = (num_routed + 7) / 8 - 1; pack.num_public_inputs = num_public_inputs;
     pack.rate_bits = 3; pack.cap_height = 4; pack.proof_of_work_bits = 16; pack.num_query_rounds = 28;
     pack.zero_knowledge = 0;
     pack.arity_bits = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5);
-    const u64 num_ops = num_routed / 4;
-    pack.num_gate_constraints = std::max<u64>(std::max<u64>(num_ops, 4), with_poseidon ? 123 : 0);
-    if (with_base_sum) pack.num_gate_constraints = std::max<u64>(pack.num_gate_constraints, num_limbs + 1);
-    // gates sorted by (degree, id) as the builder does: Noop(0), Constant(1), PublicInput(1), [BaseSum(2)], Arithmetic(3)
-    // share selector group 0; PoseidonGate (degree 7) does not fit (size + degree < 9) and gets a group of its own
-    const u64 g0 = with_base_sum ? 5 : 4;
-    pack.gates = {
-        {GATE_NOOP, 0, 0, 0, 0, g0, 0, 0},
-        {GATE_CONSTANT, 2, 0, 0, 0, g0, 2, 0},
-        {GATE_PUBLIC_INPUT, 0, 0, 0, 0, g0, 4, 0},
-    };
-    if (with_base_sum) pack.gates.push_back({GATE_BASE_SUM, num_limbs, 2, 0, 0, g0, num_limbs + 1, 0});
-    pack.gates.push_back({GATE_ARITHMETIC, num_ops, 0, 0, 0, g0, num_ops, 0});
-    if (with_poseidon) pack.gates.push_back({GATE_POSEIDON, 0, 0, 1, g0, g0 + 1, 123, 0});
-    // row kinds below use: 0 noop, 1 constant, 2 public input, 3 arithmetic, 4 poseidon, 5 base sum; gate index in the list:
-    const u64 idx_arith = with_base_sum ? 4 : 3, idx_bs = 3, idx_pos = g0;
+    pack.num_gate_constraints = 0;
+    uint64_t idx_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sel_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    pack.gates = layout;
+    for (size_t i = 0; i < layout.size(); i++) {
+        pack.num_gate_constraints = std::max(pack.num_gate_constraints, layout[i].num_constraints);
+        idx_of[layout[i].type] = i; sel_of[layout[i].type] = layout[i].selector_index;
+    }
     pack.k_is.resize(num_routed);
     { u64 k = 1; for (unsigned j = 0; j < num_routed; j++) { pack.k_is[j] = gl::canon(k); k = gl::mul(k, gl::MULT_GEN); } }
 
@@ -74,20 +117,21 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     u64 pih[4];
     host_hash_no_pad(pis.data(), pis.size(), pih);
 
-    // row layout
+    // ---- row kinds ----
     const u64 n_const_rows = 2, n_noop = std::max<u64>(1, n / 16);
-    std::vector<uint8_t> row_gate(n, 3);
-    row_gate[0] = 2;
-    for (u64 r = 1; r <= n_const_rows; r++) row_gate[r] = 1;
-    for (u64 r = n - n_noop; r < n; r++) row_gate[r] = 0;
-    if (with_poseidon) for (u64 r = 8; r + n_noop < n; r += 8) row_gate[r] = 4;   // every 8th row hashes
-    if (with_base_sum) for (u64 r = 5; r + n_noop < n; r += 8) row_gate[r] = 5;   // every 8th row range-checks
+    std::vector<uint8_t> row_gate(n, GATE_ARITHMETIC);
+    row_gate[0] = GATE_PUBLIC_INPUT;
+    for (u64 r = 1; r <= n_const_rows; r++) row_gate[r] = GATE_CONSTANT;
+    for (u64 r = n - n_noop; r < n; r++) row_gate[r] = GATE_NOOP;
+    if (with_poseidon) for (u64 r = 8; r + n_noop < n; r += 8) row_gate[r] = GATE_POSEIDON;      // every 8th row hashes
+    if (with_base_sum) for (u64 r = 5; r + n_noop < n; r += 8) row_gate[r] = GATE_BASE_SUM;      // every 8th row range-checks
+    if (with_ext) for (u64 r = 6; r + n_noop < n; r += 8) row_gate[r] = (r & 8) ? GATE_MUL_EXT : GATE_ARITHMETIC_EXT;
 
     wires.assign((size_t)num_wires * n, 0);
     auto W = [&](u64 row, u64 col) -> u64 & { return wires[col * n + row]; };
     for (u64 c = 0; c < num_wires; c++) for (u64 r = 0; r < n; r++) W(r, c) = rng.felt();  // unconstrained cells
 
-    const u64 ncs = pack.num_cs_cols();
+    const u64 ncs = pack.num_cs_cols(), sel_cols = pack.num_selectors, UNUSED = 0xFFFFFFFFull;
     pack.constants_sigmas.assign(ncs * n, 0);
     auto CS = [&](u64 row, u64 col) -> u64 & { return pack.constants_sigmas[col * n + row]; };
 
@@ -97,57 +141,59 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
     auto cell = [&](u64 row, u64 col) { return (uint32_t)(row * num_routed + col); };
     std::vector<uint32_t> pool;  // cells whose value may be copied
+    // input cell (r, col): with probability 0.7 a copy of an earlier output (adds the copy constraint), else stays random
+    auto input = [&](u64 r, u64 col) -> u64 {
+        if (!pool.empty() && rng.below(10) < 7) {
+            uint32_t src = pool[rng.below(pool.size())];
+            W(r, col) = wires[(size_t)(src % num_routed) * n + src / num_routed];
+            uint32_t a = find(src), b = find(cell(r, col));
+            if (a != b) parent[b] = a;
+        }
+        return W(r, col);
+    };
+    auto output = [&](u64 r, u64 col, u64 v) {
+        W(r, col) = gl::canon(v);
+        pool.push_back(cell(r, col));
+        if (pool.size() > 4096) pool.erase(pool.begin(), pool.begin() + 2048);
+    };
 
     for (u64 r = 0; r < n; r++) {
-        const u64 sel_cols = pack.num_selectors, UNUSED = 0xFFFFFFFFull;
         const u64 kind = row_gate[r];
-        const u64 gidx = kind == 3 ? idx_arith : kind == 5 ? idx_bs : kind == 4 ? idx_pos : kind;   // index in pack.gates
-        if (!with_poseidon) CS(r, 0) = gidx;                   // selector value = gate index
-        else { CS(r, 0) = kind == 4 ? UNUSED : gidx; CS(r, 1) = kind == 4 ? gidx : UNUSED; }
-        if (row_gate[r] == 2) {
+        for (u64 s = 0; s < sel_cols; s++) CS(r, s) = sel_of[kind] == s ? idx_of[kind] : UNUSED;   // selector polynomials
+        if (kind == GATE_PUBLIC_INPUT) {
             for (int i = 0; i < 4; i++) W(r, i) = pih[i];
-        } else if (row_gate[r] == 1) {
-            for (int i = 0; i < 2; i++) { u64 c = rng.felt(); CS(r, sel_cols + i) = c; W(r, i) = c; pool.push_back(cell(r, i)); }
-        } else if (row_gate[r] == 3) {
-            u64 c0 = (r & 1) ? rng.felt() : 1, c1 = (r & 2) ? rng.felt() : 1;
+        } else if (kind == GATE_CONSTANT) {
+            for (int i = 0; i < 2; i++) { u64 c = rng.felt(); CS(r, sel_cols + i) = c; output(r, i, c); }
+        } else if (kind == GATE_ARITHMETIC) {
+            const u64 c0 = (r & 1) ? rng.felt() : 1, c1 = (r & 2) ? rng.felt() : 1;
             CS(r, sel_cols) = c0; CS(r, sel_cols + 1) = c1;
             for (u64 op = 0; op < num_ops; op++) {
-                u64 in[3];
-                for (int k = 0; k < 3; k++) {
-                    const u64 col = 4 * op + k;
-                    if (!pool.empty() && rng.below(10) < 7) {
-                        uint32_t src = pool[rng.below(pool.size())];
-                        in[k] = wires[(size_t)(src % num_routed) * n + src / num_routed];
-                        W(r, col) = in[k];
-                        uint32_t a = find(src), b = find(cell(r, col));
-                        if (a != b) parent[b] = a;
-                    } else {
-                        in[k] = W(r, col);
-                    }
-                }
-                u64 out = gl::canon(gl::add(gl::mul(gl::mul(in[0], in[1]), c0), gl::mul(in[2], c1)));
-                W(r, 4 * op + 3) = out;
-                pool.push_back(cell(r, 4 * op + 3));
-                if (pool.size() > 4096) pool.erase(pool.begin(), pool.begin() + 2048);
+                const u64 m0 = input(r, 4 * op), m1 = input(r, 4 * op + 1), ad = input(r, 4 * op + 2);
+                output(r, 4 * op + 3, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1)));
             }
-        } else if (row_gate[r] == 5) {
+        } else if (kind == GATE_ARITHMETIC_EXT || kind == GATE_MUL_EXT) {
+            // extension-field arithmetic over F[x]/(x^2-7): each operand occupies two consecutive wires
+            const bool mul_only = kind == GATE_MUL_EXT;
+            const u64 c0 = rng.felt(), c1 = rng.felt(), stride = mul_only ? 6 : 8, ops = mul_only ? mul_ops : ext_ops;
+            CS(r, sel_cols) = c0; CS(r, sel_cols + 1) = mul_only ? 0 : c1;
+            for (u64 op = 0; op < ops; op++) {
+                const u64 b = stride * op;
+                u64 in[6] = {0, 0, 0, 0, 0, 0};
+                for (u64 k = 0; k < stride - 2; k++) in[k] = input(r, b + k);   // in wire order: the rng stream is part of the fixture
+                e2 res = gl::e2_scale(gl::e2_mul(gl::e2_make(in[0], in[1]), gl::e2_make(in[2], in[3])), c0);
+                if (!mul_only) res = gl::e2_add(res, gl::e2_scale(gl::e2_make(in[4], in[5]), c1));
+                output(r, b + stride - 2, res.a); output(r, b + stride - 1, res.b);
+            }
+        } else if (kind == GATE_BASE_SUM) {
             // BaseSumGate<2> row: a value below 2^num_limbs and its bits
-            u64 v = rng.next() & ((num_limbs >= 64 ? ~0ull : (1ull << num_limbs) - 1));
-            W(r, 0) = v; pool.push_back(cell(r, 0));
+            const u64 v = rng.next() & ((1ull << num_limbs) - 1);
+            output(r, 0, v);
             for (u64 i = 0; i < num_limbs; i++) W(r, 1 + i) = (v >> i) & 1;
-        } else if (row_gate[r] == 4) {
+        } else if (kind == GATE_POSEIDON) {
             // PoseidonGate row: inputs (some copied), swap bit, deltas, recorded S-box inputs, outputs
             const u64 *rcs = poseidon::host_round_constants();
             u64 in[12];
-            for (int k = 0; k < 12; k++) {
-                if (!pool.empty() && rng.below(10) < 7) {
-                    uint32_t src = pool[rng.below(pool.size())];
-                    in[k] = wires[(size_t)(src % num_routed) * n + src / num_routed];
-                    W(r, k) = in[k];
-                    uint32_t a = find(src), b = find(cell(r, k));
-                    if (a != b) parent[b] = a;
-                } else in[k] = W(r, k);
-            }
+            for (int k = 0; k < 12; k++) in[k] = input(r, k);
             const u64 swap = rng.below(2);
             W(r, 24) = swap;
             u64 st[12];
@@ -183,7 +229,7 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
                 poseidon::mds_layer(st);
                 for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
             }
-            for (int i = 0; i < 12; i++) { W(r, 12 + i) = st[i]; pool.push_back(cell(r, 12 + i)); }
+            for (int i = 0; i < 12; i++) output(r, 12 + i, st[i]);
         }
     }
     // sigma: cycle through each copy class

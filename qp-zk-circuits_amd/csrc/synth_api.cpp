@@ -7,6 +7,8 @@
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         uint64_t seed, unsigned flags, CircuitPack &pack, std::vector<uint64_t> &wires, std::vector<uint64_t> &pis);
 
+std::string synth_gate_layout(unsigned num_routed, unsigned flags, std::vector<GateInfo> &gates, uint64_t &num_selectors);
+
 extern "C" {
 
 // the hash constants the library derives at start-up (host only): 360 round constants, then the FAST_PARTIAL tables
@@ -18,11 +20,13 @@ size_t qpgpu_poseidon_constants(uint64_t *round_constants_360, uint64_t *fast_pa
 
 size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags) {
     (void)num_wires;
-    const bool pos = (flags & 1) != 0, bs = (flags & 2) != 0;
+    std::vector<GateInfo> gates;
+    uint64_t sels = 0;
+    if (num_routed < 8 || !synth_gate_layout(num_routed, flags, gates, sels).empty()) return 0;
     CircuitPack p;
-    p.degree_bits = degree_bits; p.num_routed_wires = num_routed; p.num_selectors = pos ? 2 : 1; p.num_constants = 2;
+    p.degree_bits = degree_bits; p.num_routed_wires = num_routed; p.num_selectors = sels; p.num_constants = 2;
     size_t arity = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5).size();
-    return 18 + arity + (4 + (pos ? 1 : 0) + (bs ? 1 : 0)) * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits);
+    return 18 + arity + gates.size() * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits);
 }
 size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed) {
     return qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, 0);

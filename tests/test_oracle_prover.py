@@ -94,3 +94,22 @@ def test_base_sum_gate_circuit(pkg, orc):
     w = wires.copy(); w[0, 5] = (int(w[0, 5]) + 1) % 0xFFFFFFFF00000001   # sum no longer matches its bits
     assert oc.verify(oc.prove(w, pis)) == 3
     oc.close()
+
+
+def test_extension_arithmetic_gates_circuit(pkg, orc):
+    """ArithmeticExtensionGate / MulExtensionGate rows (rows 6, 14, 22, ...) with every other gate present; the
+    builder's grouping rule then puts MulExtension next to Poseidon in the second selector polynomial."""
+    pack, wires, pis = pkg.synth_circuit(7, seed=6, base_sum=True, poseidon=True, ext_arith=True)
+    assert int(pack[5]) == 2 and int(pack[16]) == 8          # 2 selector polynomials, 8 gate types
+    oc = OracleCircuit(orc, pack)
+    assert oc.verify(oc.prove(wires, pis)) == 0
+    for row, col in ((6, 6), (6, 7), (14, 4), (14, 5)):      # output wires of op 0 of an ArithmeticExtension / MulExtension row
+        w = wires.copy(); w[col, row] = (int(w[col, row]) + 1) % 0xFFFFFFFF00000001
+        assert oc.verify(oc.prove(w, pis)) == 3, (row, col)
+    oc.close()
+    # without the Poseidon gate everything fits one selector polynomial
+    pack, wires, pis = pkg.synth_circuit(6, num_wires=40, num_routed=24, num_public_inputs=3, seed=7, ext_arith=True)
+    assert int(pack[5]) == 1 and int(pack[16]) == 6
+    oc = OracleCircuit(orc, pack)
+    assert oc.verify(oc.prove(wires, pis)) == 0
+    oc.close()

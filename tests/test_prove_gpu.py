@@ -9,9 +9,9 @@ from oracle_binding import OracleCircuit
 pytestmark = pytest.mark.gpu
 
 
-def run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed, poseidon=False, base_sum=False):
+def run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed, poseidon=False, base_sum=False, ext_arith=False):
     pack, wires, pis = pkg.synth_circuit(degree_bits, num_wires=num_wires, num_routed=num_routed, num_public_inputs=npis, seed=seed,
-                                         poseidon=poseidon, base_sum=base_sum)
+                                         poseidon=poseidon, base_sum=base_sum, ext_arith=ext_arith)
     oc = OracleCircuit(orc, pack)
     want = oc.prove(wires, pis)
     circ = pkg.Circuit(gpu, pack)
@@ -57,6 +57,13 @@ def test_leaf_gate_mix(pkg, gpu, orc):
     """BaseSumGate<2> range-check rows + Poseidon rows + arithmetic: the known part of the leaf circuit's gate mix."""
     run_case(pkg, gpu, orc, 9, 135, 80, 21, 31, poseidon=True, base_sum=True)
     run_case(pkg, gpu, orc, 6, 24, 16, 3, 32, base_sum=True)
+
+
+def test_extension_arithmetic_gates(pkg, gpu, orc):
+    """ArithmeticExtensionGate / MulExtensionGate (recursive-verifier arithmetic) alone and with the full gate mix."""
+    run_case(pkg, gpu, orc, 8, 135, 80, 21, 33, poseidon=True, base_sum=True, ext_arith=True)
+    run_case(pkg, gpu, orc, 6, 40, 24, 3, 34, ext_arith=True)
+    run_case(pkg, gpu, orc, 7, 135, 80, 4, 35, poseidon=True, ext_arith=True)
 
 
 def test_constants_sigmas_cap_matches_oracle(pkg, gpu, orc):
@@ -144,7 +151,7 @@ def test_shape_fuzz_against_oracle(pkg, gpu, orc):
         cases.append((d, wires, max(routed, 8), int(rng.integers(0, 9)), False, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
     for i, (d, wires_n, routed, npis, pos, bs, zk) in enumerate(cases):
         pack, wires, pis = pkg.synth_circuit(d, num_wires=wires_n, num_routed=routed, num_public_inputs=npis, seed=500 + i,
-                                             poseidon=pos, base_sum=bs)
+                                             poseidon=pos, base_sum=bs, ext_arith=(i % 3 == 1))
         if zk:
             pack = pack.copy(); pack[14] = 1
         oc = OracleCircuit(orc, pack); circ = pkg.Circuit(gpu, pack)
