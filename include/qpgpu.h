@@ -135,6 +135,61 @@ size_t qpgpu_proof_size(const qpgpu_circuit *c);   /* bytes written by qpgpu_pro
 int qpgpu_prove(qpgpu_circuit *c, const uint64_t *wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len);
 int qpgpu_prove_dev(qpgpu_circuit *c, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* ---- stage-level entry points: the circuit-independent parts of prove() ---------------------------------------
+ * For a patched `qp-plonky2::plonk::prover::prove` that keeps witness generation, partial products and the quotient
+ * evaluation (which depend on the gate set) in Rust and moves everything else to the GPU — polynomial commitments
+ * (s2/s3), opening evaluations (s7) and the whole FRI opening proof (s8..s11). Replaces, call for call:
+ *   PolynomialBatch::from_values / from_coeffs  -> qpgpu_oracle_commit
+ *   batch.merkle_tree.cap                       -> qpgpu_oracle_cap
+ *   batch.polynomials[i].to_extension().eval(z) -> qpgpu_oracle_eval           (OpeningSet::new)
+ *   batch.get_lde_values(..)                    -> qpgpu_oracle_read / qpgpu_oracle_device_ptrs (quotient inputs)
+ *   Challenger::{observe_*, get_*}              -> qpgpu_challenger_*         (host; optional, the Rust one works too)
+ *   PolynomialBatch::prove_openings             -> qpgpu_fri_prove            (returns write_fri_proof bytes)
+ * reached in the reference through wormhole/prover/src/lib.rs:171-175 and the aggregator call sites listed above. */
+typedef struct qpgpu_oracle qpgpu_oracle;
+#define QPGPU_ORACLE_VALUES 0u        /* input polynomials are values on the subgroup (from_values) */
+#define QPGPU_ORACLE_COEFFS 1u        /* input polynomials are coefficients (from_coeffs) */
+#define QPGPU_ORACLE_BLINDING 2u      /* append 4 salt elements to every leaf (zero-knowledge configs) */
+#define QPGPU_ORACLE_DEVICE_INPUT 4u  /* `polys` is a device pointer */
+/* polys: num_polys x 2^degree_bits, column-major (polynomial j at polys + j*2^degree_bits). blinding_stream selects
+ * the salt stream derived from blinding_seed (the all-in-one prover uses 1, 2, 3 for wires, Z/partial products, quotient). */
+int qpgpu_oracle_commit(qpgpu_ctx *ctx, const uint64_t *polys, uint32_t num_polys, unsigned degree_bits, unsigned rate_bits,
+                        unsigned cap_height, unsigned flags, uint64_t blinding_seed, uint32_t blinding_stream, qpgpu_oracle **out);
+void qpgpu_oracle_free(qpgpu_oracle *o);   /* overwrites the device copies before releasing them */
+int qpgpu_oracle_cap(const qpgpu_oracle *o, uint64_t *out, size_t out_words);          /* 4 << cap_height words */
+/* evaluations of polynomials [first, first+count) at an extension point; out: count x 2 words */
+int qpgpu_oracle_eval(qpgpu_oracle *o, const uint64_t point[2], uint32_t first, uint32_t count, uint64_t *out);
+#define QPGPU_ORACLE_READ_COEFFS 0u   /* count x 2^degree_bits words */
+#define QPGPU_ORACLE_READ_LDE 1u      /* count x 2^(degree_bits+rate_bits) words, slot s = value at g*w^bitrev(s): the Merkle leaf order */
+int qpgpu_oracle_read(qpgpu_oracle *o, unsigned what, uint32_t first, uint32_t count, uint64_t *out);
+/* device pointers of the resident data, same layouts as qpgpu_oracle_read (digests: leaf layer first, cap last) */
+int qpgpu_oracle_device_ptrs(const qpgpu_oracle *o, const uint64_t **d_coeffs, const uint64_t **d_lde, const uint64_t **d_digests);
+
+/* plonky2::iop::challenger::Challenger as plain data: buffers are Vec<F> contents, lengths their len() */
+typedef struct {
+    uint64_t sponge_state[12];
+    uint64_t input_buffer[8];
+    uint64_t output_buffer[8];
+    uint32_t input_len, output_len;
+} qpgpu_challenger;
+void qpgpu_challenger_init(qpgpu_challenger *c);
+void qpgpu_challenger_observe(qpgpu_challenger *c, const uint64_t *elements, size_t n);
+uint64_t qpgpu_challenger_get(qpgpu_challenger *c);
+
+typedef struct { uint32_t oracle, first, count; } qpgpu_fri_range;          /* FriPolynomialInfo::from_range */
+typedef struct { uint64_t point[2]; uint32_t num_ranges; qpgpu_fri_range ranges[8]; } qpgpu_fri_batch;   /* FriBatchInfo */
+typedef struct {                                                            /* FriParams */
+    uint32_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
+    uint32_t num_reduction_rounds; uint32_t reduction_arity_bits[16];
+} qpgpu_fri_params;
+size_t qpgpu_fri_proof_size(qpgpu_oracle *const *oracles, uint32_t num_oracles, const qpgpu_fri_params *params);
+/* PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params): `challenger` is the transcript state after
+ * the openings were observed and comes back as prove_openings leaves it. Writes the FriProof in write_fri_proof order
+ * (commit-phase caps, query rounds, final polynomial, pow witness; minimum valid nonce). */
+int qpgpu_fri_prove(qpgpu_ctx *ctx, qpgpu_oracle *const *oracles, uint32_t num_oracles, const qpgpu_fri_batch *batches,
+                    uint32_t num_batches, const qpgpu_fri_params *params, qpgpu_challenger *challenger,
+                    uint8_t *out, size_t out_cap, size_t *out_len);
+
 /* Hash constants the library derives at start-up (host only, no GPU): the 360 Poseidon round constants and plonky2's
  * FAST_PARTIAL_* tables flattened as FIRST[12] | RC[22] | VS[22][11] | W_HATS[22][11] | INIT[11][11] (row c of INIT
  * produces element 1+c). Returns the number of words of the second table. */

@@ -67,6 +67,19 @@ def load_library():
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_poseidon_constants": (c.c_size_t, [u64p, u64p, c.c_size_t]),
+        "qpgpu_oracle_commit": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint32,
+                                          c.POINTER(vp)]),
+        "qpgpu_oracle_free": (None, [vp]),
+        "qpgpu_oracle_cap": (c.c_int, [vp, u64p, c.c_size_t]),
+        "qpgpu_oracle_eval": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint32, u64p]),
+        "qpgpu_oracle_read": (c.c_int, [vp, c.c_uint, c.c_uint32, c.c_uint32, u64p]),
+        "qpgpu_oracle_device_ptrs": (c.c_int, [vp, c.POINTER(vp), c.POINTER(vp), c.POINTER(vp)]),
+        "qpgpu_challenger_init": (None, [vp]),
+        "qpgpu_challenger_observe": (None, [vp, u64p, c.c_size_t]),
+        "qpgpu_challenger_get": (c.c_uint64, [vp]),
+        "qpgpu_fri_proof_size": (c.c_size_t, [c.POINTER(vp), c.c_uint32, vp]),
+        "qpgpu_fri_prove": (c.c_int, [vp, c.POINTER(vp), c.c_uint32, vp, c.c_uint32, vp, vp, vp, c.c_size_t,
+                                      c.POINTER(c.c_size_t)]),
         "qpgpu_synth_pack_words": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint]),
         "qpgpu_synth_pack_words_ex": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint, c.c_uint]),
         "qpgpu_synth_circuit_ex": (c.c_int, [c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint, u64p, c.c_size_t,
@@ -193,6 +206,117 @@ class Circuit:
         ln = ctypes.c_size_t()
         self.gpu._check(self.gpu.lib.qpgpu_prove_dev(self.h, _ptr(d_wires), p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(ln)))
         return out[:ln.value].tobytes()
+
+
+ORACLE_VALUES, ORACLE_COEFFS, ORACLE_BLINDING, ORACLE_DEVICE_INPUT = 0, 1, 2, 4
+
+
+class ChallengerState(ctypes.Structure):
+    """qpgpu_challenger: plonky2's Challenger as plain data (host only)."""
+    _fields_ = [("sponge_state", ctypes.c_uint64 * 12), ("input_buffer", ctypes.c_uint64 * 8),
+                ("output_buffer", ctypes.c_uint64 * 8), ("input_len", ctypes.c_uint32), ("output_len", ctypes.c_uint32)]
+
+
+class Challenger:
+    def __init__(self):
+        self.lib = load_library()
+        self.state = ChallengerState()
+        self.lib.qpgpu_challenger_init(ctypes.byref(self.state))
+
+    def observe(self, xs):
+        x = np.ascontiguousarray(xs, dtype=np.uint64).ravel()
+        self.lib.qpgpu_challenger_observe(ctypes.byref(self.state), x.ctypes.data, x.size)
+
+    def get(self):
+        return int(self.lib.qpgpu_challenger_get(ctypes.byref(self.state)))
+
+    def get_n(self, n):
+        return [self.get() for _ in range(n)]
+
+
+class _FriRange(ctypes.Structure):
+    _fields_ = [("oracle", ctypes.c_uint32), ("first", ctypes.c_uint32), ("count", ctypes.c_uint32)]
+
+
+class _FriBatch(ctypes.Structure):
+    _fields_ = [("point", ctypes.c_uint64 * 2), ("num_ranges", ctypes.c_uint32), ("ranges", _FriRange * 8)]
+
+
+class _FriParams(ctypes.Structure):
+    _fields_ = [("rate_bits", ctypes.c_uint32), ("cap_height", ctypes.c_uint32), ("proof_of_work_bits", ctypes.c_uint32),
+                ("num_query_rounds", ctypes.c_uint32), ("num_reduction_rounds", ctypes.c_uint32),
+                ("reduction_arity_bits", ctypes.c_uint32 * 16)]
+
+
+class PolyOracle:
+    """A committed polynomial batch (plonky2 PolynomialBatch) resident on the GPU."""
+
+    def __init__(self, gpu, polys, rate_bits=3, cap_height=4, coeffs=False, blinding=False, blinding_seed=0,
+                 blinding_stream=0):
+        self.gpu = gpu
+        if isinstance(polys, np.ndarray):
+            a = np.ascontiguousarray(polys, dtype=np.uint64)
+            num_polys, n = a.shape
+            ptr, flags = a.ctypes.data, 0
+        else:                       # (device pointer, num_polys, n)
+            dev, num_polys, n = polys
+            ptr, flags = _ptr(dev), ORACLE_DEVICE_INPUT
+        self.num_polys, self.n = num_polys, n
+        self.degree_bits, self.rate_bits, self.cap_height = n.bit_length() - 1, rate_bits, cap_height
+        assert 1 << self.degree_bits == n
+        flags |= (ORACLE_COEFFS if coeffs else ORACLE_VALUES) | (ORACLE_BLINDING if blinding else 0)
+        h = ctypes.c_void_p()
+        gpu._check(gpu.lib.qpgpu_oracle_commit(gpu.ctx, ptr, num_polys, self.degree_bits, rate_bits, cap_height, flags,
+                                               blinding_seed, blinding_stream, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.gpu.lib.qpgpu_oracle_free(self.h)
+            self.h = None
+
+    def cap(self):
+        out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_oracle_cap(self.h, out.ctypes.data, out.size))
+        return out
+
+    def eval(self, point, first=0, count=None):
+        """Evaluations at an extension point (a, b): array [count, 2]."""
+        count = self.num_polys - first if count is None else count
+        pt = np.array(point, dtype=np.uint64)
+        out = np.empty((count, 2), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_oracle_eval(self.h, pt.ctypes.data, first, count, out.ctypes.data))
+        return out
+
+    def read(self, lde=False, first=0, count=None):
+        count = self.num_polys - first if count is None else count
+        out = np.empty((count, self.n << (self.rate_bits if lde else 0)), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_oracle_read(self.h, 1 if lde else 0, first, count, out.ctypes.data))
+        return out
+
+
+def fri_prove(gpu, oracles, batches, challenger, reduction_arity_bits, rate_bits=3, cap_height=4, proof_of_work_bits=16,
+              num_query_rounds=28):
+    """PolynomialBatch::prove_openings. batches: [(point(a, b), [(oracle, first, count), ...]), ...]; challenger is
+    advanced in place. Returns the FriProof bytes."""
+    hs = (ctypes.c_void_p * len(oracles))(*[o.h for o in oracles])
+    bs = (_FriBatch * len(batches))()
+    for b, (point, ranges) in zip(bs, batches):
+        b.point[0], b.point[1] = int(point[0]), int(point[1])
+        b.num_ranges = len(ranges)
+        for r, (o, f, cnt) in zip(b.ranges, ranges):
+            r.oracle, r.first, r.count = o, f, cnt
+    prm = _FriParams(rate_bits, cap_height, proof_of_work_bits, num_query_rounds, len(reduction_arity_bits))
+    for i, a in enumerate(reduction_arity_bits):
+        prm.reduction_arity_bits[i] = a
+    size = gpu.lib.qpgpu_fri_proof_size(hs, len(oracles), ctypes.byref(prm))
+    if size == 0:
+        raise QpGpuError(-1, "fri_prove: bad oracles or FRI parameters")
+    out = np.empty(size, dtype=np.uint8)
+    ln = ctypes.c_size_t()
+    gpu._check(gpu.lib.qpgpu_fri_prove(gpu.ctx, hs, len(oracles), ctypes.byref(bs), len(batches), ctypes.byref(prm),
+                                       ctypes.byref(challenger.state), out.ctypes.data, out.size, ctypes.byref(ln)))
+    return out[:ln.value].tobytes()
 
 
 class _Stage3:

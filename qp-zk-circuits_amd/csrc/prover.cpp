@@ -17,31 +17,13 @@
 #include "gl64.hpp"
 #include "merkle.hpp"
 #include "poseidon.hpp"
+#include "prover_host.hpp"
 #include "prover_kernels.hpp"
 
 using gl::e2;
 using gl::u64;
 
 namespace {
-
-// ---- host duplex challenger (plonky2::iop::challenger::Challenger) ----
-struct Challenger {
-    u64 state[12] = {0};
-    u64 in[8]; int n_in = 0;
-    u64 out[8]; int n_out = 0;
-    void duplex() {
-        for (int i = 0; i < n_in; i++) state[i] = in[i];
-        n_in = 0;
-        poseidon::permute(state, poseidon::host_round_constants());
-        std::memcpy(out, state, sizeof out);
-        n_out = 8;
-    }
-    void observe(const u64 *x, size_t n) {
-        for (size_t i = 0; i < n; i++) { n_out = 0; in[n_in++] = gl::canon(x[i]); if (n_in == 8) duplex(); }
-    }
-    u64 get() { if (n_in > 0 || n_out == 0) duplex(); return out[--n_out]; }
-    e2 get_ext() { u64 a = get(), b = get(); return gl::e2_make(a, b); }
-};
 
 void host_hash_no_pad(const u64 *in, size_t n, u64 out[4]) {
     u64 st[12] = {0};
@@ -60,15 +42,6 @@ std::vector<u64> powers_table(u64 base, u64 count) {
     return t;
 }
 
-struct DevBatch {
-    uint32_t ncols = 0;
-    unsigned log_n = 0;
-    u64 *coeffs = nullptr, *lde = nullptr, *digests = nullptr;
-    u64 *salt = nullptr;            // [4][lde_n] when the oracle is blinded
-    uint32_t oracle_index = 0;
-    std::vector<u64> cap;
-};
-
 }  // namespace
 
 struct qpgpu_circuit {
@@ -77,7 +50,7 @@ struct qpgpu_circuit {
     std::vector<void *> allocs;
     // setup-time residents
     u64 *d_cs_values = nullptr;
-    DevBatch cs;
+    PolyOracle cs;
     GateDev *d_gates = nullptr;
     std::vector<GateDev> h_gates;
     u64 *d_qacc = nullptr;
@@ -86,17 +59,13 @@ struct qpgpu_circuit {
     u64 *d_ginv_lo = nullptr, *d_ginv_hi = nullptr; uint32_t ginv_lo_bits = 0;
     // per-proof workspace
     u64 *d_wires_vals = nullptr;
-    DevBatch wires, zs, quot;
+    PolyOracle wires, zs, quot;
     u64 *d_qcp = nullptr, *d_rowprod = nullptr, *d_z = nullptr, *d_zs_vals = nullptr;
     u64 *d_small = nullptr;          // betas, gammas, beta_k_is, alpha pows, pi hash
-    e2 *d_points = nullptr, *d_open = nullptr, *d_alpha_ext = nullptr;
-    u64 *d_comp = nullptr, *d_fin = nullptr;     // [2][n] each
-    u64 *d_fri_vals = nullptr, *d_fri_rows = nullptr, *d_fri_coeffs[2] = {nullptr, nullptr};
-    std::vector<u64 *> d_fri_digests, d_fri_leafrows;
-    u64 *d_pow = nullptr, *d_qidx = nullptr, *d_gather = nullptr;
-    size_t gather_words = 0;
-    u64 *h_stage = nullptr;          // pinned host staging for the small per-proof tables (no sync on upload)
-    size_t stage_words = 0, stage_pos = 0;
+    e2 *d_points = nullptr, *d_open = nullptr;
+    FriParams fri;
+    FriWork fri_work;                // s8..s11 workspace, one allocation
+    Stager stage;                    // pinned host staging for the small per-proof tables (no sync on upload)
     bool seed_set = false;
     bool check_witness = false;
     u64 *d_check = nullptr;          // [2]: first bad row, permutation flag
@@ -114,16 +83,12 @@ struct qpgpu_circuit {
 
 namespace {
 
-size_t digest_words(unsigned log_leaves, unsigned cap_h) { return ((2ull << log_leaves) - (1ull << cap_h)) * 4; }
-
-#define QP_TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
-
-int alloc_batch(qpgpu_circuit *c, DevBatch &b, uint32_t ncols, bool need_coeffs = true, uint32_t oracle_index = 0) {
+int alloc_batch(qpgpu_circuit *c, PolyOracle &b, uint32_t ncols, bool need_coeffs = true, uint32_t oracle_index = 0) {
     b.oracle_index = oracle_index;
     if (oracle_index > 0 && c->pack.zero_knowledge) QP_TRY(c->alloc(&b.salt, (size_t)4 << (c->pack.degree_bits + c->pack.rate_bits)));
     const CircuitPack &p = c->pack;
     const u64 n = p.n(), lde_n = n << p.rate_bits;
-    b.ncols = ncols; b.log_n = (unsigned)p.degree_bits;
+    b.ncols = ncols; b.log_n = (unsigned)p.degree_bits; b.rate_bits = (unsigned)p.rate_bits; b.cap_h = (unsigned)p.cap_height;
     if (need_coeffs) QP_TRY(c->alloc(&b.coeffs, (size_t)ncols * n));
     QP_TRY(c->alloc(&b.lde, (size_t)ncols * lde_n));
     QP_TRY(c->alloc(&b.digests, digest_words((unsigned)(p.degree_bits + p.rate_bits), (unsigned)p.cap_height)));
@@ -131,59 +96,15 @@ int alloc_batch(qpgpu_circuit *c, DevBatch &b, uint32_t ncols, bool need_coeffs 
     return QPGPU_OK;
 }
 
-// PolynomialBatch::from_coeffs: LDE on the coset g<w>, leaf order, Merkle tree, cap to the host (syncs)
-int commit_coeffs(qpgpu_circuit *c, DevBatch &b) {
-    qpgpu_ctx *ctx = c->ctx;
-    const CircuitPack &p = c->pack;
-    const unsigned L = (unsigned)(p.degree_bits + p.rate_bits);
-    QP_TRY(ntt_run(ctx, b.coeffs, b.lde, b.log_n, L, b.ncols, false, true, gl::MULT_GEN));
-    MerkleLeafArgs a{};
-    a.src0 = b.lde; a.stride0 = 1ull << L; a.ncols0 = b.ncols; a.n_leaves = 1ull << L; a.digests = b.digests;
-    if (b.salt) {
-        QP_HIP(ctx, pk_salt(c->blinding_seed, b.oracle_index, 1ull << L, b.salt, ctx->stream));
-        a.src1 = b.salt; a.stride1 = 1ull << L; a.ncols1 = 4;
-    }
-    QP_TRY(merkle_build(ctx, a, L, (unsigned)p.cap_height, b.digests));
-    const size_t total = digest_words(L, (unsigned)p.cap_height);
-    QP_HIP(ctx, hipMemcpyAsync(b.cap.data(), b.digests + total - b.cap.size(), b.cap.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return QPGPU_OK;
-}
-// PolynomialBatch::from_values
-int commit_values(qpgpu_circuit *c, const u64 *d_values, DevBatch &b) {
-    QP_TRY(ntt_run(c->ctx, d_values, b.coeffs, b.log_n, b.log_n, b.ncols, true, false, 0));
-    return commit_coeffs(c, b);
-}
-
-// Upload a small table through the circuit's pinned staging area: asynchronous, no stream sync. Each proof uses a
-// fresh region per table; regions are recycled at the start of the next proof (the previous one has completed).
-int h2d_staged(qpgpu_circuit *c, void *dst, const void *src, size_t bytes) {
-    const size_t words = (bytes + 7) / 8;
-    if (c->stage_pos + words > c->stage_words) {   // should not happen: sized at load time
-        QP_HIP(c->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->ctx->stream));
-        QP_HIP(c->ctx, hipStreamSynchronize(c->ctx->stream));
-        return QPGPU_OK;
-    }
-    u64 *slot = c->h_stage + c->stage_pos;
-    c->stage_pos += words;
-    std::memcpy(slot, src, bytes);
-    QP_HIP(c->ctx, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->ctx->stream));
-    return QPGPU_OK;
-}
+int commit_coeffs(qpgpu_circuit *c, PolyOracle &b) { return oracle_commit_coeffs(c->ctx, b, c->blinding_seed); }
+int commit_values(qpgpu_circuit *c, const u64 *d_values, PolyOracle &b) { return oracle_commit_values(c->ctx, d_values, b, c->blinding_seed); }
+int h2d_staged(qpgpu_circuit *c, void *dst, const void *src, size_t bytes) { return c->stage.put(c->ctx, dst, src, bytes); }
 
 int h2d(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     QP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // source is pageable and may go out of scope
     return QPGPU_OK;
 }
-
-struct ByteWriter {
-    uint8_t *p; size_t cap, len = 0; bool overflow = false;
-    void u64le(u64 v) { if (len + 8 > cap) { overflow = true; len += 8; return; } std::memcpy(p + len, &v, 8); len += 8; }
-    void u8(uint8_t v) { if (len + 1 > cap) { overflow = true; len += 1; return; } p[len++] = v; }
-    void vec(const u64 *v, size_t n) { for (size_t i = 0; i < n; i++) u64le(v[i]); }
-    void ext(e2 v) { u64le(v.a); u64le(v.b); }
-};
 
 }  // namespace
 
@@ -207,7 +128,7 @@ void qpgpu_circuit_free(qpgpu_circuit *c) {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->stage.h) (void)hipHostFree(c->stage.h);
     for (void *p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -291,38 +212,24 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     const size_t n_open = p.num_cs_cols() + p.num_wires + p.num_zs_pp_cols() + p.num_quotient_cols();
     CK(c->alloc(&c->d_points, 2));
     CK(c->alloc(&c->d_open, n_open + nch));
-    CK(c->alloc(&c->d_alpha_ext, n_open));
-    CK(c->alloc(&c->d_comp, 2 * n));
-    CK(c->alloc(&c->d_fin, 2 * n));
-    CK(c->alloc(&c->d_fri_vals, 2 * lde_n));
-    CK(c->alloc(&c->d_fri_rows, 2 * lde_n));
-    CK(c->alloc(&c->d_fri_coeffs[0], 2 * n)); CK(c->alloc(&c->d_fri_coeffs[1], 2 * n));
     {
-        unsigned lvl = L;
-        size_t gw = 0;
+        // FRI opening proof over the four oracles: workspace carved out of one allocation
+        c->fri.degree_bits = d; c->fri.rate_bits = (unsigned)p.rate_bits; c->fri.cap_h = (unsigned)p.cap_height;
+        c->fri.pow_bits = (unsigned)p.proof_of_work_bits; c->fri.num_queries = (uint32_t)p.num_query_rounds;
+        for (u64 a : p.arity_bits) c->fri.arity_bits.push_back((unsigned)a);
         const size_t salt = p.zero_knowledge ? 4 : 0;
-        const size_t widths[4] = {(size_t)p.num_cs_cols(), (size_t)p.num_wires + salt, (size_t)p.num_zs_pp_cols() + salt, (size_t)p.num_quotient_cols() + salt};
-        for (size_t w : widths) gw += w + (L - p.cap_height) * 4;
-        for (u64 a : p.arity_bits) {
-            lvl -= (unsigned)a;
-            u64 *dg = nullptr, *rows = nullptr;
-            CK(c->alloc(&dg, digest_words(lvl, (unsigned)p.cap_height)));
-            CK(c->alloc(&rows, (size_t)2 << (lvl + a)));
-            c->d_fri_digests.push_back(dg); c->d_fri_leafrows.push_back(rows);
-            gw += (2ull << a) + (lvl - p.cap_height) * 4;
-        }
-        c->gather_words = gw * p.num_query_rounds;
-        CK(c->alloc(&c->d_gather, c->gather_words));
-        CK(c->alloc(&c->d_qidx, p.num_query_rounds));
-        CK(c->alloc(&c->d_pow, 1));
+        const std::vector<size_t> widths = {(size_t)p.num_cs_cols(), (size_t)p.num_wires + salt, (size_t)p.num_zs_pp_cols() + salt, (size_t)p.num_quotient_cols() + salt};
+        u64 *base = nullptr;
+        CK(c->alloc(&base, FriWork::words(c->fri, widths, n_open)));
+        c->fri_work.bind(base, c->fri, widths, n_open);
         CK(c->alloc(&c->d_check, 2));
     }
     {
-        c->stage_words = 2 * nch + nch * R + nch * nterms + 4 + 4 + 2 * n_open + p.num_query_rounds + 64 + 8;
+        c->stage.words = 2 * nch + nch * R + nch * nterms + 4 + 4 + FriWork::stage_words(c->fri, n_open) + 64 + 8;
         void *hp = nullptr;
-        hipError_t e = hipHostMalloc(&hp, c->stage_words * 8, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&hp, c->stage.words * 8, hipHostMallocDefault);
         if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipHostMalloc(stage)"));
-        c->h_stage = (u64 *)hp;
+        c->stage.h = (u64 *)hp;
     }
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #undef CK
@@ -359,7 +266,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     const size_t sig0 = p.num_selectors + p.num_constants, cap_words = (1ull << cap_h) * 4;
     const size_t nterms = nch + nch * nchunks + p.num_gate_constraints;
 
-    c->stage_pos = 0;
+    c->stage.pos = 0;
     u64 pih[4];
     host_hash_no_pad(public_inputs, p.num_public_inputs, pih);
     if (p.zero_knowledge && !c->seed_set) {   // fresh randomness per proof unless the caller injected a seed
@@ -460,9 +367,9 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     {
         e2 pts[2] = {zeta, g_zeta};
         QP_TRY(h2d_staged(c, c->d_points, pts, sizeof pts));
-        const DevBatch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
+        const PolyOracle *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
         size_t off = 0;
-        for (const DevBatch *b : bs) { QP_HIP(ctx, pk_poly_eval(b->coeffs, n, b->ncols, c->d_points, 1, nullptr, c->d_open + off, st)); off += b->ncols; }
+        for (const PolyOracle *b : bs) { QP_HIP(ctx, pk_poly_eval(b->coeffs, n, b->ncols, c->d_points, 1, nullptr, c->d_open + off, st)); off += b->ncols; }
         QP_HIP(ctx, pk_poly_eval(c->zs.coeffs, n, nch, c->d_points + 1, 1, nullptr, c->d_open + n_open, st));
     }
     std::vector<e2> open(n_open + nch);
@@ -471,145 +378,8 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     ctx->prof_end();
     ch.observe((const u64 *)open.data(), n_open * 2);
     ch.observe((const u64 *)(open.data() + n_open), (size_t)nch * 2);
-    const e2 fri_alpha = ch.get_ext();
 
-    // ---- s8 batched opening polynomial ----
-    ctx->prof_begin("prove_fri_batch");
-    {
-        std::vector<e2> apw(n_open);
-        e2 a = gl::e2_from(1);
-        for (size_t i = 0; i < n_open; i++) { apw[i] = gl::e2_canon(a); a = gl::e2_mul(a, fri_alpha); }
-        QP_TRY(h2d_staged(c, c->d_alpha_ext, apw.data(), apw.size() * sizeof(e2)));
-        ReduceArgs ra{};
-        ra.src[0] = c->cs.coeffs; ra.src[1] = c->wires.coeffs; ra.src[2] = c->zs.coeffs; ra.src[3] = c->quot.coeffs;
-        ra.ncols[0] = (uint32_t)ncs; ra.ncols[1] = (uint32_t)NW; ra.ncols[2] = (uint32_t)nzp; ra.ncols[3] = (uint32_t)nq; ra.nsrc = 4;
-        ra.alpha_pows = c->d_alpha_ext; ra.comp_a = c->d_comp; ra.comp_b = c->d_comp + n; ra.n = n;
-        QP_HIP(ctx, pk_reduce_polys(ra, st));
-        QP_HIP(ctx, pk_divide_linear(c->d_comp, c->d_comp + n, n, zeta, gl::e2_from(1), 0, c->d_fin, c->d_fin + n, st));
-        ra.src[0] = c->zs.coeffs; ra.ncols[0] = nch; ra.nsrc = 1;
-        QP_HIP(ctx, pk_reduce_polys(ra, st));
-        QP_HIP(ctx, pk_divide_linear(c->d_comp, c->d_comp + n, n, g_zeta, gl::e2_pow(fri_alpha, nch), 1, c->d_fin, c->d_fin + n, st));
-    }
-    ctx->prof_end();
-
-    // ---- s9 FRI commit phase ----
-    ctx->prof_begin("prove_fri_commit");
-    std::vector<std::vector<u64>> fri_caps;
-    std::vector<unsigned> tree_log_leaves;
-    u64 shift = gl::MULT_GEN;
-    u64 *coef = c->d_fin;           // [2][valid]
-    u64 valid = n; unsigned log_len = L;
-    size_t fri_slot = 0;
-    // values of the first layer: LDE of the two component columns, leaf order
-    QP_TRY(ntt_run(ctx, coef, c->d_fri_vals, d, L, 2, false, true, shift));
-    for (size_t r = 0; r < p.arity_bits.size(); r++) {
-        const unsigned ab = (unsigned)p.arity_bits[r];
-        const u64 len = 1ull << log_len, arity = 1ull << ab;
-        const unsigned log_leaves = log_len - ab;
-        u64 *rows = c->d_fri_leafrows[r];
-        QP_HIP(ctx, pk_interleave_ext(c->d_fri_vals, c->d_fri_vals + len, len, rows, st));
-        // leaves = chunks of `arity` extension values = 2*arity consecutive felts
-        MerkleLeafArgs unused{}; (void)unused;
-        QP_HIP(ctx, merkle_leaf_hash_rows(rows, 1ull << log_leaves, (uint32_t)(2 * arity), c->d_fri_digests[r], st));
-        {
-            u64 cnt = 1ull << log_leaves; u64 *lvl = c->d_fri_digests[r];
-            while (cnt > (1ull << cap_h)) { QP_HIP(ctx, merkle_reduce_level(lvl, lvl + cnt * 4, cnt / 2, st)); lvl += cnt * 4; cnt >>= 1; }
-            std::vector<u64> capv(cap_words);
-            QP_HIP(ctx, hipMemcpyAsync(capv.data(), lvl, cap_words * 8, hipMemcpyDeviceToHost, st));
-            QP_HIP(ctx, hipStreamSynchronize(st));
-            fri_caps.push_back(capv);
-        }
-        tree_log_leaves.push_back(log_leaves);
-        ch.observe(fri_caps.back().data(), cap_words);
-        const e2 beta = ch.get_ext();
-        const u64 new_valid = valid >> ab;
-        u64 *ncoef = c->d_fri_coeffs[fri_slot]; fri_slot ^= 1;
-        QP_HIP(ctx, pk_fri_fold(coef, coef + valid, new_valid, (uint32_t)arity, beta, ncoef, ncoef + new_valid, st));
-        coef = ncoef; valid = new_valid; log_len -= ab;
-        shift = gl::pow(shift, arity);
-        if (r + 1 < p.arity_bits.size()) {
-            unsigned lv = 0; while ((1ull << lv) < valid) lv++;
-            QP_TRY(ntt_run(ctx, coef, c->d_fri_vals, lv, log_len, 2, false, true, shift));
-        }
-    }
-    std::vector<u64> final_coeffs(2 * valid);   // component arrays [a...][b...]
-    QP_HIP(ctx, hipMemcpyAsync(final_coeffs.data(), coef, final_coeffs.size() * 8, hipMemcpyDeviceToHost, st));
-    QP_HIP(ctx, hipStreamSynchronize(st));
-    ctx->prof_end();
-    std::vector<e2> final_poly(valid);
-    for (u64 i = 0; i < valid; i++) final_poly[i] = gl::e2_make(final_coeffs[i], final_coeffs[valid + i]);
-    ch.observe((const u64 *)final_poly.data(), 2 * valid);
-
-    // ---- s10 proof of work: minimum nonce ----
-    ctx->prof_begin("prove_pow");
-    u64 pow_witness = 0;
-    {
-        PowArgs pw{};
-        std::memcpy(pw.state, ch.state, sizeof pw.state);
-        for (int i = 0; i < ch.n_in; i++) pw.state[i] = ch.in[i];
-        pw.pos = (uint32_t)ch.n_in; pw.pow_bits = (uint32_t)p.proof_of_work_bits; pw.result = c->d_pow;
-        if (pw.pow_bits == 0) pow_witness = 0;
-        else {
-            // expected 2^pow_bits candidates; a batch of 2x that finds it 86% of the time and costs one wave per SIMD
-            const u64 batch = std::max<u64>(1ull << 16, 2ull << pw.pow_bits);
-            bool found = false;
-            for (u64 base = 0; !found; base += batch) {
-                const u64 sentinel = ~0ull;
-                QP_HIP(ctx, hipMemcpyAsync(c->d_pow, &sentinel, 8, hipMemcpyHostToDevice, st));
-                pw.base = base; pw.count = batch;
-                QP_HIP(ctx, pk_pow(pw, st));
-                u64 res = 0;
-                QP_HIP(ctx, hipMemcpyAsync(&res, c->d_pow, 8, hipMemcpyDeviceToHost, st));
-                QP_HIP(ctx, hipStreamSynchronize(st));
-                if (res != sentinel) { pow_witness = res; found = true; }
-                if (base > (1ull << 40)) return ctx->fail(QPGPU_EDEVICE, "prove: proof of work not found");
-            }
-        }
-    }
-    ctx->prof_end();
-    ch.observe(&pow_witness, 1);
-    (void)ch.get();   // the response, re-derived by the verifier
-
-    // ---- s11 queries ----
-    ctx->prof_begin("prove_queries");
-    const uint32_t nqr = (uint32_t)p.num_query_rounds;
-    std::vector<u64> qidx(nqr);
-    for (auto &x : qidx) x = ch.get() % lde_n;
-    QP_TRY(h2d_staged(c, c->d_qidx, qidx.data(), nqr * 8));
-    // gather layout (per section, all queries contiguous): for each oracle rows then paths; for each FRI round evals then paths
-    struct Sec { size_t off, words; bool is_path; };
-    std::vector<Sec> secs;
-    size_t goff = 0;
-    const DevBatch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
-    const uint32_t plen0 = L - cap_h;
-    for (const DevBatch *b : bs) {
-        QP_HIP(ctx, pk_gather_rows(b->lde, lde_n, b->ncols, c->d_qidx, nqr, c->d_gather + goff, st));
-        secs.push_back({goff, b->ncols, false}); goff += (size_t)b->ncols * nqr;
-        if (b->salt) {
-            QP_HIP(ctx, pk_gather_rows(b->salt, lde_n, 4, c->d_qidx, nqr, c->d_gather + goff, st));
-            secs.push_back({goff, 4, false}); goff += (size_t)4 * nqr;
-        }
-        QP_HIP(ctx, pk_gather_paths(b->digests, lde_n, plen0, c->d_qidx, 0, nqr, c->d_gather + goff, st));
-        secs.push_back({goff, (size_t)plen0 * 4, true}); goff += (size_t)plen0 * 4 * nqr;
-    }
-    {
-        uint32_t sh = 0;
-        for (size_t r = 0; r < p.arity_bits.size(); r++) {
-            const uint32_t ab = (uint32_t)p.arity_bits[r], width = 2u << ab, pl = tree_log_leaves[r] - cap_h;
-            sh += ab;
-            QP_HIP(ctx, pk_gather_leaf_rows(c->d_fri_leafrows[r], width, c->d_qidx, sh, nqr, c->d_gather + goff, st));
-            secs.push_back({goff, width, false}); goff += (size_t)width * nqr;
-            QP_HIP(ctx, pk_gather_paths(c->d_fri_digests[r], 1ull << tree_log_leaves[r], pl, c->d_qidx, sh, nqr, c->d_gather + goff, st));
-            secs.push_back({goff, (size_t)pl * 4, true}); goff += (size_t)pl * 4 * nqr;
-        }
-    }
-    if (goff != c->gather_words) return ctx->fail(QPGPU_EDEVICE, "prove: internal gather size mismatch");
-    std::vector<u64> gathered(goff);
-    QP_HIP(ctx, hipMemcpyAsync(gathered.data(), c->d_gather, goff * 8, hipMemcpyDeviceToHost, st));
-    QP_HIP(ctx, hipStreamSynchronize(st));
-    ctx->prof_end();
-
-    // ---- s12 ProofWithPublicInputs::to_bytes ----
+    // ---- s12 ProofWithPublicInputs::to_bytes: caps and openings, then the FRI proof, then the public inputs ----
     ByteWriter w{out, out_cap};
     w.vec(c->wires.cap.data(), cap_words); w.vec(c->zs.cap.data(), cap_words); w.vec(c->quot.cap.data(), cap_words);
     const e2 *o_cs = open.data(), *o_w = o_cs + ncs, *o_zs = o_w + NW, *o_pp = o_zs + nch, *o_q = o_pp + (size_t)nch * npp, *o_zn = open.data() + n_open;
@@ -619,15 +389,15 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     for (size_t i = 0; i < nch; i++) w.ext(o_zn[i]);          // plonk_zs_next
     for (size_t i = 0; i < (size_t)nch * npp; i++) w.ext(o_pp[i]);   // partial_products
     for (size_t i = 0; i < nq; i++) w.ext(o_q[i]);            // quotient_polys (lookup vectors are empty)
-    for (auto &cp : fri_caps) w.vec(cp.data(), cap_words);
-    for (uint32_t q = 0; q < nqr; q++) {
-        for (const Sec &sc : secs) {
-            if (sc.is_path) w.u8((uint8_t)(sc.words / 4));   // write_merkle_proof: one-byte sibling count
-            w.vec(gathered.data() + sc.off + (size_t)q * sc.words, sc.words);
-        }
-    }
-    for (u64 i = 0; i < valid; i++) w.ext(final_poly[i]);
-    w.u64le(pow_witness);
+
+    // ---- s8..s11 PolynomialBatch::prove_openings: every polynomial at zeta, the Zs also at g*zeta ----
+    const PolyOracle *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
+    std::vector<FriBatch> batches(2);
+    batches[0].point = zeta;
+    batches[0].ranges = {{0, 0, (uint32_t)ncs}, {1, 0, (uint32_t)NW}, {2, 0, (uint32_t)nzp}, {3, 0, (uint32_t)nq}};
+    batches[1].point = g_zeta;
+    batches[1].ranges = {{2, 0, nch}};
+    QP_TRY(fri_prove(ctx, c->fri, bs, 4, batches, ch, c->fri_work, c->stage, w));
     for (size_t i = 0; i < p.num_public_inputs; i++) w.u64le(gl::canon(public_inputs[i]));
     if (out_len) *out_len = w.len;
     if (w.overflow) return ctx->fail(QPGPU_EBUFSIZE, "prove: output buffer too small");

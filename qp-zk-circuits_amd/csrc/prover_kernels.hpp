@@ -34,8 +34,8 @@ struct QuotientArgs {
 };
 
 struct ReduceArgs {
-    const uint64_t *src[4];
-    uint32_t ncols[4];
+    const uint64_t *src[8];
+    uint32_t ncols[8];
     uint32_t nsrc;
     const gl::e2 *alpha_pows;
     uint64_t *comp_a, *comp_b;

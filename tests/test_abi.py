@@ -46,3 +46,19 @@ def test_c_example_compiles_against_the_header():
                            "-L", os.path.join(root, "qp-zk-circuits_amd"), "-lqpgpu",
                            "-Wl,-rpath," + os.path.join(root, "qp-zk-circuits_amd"), "-o", out])
     assert os.path.exists(out)
+
+
+def test_library_challenger_matches_oracle(pkg, orc):
+    """qpgpu_challenger_* (host only) against the restated duplex challenger on a mixed observe/squeeze schedule."""
+    import numpy as np
+    from oracle_binding import Challenger as OracleChallenger
+    rng = np.random.default_rng(11)
+    a, b = pkg.Challenger(), OracleChallenger(orc)
+    for step in range(40):
+        k = int(rng.integers(0, 20))
+        xs = rng.integers(0, 0xFFFFFFFF00000001, size=k, dtype=np.uint64)
+        if k:
+            a.observe(xs); b.observe(xs)
+        m = int(rng.integers(0, 11))
+        assert a.get_n(m) == b.get_n(m), step
+    assert a.state.input_len == 0 or a.state.output_len == 0
