@@ -206,7 +206,9 @@ size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned
 /* flags bit 0: every 8th row is a PoseidonGate row (135 wires, 123 constraints of degree 7, its own selector group),
  * the gate that dominates the recursive (aggregator) circuits. bit 1: every 8th row is a BaseSumGate<2> row (the leaf
  * circuit's range checks, reference wormhole/circuit/src/zk_merkle_proof.rs:486-504). bit 2: every 8th row alternates
- * ArithmeticExtensionGate / MulExtensionGate (quadratic-extension arithmetic of the recursive verifier circuits). */
+ * ArithmeticExtensionGate / MulExtensionGate (quadratic-extension arithmetic of the recursive verifier circuits).
+ * bit 3: every 8th row cycles through ReducingGate, ReducingExtensionGate, RandomAccessGate(4 bits), ExponentiationGate
+ * and PoseidonMdsGate, the rest of the gates plonky2's in-circuit verifier uses (needs >= 48 routed wires). */
 size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags);
 int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                            uint64_t seed, unsigned flags, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,

@@ -102,6 +102,8 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
     for (size_t i = 0; i < c->n_arity; i++) c->arity[i] = w[p++];
     c->gates = (orc_gate *)malloc(sizeof(orc_gate) * c->n_gates);
     memcpy(c->gates, w + p, sizeof(orc_gate) * c->n_gates); p += 8 * c->n_gates;
+    for (size_t i = 0; i < c->n_gates; i++)   /* scratch bounds of the recursion gates (gates_recursion.inc) */
+        if (c->gates[i].type >= OG_REDUCING && (c->gates[i].num_constraints > 256 || (c->gates[i].type == OG_RANDOM_ACCESS && c->gates[i].param0 > 6))) { free(c->gates); free(c); return NULL; }
     c->k_is = (gl_t *)malloc(sizeof(gl_t) * c->num_routed);
     memcpy(c->k_is, w + p, sizeof(gl_t) * c->num_routed); p += c->num_routed;
     memcpy(c->digest, w + p, 32); p += 4;
@@ -288,6 +290,35 @@ static void poseidon_gate_ext(const gl2_t *w, gl2_t *out) {
     for (int i = 0; i < 12; i++) out[k++] = gl2_sub(st[i], w[12 + i]);
 }
 
+/* the recursion gate set, once per scalar type */
+#define GN(name) name##_base
+#define T gl_t
+#define T_ADD gl_add
+#define T_SUB gl_sub
+#define T_MUL gl_mul
+#define T_FROM(x) ((gl_t)(x))
+#include "gates_recursion.inc"
+#undef GN
+#undef T
+#undef T_ADD
+#undef T_SUB
+#undef T_MUL
+#undef T_FROM
+#define GN(name) name##_ext
+#define T gl2_t
+#define T_ADD gl2_add
+#define T_SUB gl2_sub
+#define T_MUL gl2_mul
+#define T_FROM(x) gl2_from((gl_t)(x))
+#include "gates_recursion.inc"
+#undef GN
+#undef T
+#undef T_ADD
+#undef T_SUB
+#undef T_MUL
+#undef T_FROM
+#define MAX_GATE_CONSTRAINTS 256
+
 /* adds filter * constraint_k into acc[k]. consts = local constants after the selector prefix. */
 static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t *wires, const gl_t pih[4], gl_t *acc) {
     const gl_t *consts = cs_row + c->num_selectors;
@@ -335,6 +366,12 @@ static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t
             for (uint64_t i = g->param0; i-- > 0;) s2 = gl_add(gl_add(s2, s2), wires[1 + i]);
             acc[0] = gl_add(acc[0], gl_mul(f, gl_sub(s2, wires[0])));
             for (uint64_t i = 0; i < g->param0; i++) acc[1 + i] = gl_add(acc[1 + i], gl_mul(f, gl_mul(wires[1 + i], gl_sub(wires[1 + i], 1))));
+            break;
+        }
+        case OG_REDUCING: case OG_REDUCING_EXT: case OG_RANDOM_ACCESS: case OG_EXPONENTIATION: case OG_POSEIDON_MDS: {
+            gl_t cst[MAX_GATE_CONSTRAINTS];
+            recursion_gate_base(g, consts, wires, cst);
+            for (uint64_t i = 0; i < g->num_constraints; i++) acc[i] = gl_add(acc[i], gl_mul(f, cst[i]));
             break;
         }
         default: break;
@@ -398,6 +435,12 @@ void orc_eval_gates_ext(const orc_circuit *c, const gl2_t *cs_row, const gl2_t *
             for (uint64_t i = g->param0; i-- > 0;) s2 = gl2_add(gl2_add(s2, s2), wires[1 + i]);
             acc[0] = gl2_add(acc[0], gl2_mul(f, gl2_sub(s2, wires[0])));
             for (uint64_t i = 0; i < g->param0; i++) acc[1 + i] = gl2_add(acc[1 + i], gl2_mul(f, gl2_mul(wires[1 + i], gl2_sub(wires[1 + i], gl2_from(1)))));
+            break;
+        }
+        case OG_REDUCING: case OG_REDUCING_EXT: case OG_RANDOM_ACCESS: case OG_EXPONENTIATION: case OG_POSEIDON_MDS: {
+            gl2_t cst[MAX_GATE_CONSTRAINTS];
+            recursion_gate_ext(g, consts, wires, cst);
+            for (uint64_t i = 0; i < g->num_constraints; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, cst[i]));
             break;
         }
         default: break;

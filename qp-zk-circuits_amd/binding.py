@@ -113,12 +113,13 @@ def poseidon_constants():
 
 
 def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=21, seed=1, poseidon=False, base_sum=False,
-                  ext_arith=False):
+                  ext_arith=False, recursion=False):
     """Synthetic satisfied circuit: returns (pack_words, wires[num_wires, n], public_inputs). Host only.
     poseidon=True adds PoseidonGate rows (needs 135 wires), base_sum=True BaseSumGate<2> rows, ext_arith=True
-    ArithmeticExtensionGate and MulExtensionGate rows."""
+    ArithmeticExtensionGate and MulExtensionGate rows, recursion=True Reducing / ReducingExtension / RandomAccess /
+    Exponentiation / PoseidonMds rows."""
     lib = load_library()
-    flags = (1 if poseidon else 0) | (2 if base_sum else 0) | (4 if ext_arith else 0)
+    flags = (1 if poseidon else 0) | (2 if base_sum else 0) | (4 if ext_arith else 0) | (8 if recursion else 0)
     words = lib.qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, flags)
     pack = np.empty(words, dtype=np.uint64)
     wires = np.empty((num_wires, 1 << degree_bits), dtype=np.uint64)

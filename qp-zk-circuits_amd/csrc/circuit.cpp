@@ -11,7 +11,7 @@ std::vector<uint64_t> CircuitPack::serialize() const {
     w.insert(w.end(), hdr, hdr + 17);
     w.insert(w.end(), arity_bits.begin(), arity_bits.end());
     for (const auto &g : gates) {
-        const uint64_t gw[] = {g.type, g.param0, g.param1, g.selector_index, g.group_start, g.group_end, g.num_constraints, g.reserved};
+        const uint64_t gw[] = {g.type, g.param0, g.param1, g.selector_index, g.group_start, g.group_end, g.num_constraints, g.param2};
         w.insert(w.end(), gw, gw + 8);
     }
     w.insert(w.end(), k_is.begin(), k_is.end());
@@ -37,7 +37,7 @@ std::string CircuitPack::parse(const uint64_t *words, size_t n_words) {
     gates.resize(ng);
     for (auto &g : gates) {
         g.type = words[pos]; g.param0 = words[pos + 1]; g.param1 = words[pos + 2]; g.selector_index = words[pos + 3];
-        g.group_start = words[pos + 4]; g.group_end = words[pos + 5]; g.num_constraints = words[pos + 6]; g.reserved = words[pos + 7];
+        g.group_start = words[pos + 4]; g.group_end = words[pos + 5]; g.num_constraints = words[pos + 6]; g.param2 = words[pos + 7];
         pos += 8;
     }
     if (!need(num_routed_wires + 4)) return "truncated k_is";
@@ -62,7 +62,7 @@ std::string CircuitPack::validate() const {
     for (auto a : arity_bits) { if (a == 0 || a > 4) return "unsupported FRI arity"; sum += a; }
     if (sum > degree_bits) return "FRI reductions exceed degree";
     for (const auto &g : gates) {
-        if (g.type > GATE_MUL_EXT) return "unknown gate type";
+        if (g.type > GATE_POSEIDON_MDS) return "unknown gate type";
         if (g.selector_index >= num_selectors) return "gate selector index out of range";
         if (g.group_end > gates.size() || g.group_start >= g.group_end) return "gate group out of range";
         if (g.num_constraints > num_gate_constraints) return "gate constraint count exceeds num_gate_constraints";
@@ -72,6 +72,16 @@ std::string CircuitPack::validate() const {
         if (g.type == GATE_ARITHMETIC_EXT && (g.param0 * 8 > num_routed_wires || g.num_constraints != 2 * g.param0 || num_constants < 2)) return "bad arithmetic-extension gate";
         if (g.type == GATE_MUL_EXT && (g.param0 * 6 > num_routed_wires || g.num_constraints != 2 * g.param0 || num_constants < 1)) return "bad mul-extension gate";
         if (g.type == GATE_BASE_SUM && (g.param0 == 0 || g.param0 > 63 || g.param0 + 1 > num_routed_wires || g.num_constraints != g.param0 + 1)) return "bad base-sum gate";
+        if (g.type == GATE_REDUCING && (g.param0 == 0 || 6 + g.param0 > num_routed_wires || 6 + 3 * g.param0 - 2 > num_wires || g.num_constraints != 2 * g.param0)) return "bad reducing gate";
+        if (g.type == GATE_REDUCING_EXT && (g.param0 == 0 || 6 + 2 * g.param0 > num_routed_wires || 6 + 4 * g.param0 - 2 > num_wires || g.num_constraints != 2 * g.param0)) return "bad reducing-extension gate";
+        if (g.type == GATE_RANDOM_ACCESS) {
+            const uint64_t bits = g.param0, copies = g.param1, extra = g.param2;
+            if (bits == 0 || bits > 5 || copies == 0) return "bad random-access gate";
+            const uint64_t routed = (2 + (1ull << bits)) * copies + extra;
+            if (routed > num_routed_wires || routed + copies * bits > num_wires || extra > num_constants || g.num_constraints != copies * (bits + 2) + extra) return "bad random-access gate";
+        }
+        if (g.type == GATE_EXPONENTIATION && (g.param0 == 0 || g.param0 + 2 > num_routed_wires || 2 * g.param0 + 2 > num_wires || g.num_constraints != g.param0 + 1)) return "bad exponentiation gate";
+        if (g.type == GATE_POSEIDON_MDS && (num_routed_wires < 48 || g.num_constraints != 24)) return "bad poseidon-mds gate";
         if (g.type == GATE_POSEIDON && (num_wires < 135 || num_routed_wires < 25 || g.num_constraints != 123)) return "bad poseidon gate";
     }
     return "";

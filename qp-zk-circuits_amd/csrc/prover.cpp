@@ -161,7 +161,7 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     for (size_t i = 0; i < gd.size(); i++) {
         const GateInfo &g = p.gates[i];
         gd[i] = {(uint32_t)g.type, (uint32_t)g.param0, (uint32_t)g.param1, (uint32_t)g.selector_index, (uint32_t)g.group_start,
-                 (uint32_t)g.group_end, (uint32_t)g.num_constraints, 0};
+                 (uint32_t)g.group_end, (uint32_t)g.num_constraints, (uint32_t)g.param2};
     }
     c->h_gates = gd;
     CK(c->alloc(&c->d_gates, gd.size()));

@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
     for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = acc[c];
 }
 
-// (2) the low-degree gates: Constant, PublicInput, BaseSum<2>, Arithmetic. t0 = index of the first gate constraint.
+// (2) every gate except PoseidonGate: Constant, PublicInput, BaseSum<2>, Arithmetic, the extension-arithmetic pair and the
+// recursion set (Reducing*, RandomAccess, Exponentiation, PoseidonMds). t0 = index of the first gate constraint.
 template <int NCH>
 __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -205,6 +206,64 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
                 const e2 d = gl::e2_sub(gl::e2_make(w[4 * S], w[5 * S]),
                                         gl::e2_scale(gl::e2_mul(gl::e2_make(w[0], w[S]), gl::e2_make(w[2 * S], w[3 * S])), c0));
                 emit(2 * q, d.a); emit(2 * q + 1, d.b);
+            }
+        } else if (g.type == 8 || g.type == 9) {   // ReducingGate / ReducingExtensionGate: acc*alpha + coeff_i - acc_i, chained
+            const bool ext = g.type == 9;
+            const u32 nc = g.param0, start_accs = 6 + (ext ? 2 * nc : nc);
+            const u64 *w = a.wires + j;
+            const e2 alpha = gl::e2_make(w[2 * S], w[3 * S]);
+            e2 acc = gl::e2_make(w[4 * S], w[5 * S]);
+            for (u32 q = 0; q < nc; q++) {
+                const u32 nx = q == nc - 1 ? 0 : start_accs + 2 * q;
+                const e2 next = gl::e2_make(w[(u64)nx * S], w[(u64)(nx + 1) * S]);
+                e2 t = gl::e2_mul(acc, alpha);
+                if (ext) t = gl::e2_add(t, gl::e2_make(w[(u64)(6 + 2 * q) * S], w[(u64)(7 + 2 * q) * S]));
+                else t.a = gl::add(t.a, w[(u64)(6 + q) * S]);
+                emit(2 * q, gl::sub(t.a, next.a)); emit(2 * q + 1, gl::sub(t.b, next.b));
+                acc = next;
+            }
+        } else if (g.type == 10) {    // RandomAccessGate(bits, copies, extra constants)
+            const u32 bits = g.param0, copies = g.param1, extra = g.param2, vec = 1u << bits;
+            const u32 routed = (2 + vec) * copies + extra;
+            u32 q = 0;
+            for (u32 cp = 0; cp < copies; cp++) {
+                const u64 *cw = a.wires + (u64)((2 + vec) * cp) * S + j, *bw = a.wires + (u64)(routed + cp * bits) * S + j;
+                u64 items[32];
+                for (u32 i = 0; i < vec; i++) items[i] = cw[(u64)(2 + i) * S];
+                u64 idx = 0;
+                for (u32 i = 0; i < bits; i++) { const u64 b = bw[(u64)i * S]; emit(q++, gl::mul(b, gl::sub(b, 1))); }
+                for (u32 i = bits; i-- > 0;) idx = gl::add(gl::add(idx, idx), bw[(u64)i * S]);
+                emit(q++, gl::sub(idx, cw[0]));
+                u32 len = vec;
+                for (u32 b = 0; b < bits; b++) {
+                    const u64 bit = bw[(u64)b * S];
+                    for (u32 i = 0; i < len / 2; i++) items[i] = gl::add(items[2 * i], gl::mul(bit, gl::sub(items[2 * i + 1], items[2 * i])));
+                    len >>= 1;
+                }
+                emit(q++, gl::sub(items[0], cw[S]));
+            }
+            for (u32 i = 0; i < extra; i++) emit(q++, gl::sub(consts_base[(u64)i * S], a.wires[(u64)((2 + vec) * copies + i) * S + j]));
+        } else if (g.type == 11) {    // ExponentiationGate: square-and-multiply chain over the power bits (big-endian walk)
+            const u32 n = g.param0;
+            const u64 *w = a.wires + j;
+            const u64 base = w[0];
+            for (u32 q = 0; q < n; q++) {
+                const u64 pi = q == 0 ? 1 : w[(u64)(2 + n + q - 1) * S];
+                const u64 prev = q == 0 ? 1 : gl::mul(pi, pi);
+                const u64 bit = w[(u64)(1 + (n - 1 - q)) * S];
+                const u64 computed = gl::mul(prev, gl::add(gl::mul(bit, base), gl::sub(1, bit)));
+                emit(q, gl::sub(computed, w[(u64)(2 + n + q) * S]));
+            }
+            emit(n, gl::sub(w[(u64)(1 + n) * S], w[(u64)(2 + n + n - 1) * S]));
+        } else if (g.type == 12) {    // PoseidonMdsGate: out - MDS(in) on 12 extension-algebra elements, component by component
+            const u64 *w = a.wires + j;
+            for (u32 comp = 0; comp < 2; comp++) {
+                u64 st[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) st[i] = w[(u64)(2 * i + comp) * S];
+                poseidon::mds_layer(st);
+#pragma unroll
+                for (int i = 0; i < 12; i++) emit(2 * i + comp, gl::sub(w[(u64)(24 + 2 * i + comp) * S], st[i]));
             }
         } else if (g.type == 5) {     // BaseSumGate<2>: sum - sum_i 2^i limb_i, and limb_i (limb_i - 1)
             u64 s2 = 0;

@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include "gl64.hpp"
 
-struct GateDev { uint32_t type, param0, param1, selector_index, group_start, group_end, num_constraints, pad; };
+struct GateDev { uint32_t type, param0, param1, selector_index, group_start, group_end, num_constraints, param2; };
 
 struct PpArgs {
     const uint64_t *wires;      // [num_wires][n] values, natural order

@@ -33,13 +33,14 @@ void host_hash_no_pad(const u64 *in, size_t n, u64 out[4]) {
     }
     for (int i = 0; i < 4; i++) out[i] = st[i];
 }
-struct GateSpec { uint64_t type, p0, p1, degree, ncons; std::string id; };
+struct GateSpec { uint64_t type, p0, p1, degree, ncons; std::string id; uint64_t p2 = 0; };
 }  // namespace
 
 // Gate list of a synthetic circuit: sorted by (degree, id) and grouped into selector polynomials the way
 // CircuitBuilder::build does (a group holds gates while size + degree < max_degree; one group if everything fits).
-std::string synth_gate_layout(unsigned num_routed, unsigned flags, std::vector<GateInfo> &gates, u64 &num_selectors) {
-    const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0;
+std::string synth_gate_layout(unsigned num_wires, unsigned num_routed, unsigned flags, std::vector<GateInfo> &gates, u64 &num_selectors) {
+    const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0, with_rec = (flags & 8) != 0;
+    if (with_rec && (num_routed < 48 || num_wires < 64)) return "recursion gates need at least 48 routed wires and 64 wires";
     const u64 num_limbs = std::min<u64>(63, num_routed - 1), num_ops = num_routed / 4;
     const u64 ext_ops = num_routed / 8, mul_ops = num_routed / 6;
     std::vector<GateSpec> gs = {
@@ -53,6 +54,17 @@ std::string synth_gate_layout(unsigned num_routed, unsigned flags, std::vector<G
     if (with_ext) {
         gs.push_back({GATE_ARITHMETIC_EXT, ext_ops, 0, 3, 2 * ext_ops, "ArithmeticExtensionGate { num_ops: " + std::to_string(ext_ops) + " }"});
         gs.push_back({GATE_MUL_EXT, mul_ops, 0, 3, 2 * mul_ops, "MulExtensionGate { num_ops: " + std::to_string(mul_ops) + " }"});
+    }
+    if (with_rec) {
+        // parameters as the gates' new_from_config / max_coeffs_len pick them for this (num_wires, num_routed)
+        const u64 red = std::min<u64>((num_wires - 6) / 3, num_routed - 6), redx = std::min<u64>((num_wires - 6) / 4, (num_routed - 6) / 2);
+        const u64 ra_bits = 4, ra_copies = std::min<u64>(num_routed / 18, num_wires / 22), ra_extra = std::min<u64>(num_routed - 18 * ra_copies, 2);
+        const u64 exp_bits = std::min<u64>(num_routed - 2, (num_wires - 2) / 2);
+        gs.push_back({GATE_REDUCING, red, 0, 2, 2 * red, "ReducingGate { num_coeffs: " + std::to_string(red) + " }", 0});
+        gs.push_back({GATE_REDUCING_EXT, redx, 0, 2, 2 * redx, "ReducingExtensionGate { num_coeffs: " + std::to_string(redx) + " }", 0});
+        gs.push_back({GATE_RANDOM_ACCESS, ra_bits, ra_copies, ra_bits + 1, ra_copies * (ra_bits + 2) + ra_extra, "RandomAccessGate { bits: 4, num_copies: " + std::to_string(ra_copies) + " }", ra_extra});
+        gs.push_back({GATE_EXPONENTIATION, exp_bits, 0, 4, exp_bits + 1, "ExponentiationGate { num_power_bits: " + std::to_string(exp_bits) + " }", 0});
+        gs.push_back({GATE_POSEIDON_MDS, 0, 0, 1, 24, "PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", 0});
     }
     std::sort(gs.begin(), gs.end(), [](const GateSpec &a, const GateSpec &b) { return a.degree != b.degree ? a.degree < b.degree : a.id < b.id; });
     const u64 max_degree = 9;   // quotient_degree_factor + 1
@@ -71,7 +83,7 @@ std::string synth_gate_layout(unsigned num_routed, unsigned flags, std::vector<G
     for (size_t i = 0; i < gs.size(); i++) {
         size_t grp = 0;
         while (!(groups[grp].first <= i && i < groups[grp].second)) grp++;
-        gates.push_back({gs[i].type, gs[i].p0, gs[i].p1, grp, groups[grp].first, groups[grp].second, gs[i].ncons, 0});
+        gates.push_back({gs[i].type, gs[i].p0, gs[i].p1, grp, groups[grp].first, groups[grp].second, gs[i].ncons, gs[i].p2});
     }
     num_selectors = groups.size();
     return "";
@@ -79,11 +91,12 @@ std::string synth_gate_layout(unsigned num_routed, unsigned flags, std::vector<G
 
 void synth_public_inputs_hash(const u64 *pis, size_t n, u64 out[4]) { host_hash_no_pad(pis, n, out); }
 
-// flags: bit 0 PoseidonGate rows, bit 1 BaseSumGate<2> rows, bit 2 ArithmeticExtension + MulExtension rows.
+// flags: bit 0 PoseidonGate rows, bit 1 BaseSumGate<2> rows, bit 2 ArithmeticExtension + MulExtension rows,
+// bit 3 Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds rows (the recursive verifier's set).
 // Builds the pack and the witness. wires: num_wires x n column-major. Returns "" or an error.
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         u64 seed, unsigned flags, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
-    const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0;
+    const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0, with_rec = (flags & 8) != 0;
     if (degree_bits < 3 || degree_bits > 20) return "degree_bits out of range";
     if (num_routed < 8 || num_routed > num_wires || num_routed % 4) return "num_routed_wires must be a multiple of 4, >= 8";
     if (with_poseidon && (num_wires < 135 || num_routed < 28)) return "poseidon gates need 135 wires";
@@ -94,7 +107,7 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
 
     std::vector<GateInfo> layout;
     u64 n_groups = 0;
-    { std::string e = synth_gate_layout(num_routed, flags, layout, n_groups); if (!e.empty()) return e; }
+    { std::string e = synth_gate_layout(num_wires, num_routed, flags, layout, n_groups); if (!e.empty()) return e; }
     pack = CircuitPack();
     pack.degree_bits = degree_bits; pack.num_wires = num_wires; pack.num_routed_wires = num_routed;
     pack.num_constants = 2; pack.num_selectors = n_groups; pack.num_challenges = 2; pack.quotient_degree_factor = 8;
@@ -103,11 +116,12 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     pack.zero_knowledge = 0;
     pack.arity_bits = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5);
     pack.num_gate_constraints = 0;
-    uint64_t idx_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sel_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t idx_of[16] = {0}, sel_of[16] = {0};
+    const GateInfo *info_of[16] = {nullptr};
     pack.gates = layout;
     for (size_t i = 0; i < layout.size(); i++) {
         pack.num_gate_constraints = std::max(pack.num_gate_constraints, layout[i].num_constraints);
-        idx_of[layout[i].type] = i; sel_of[layout[i].type] = layout[i].selector_index;
+        idx_of[layout[i].type] = i; sel_of[layout[i].type] = layout[i].selector_index; info_of[layout[i].type] = &layout[i];
     }
     pack.k_is.resize(num_routed);
     { u64 k = 1; for (unsigned j = 0; j < num_routed; j++) { pack.k_is[j] = gl::canon(k); k = gl::mul(k, gl::MULT_GEN); } }
@@ -126,6 +140,10 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     if (with_poseidon) for (u64 r = 8; r + n_noop < n; r += 8) row_gate[r] = GATE_POSEIDON;      // every 8th row hashes
     if (with_base_sum) for (u64 r = 5; r + n_noop < n; r += 8) row_gate[r] = GATE_BASE_SUM;      // every 8th row range-checks
     if (with_ext) for (u64 r = 6; r + n_noop < n; r += 8) row_gate[r] = (r & 8) ? GATE_MUL_EXT : GATE_ARITHMETIC_EXT;
+    if (with_rec) {
+        const uint8_t cyc[5] = {GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS, GATE_EXPONENTIATION, GATE_POSEIDON_MDS};
+        for (u64 r = 7, k = 0; r + n_noop < n; r += 8, k++) row_gate[r] = cyc[k % 5];
+    }
 
     wires.assign((size_t)num_wires * n, 0);
     auto W = [&](u64 row, u64 col) -> u64 & { return wires[col * n + row]; };
@@ -183,6 +201,53 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
                 e2 res = gl::e2_scale(gl::e2_mul(gl::e2_make(in[0], in[1]), gl::e2_make(in[2], in[3])), c0);
                 if (!mul_only) res = gl::e2_add(res, gl::e2_scale(gl::e2_make(in[4], in[5]), c1));
                 output(r, b + stride - 2, res.a); output(r, b + stride - 1, res.b);
+            }
+        } else if (kind == GATE_REDUCING || kind == GATE_REDUCING_EXT) {
+            // acc_{i} = acc_{i-1} * alpha + coeff_i over the extension; the last accumulator is the output (wires 0..1)
+            const bool ext = kind == GATE_REDUCING_EXT;
+            const u64 nc = info_of[kind]->param0, start_accs = 6 + (ext ? 2 * nc : nc);
+            u64 head[4];
+            for (u64 k = 0; k < 4; k++) head[k] = input(r, 2 + k);
+            const e2 alpha = gl::e2_make(head[0], head[1]);
+            e2 acc = gl::e2_make(head[2], head[3]);
+            for (u64 i = 0; i < nc; i++) {
+                e2 cf = gl::e2_from(0);
+                if (ext) { const u64 c0 = input(r, 6 + 2 * i), c1 = input(r, 7 + 2 * i); cf = gl::e2_make(c0, c1); }
+                else cf = gl::e2_from(input(r, 6 + i));
+                acc = gl::e2_canon(gl::e2_add(gl::e2_mul(acc, alpha), cf));
+                if (i == nc - 1) { output(r, 0, acc.a); output(r, 1, acc.b); }
+                else { W(r, start_accs + 2 * i) = acc.a; W(r, start_accs + 2 * i + 1) = acc.b; }
+            }
+        } else if (kind == GATE_RANDOM_ACCESS) {
+            const GateInfo &g = *info_of[kind];
+            const u64 bits = g.param0, copies = g.param1, extra = g.param2, vec = 1ull << bits, routed = (2 + vec) * copies + extra;
+            for (u64 cp = 0; cp < copies; cp++) {
+                const u64 b0 = (2 + vec) * cp, idx = rng.below(vec);
+                W(r, b0) = idx;
+                u64 chosen = 0;
+                for (u64 i = 0; i < vec; i++) { const u64 v = input(r, b0 + 2 + i); if (i == idx) chosen = v; }
+                output(r, b0 + 1, chosen);
+                for (u64 i = 0; i < bits; i++) W(r, routed + cp * bits + i) = (idx >> i) & 1;
+            }
+            for (u64 i = 0; i < extra; i++) { const u64 c = rng.felt(); CS(r, sel_cols + i) = c; output(r, (2 + vec) * copies + i, c); }
+        } else if (kind == GATE_EXPONENTIATION) {
+            const u64 nb = info_of[kind]->param0, base = input(r, 0);
+            u64 cur = 1;
+            for (u64 i = 0; i < nb; i++) W(r, 1 + i) = rng.below(2);
+            for (u64 i = 0; i < nb; i++) {
+                const u64 prev = i == 0 ? 1 : gl::mul(cur, cur), bit = W(r, 1 + (nb - 1 - i));
+                cur = gl::canon(bit ? gl::mul(prev, base) : prev);
+                W(r, 2 + nb + i) = cur;
+            }
+            output(r, 1 + nb, cur);
+        } else if (kind == GATE_POSEIDON_MDS) {
+            u64 in[24];
+            for (u64 k = 0; k < 24; k++) in[k] = input(r, k);
+            for (int comp = 0; comp < 2; comp++) {
+                u64 st[12];
+                for (int i = 0; i < 12; i++) st[i] = in[2 * i + comp];
+                poseidon::mds_layer(st);
+                for (int i = 0; i < 12; i++) output(r, 24 + 2 * i + comp, st[i]);
             }
         } else if (kind == GATE_BASE_SUM) {
             // BaseSumGate<2> row: a value below 2^num_limbs and its bits

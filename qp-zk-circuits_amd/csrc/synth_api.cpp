@@ -7,7 +7,7 @@
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         uint64_t seed, unsigned flags, CircuitPack &pack, std::vector<uint64_t> &wires, std::vector<uint64_t> &pis);
 
-std::string synth_gate_layout(unsigned num_routed, unsigned flags, std::vector<GateInfo> &gates, uint64_t &num_selectors);
+std::string synth_gate_layout(unsigned num_wires, unsigned num_routed, unsigned flags, std::vector<GateInfo> &gates, uint64_t &num_selectors);
 
 extern "C" {
 
@@ -19,10 +19,9 @@ size_t qpgpu_poseidon_constants(uint64_t *round_constants_360, uint64_t *fast_pa
 }
 
 size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags) {
-    (void)num_wires;
     std::vector<GateInfo> gates;
     uint64_t sels = 0;
-    if (num_routed < 8 || !synth_gate_layout(num_routed, flags, gates, sels).empty()) return 0;
+    if (num_routed < 8 || !synth_gate_layout(num_wires, num_routed, flags, gates, sels).empty()) return 0;
     CircuitPack p;
     p.degree_bits = degree_bits; p.num_routed_wires = num_routed; p.num_selectors = sels; p.num_constants = 2;
     size_t arity = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5).size();

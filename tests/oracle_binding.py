@@ -18,7 +18,7 @@ def _vp(a):
 class Oracle:
     def __init__(self):
         so = os.path.join(ORACLE_DIR, "liboracle.so")
-        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h", ".inc"))]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["make", "-C", ORACLE_DIR])
         self.lib = L = ctypes.CDLL(so)

@@ -9,9 +9,9 @@ from oracle_binding import OracleCircuit
 pytestmark = pytest.mark.gpu
 
 
-def run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed, poseidon=False, base_sum=False, ext_arith=False):
+def run_case(pkg, gpu, orc, degree_bits, num_wires, num_routed, npis, seed, poseidon=False, base_sum=False, ext_arith=False, recursion=False):
     pack, wires, pis = pkg.synth_circuit(degree_bits, num_wires=num_wires, num_routed=num_routed, num_public_inputs=npis, seed=seed,
-                                         poseidon=poseidon, base_sum=base_sum, ext_arith=ext_arith)
+                                         poseidon=poseidon, base_sum=base_sum, ext_arith=ext_arith, recursion=recursion)
     oc = OracleCircuit(orc, pack)
     want = oc.prove(wires, pis)
     circ = pkg.Circuit(gpu, pack)
@@ -64,6 +64,14 @@ def test_extension_arithmetic_gates(pkg, gpu, orc):
     run_case(pkg, gpu, orc, 8, 135, 80, 21, 33, poseidon=True, base_sum=True, ext_arith=True)
     run_case(pkg, gpu, orc, 6, 40, 24, 3, 34, ext_arith=True)
     run_case(pkg, gpu, orc, 7, 135, 80, 4, 35, poseidon=True, ext_arith=True)
+
+
+def test_recursion_gate_set(pkg, gpu, orc):
+    """Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds: with every other gate (13 types, 3
+    selector polynomials), and alone on narrower rows."""
+    run_case(pkg, gpu, orc, 9, 135, 80, 21, 36, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+    run_case(pkg, gpu, orc, 7, 80, 48, 2, 37, recursion=True)
+    run_case(pkg, gpu, orc, 8, 140, 60, 5, 38, poseidon=True, recursion=True)      # the private-batch routing width
 
 
 def test_constants_sigmas_cap_matches_oracle(pkg, gpu, orc):
@@ -151,7 +159,7 @@ def test_shape_fuzz_against_oracle(pkg, gpu, orc):
         cases.append((d, wires, max(routed, 8), int(rng.integers(0, 9)), False, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
     for i, (d, wires_n, routed, npis, pos, bs, zk) in enumerate(cases):
         pack, wires, pis = pkg.synth_circuit(d, num_wires=wires_n, num_routed=routed, num_public_inputs=npis, seed=500 + i,
-                                             poseidon=pos, base_sum=bs, ext_arith=(i % 3 == 1))
+                                             poseidon=pos, base_sum=bs, ext_arith=(i % 3 == 1), recursion=(i % 4 == 2 and routed >= 48 and wires_n >= 64))
         if zk:
             pack = pack.copy(); pack[14] = 1
         oc = OracleCircuit(orc, pack); circ = pkg.Circuit(gpu, pack)
