@@ -13,7 +13,7 @@
 #include "gl.h"
 
 enum { OG_NOOP = 0, OG_CONSTANT = 1, OG_PUBLIC_INPUT = 2, OG_ARITHMETIC = 3, OG_POSEIDON = 4, OG_BASE_SUM = 5, OG_ARITHMETIC_EXT = 6, OG_MUL_EXT = 7,
-       OG_REDUCING = 8, OG_REDUCING_EXT = 9, OG_RANDOM_ACCESS = 10, OG_EXPONENTIATION = 11, OG_POSEIDON_MDS = 12 };
+       OG_REDUCING = 8, OG_REDUCING_EXT = 9, OG_RANDOM_ACCESS = 10, OG_EXPONENTIATION = 11, OG_POSEIDON_MDS = 12, OG_COSET_INTERP = 13 };
 
 typedef struct { uint64_t type, param0, param1, selector_index, group_start, group_end, num_constraints, reserved; } orc_gate;
 

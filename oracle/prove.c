@@ -103,7 +103,8 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
     c->gates = (orc_gate *)malloc(sizeof(orc_gate) * c->n_gates);
     memcpy(c->gates, w + p, sizeof(orc_gate) * c->n_gates); p += 8 * c->n_gates;
     for (size_t i = 0; i < c->n_gates; i++)   /* scratch bounds of the recursion gates (gates_recursion.inc) */
-        if (c->gates[i].type >= OG_REDUCING && (c->gates[i].num_constraints > 256 || (c->gates[i].type == OG_RANDOM_ACCESS && c->gates[i].param0 > 6))) { free(c->gates); free(c); return NULL; }
+        if (c->gates[i].type >= OG_REDUCING && (c->gates[i].num_constraints > 256 || (c->gates[i].type == OG_RANDOM_ACCESS && c->gates[i].param0 > 6) ||
+                                               (c->gates[i].type == OG_COSET_INTERP && (c->gates[i].param0 > 6 || c->gates[i].param1 < 2)))) { free(c->gates); free(c); return NULL; }
     c->k_is = (gl_t *)malloc(sizeof(gl_t) * c->num_routed);
     memcpy(c->k_is, w + p, sizeof(gl_t) * c->num_routed); p += c->num_routed;
     memcpy(c->digest, w + p, 32); p += 4;
@@ -291,6 +292,32 @@ static void poseidon_gate_ext(const gl2_t *w, gl2_t *out) {
 }
 
 /* the recursion gate set, once per scalar type */
+/* CosetInterpolationGate tables: the subgroup of order 2^bits and barycentric_weights = 1 / prod_{j != i} (x_i - x_j),
+   by the definition (the GPU side uses the closed form x_i / n; the parity tests therefore check that identity too) */
+static void coset_interp_tables(unsigned bits, gl_t *dom, gl_t *wt) {
+    static gl_t c_dom[7][64], c_wt[7][64];
+    static int ready[7];
+    int ok;
+    #pragma omp atomic read
+    ok = ready[bits];
+    if (!ok) {
+        #pragma omp critical(coset_interp_tables)
+        if (!ready[bits]) {
+            const size_t np = (size_t)1 << bits;
+            gl_t om = 7277203076849721926ULL, x = 1;
+            for (unsigned i = bits; i < 32; i++) om = gl_mul(om, om);
+            for (size_t i = 0; i < np; i++) { c_dom[bits][i] = x; x = gl_mul(x, om); }
+            for (size_t i = 0; i < np; i++) {
+                gl_t pr = 1;
+                for (size_t j = 0; j < np; j++) if (j != i) pr = gl_mul(pr, gl_sub(c_dom[bits][i], c_dom[bits][j]));
+                c_wt[bits][i] = gl_inv(pr);
+            }
+            #pragma omp atomic write
+            ready[bits] = 1;
+        }
+    }
+    memcpy(dom, c_dom[bits], sizeof(gl_t) << bits); memcpy(wt, c_wt[bits], sizeof(gl_t) << bits);
+}
 #define GN(name) name##_base
 #define T gl_t
 #define T_ADD gl_add
@@ -368,7 +395,7 @@ static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t
             for (uint64_t i = 0; i < g->param0; i++) acc[1 + i] = gl_add(acc[1 + i], gl_mul(f, gl_mul(wires[1 + i], gl_sub(wires[1 + i], 1))));
             break;
         }
-        case OG_REDUCING: case OG_REDUCING_EXT: case OG_RANDOM_ACCESS: case OG_EXPONENTIATION: case OG_POSEIDON_MDS: {
+        case OG_REDUCING: case OG_REDUCING_EXT: case OG_RANDOM_ACCESS: case OG_EXPONENTIATION: case OG_POSEIDON_MDS: case OG_COSET_INTERP: {
             gl_t cst[MAX_GATE_CONSTRAINTS];
             recursion_gate_base(g, consts, wires, cst);
             for (uint64_t i = 0; i < g->num_constraints; i++) acc[i] = gl_add(acc[i], gl_mul(f, cst[i]));
@@ -437,7 +464,7 @@ void orc_eval_gates_ext(const orc_circuit *c, const gl2_t *cs_row, const gl2_t *
             for (uint64_t i = 0; i < g->param0; i++) acc[1 + i] = gl2_add(acc[1 + i], gl2_mul(f, gl2_mul(wires[1 + i], gl2_sub(wires[1 + i], gl2_from(1)))));
             break;
         }
-        case OG_REDUCING: case OG_REDUCING_EXT: case OG_RANDOM_ACCESS: case OG_EXPONENTIATION: case OG_POSEIDON_MDS: {
+        case OG_REDUCING: case OG_REDUCING_EXT: case OG_RANDOM_ACCESS: case OG_EXPONENTIATION: case OG_POSEIDON_MDS: case OG_COSET_INTERP: {
             gl2_t cst[MAX_GATE_CONSTRAINTS];
             recursion_gate_ext(g, consts, wires, cst);
             for (uint64_t i = 0; i < g->num_constraints; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, cst[i]));

@@ -62,7 +62,7 @@ std::string CircuitPack::validate() const {
     for (auto a : arity_bits) { if (a == 0 || a > 4) return "unsupported FRI arity"; sum += a; }
     if (sum > degree_bits) return "FRI reductions exceed degree";
     for (const auto &g : gates) {
-        if (g.type > GATE_POSEIDON_MDS) return "unknown gate type";
+        if (g.type > GATE_COSET_INTERPOLATION) return "unknown gate type";
         if (g.selector_index >= num_selectors) return "gate selector index out of range";
         if (g.group_end > gates.size() || g.group_start >= g.group_end) return "gate group out of range";
         if (g.num_constraints > num_gate_constraints) return "gate constraint count exceeds num_gate_constraints";
@@ -82,6 +82,12 @@ std::string CircuitPack::validate() const {
         }
         if (g.type == GATE_EXPONENTIATION && (g.param0 == 0 || g.param0 + 2 > num_routed_wires || 2 * g.param0 + 2 > num_wires || g.num_constraints != g.param0 + 1)) return "bad exponentiation gate";
         if (g.type == GATE_POSEIDON_MDS && (num_routed_wires < 48 || g.num_constraints != 24)) return "bad poseidon-mds gate";
+        if (g.type == GATE_COSET_INTERPOLATION) {
+            const uint64_t bits = g.param0, deg = g.param1;
+            if (bits < 2 || bits > 5 || deg < 2) return "bad coset-interpolation gate";
+            const uint64_t np = 1ull << bits, ni = (np - 2) / (deg - 1), start_int = 1 + 2 * np + 4;
+            if (start_int > num_routed_wires || start_int + 2 * (2 * ni + 1) > num_wires || g.num_constraints != 2 * (2 + 2 * ni)) return "bad coset-interpolation gate";
+        }
         if (g.type == GATE_POSEIDON && (num_wires < 135 || num_routed_wires < 25 || g.num_constraints != 123)) return "bad poseidon gate";
     }
     return "";

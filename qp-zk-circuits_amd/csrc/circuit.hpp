@@ -15,7 +15,7 @@
 //           (type, param0, param1, param2): 0 Noop; 1 Constant(num_consts); 2 PublicInput; 3 Arithmetic(num_ops); 4 Poseidon;
 //           5 BaseSum(num_limbs, base 2); 6 ArithmeticExtension(num_ops); 7 MulExtension(num_ops); 8 Reducing(num_coeffs);
 //           9 ReducingExtension(num_coeffs); 10 RandomAccess(bits, num_copies, num_extra_constants);
-//           11 Exponentiation(num_power_bits); 12 PoseidonMds
+//           11 Exponentiation(num_power_bits); 12 PoseidonMds; 13 CosetInterpolation(subgroup_bits, degree)
 //   k_is[num_routed_wires]; circuit_digest[4]
 //   constants_sigmas values: (num_selectors + num_constants + num_routed_wires) columns x 2^degree_bits,
 //           column-major, natural subgroup order (column order = plonky2's constants_sigmas oracle:
@@ -26,7 +26,7 @@
 #include <vector>
 
 enum GateType : uint64_t { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4, GATE_BASE_SUM = 5, GATE_ARITHMETIC_EXT = 6, GATE_MUL_EXT = 7,
-                           GATE_REDUCING = 8, GATE_REDUCING_EXT = 9, GATE_RANDOM_ACCESS = 10, GATE_EXPONENTIATION = 11, GATE_POSEIDON_MDS = 12 };
+                           GATE_REDUCING = 8, GATE_REDUCING_EXT = 9, GATE_RANDOM_ACCESS = 10, GATE_EXPONENTIATION = 11, GATE_POSEIDON_MDS = 12, GATE_COSET_INTERPOLATION = 13 };
 
 struct GateInfo {
     uint64_t type, param0, param1, selector_index, group_start, group_end, num_constraints, param2;

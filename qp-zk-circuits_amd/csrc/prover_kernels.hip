@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
 }
 
 // (2) every gate except PoseidonGate: Constant, PublicInput, BaseSum<2>, Arithmetic, the extension-arithmetic pair and the
-// recursion set (Reducing*, RandomAccess, Exponentiation, PoseidonMds). t0 = index of the first gate constraint.
+// recursion set (Reducing*, RandomAccess, Exponentiation, PoseidonMds, CosetInterpolation). t0 = index of the first gate constraint.
 template <int NCH>
 __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -265,6 +265,37 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
 #pragma unroll
                 for (int i = 0; i < 12; i++) emit(2 * i + comp, gl::sub(w[(u64)(24 + 2 * i + comp) * S], st[i]));
             }
+        } else if (g.type == 13) {    // CosetInterpolationGate(subgroup_bits, degree): chunked barycentric interpolation
+            const u32 bits = g.param0, deg = g.param1, np = 1u << bits, ni = (np - 2) / (deg - 1);
+            const u32 s_ep = 1 + 2 * np, s_ev = s_ep + 2, s_int = s_ev + 2;
+            const u64 *w = a.wires + j;
+            auto ld = [&](u32 c) { return gl::e2_make(w[(u64)c * S], w[(u64)(c + 1) * S]); };
+            const u64 shift = w[0];
+            const e2 ep = ld(s_ep), sp = ld(s_int + 4 * ni);
+            emit(0, gl::sub(ep.a, gl::mul(sp.a, shift))); emit(1, gl::sub(ep.b, gl::mul(sp.b, shift)));
+            // subgroup of order 2^bits: generator 2^(192 >> bits); barycentric weight of x_i is x_i / 2^bits, and
+            // 1 / 2^bits = -2^(96 - bits) = p - (2^(64-bits) - 2^(32-bits))
+            const u64 omega = 1ull << (192u >> bits), inv_n = gl::P - ((1ull << (64 - bits)) - (1ull << (32 - bits)));
+            e2 ev = gl::e2_from(0), pr = gl::e2_from(1);
+            u64 x = 1;
+            u32 lo = 0, hi = deg, q_out = 2;
+            for (u32 c = 0; c <= ni; c++) {
+                for (u32 q = lo; q < hi; q++) {
+                    e2 term = sp; term.a = gl::sub(term.a, x);
+                    const e2 t = gl::e2_scale(gl::e2_mul(ld(1 + 2 * q), pr), gl::mul(x, inv_n));
+                    ev = gl::e2_add(gl::e2_mul(ev, term), t);
+                    pr = gl::e2_mul(pr, term);
+                    x = gl::mul(x, omega);
+                }
+                if (c == ni) break;
+                const e2 ie = ld(s_int + 2 * c), ip = ld(s_int + 2 * (ni + c));
+                emit(q_out++, gl::sub(ie.a, ev.a)); emit(q_out++, gl::sub(ie.b, ev.b));
+                emit(q_out++, gl::sub(ip.a, pr.a)); emit(q_out++, gl::sub(ip.b, pr.b));
+                ev = ie; pr = ip;
+                lo = 1 + (deg - 1) * (c + 1); hi = lo + deg - 1 < np ? lo + deg - 1 : np;
+            }
+            const e2 val = ld(s_ev);
+            emit(q_out++, gl::sub(val.a, ev.a)); emit(q_out++, gl::sub(val.b, ev.b));
         } else if (g.type == 5) {     // BaseSumGate<2>: sum - sum_i 2^i limb_i, and limb_i (limb_i - 1)
             u64 s2 = 0;
             for (u32 q = g.param0; q-- > 0;) s2 = gl::add(gl::add(s2, s2), a.wires[(u64)(1 + q) * S + j]);

@@ -64,6 +64,9 @@ std::string synth_gate_layout(unsigned num_wires, unsigned num_routed, unsigned 
         gs.push_back({GATE_REDUCING_EXT, redx, 0, 2, 2 * redx, "ReducingExtensionGate { num_coeffs: " + std::to_string(redx) + " }", 0});
         gs.push_back({GATE_RANDOM_ACCESS, ra_bits, ra_copies, ra_bits + 1, ra_copies * (ra_bits + 2) + ra_extra, "RandomAccessGate { bits: 4, num_copies: " + std::to_string(ra_copies) + " }", ra_extra});
         gs.push_back({GATE_EXPONENTIATION, exp_bits, 0, 4, exp_bits + 1, "ExponentiationGate { num_power_bits: " + std::to_string(exp_bits) + " }", 0});
+        // CosetInterpolationGate::with_max_degree(4, max_quotient_degree_factor = 8): 2 intermediates, degree 6
+        { const u64 np = 16, max_degree = 8, ni = (np - 2) / (max_degree - 1), deg = (np - 2) / (ni + 1) + 2;
+          gs.push_back({GATE_COSET_INTERPOLATION, 4, deg, deg, 2 * (2 + 2 * ((np - 2) / (deg - 1))), "CosetInterpolationGate { subgroup_bits: 4, degree: " + std::to_string(deg) + " }", 0}); }
         gs.push_back({GATE_POSEIDON_MDS, 0, 0, 1, 24, "PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", 0});
     }
     std::sort(gs.begin(), gs.end(), [](const GateSpec &a, const GateSpec &b) { return a.degree != b.degree ? a.degree < b.degree : a.id < b.id; });
@@ -92,7 +95,8 @@ std::string synth_gate_layout(unsigned num_wires, unsigned num_routed, unsigned 
 void synth_public_inputs_hash(const u64 *pis, size_t n, u64 out[4]) { host_hash_no_pad(pis, n, out); }
 
 // flags: bit 0 PoseidonGate rows, bit 1 BaseSumGate<2> rows, bit 2 ArithmeticExtension + MulExtension rows,
-// bit 3 Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds rows (the recursive verifier's set).
+// bit 3 Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds / CosetInterpolation rows (the
+// recursive verifier's set).
 // Builds the pack and the witness. wires: num_wires x n column-major. Returns "" or an error.
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         u64 seed, unsigned flags, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
@@ -141,8 +145,8 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     if (with_base_sum) for (u64 r = 5; r + n_noop < n; r += 8) row_gate[r] = GATE_BASE_SUM;      // every 8th row range-checks
     if (with_ext) for (u64 r = 6; r + n_noop < n; r += 8) row_gate[r] = (r & 8) ? GATE_MUL_EXT : GATE_ARITHMETIC_EXT;
     if (with_rec) {
-        const uint8_t cyc[5] = {GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS, GATE_EXPONENTIATION, GATE_POSEIDON_MDS};
-        for (u64 r = 7, k = 0; r + n_noop < n; r += 8, k++) row_gate[r] = cyc[k % 5];
+        const uint8_t cyc[6] = {GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS, GATE_EXPONENTIATION, GATE_POSEIDON_MDS, GATE_COSET_INTERPOLATION};
+        for (u64 r = 7, k = 0; r + n_noop < n; r += 8, k++) row_gate[r] = cyc[k % 6];
     }
 
     wires.assign((size_t)num_wires * n, 0);
@@ -249,6 +253,36 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
                 poseidon::mds_layer(st);
                 for (int i = 0; i < 12; i++) output(r, 24 + 2 * i + comp, st[i]);
             }
+        } else if (kind == GATE_COSET_INTERPOLATION) {
+            // interpolate 2^bits extension values given on the coset shift*H at an extension point, in chunks of `degree` points
+            const GateInfo &g = *info_of[kind];
+            const u64 bits = g.param0, deg = g.param1, np = 1ull << bits, ni = (np - 2) / (deg - 1);
+            const u64 s_ep = 1 + 2 * np, s_ev = s_ep + 2, s_int = s_ev + 2;
+            u64 shift = input(r, 0);
+            if (gl::canon(shift) == 0) { shift = 1; W(r, 0) = 1; }   // (a copied zero cannot happen: pool values are outputs of random data)
+            std::vector<u64> vals(2 * np);
+            for (u64 k = 0; k < 2 * np; k++) vals[k] = input(r, 1 + k);
+            const u64 e0 = input(r, s_ep), e1 = input(r, s_ep + 1), sinv = gl::inv(shift);
+            const e2 sp = gl::e2_canon(gl::e2_scale(gl::e2_make(e0, e1), sinv));
+            W(r, s_int + 4 * ni) = sp.a; W(r, s_int + 4 * ni + 1) = sp.b;
+            const u64 omega = gl::root_of_unity((unsigned)bits), inv_n = gl::inv(np);
+            e2 ev = gl::e2_from(0), pr = gl::e2_from(1);
+            u64 x = 1, lo = 0, hi = deg;
+            for (u64 c = 0; c <= ni; c++) {
+                for (u64 q = lo; q < hi; q++) {
+                    e2 term = sp; term.a = gl::sub(term.a, x);
+                    const e2 t = gl::e2_scale(gl::e2_mul(gl::e2_make(vals[2 * q], vals[2 * q + 1]), pr), gl::mul(x, inv_n));
+                    ev = gl::e2_add(gl::e2_mul(ev, term), t);
+                    pr = gl::e2_mul(pr, term);
+                    x = gl::mul(x, omega);
+                }
+                ev = gl::e2_canon(ev); pr = gl::e2_canon(pr);
+                if (c == ni) break;
+                W(r, s_int + 2 * c) = ev.a; W(r, s_int + 2 * c + 1) = ev.b;
+                W(r, s_int + 2 * (ni + c)) = pr.a; W(r, s_int + 2 * (ni + c) + 1) = pr.b;
+                lo = 1 + (deg - 1) * (c + 1); hi = std::min<u64>(lo + deg - 1, np);
+            }
+            output(r, s_ev, ev.a); output(r, s_ev + 1, ev.b);
         } else if (kind == GATE_BASE_SUM) {
             // BaseSumGate<2> row: a value below 2^num_limbs and its bits
             const u64 v = rng.next() & ((1ull << num_limbs) - 1);

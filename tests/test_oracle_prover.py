@@ -116,16 +116,17 @@ def test_extension_arithmetic_gates_circuit(pkg, orc):
 
 
 def test_recursion_gate_set_circuit(pkg, orc):
-    """Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds rows (rows 7, 15, 23, 31, 39, ...),
-    all thirteen gate types together: three selector polynomials under the builder's grouping rule."""
+    """Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds / CosetInterpolation rows (rows 7, 15,
+    23, 31, 39, 47, ...), all fourteen gate types together: four selector polynomials under the builder's grouping rule."""
     pack, wires, pis = pkg.synth_circuit(8, seed=9, base_sum=True, poseidon=True, ext_arith=True, recursion=True)
-    assert int(pack[5]) == 3 and int(pack[16]) == 13
+    assert int(pack[5]) == 4 and int(pack[16]) == 14
     oc = OracleCircuit(orc, pack)
     assert oc.verify(oc.prove(wires, pis)) == 0
     P = 0xFFFFFFFF00000001
     # (row, wire): Reducing output, ReducingExtension inner accumulator, RandomAccess claimed element and a bit wire,
-    # Exponentiation intermediate and output, PoseidonMds output
-    for row, col in ((7, 0), (15, 6 + 2 * 32 + 3), (23, 1), (23, 74), (31, 2 + 66 + 5), (31, 1 + 66), (39, 24 + 7)):
+    # Exponentiation intermediate and output, PoseidonMds output, CosetInterpolation value / intermediate / shifted point / shift
+    for row, col in ((7, 0), (15, 6 + 2 * 32 + 3), (23, 1), (23, 74), (31, 2 + 66 + 5), (31, 1 + 66), (39, 24 + 7),
+                     (47, 35), (47, 38), (47, 45), (47, 0), (47, 9)):
         w = wires.copy(); w[col, row] = (int(w[col, row]) + 1) % P
         assert oc.verify(oc.prove(w, pis)) == 3, (row, col)
     oc.close()

@@ -67,7 +67,7 @@ def test_extension_arithmetic_gates(pkg, gpu, orc):
 
 
 def test_recursion_gate_set(pkg, gpu, orc):
-    """Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds: with every other gate (13 types, 3
+    """Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds: CosetInterpolation: with every other gate (14 types, 4
     selector polynomials), and alone on narrower rows."""
     run_case(pkg, gpu, orc, 9, 135, 80, 21, 36, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
     run_case(pkg, gpu, orc, 7, 80, 48, 2, 37, recursion=True)
