@@ -206,12 +206,19 @@ def main():
     if not args.no_tree:
         plan = pkg.sharding.aggregation_schedule(64, 8, world)
         mine = plan["ranks"][rank]
-        bpack, bwires, bpis = pkg.synth_circuit(16, num_wires=135, num_routed=80, num_public_inputs=21 * 8 + 8, seed=77,
-                                                poseidon=True, base_sum=True)
-        zpack = bpack.copy(); zpack[14] = 1                    # private batch: standard_recursion_zk_config
-        bw_t = torch.from_numpy(bwires.view(np.int64)).to(dev)
+        # recursive-verifier gate mix (Poseidon, extension arithmetic, Reducing*, RandomAccess, Exponentiation, PoseidonMds,
+        # CosetInterpolation); private batch: standard_recursion_zk_config with 60 routed wires
+        # (reference common/src/circuit.rs:396-402), public batch: standard_recursion_config
+        rec = dict(poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+        zpack, zwires, zpis = pkg.synth_circuit(16, num_wires=135, num_routed=60, num_public_inputs=21 * 8 + 8, seed=78, **rec)
+        zpack[14] = 1
+        zw_t = torch.from_numpy(zwires.view(np.int64)).to(dev)
         priv = pkg.Circuit(gpus[0], zpack)
-        pub = pkg.Circuit(gpus[1 % S], bpack) if rank == plan["root"] else None
+        pub = None
+        if rank == plan["root"]:
+            bpack, bwires, bpis = pkg.synth_circuit(16, num_wires=135, num_routed=80, num_public_inputs=21 * 8 + 8, seed=77, **rec)
+            bw_t = torch.from_numpy(bwires.view(np.int64)).to(dev)
+            pub = pkg.Circuit(gpus[1 % S], bpack)
         priv_out = np.empty(priv.proof_size(), dtype=np.uint8)
 
         def tree_once():
@@ -223,7 +230,7 @@ def main():
                 leaf_proofs += [f.result() for f in futs]
             g0 = pkg.sharding.gather_proof_bytes(leaf_proofs, dist if world > 1 else None, coll_dev)
             # level 1: this rank's private batches
-            pb = [priv.prove_dev(bw_t, bpis, priv_out) for _ in mine["private_batches"]]
+            pb = [priv.prove_dev(zw_t, zpis, priv_out) for _ in mine["private_batches"]]
             g1 = pkg.sharding.gather_proof_bytes(pb, dist if world > 1 else None, coll_dev)
             # level 2: the root proves the public batch over the gathered private-batch proofs
             root_proof = pub.prove_dev(bw_t, bpis) if pub is not None else None
@@ -242,14 +249,16 @@ def main():
         assert n_leaf == 64 and n_priv == 8
         tree = {"leaves": 64, "private_batches": 8, "public_batches": 1, "seconds": round(tdt, 4),
                 "trees_per_s": round(1.0 / tdt, 3),
-                "shape": "leaf 2^13 rows; private batch 2^16 rows zero-knowledge; public batch 2^16 rows; 135 wires",
+                "shape": "leaf 2^13 rows (80 routed); private batch 2^16 rows zero-knowledge, 60 routed wires; public batch 2^16 rows, "
+                         "80 routed; 135 wires; batches carry the 14-gate recursive-verifier mix",
                 "note": "shape-equivalent synthetic circuits per level; sharding + RCCL gathers + proving are real, recursive "
                         "witness generation is not included; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
                         "sequential on an M2 Max including witness generation"}
         priv.close()
+        del zw_t
         if pub is not None:
             pub.close()
-        del bw_t
+            del bw_t
     if rank == 0:
         extra["aggregation_tree"] = tree
         # per-stage breakdown (HIP events recorded by the library on the launch stream; separate leg)
