@@ -31,14 +31,14 @@ typedef unsigned __int128 u128;
 #define GL_ROOT_2_32 7277203076849721926ULL  /* primitive 2^32-th root of unity */
 #define GL_EXT_W 7ULL                        /* x^2 = 7 */
 
-static inline gl_t gl_canon(gl_t x) { return x >= GL_P ? x - GL_P : x; }
+/* written with masks rather than branches: the conditions are data dependent (about 50 % taken) */
+static inline gl_t gl_canon(gl_t x) { return x - (GL_P & (gl_t)-(gl_t)(x >= GL_P)); }
 
-static inline gl_t gl_add(gl_t a, gl_t b) {
-    u128 s = (u128)a + b;
-    if (s >= GL_P) s -= GL_P;
-    return (gl_t)s;
+static inline gl_t gl_add(gl_t a, gl_t b) {   /* canonical inputs: a + b < 2p */
+    gl_t s = a + b;
+    return s - (GL_P & (gl_t)-(gl_t)((s < a) | (s >= GL_P)));
 }
-static inline gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a + (GL_P - b); }
+static inline gl_t gl_sub(gl_t a, gl_t b) { gl_t d = a - b; return d + (GL_P & (gl_t)-(gl_t)(a < b)); }
 static inline gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
 
 /* 128-bit -> field reduction, the three-step form of SURVEY.md Appendix A.1. */
@@ -46,10 +46,10 @@ static inline gl_t gl_reduce128(u128 x) {
     uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
     uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;            /* borrow: subtract 2^64 mod p */
+    t0 -= GL_EPS & (uint64_t)-(uint64_t)(lo < hi_hi);   /* borrow: subtract 2^64 mod p */
     uint64_t t1 = hi_lo * GL_EPS;
     uint64_t t2 = t0 + t1;
-    if (t2 < t1) t2 += GL_EPS;               /* carry */
+    t2 += GL_EPS & (uint64_t)-(uint64_t)(t2 < t1);      /* carry */
     return gl_canon(t2);
 }
 static inline gl_t gl_mul(gl_t a, gl_t b) { return gl_reduce128((u128)a * b); }

@@ -83,7 +83,8 @@ void orc_poseidon_round_constants(gl_t *out) { init_rc(); memcpy(out, RC, sizeof
 
 /* ---- permutation (naive HADES schedule; upstream's fast partial rounds compute the same map) ---- */
 static inline gl_t sbox7(gl_t x) { gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2); return gl_mul(x3, x4); }
-static void mds_layer(gl_t s[12]) {
+/* definition: row r of the MDS matrix is the circulant shifted by r, plus the diagonal */
+static void mds_layer_naive(gl_t s[12]) {
     gl_t o[12];
     for (int r = 0; r < 12; r++) {
         u128 acc = 0;
@@ -92,6 +93,35 @@ static void mds_layer(gl_t s[12]) {
         o[r] = gl_reduce128(acc);
     }
     memcpy(s, o, sizeof o);
+}
+/* same map, the way CPU implementations organise it: entries are < 2^6, so the 32-bit halves of the state are
+   combined in plain 64-bit accumulators (12 * 2^32 * 41 < 2^42) and each output is reduced once */
+static void mds_layer(gl_t s[12]) {
+    uint64_t lo[24], hi[24];
+    for (int i = 0; i < 12; i++) { lo[i] = lo[i + 12] = (uint32_t)s[i]; hi[i] = hi[i + 12] = s[i] >> 32; }
+    for (int r = 0; r < 12; r++) {
+        uint64_t al = 0, ah = 0;
+        for (int i = 0; i < 12; i++) { al += lo[i + r] * MDS_CIRC[i]; ah += hi[i + r] * MDS_CIRC[i]; }
+        if (r == 0) { al += lo[0] * MDS_DIAG[0]; ah += hi[0] * MDS_DIAG[0]; }
+        s[r] = gl_reduce128((u128)al + ((u128)ah << 32));
+    }
+}
+void orc_poseidon_permute_naive(gl_t s[12]) {
+    init_rc();
+    int rc = 0;
+    for (int r = 0; r < N_FULL_HALF; r++, rc++) {
+        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], RC[rc * 12 + i]));
+        mds_layer_naive(s);
+    }
+    for (int r = 0; r < N_PARTIAL; r++, rc++) {
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[rc * 12 + i]);
+        s[0] = sbox7(s[0]);
+        mds_layer_naive(s);
+    }
+    for (int r = 0; r < N_FULL_HALF; r++, rc++) {
+        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], RC[rc * 12 + i]));
+        mds_layer_naive(s);
+    }
 }
 void orc_poseidon_permute(gl_t s[12]) {
     init_rc();

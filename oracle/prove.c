@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 #define QPCP_MAGIC 0x0000003150435051ULL
 #define MAXC 4
@@ -21,6 +22,9 @@ static trace_item g_trace[64];
 static int g_ntrace = 0;
 static void trace_clear(void) { for (int i = 0; i < g_ntrace; i++) free(g_trace[i].data); g_ntrace = 0; }
 static void trace_put(const char *name, const void *data, size_t words) {
+    static double t_last = 0; static int timing = -1;
+    if (timing < 0) timing = getenv("ORC_TIMING") != NULL;
+    if (timing) { double t = omp_get_wtime(); fprintf(stderr, "[orc] %-24s +%.3f s\n", name, t_last ? t - t_last : 0.0); t_last = t; }
     if (g_ntrace >= 64) return;
     trace_item *t = &g_trace[g_ntrace++];
     snprintf(t->name, sizeof t->name, "%s", name);
@@ -774,9 +778,16 @@ int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public
     gl_t pow_witness = 0;
     {
         unsigned min_lz = (unsigned)c->pow_bits;
-        for (gl_t cand = 0;; cand++) {
-            gl_t resp = orc_challenger_pow_response(&ch, cand);
-            if (min_lz == 0 || (resp >> (64 - min_lz)) == 0) { pow_witness = cand; break; }
+        /* windows of candidates searched in parallel; the smallest hit of the first window that has one is the minimum */
+        const gl_t window = 1u << 14;
+        for (gl_t base = 0; min_lz != 0; base += window) {
+            gl_t best = ~(gl_t)0;
+            #pragma omp parallel for schedule(static) reduction(min : best)
+            for (gl_t k = 0; k < window; k++) {
+                gl_t resp = orc_challenger_pow_response(&ch, base + k);
+                if ((resp >> (64 - min_lz)) == 0 && base + k < best) best = base + k;
+            }
+            if (best != ~(gl_t)0) { pow_witness = best; break; }
         }
         orc_challenger_observe(&ch, &pow_witness, 1);
         gl_t resp = orc_challenger_get(&ch);

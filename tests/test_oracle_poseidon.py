@@ -160,3 +160,20 @@ def test_fast_partial_tables(orc, pkg):
     assert [hex(x) for x in init_t[0][:2]] == a["initial_matrix_row0"]
     assert int(G["m00"]) == 25
     assert [int(x) for x in orc.poseidon(np.array(G["check_vector"]["input"], dtype=np.uint64))] == G["check_vector"]["output"]
+
+
+def test_fast_mds_layer_matches_the_definition(orc):
+    """orc_poseidon_permute (32-bit-halves MDS) against the definitional circulant-plus-diagonal form."""
+    import ctypes
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        s = rng.integers(0, 0xFFFFFFFF00000001, size=12, dtype=np.uint64)
+        a, b = s.copy(), s.copy()
+        orc.lib.orc_poseidon_permute(a.ctypes.data_as(ctypes.c_void_p))
+        orc.lib.orc_poseidon_permute_naive(b.ctypes.data_as(ctypes.c_void_p))
+        assert (a == b).all()
+    edge = np.array([0xFFFFFFFF00000000] * 12, dtype=np.uint64)
+    a, b = edge.copy(), edge.copy()
+    orc.lib.orc_poseidon_permute(a.ctypes.data_as(ctypes.c_void_p))
+    orc.lib.orc_poseidon_permute_naive(b.ctypes.data_as(ctypes.c_void_p))
+    assert (a == b).all()
