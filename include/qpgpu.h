@@ -135,6 +135,25 @@ size_t qpgpu_proof_size(const qpgpu_circuit *c);   /* bytes written by qpgpu_pro
 int qpgpu_prove(qpgpu_circuit *c, const uint64_t *wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len);
 int qpgpu_prove_dev(qpgpu_circuit *c, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* ---- stage s1: witness generation on the device ------------------------------------------------------------------
+ * `iop::generator::generate_partial_witness` for the gate-attached generators of the supported gate set (Constant,
+ * Arithmetic, ArithmeticExtension, MulExtension, BaseSum split, Poseidon, Reducing*, RandomAccess, Exponentiation,
+ * PoseidonMds, CosetInterpolation) plus copy-constraint propagation. The dependency order is resolved once per circuit
+ * from the pack (copy classes are the cycles of the sigma permutation); generation is one kernel launch per dependency
+ * level. The caller supplies the cells no generator produces — plonky2's PartialWitness; qpgpu_witness_free_mask marks
+ * them (1 byte per cell, num_wires x 2^degree_bits, column-major like the wire matrix) — every other cell is
+ * overwritten. Generators that are not attached to a gate (hints such as inverse / is_equal / split across gates) are
+ * not part of a circuit pack yet: their outputs count as caller-supplied cells. */
+int qpgpu_witness_info(qpgpu_circuit *c, uint64_t *num_generators, uint64_t *num_levels, uint64_t *num_free_cells);
+int qpgpu_witness_free_mask(qpgpu_circuit *c, uint8_t *mask, size_t mask_len);
+/* in place on a device-resident wire matrix / on a host matrix (uploaded, generated, downloaded, device copy scrubbed) */
+int qpgpu_generate_witness_dev(qpgpu_circuit *c, uint64_t *d_wires, const uint64_t *public_inputs);
+int qpgpu_generate_witness(qpgpu_circuit *c, uint64_t *wires, const uint64_t *public_inputs);
+/* `batch` witnesses of the same circuit at once (wire matrices back to back, public inputs back to back): the dependency
+ * levels are walked once for all of them, which is how the device pays off — a single witness is latency-bound by the
+ * circuit's dependency depth, exactly the part a host core does well. */
+int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs);
+
 /* ---- stage-level entry points: the circuit-independent parts of prove() ---------------------------------------
  * For a patched `qp-plonky2::plonk::prover::prove` that keeps witness generation, partial products and the quotient
  * evaluation (which depend on the gate set) in Rust and moves everything else to the GPU — polynomial commitments

@@ -67,6 +67,11 @@ def load_library():
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_poseidon_constants": (c.c_size_t, [u64p, u64p, c.c_size_t]),
+        "qpgpu_witness_info": (c.c_int, [vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)]),
+        "qpgpu_witness_free_mask": (c.c_int, [vp, vp, c.c_size_t]),
+        "qpgpu_generate_witness_dev": (c.c_int, [vp, u64p, u64p]),
+        "qpgpu_generate_witness": (c.c_int, [vp, u64p, u64p]),
+        "qpgpu_generate_witness_batch_dev": (c.c_int, [vp, u64p, c.c_uint32, u64p]),
         "qpgpu_oracle_commit": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint32,
                                           c.POINTER(vp)]),
         "qpgpu_oracle_free": (None, [vp]),
@@ -189,6 +194,30 @@ class Circuit:
         out = np.empty((1 << cap_height, 4), dtype=np.uint64)
         self.gpu._check(self.gpu.lib.qpgpu_circuit_constants_sigmas_cap(self.h, out.ctypes.data, out.size))
         return out
+
+    def witness_info(self):
+        """(generator instances, dependency levels, caller-supplied cells) of the witness-generation plan."""
+        a, b, c3 = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self.gpu._check(self.gpu.lib.qpgpu_witness_info(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c3)))
+        return a.value, b.value, c3.value
+
+    def witness_free_mask(self, num_wires, n):
+        """uint8 [num_wires, n]: 1 where the caller supplies the cell (PartialWitness), 0 where generation writes it."""
+        m = np.empty((num_wires, n), dtype=np.uint8)
+        self.gpu._check(self.gpu.lib.qpgpu_witness_free_mask(self.h, m.ctypes.data, m.size))
+        return m
+
+    def generate_witness(self, wires, public_inputs):
+        """Fills every generator- or copy-determined cell of a host wire matrix [num_wires, n]; returns the full matrix."""
+        w = np.array(wires, dtype=np.uint64, order="C", copy=True)
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_generate_witness(self.h, w.ctypes.data, p.ctypes.data))
+        return w
+
+    def generate_witness_dev(self, d_wires, public_inputs, batch=1):
+        """In place on `batch` device-resident wire matrices laid out back to back; public_inputs [batch, num_pis]."""
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_generate_witness_batch_dev(self.h, _ptr(d_wires), batch, p.ctypes.data))
 
     def prove(self, wires, public_inputs):
         """wires: host array [num_wires, n]; returns proof bytes."""

@@ -18,6 +18,7 @@
 #include "merkle.hpp"
 #include "poseidon.hpp"
 #include "prover_host.hpp"
+#include "circuit_state.hpp"
 #include "prover_kernels.hpp"
 
 using gl::e2;
@@ -44,42 +45,6 @@ std::vector<u64> powers_table(u64 base, u64 count) {
 
 }  // namespace
 
-struct qpgpu_circuit {
-    qpgpu_ctx *ctx = nullptr;
-    CircuitPack pack;
-    std::vector<void *> allocs;
-    // setup-time residents
-    u64 *d_cs_values = nullptr;
-    PolyOracle cs;
-    GateDev *d_gates = nullptr;
-    std::vector<GateDev> h_gates;
-    u64 *d_qacc = nullptr;
-    u64 *d_poseidon_rc = nullptr, *d_poseidon_fast = nullptr;
-    u64 *d_omega = nullptr, *d_x_coset = nullptr, *d_l0_coset = nullptr, *d_zh_inv = nullptr;
-    u64 *d_ginv_lo = nullptr, *d_ginv_hi = nullptr; uint32_t ginv_lo_bits = 0;
-    // per-proof workspace
-    u64 *d_wires_vals = nullptr;
-    PolyOracle wires, zs, quot;
-    u64 *d_qcp = nullptr, *d_rowprod = nullptr, *d_z = nullptr, *d_zs_vals = nullptr;
-    u64 *d_small = nullptr;          // betas, gammas, beta_k_is, alpha pows, pi hash
-    e2 *d_points = nullptr, *d_open = nullptr;
-    FriParams fri;
-    FriWork fri_work;                // s8..s11 workspace, one allocation
-    Stager stage;                    // pinned host staging for the small per-proof tables (no sync on upload)
-    bool seed_set = false;
-    bool check_witness = false;
-    u64 *d_check = nullptr;          // [2]: first bad row, permutation flag
-    u64 blinding_seed = 0;
-
-    template <class T> int alloc(T **p, size_t count) {
-        void *v = nullptr;
-        hipError_t e = hipMalloc(&v, std::max<size_t>(count * sizeof(T), 8));
-        if (e != hipSuccess) return ctx->hip_fail(e, "hipMalloc(circuit)");
-        allocs.push_back(v);
-        *p = (T *)v;
-        return QPGPU_OK;
-    }
-};
 
 namespace {
 
@@ -130,6 +95,7 @@ void qpgpu_circuit_free(qpgpu_circuit *c) {
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->stage.h) (void)hipHostFree(c->stage.h);
     for (void *p : c->allocs) (void)hipFree(p);
+    witness_plan_free(c->wplan);
     delete c;
 }
 

@@ -1,0 +1,28 @@
+// witness.hpp — stage s1 on the device: plonky2's `generate_partial_witness` for the gate generators this backend
+// knows. The plan (built once per circuit on the host) is the dependency-levelled list of generator instances;
+// each level is one kernel launch. See witness_plan.cpp.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "prover_kernels.hpp"
+
+// one generator instance = one gate generator of plonky2 (a whole row for most gates, one operation of the row for
+// Arithmetic / ArithmeticExtension / MulExtension / RandomAccess copies / Constant wires)
+struct WitnessInst { uint32_t row, gate, op; };
+
+struct WitnessArgs {
+    uint64_t *wires;            // [num_wires][n] in place
+    const uint32_t *src_of;     // [n][num_routed] flat index (col*n + row) of the cell every member of the copy class reads
+    const WitnessInst *insts;   // sorted by level
+    const GateDev *gates;
+    const uint64_t *cs;         // constants_sigmas VALUES [ncs][n] (constants of the row)
+    const uint64_t *poseidon_rc, *poseidon_fast;
+    const uint64_t *pi_hash;    // [batch][4]: PublicInputGate wires
+    uint64_t n;
+    uint64_t batch_stride;      // words between the wire matrices of a batch (blockIdx.y = witness index)
+    uint32_t num_routed, num_selectors;
+};
+
+hipError_t wk_run_level(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st);
+hipError_t wk_run_poseidon(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st);   // PoseidonGate instances, 16 lanes each
+hipError_t wk_fill_copies(const WitnessArgs &a, uint32_t batch, hipStream_t st);

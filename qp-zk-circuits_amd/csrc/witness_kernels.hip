@@ -1,0 +1,241 @@
+// witness_kernels.hip — stage s1 (`generate_partial_witness`) on the device: the witness generators of the gates this
+// backend evaluates, run level by level over the circuit's dependency order.
+//
+// Replaces, inside qp-plonky2 1.5.5 `plonk::prover::prove` (reference call site wormhole/prover/src/lib.rs:171-175), the
+// generator loop of `iop::generator::generate_partial_witness` for the gate-attached generators: ConstantGenerator,
+// ArithmeticBaseGenerator, ArithmeticExtensionGenerator, MulExtensionGenerator, BaseSplitGenerator, PoseidonGenerator,
+// ReducingGenerator (both), RandomAccessGenerator, ExponentiationGenerator, PoseidonMdsGenerator,
+// InterpolationGenerator. One thread runs one generator instance; copy constraints are resolved by reading every routed
+// input through the source cell of its copy class (src_of), and a final pass copies sources to all class members.
+#include <hip/hip_runtime.h>
+#include "gl64.hpp"
+#include "poseidon.hpp"
+#include "witness.hpp"
+
+using gl::e2;
+using gl::u32;
+using gl::u64;
+
+namespace {
+
+__global__ void __launch_bounds__(128) witness_level_kernel(WitnessArgs a, u32 first, u32 count) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const WitnessInst in = a.insts[first + t];
+    const GateDev g = a.gates[in.gate];
+    const u64 n = a.n;
+    a.wires += (u64)blockIdx.y * a.batch_stride;        // one wire matrix per witness of the batch
+    a.pi_hash += 4 * blockIdx.y;
+    const u32 R = a.num_routed, row = in.row, op = in.op;
+    auto RD = [&](u32 col) -> u64 { return col < R ? a.wires[a.src_of[(u64)row * R + col]] : a.wires[(u64)col * n + row]; };
+    auto WR = [&](u32 col, u64 v) { a.wires[(u64)col * n + row] = gl::canon(v); };
+    auto RD2 = [&](u32 col) { const u64 x = RD(col), y = RD(col + 1); return gl::e2_make(x, y); };
+    auto WR2 = [&](u32 col, e2 v) { WR(col, v.a); WR(col + 1, v.b); };
+    const u64 *consts = a.cs + (u64)a.num_selectors * n + row;   // constant i of this row at consts[i * n]
+    switch (g.type) {
+    case 1: WR(op, consts[(u64)op * n]); break;                                         // ConstantGate
+    case 2: for (u32 i = 0; i < 4; i++) WR(i, a.pi_hash[i]); break;                    // PublicInputGate
+    case 3: {                                                                           // ArithmeticGate, one operation
+        const u64 m0 = RD(4 * op), m1 = RD(4 * op + 1), ad = RD(4 * op + 2);
+        WR(4 * op + 3, gl::add(gl::mul(gl::mul(m0, m1), consts[0]), gl::mul(ad, consts[n])));
+        break;
+    }
+    case 6: {                                                                           // ArithmeticExtensionGate
+        const e2 m0 = RD2(8 * op), m1 = RD2(8 * op + 2), ad = RD2(8 * op + 4);
+        WR2(8 * op + 6, gl::e2_add(gl::e2_scale(gl::e2_mul(m0, m1), consts[0]), gl::e2_scale(ad, consts[n])));
+        break;
+    }
+    case 7: WR2(6 * op + 4, gl::e2_scale(gl::e2_mul(RD2(6 * op), RD2(6 * op + 2)), consts[0])); break;   // MulExtensionGate
+    case 5: {                                                                           // BaseSumGate<2>: limbs of the sum
+        const u64 v = gl::canon(RD(0));
+        for (u32 i = 0; i < g.param0; i++) WR(1 + i, (v >> i) & 1);
+        break;
+    }
+    case 4: {                                                                           // PoseidonGate
+        const u64 *rcs = a.poseidon_rc, *fpt = a.poseidon_fast;
+        u64 st[12], inp[12];
+        for (int i = 0; i < 12; i++) inp[i] = RD(i);
+        const u64 swap = gl::canon(RD(24));
+        for (int i = 0; i < 4; i++) {
+            const u64 delta = swap ? gl::canon(gl::sub(inp[i + 4], inp[i])) : 0;
+            WR(25 + i, delta);
+            st[i] = gl::add(inp[i], delta); st[i + 4] = gl::sub(inp[i + 4], delta);
+        }
+        for (int i = 8; i < 12; i++) st[i] = inp[i];
+        int rc = 0;
+        for (int r = 0; r < 4; r++, rc++) {
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
+            if (r) for (int i = 0; i < 12; i++) WR(29 + 12 * (r - 1) + i, st[i]);
+            for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+            poseidon::mds_layer(st);
+        }
+        poseidon::fast_partial_enter(st, fpt);
+        for (int r = 0; r < 22; r++) {
+            st[0] = gl::canon(st[0]);
+            WR(65 + r, st[0]);
+            st[0] = poseidon::sbox7(st[0]);
+            poseidon::fast_partial_linear(st, fpt, r);
+        }
+        rc += 22;
+        for (int r = 0; r < 4; r++, rc++) {
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
+            for (int i = 0; i < 12; i++) WR(87 + 12 * r + i, st[i]);
+            for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+            poseidon::mds_layer(st);
+        }
+        for (int i = 0; i < 12; i++) WR(12 + i, st[i]);
+        break;
+    }
+    case 8: case 9: {                                                                   // ReducingGate / ReducingExtensionGate
+        const bool ext = g.type == 9;
+        const u32 nc = g.param0, start_accs = 6 + (ext ? 2 * nc : nc);
+        const e2 alpha = RD2(2);
+        e2 acc = RD2(4);
+        for (u32 i = 0; i < nc; i++) {
+            const e2 cf = ext ? RD2(6 + 2 * i) : gl::e2_from(RD(6 + i));
+            acc = gl::e2_canon(gl::e2_add(gl::e2_mul(acc, alpha), cf));
+            WR2(i == nc - 1 ? 0 : start_accs + 2 * i, acc);
+        }
+        break;
+    }
+    case 10: {                                                                          // RandomAccessGate: one copy, or the extra constants
+        const u32 bits = g.param0, copies = g.param1, extra = g.param2, vec = 1u << bits, routed = (2 + vec) * copies + extra;
+        if (op == copies) { for (u32 i = 0; i < extra; i++) WR((2 + vec) * copies + i, consts[(u64)i * n]); break; }
+        const u32 b0 = (2 + vec) * op;
+        const u64 idx = gl::canon(RD(b0)) & (vec - 1);
+        WR(b0 + 1, RD(b0 + 2 + (u32)idx));
+        for (u32 i = 0; i < bits; i++) WR(routed + op * bits + i, (idx >> i) & 1);
+        break;
+    }
+    case 11: {                                                                          // ExponentiationGate
+        const u32 nb = g.param0;
+        const u64 base = RD(0);
+        u64 cur = 1;
+        for (u32 i = 0; i < nb; i++) {
+            const u64 prev = i == 0 ? 1 : gl::mul(cur, cur), bit = gl::canon(RD(1 + (nb - 1 - i)));
+            cur = gl::canon(bit ? gl::mul(prev, base) : prev);
+            WR(2 + nb + i, cur);
+        }
+        WR(1 + nb, cur);
+        break;
+    }
+    case 12: {                                                                          // PoseidonMdsGate
+        for (u32 comp = 0; comp < 2; comp++) {
+            u64 st[12];
+            for (int i = 0; i < 12; i++) st[i] = RD(2 * i + comp);
+            poseidon::mds_layer(st);
+            for (int i = 0; i < 12; i++) WR(24 + 2 * i + comp, st[i]);
+        }
+        break;
+    }
+    case 13: {                                                                          // CosetInterpolationGate
+        const u32 bits = g.param0, deg = g.param1, np = 1u << bits, ni = (np - 2) / (deg - 1);
+        const u32 s_ep = 1 + 2 * np, s_ev = s_ep + 2, s_int = s_ev + 2;
+        const u64 shift = RD(0);
+        const e2 sp = gl::e2_canon(gl::e2_scale(RD2(s_ep), gl::inv(shift)));
+        WR2(s_int + 4 * ni, sp);
+        const u64 omega = 1ull << (192u >> bits), inv_n = gl::P - ((1ull << (64 - bits)) - (1ull << (32 - bits)));
+        e2 ev = gl::e2_from(0), pr = gl::e2_from(1);
+        u64 x = 1;
+        u32 lo = 0, hi = deg;
+        for (u32 c = 0; c <= ni; c++) {
+            for (u32 q = lo; q < hi; q++) {
+                e2 term = sp; term.a = gl::sub(term.a, x);
+                const e2 tv = gl::e2_scale(gl::e2_mul(RD2(1 + 2 * q), pr), gl::mul(x, inv_n));
+                ev = gl::e2_add(gl::e2_mul(ev, term), tv);
+                pr = gl::e2_mul(pr, term);
+                x = gl::mul(x, omega);
+            }
+            ev = gl::e2_canon(ev); pr = gl::e2_canon(pr);
+            if (c == ni) break;
+            WR2(s_int + 2 * c, ev); WR2(s_int + 2 * (ni + c), pr);
+            lo = 1 + (deg - 1) * (c + 1); hi = lo + deg - 1 < np ? lo + deg - 1 : np;
+        }
+        WR2(s_ev, ev);
+        break;
+    }
+    default: break;
+    }
+}
+
+// PoseidonGate generator, lane-cooperative: one instance per 16 lanes (state element g in lane g, 12 used), S-box layer in
+// parallel, MDS gathered with wave shuffles. A single thread needs ~100 us for the 30 rounds, and a dependency level ends
+// when its slowest generator does. The S-box inputs recorded for the partial rounds are those of the textbook schedule:
+// the fast-basis formulation the gate's constraints use feeds the same values to the S-box.
+__global__ void __launch_bounds__(256) witness_poseidon_kernel(WitnessArgs a, u32 first, u32 count) {
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x, slot = tid >> 4;
+    const int g = threadIdx.x & 15, lane_base = (threadIdx.x & 63) & ~15;
+    const bool live = slot < count;
+    const WitnessInst in = a.insts[first + (live ? slot : count - 1)];   // idle groups shadow the last instance, without stores
+    const u64 n = a.n;
+    const u32 R = a.num_routed, row = in.row;
+    a.wires += (u64)blockIdx.y * a.batch_stride;
+    auto RD = [&](u32 col) -> u64 { return col < R ? a.wires[a.src_of[(u64)row * R + col]] : a.wires[(u64)col * n + row]; };
+    auto WR = [&](u32 col, u64 v) { if (live) a.wires[(u64)col * n + row] = gl::canon(v); };
+    auto shfl64 = [&](u64 v, int src) { return ((u64)(u32)__shfl((int)(v >> 32), src, 64) << 32) | (u32)__shfl((int)(u32)v, src, 64); };
+    int src[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { int e = g + i; e -= e >= 12 ? 12 : 0; src[i] = lane_base + (g < 12 ? e : i); }
+    u64 s = g < 12 ? RD(g) : 0;
+    const u64 swap = gl::canon(RD(24));
+    {
+        const u64 partner = shfl64(s, lane_base + (g < 4 ? g + 4 : (g < 8 ? g - 4 : g)));
+        if (g < 4) { const u64 delta = swap ? gl::canon(gl::sub(partner, s)) : 0; WR(25 + g, delta); s = gl::add(s, delta); }
+        else if (g < 8) { const u64 delta = swap ? gl::canon(gl::sub(s, partner)) : 0; s = gl::sub(s, delta); }
+    }
+#pragma unroll 1
+    for (int r = 0; r < poseidon::ROUNDS; r++) {
+        s = gl::canon(gl::add(s, g < 12 ? a.poseidon_rc[r * 12 + g] : 0));
+        const bool full = r < poseidon::HALF_FULL || r >= poseidon::HALF_FULL + poseidon::PARTIAL;
+        if (g < 12) {
+            if (full && r >= 1 && r < poseidon::HALF_FULL) WR(29 + 12 * (r - 1) + g, s);
+            if (full && r >= poseidon::HALF_FULL + poseidon::PARTIAL) WR(87 + 12 * (r - poseidon::HALF_FULL - poseidon::PARTIAL) + g, s);
+            if (!full && g == 0) WR(65 + (r - poseidon::HALF_FULL), s);
+        }
+        const u64 sb = poseidon::sbox7(s);
+        s = (full || g == 0) ? sb : s;
+        const u32 lo = (u32)s, hi = (u32)(s >> 32);
+        u64 al = 0, ah = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const u32 l = (u32)__shfl((int)lo, src[i], 64), h = (u32)__shfl((int)hi, src[i], 64);
+            al += (u64)l * C[i];
+            ah += (u64)h * C[i];
+        }
+        if (g == 0) { al += (u64)lo * 8u; ah += (u64)hi * 8u; }
+        const u64 low = al + (ah << 32);
+        const u32 top = (u32)(ah >> 32) + (low < al ? 1u : 0u);
+        s = gl::reduce96(low, top);
+    }
+    if (g < 12) WR(12 + g, s);
+}
+
+// every routed cell takes the value of its copy class's source cell
+__global__ void __launch_bounds__(256) witness_fill_kernel(WitnessArgs a) {
+    const u64 cell = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (cell >= a.n * a.num_routed) return;
+    a.wires += (u64)blockIdx.y * a.batch_stride;
+    const u64 row = cell / a.num_routed, col = cell % a.num_routed, own = col * a.n + row;
+    const u32 src = a.src_of[cell];
+    if (src != own) a.wires[own] = a.wires[src];
+}
+
+}  // namespace
+
+hipError_t wk_run_level(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st) {
+    if (count == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(witness_level_kernel, dim3((count + 127) / 128, batch), dim3(128), 0, st, a, first, count);
+    return hipGetLastError();
+}
+hipError_t wk_run_poseidon(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st) {
+    if (count == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(witness_poseidon_kernel, dim3((count + 15) / 16, batch), dim3(256), 0, st, a, first, count);
+    return hipGetLastError();
+}
+hipError_t wk_fill_copies(const WitnessArgs &a, uint32_t batch, hipStream_t st) {
+    const uint64_t cells = a.n * a.num_routed;
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(witness_fill_kernel, dim3((unsigned)((cells + 255) / 256), batch), dim3(256), 0, st, a);
+    return hipGetLastError();
+}

@@ -1,0 +1,320 @@
+// witness_plan.cpp — stage s1: the witness-generation plan of a loaded circuit and its C ABI.
+//
+// plonky2 runs its witness generators to a fixpoint over a dependency DAG on the host. Here the
+// DAG is resolved once per circuit: copy classes are recovered from the sigma polynomials (a class is a cycle of the wire
+// permutation), every gate row contributes its gate-attached generator instances with the cells they read and write,
+// and instances are sorted by dependency depth. Generation is then one kernel launch per level plus a copy-fill pass
+// (witness_kernels.hip). Cells no generator produces are the caller's inputs (the PartialWitness): qpgpu_witness_free_mask
+// reports them.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "circuit_state.hpp"
+#include "witness.hpp"
+
+using gl::u64;
+
+struct WitnessPlan {
+    std::vector<WitnessInst> insts;          // sorted by level
+    std::vector<uint32_t> level_start;       // level l = insts[level_start[l] .. level_start[l+1])
+    std::vector<uint32_t> level_poseidon;    // first PoseidonGate instance of level l (they come last in their level)
+    std::vector<uint8_t> free_mask;          // [num_wires][n]: 1 = supplied by the caller
+    uint64_t num_free = 0;
+    uint32_t *d_src_of = nullptr;
+    WitnessInst *d_insts = nullptr;
+    u64 *d_pi_hash = nullptr;
+    uint32_t pi_cap = 0;                     // witnesses d_pi_hash has room for
+};
+
+void witness_plan_free(WitnessPlan *p) {
+    if (!p) return;
+    if (p->d_src_of) (void)hipFree(p->d_src_of);
+    if (p->d_insts) (void)hipFree(p->d_insts);
+    if (p->d_pi_hash) (void)hipFree(p->d_pi_hash);
+    delete p;
+}
+
+namespace {
+
+struct IO { std::vector<uint32_t> in, out; };
+
+// the cells (wire columns of its row) a generator instance reads and writes; must match witness_level_kernel
+void describe(const GateInfo &g, uint32_t op, IO &io) {
+    io.in.clear(); io.out.clear();
+    auto range = [](std::vector<uint32_t> &v, uint32_t a, uint32_t b) { for (uint32_t i = a; i < b; i++) v.push_back(i); };
+    switch (g.type) {
+    case GATE_CONSTANT: io.out = {op}; break;
+    case GATE_PUBLIC_INPUT: range(io.out, 0, 4); break;
+    case GATE_ARITHMETIC: range(io.in, 4 * op, 4 * op + 3); io.out = {4 * op + 3}; break;
+    case GATE_ARITHMETIC_EXT: range(io.in, 8 * op, 8 * op + 6); range(io.out, 8 * op + 6, 8 * op + 8); break;
+    case GATE_MUL_EXT: range(io.in, 6 * op, 6 * op + 4); range(io.out, 6 * op + 4, 6 * op + 6); break;
+    case GATE_BASE_SUM: io.in = {0}; range(io.out, 1, 1 + (uint32_t)g.param0); break;
+    case GATE_POSEIDON: range(io.in, 0, 12); io.in.push_back(24); range(io.out, 12, 24); range(io.out, 25, 135); break;
+    case GATE_REDUCING: case GATE_REDUCING_EXT: {
+        const uint32_t nc = (uint32_t)g.param0, ncw = g.type == GATE_REDUCING_EXT ? 2 * nc : nc;
+        range(io.in, 2, 6 + ncw); range(io.out, 0, 2); range(io.out, 6 + ncw, 6 + ncw + 2 * (nc - 1));
+        break;
+    }
+    case GATE_RANDOM_ACCESS: {
+        const uint32_t bits = (uint32_t)g.param0, copies = (uint32_t)g.param1, extra = (uint32_t)g.param2, vec = 1u << bits;
+        const uint32_t routed = (2 + vec) * copies + extra;
+        if (op == copies) { range(io.out, (2 + vec) * copies, routed); break; }
+        const uint32_t b0 = (2 + vec) * op;
+        io.in.push_back(b0); range(io.in, b0 + 2, b0 + 2 + vec);
+        io.out.push_back(b0 + 1); range(io.out, routed + op * bits, routed + (op + 1) * bits);
+        break;
+    }
+    case GATE_EXPONENTIATION: {
+        const uint32_t nb = (uint32_t)g.param0;
+        range(io.in, 0, 1 + nb); range(io.out, 1 + nb, 2 + 2 * nb);
+        break;
+    }
+    case GATE_POSEIDON_MDS: range(io.in, 0, 24); range(io.out, 24, 48); break;
+    case GATE_COSET_INTERPOLATION: {
+        const uint32_t np = 1u << g.param0, deg = (uint32_t)g.param1, ni = (np - 2) / (deg - 1), s_ep = 1 + 2 * np;
+        range(io.in, 0, s_ep + 2); range(io.out, s_ep + 2, s_ep + 4 + 4 * ni + 2);
+        break;
+    }
+    default: break;
+    }
+}
+uint32_t num_instances(const GateInfo &g) {
+    switch (g.type) {
+    case GATE_NOOP: return 0;
+    case GATE_CONSTANT: case GATE_ARITHMETIC: case GATE_ARITHMETIC_EXT: case GATE_MUL_EXT: return (uint32_t)g.param0;
+    case GATE_RANDOM_ACCESS: return (uint32_t)g.param1 + (g.param2 ? 1 : 0);
+    default: return 1;
+    }
+}
+
+std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
+    const CircuitPack &p = c->pack;
+    const u64 n = p.n(), R = p.num_routed_wires, NW = p.num_wires;
+    const size_t sig0 = p.num_selectors + p.num_constants;
+    if (NW * n >= (1ull << 32)) return "witness plan: circuit too large for 32-bit cell indices";
+    auto CS = [&](u64 row, u64 col) { return p.constants_sigmas[col * n + row]; };
+
+    // ---- copy classes from sigma: sigma(row, col) = k_is[col'] * w^row' names the next cell of the cycle ----
+    std::unordered_map<u64, uint32_t> row_of;           // w^r -> r
+    row_of.reserve(n * 2);
+    { const u64 w = gl::root_of_unity((unsigned)p.degree_bits); u64 a = 1; for (u64 r = 0; r < n; r++) { row_of[gl::canon(a)] = (uint32_t)r; a = gl::mul(a, w); } }
+    std::unordered_map<u64, uint32_t> col_of;           // k_is[c]^n -> c (cosets of the subgroup are told apart by x^n)
+    std::vector<u64> k_inv(R);
+    for (u64 cidx = 0; cidx < R; cidx++) {
+        u64 t = p.k_is[cidx];
+        for (unsigned i = 0; i < p.degree_bits; i++) t = gl::mul(t, t);
+        if (!col_of.emplace(gl::canon(t), (uint32_t)cidx).second) return "witness plan: k_is are not in distinct cosets";
+        k_inv[cidx] = gl::inv(p.k_is[cidx]);
+    }
+    std::vector<uint32_t> parent(n * R);
+    std::iota(parent.begin(), parent.end(), 0u);
+    auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    for (u64 r = 0; r < n; r++)
+        for (u64 cidx = 0; cidx < R; cidx++) {
+            const u64 s = CS(r, sig0 + cidx);
+            u64 t = s;
+            for (unsigned i = 0; i < p.degree_bits; i++) t = gl::mul(t, t);
+            auto ci = col_of.find(gl::canon(t));
+            if (ci == col_of.end()) return "witness plan: a sigma value is outside the wire cosets";
+            auto ri = row_of.find(gl::canon(gl::mul(s, k_inv[ci->second])));
+            if (ri == row_of.end()) return "witness plan: a sigma value is outside the wire cosets";
+            const uint32_t a = find((uint32_t)(r * R + cidx)), b = find((uint32_t)((u64)ri->second * R + ci->second));
+            if (a != b) parent[std::max(a, b)] = std::min(a, b);
+        }
+
+    // ---- generator instances per row ----
+    std::vector<int32_t> gate_of_row(n, -1);
+    for (u64 r = 0; r < n; r++)
+        for (size_t gi = 0; gi < p.gates.size(); gi++)
+            if (CS(r, p.gates[gi].selector_index) == gi) { gate_of_row[r] = (int32_t)gi; break; }
+    std::vector<WitnessInst> insts;
+    for (u64 r = 0; r < n; r++) {
+        if (gate_of_row[r] < 0) return "witness plan: row " + std::to_string(r) + " selects no gate";
+        const GateInfo &g = p.gates[gate_of_row[r]];
+        for (uint32_t op = 0, k = num_instances(g); op < k; op++) insts.push_back({(uint32_t)r, (uint32_t)gate_of_row[r], op});
+    }
+    // producer of each copy class (by class root), and the source cell every member reads
+    std::vector<int32_t> producer(n * R, -1);           // indexed by class root: instance id
+    std::vector<uint32_t> source(n * R);                // indexed by class root: cell (row * R + col)
+    for (uint32_t i = 0; i < n * R; i++) source[i] = i;
+    plan.free_mask.assign(NW * n, 1);
+    IO io;
+    for (size_t id = 0; id < insts.size(); id++) {
+        describe(p.gates[insts[id].gate], insts[id].op, io);
+        for (uint32_t col : io.out) {
+            if (col >= NW) return "witness plan: generator output beyond num_wires";
+            plan.free_mask[(u64)col * n + insts[id].row] = 0;
+            if (col >= R) continue;
+            const uint32_t cell = (uint32_t)((u64)insts[id].row * R + col), root = find(cell);
+            if (producer[root] >= 0) return "witness plan: two generators write one copy class (row " + std::to_string(insts[id].row) + ")";
+            producer[root] = (int32_t)id; source[root] = cell;
+        }
+    }
+    std::vector<uint32_t> src_of(n * R);
+    for (uint32_t cell = 0; cell < n * R; cell++) {
+        const uint32_t s = source[find(cell)];
+        src_of[cell] = (uint32_t)((u64)(s % R) * n + s / R);
+        if (s != cell) plan.free_mask[(u64)(cell % R) * n + cell / R] = 0;      // filled by the copy pass
+    }
+    plan.num_free = 0;
+    for (uint8_t m : plan.free_mask) plan.num_free += m;
+
+    // ---- levels: 1 + the deepest producer among the inputs (iterative depth-first, cycles rejected) ----
+    std::vector<int32_t> level(insts.size(), 0);        // 0 = unvisited, -1 = on the stack
+    std::vector<std::pair<uint32_t, uint32_t>> stack;   // (instance, next input position)
+    std::vector<std::vector<uint32_t>> deps(insts.size());
+    for (size_t id = 0; id < insts.size(); id++) {
+        describe(p.gates[insts[id].gate], insts[id].op, io);
+        for (uint32_t col : io.in) {
+            if (col >= R) continue;
+            const int32_t pr = producer[find((uint32_t)((u64)insts[id].row * R + col))];
+            if (pr >= 0 && (size_t)pr != id) deps[id].push_back((uint32_t)pr);
+        }
+    }
+    for (size_t start = 0; start < insts.size(); start++) {
+        if (level[start] > 0) continue;
+        stack.push_back({(uint32_t)start, 0}); level[start] = -1;
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            if (top.second < deps[top.first].size()) {
+                const uint32_t d = deps[top.first][top.second++];
+                if (level[d] == -1) return "witness plan: cyclic generator dependency";
+                if (level[d] == 0) { level[d] = -1; stack.push_back({d, 0}); }
+            } else {
+                int32_t lv = 1;
+                for (uint32_t d : deps[top.first]) lv = std::max(lv, level[d] + 1);
+                level[top.first] = lv;
+                stack.pop_back();
+            }
+        }
+    }
+    int32_t max_level = 0;
+    for (int32_t l : level) max_level = std::max(max_level, l);
+    std::vector<uint32_t> order(insts.size());
+    std::iota(order.begin(), order.end(), 0u);
+    auto is_pos = [&](uint32_t i) { return p.gates[insts[i].gate].type == GATE_POSEIDON ? 1 : 0; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return level[a] != level[b] ? level[a] < level[b] : is_pos(a) < is_pos(b); });
+    plan.insts.resize(insts.size());
+    plan.level_start.assign(max_level + 1, 0);
+    for (size_t i = 0; i < order.size(); i++) { plan.insts[i] = insts[order[i]]; plan.level_start[level[order[i]]]++; }
+    {   // counts per level (index 1..max) -> start offsets; level_start[l] = first instance of level l+1
+        uint32_t acc = 0;
+        for (int32_t l = 1; l <= max_level; l++) { const uint32_t cnt = plan.level_start[l]; plan.level_start[l - 1] = acc; acc += cnt; }
+        plan.level_start[max_level] = acc;
+    }
+    plan.level_poseidon.assign(max_level, 0);
+    for (int32_t l = 0; l < max_level; l++) {
+        uint32_t k = plan.level_start[l];
+        while (k < plan.level_start[l + 1] && p.gates[plan.insts[k].gate].type != GATE_POSEIDON) k++;
+        plan.level_poseidon[l] = k;
+    }
+
+    // ---- device copies ----
+    qpgpu_ctx *ctx = c->ctx;
+    auto up = [&](const void *src, size_t bytes, void **dst) -> bool {
+        if (hipMalloc(dst, std::max<size_t>(bytes, 8)) != hipSuccess) return false;
+        return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    };
+    if (!up(src_of.data(), src_of.size() * 4, (void **)&plan.d_src_of)) return "witness plan: device allocation failed";
+    if (!up(plan.insts.data(), plan.insts.size() * sizeof(WitnessInst), (void **)&plan.d_insts)) return "witness plan: device allocation failed";
+    return "";
+}
+
+int ensure_plan(qpgpu_circuit *c) {
+    if (c->wplan) return QPGPU_OK;
+    WitnessPlan *plan = new WitnessPlan();
+    const std::string err = build_plan(c, *plan);
+    if (!err.empty()) { witness_plan_free(plan); return c->ctx->fail(QPGPU_EINVAL, err); }
+    c->wplan = plan;
+    return QPGPU_OK;
+}
+
+void host_pi_hash(const u64 *pis, size_t n, u64 out[4]) {
+    u64 st[12] = {0};
+    for (size_t i = 0; i < n; i += 8) {
+        const size_t len = std::min<size_t>(8, n - i);
+        for (size_t k = 0; k < len; k++) st[k] = gl::canon(pis[i + k]);
+        poseidon::permute(st, poseidon::host_round_constants());
+    }
+    std::memcpy(out, st, 32);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qpgpu_witness_info(qpgpu_circuit *c, uint64_t *num_generators, uint64_t *num_levels, uint64_t *num_free_cells) {
+    if (!c) return QPGPU_EINVAL;
+    QP_DEV(c->ctx);
+    QP_TRY(ensure_plan(c));
+    if (num_generators) *num_generators = c->wplan->insts.size();
+    if (num_levels) *num_levels = c->wplan->level_start.empty() ? 0 : c->wplan->level_start.size() - 1;
+    if (num_free_cells) *num_free_cells = c->wplan->num_free;
+    return QPGPU_OK;
+}
+
+int qpgpu_witness_free_mask(qpgpu_circuit *c, uint8_t *mask, size_t mask_len) {
+    if (!c || !mask) return QPGPU_EINVAL;
+    QP_DEV(c->ctx);
+    QP_TRY(ensure_plan(c));
+    if (mask_len < c->wplan->free_mask.size()) return c->ctx->fail(QPGPU_EBUFSIZE, "witness_free_mask: buffer too small");
+    std::memcpy(mask, c->wplan->free_mask.data(), c->wplan->free_mask.size());
+    return QPGPU_OK;
+}
+
+int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs) {
+    if (!c) return QPGPU_EINVAL;
+    qpgpu_ctx *ctx = c->ctx;
+    QP_DEV(ctx);
+    if (!d_wires || batch == 0 || batch > 65535 || (!public_inputs && c->pack.num_public_inputs)) return ctx->fail(QPGPU_EINVAL, "generate_witness: bad argument");
+    QP_TRY(ensure_plan(c));
+    WitnessPlan &plan = *c->wplan;
+    if (plan.pi_cap < batch) {
+        if (plan.d_pi_hash) { QP_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(plan.d_pi_hash); plan.d_pi_hash = nullptr; plan.pi_cap = 0; }
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_hash, (size_t)batch * 32));
+        plan.pi_cap = batch;
+    }
+    std::vector<u64> pih((size_t)batch * 4);
+    for (uint32_t b = 0; b < batch; b++) host_pi_hash(public_inputs + (size_t)b * c->pack.num_public_inputs, c->pack.num_public_inputs, pih.data() + 4 * b);
+    QP_HIP(ctx, hipMemcpyAsync(plan.d_pi_hash, pih.data(), pih.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));       // pih goes out of scope
+    WitnessArgs a{};
+    a.wires = d_wires; a.src_of = plan.d_src_of; a.insts = plan.d_insts; a.gates = c->d_gates; a.cs = c->d_cs_values;
+    a.poseidon_rc = c->d_poseidon_rc; a.poseidon_fast = c->d_poseidon_fast; a.pi_hash = plan.d_pi_hash;
+    a.n = c->pack.n(); a.batch_stride = c->pack.num_wires * c->pack.n();
+    a.num_routed = (uint32_t)c->pack.num_routed_wires; a.num_selectors = (uint32_t)c->pack.num_selectors;
+    ctx->prof_begin("witness_generate");
+    for (size_t l = 0; l + 1 < plan.level_start.size(); l++) {
+        const uint32_t lo = plan.level_start[l], mid = plan.level_poseidon[l], hi = plan.level_start[l + 1];
+        QP_HIP(ctx, wk_run_level(a, lo, mid - lo, batch, ctx->stream));
+        QP_HIP(ctx, wk_run_poseidon(a, mid, hi - mid, batch, ctx->stream));
+    }
+    QP_HIP(ctx, wk_fill_copies(a, batch, ctx->stream));
+    ctx->prof_end();
+    return QPGPU_OK;
+}
+
+int qpgpu_generate_witness_dev(qpgpu_circuit *c, uint64_t *d_wires, const uint64_t *public_inputs) {
+    return qpgpu_generate_witness_batch_dev(c, d_wires, 1, public_inputs);
+}
+
+int qpgpu_generate_witness(qpgpu_circuit *c, uint64_t *wires, const uint64_t *public_inputs) {
+    if (!c) return QPGPU_EINVAL;
+    qpgpu_ctx *ctx = c->ctx;
+    QP_DEV(ctx);
+    if (!wires) return ctx->fail(QPGPU_EINVAL, "generate_witness: null argument");
+    const size_t bytes = (size_t)c->pack.num_wires * c->pack.n() * 8;
+    QP_HIP(ctx, hipMemcpyAsync(c->d_wires_vals, wires, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    QP_TRY(qpgpu_generate_witness_dev(c, c->d_wires_vals, public_inputs));
+    QP_HIP(ctx, hipMemcpyAsync(wires, c->d_wires_vals, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QP_HIP(ctx, hipMemsetAsync(c->d_wires_vals, 0, bytes, ctx->stream));   // the witness carries the spend secret
+    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QPGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""Stage s1 on the device (qpgpu_generate_witness*): from the caller-supplied cells alone (the PartialWitness) the
+generated wire matrix must equal the generator's full witness cell for cell, satisfy every gate and copy constraint
+(the witness check and the restated verifier are the reference's own acceptance criterion), and prove to the same bytes."""
+import numpy as np
+import pytest
+
+from oracle_binding import OracleCircuit
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(degree_bits=6, num_wires=24, num_routed=16, num_public_inputs=3, seed=71),
+    dict(degree_bits=8, seed=72, poseidon=True, base_sum=True),
+    dict(degree_bits=9, seed=73, poseidon=True, base_sum=True, ext_arith=True, recursion=True),
+    dict(degree_bits=7, num_wires=80, num_routed=48, num_public_inputs=0, seed=74, recursion=True),
+]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_generated_witness_equals_the_full_witness(pkg, gpu, orc, kw):
+    kw = dict(kw)
+    d = kw.pop("degree_bits")
+    pack, wires, pis = pkg.synth_circuit(d, **kw)
+    circ = pkg.Circuit(gpu, pack)
+    try:
+        gens, levels, free = circ.witness_info()
+        mask = circ.witness_free_mask(*wires.shape)
+        assert free == int(mask.sum()) and 0 < free < wires.size and gens > 0 and levels >= 1
+        rng = np.random.default_rng(1)
+        partial = np.where(mask == 1, wires, rng.integers(0, 2**63, size=wires.shape, dtype=np.uint64))   # junk in every determined cell
+        full = circ.generate_witness(partial, pis)
+        bad = np.argwhere(full != wires)
+        assert bad.size == 0, f"{len(bad)} cells differ, first (wire, row) = {tuple(bad[0])}"
+        # and the result is a witness: gate + copy constraints hold, proof bytes match the CPU restatement
+        circ.set_witness_check(True)
+        proof = circ.prove(full, pis)
+        oc = OracleCircuit(orc, pack)
+        assert proof == oc.prove(wires, pis) and oc.verify(proof) == 0
+        oc.close()
+    finally:
+        circ.close()
+
+
+def test_generation_follows_the_inputs(pkg, gpu):
+    """Changing one supplied cell changes what depends on it and the result is again a valid witness."""
+    pack, wires, pis = pkg.synth_circuit(8, seed=75, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+    circ = pkg.Circuit(gpu, pack)
+    try:
+        mask = circ.witness_free_mask(*wires.shape)
+        # a free routed cell of an arithmetic row (row 3, multiplicand 0 of operation 0 when it is not a copy)
+        cols = [c for c in (0, 1, 2, 4, 5, 6) if mask[c, 3]]
+        assert cols, "expected at least one free arithmetic input in row 3"
+        partial = wires.copy(); partial[cols[0], 3] = (int(partial[cols[0], 3]) + 12345) % 0xFFFFFFFF00000001
+        full = circ.generate_witness(partial, pis)
+        assert (full != wires).any() and (full[mask == 1] == partial[mask == 1]).all()
+        circ.set_witness_check(True)
+        circ.prove(full, pis)                     # QPGPU_EUNSAT would raise
+    finally:
+        circ.close()
+
+
+def test_device_resident_generation_then_prove(pkg, gpu, orc):
+    pack, wires, pis = pkg.synth_circuit(10, seed=76, poseidon=True, base_sum=True)
+    circ = pkg.Circuit(gpu, pack)
+    try:
+        mask = circ.witness_free_mask(*wires.shape)
+        partial = np.where(mask == 1, wires, 0).astype(np.uint64)
+        d = gpu.to_device(partial)
+        circ.generate_witness_dev(d, pis)
+        gpu.sync()
+        assert (d.download().reshape(wires.shape) == wires).all()
+        oc = OracleCircuit(orc, pack)
+        assert circ.prove_dev(d, pis) == oc.prove(wires, pis)
+        oc.close()
+        d.free()
+    finally:
+        circ.close()
+
+
+def test_batched_generation(pkg, gpu):
+    """Several witnesses of one circuit in one pass: different free cells and public inputs per witness."""
+    pack, wires, pis = pkg.synth_circuit(8, seed=77, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+    circ = pkg.Circuit(gpu, pack)
+    try:
+        mask = circ.witness_free_mask(*wires.shape)
+        B = 3
+        partials, all_pis = [], []
+        rng = np.random.default_rng(9)
+        for b in range(B):
+            part = np.where(mask == 1, wires, 0).astype(np.uint64)
+            if b:                                      # perturb a free arithmetic input of row 3 and the public inputs
+                col = next(c for c in (0, 1, 2, 4, 5, 6) if mask[c, 3])
+                part[col, 3] = np.uint64(int(rng.integers(1, 2**62)))
+            partials.append(part)
+            all_pis.append((pis + np.uint64(b)) % np.uint64(0xFFFFFFFF00000001))
+        d = gpu.to_device(np.stack(partials))
+        circ.generate_witness_dev(d, np.stack(all_pis), batch=B)
+        gpu.sync()
+        got = d.download().reshape(B, *wires.shape)
+        d.free()
+        assert (got[0] == wires).all()
+        circ.set_witness_check(True)
+        for b in range(B):
+            assert (got[b][mask == 1] == partials[b][mask == 1]).all()
+            if b:
+                assert (got[b] != wires).any()
+                assert (got[b] == circ.generate_witness(partials[b], all_pis[b])).all()    # same as one at a time
+            circ.prove(got[b], all_pis[b])             # every witness satisfies the circuit
+    finally:
+        circ.close()
