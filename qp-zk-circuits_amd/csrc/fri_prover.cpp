@@ -114,11 +114,20 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
     const e2 fri_alpha = ch.get_ext();
 
     // ---- s8 batched opening polynomial: final = sum over batches, each shifted by alpha^(#polys of the later ones) ----
+    size_t max_count = 0;
+    for (const FriBatch &fb : batches) {
+        if (fb.ranges.empty() || fb.ranges.size() > 8) return ctx->fail(QPGPU_EINVAL, "fri_prove: a batch needs 1..8 polynomial ranges");
+        size_t cnt = 0;
+        for (const FriRange &rg : fb.ranges) {
+            if (rg.oracle >= n_oracles || (size_t)rg.first + rg.count > oracles[rg.oracle]->ncols || rg.count == 0)
+                return ctx->fail(QPGPU_EINVAL, "fri_prove: polynomial range outside its oracle");
+            cnt += rg.count;
+        }
+        max_count = std::max(max_count, cnt);
+    }
+    if (max_count == 0 || max_count > w.max_batch_polys) return ctx->fail(QPGPU_EINVAL, "fri_prove: empty batch or workspace too small");
     ctx->prof_begin("prove_fri_batch");
     {   // alpha powers always start at 1: one table, every batch reads a prefix
-        size_t max_count = 0;
-        for (const FriBatch &fb : batches) { size_t c = 0; for (const FriRange &rg : fb.ranges) c += rg.count; max_count = std::max(max_count, c); }
-        if (max_count == 0 || max_count > w.max_batch_polys) return ctx->fail(QPGPU_EINVAL, "fri_prove: empty batch or workspace too small");
         std::vector<e2> apw(max_count);
         e2 a = gl::e2_from(1);
         for (size_t i = 0; i < max_count; i++) { apw[i] = gl::e2_canon(a); a = gl::e2_mul(a, fri_alpha); }
@@ -128,11 +137,8 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
         const FriBatch &fb = batches[b];
         ReduceArgs ra{};
         size_t count = 0;
-        if (fb.ranges.empty() || fb.ranges.size() > 8) return ctx->fail(QPGPU_EINVAL, "fri_prove: a batch needs 1..8 polynomial ranges");
         for (size_t r = 0; r < fb.ranges.size(); r++) {
             const FriRange &rg = fb.ranges[r];
-            if (rg.oracle >= n_oracles || (size_t)rg.first + rg.count > oracles[rg.oracle]->ncols || rg.count == 0)
-                return ctx->fail(QPGPU_EINVAL, "fri_prove: polynomial range outside its oracle");
             ra.src[r] = oracles[rg.oracle]->coeffs + (size_t)rg.first * n; ra.ncols[r] = rg.count;
             count += rg.count;
         }
