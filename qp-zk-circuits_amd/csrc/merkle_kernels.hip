@@ -8,6 +8,7 @@
 // slot j of each column: a wave reads 512 contiguous bytes per column, no transpose in HBM.
 // One thread = one sponge (state in 24 VGPRs). Integer-ALU-bound: ceil(W/8) permutations per leaf.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "merkle.hpp"
 #include "poseidon.hpp"
 #include "prover_kernels.hpp"
@@ -211,8 +212,14 @@ hipError_t pk_pow(const PowArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// below this many independent hashes a level is latency-bound and the lane-cooperative form wins
-static const u64 COOP_MAX = 16384;
+// below this many independent hashes a level is latency-bound and the lane-cooperative form wins. The cooperative form
+// does about 3x the work, so the crossover depends on how many proofs share the GPU: QPGPU_COOP_MAX overrides it.
+static u64 coop_max_init() {
+    const char *e = getenv("QPGPU_COOP_MAX");
+    if (e && *e) { const long long v = atoll(e); if (v >= 0) return (u64)v; }
+    return 16384;
+}
+static const u64 COOP_MAX = coop_max_init();
 
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, hipStream_t st) {
     if (a.n_leaves == 0) return hipSuccess;

@@ -1,0 +1,26 @@
+"""Summarise a rocprofv3 --kernel-trace --stats output directory: copies the kernel stats table and extracts the
+per-launch durations of the 2^20 x 128 NTT launches (Grid_Size_Y == 128) the bench's roofline object refers to.
+usage: python tools/profile_summary.py <rocprof_dir> <out_prefix>"""
+import csv, glob, json, os, shutil, sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+stats = sorted(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True))
+trace = sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))
+if stats:
+    shutil.copy(stats[-1], prefix + "_kernel_stats.csv")
+launches = {}
+for path in trace:
+    for r in csv.DictReader(open(path)):
+        name = r.get("Kernel_Name", "")
+        if "ntt_pass_kernel<5, 5" not in name:
+            continue
+        gy = int(r.get("Grid_Size_Y", r.get("Grid_Size_y", "0")) or 0)
+        wy = int(r.get("Workgroup_Size_Y", "1") or 1)
+        if gy // max(wy, 1) != 128 and gy != 128:
+            continue
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        launches.setdefault(name.split("(anonymous namespace)::")[-1], []).append(dur)
+out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py (default command), MI355X; 2^20 x 128 launches selected by grid Y == 128",
+       "launches": [{"kernel": k, "calls": len(v), "avg_ms": round(sum(v) / len(v), 4), "min_ms": round(min(v), 4)} for k, v in sorted(launches.items())]}
+json.dump(out, open(prefix + "_ntt_2p20_launches.json", "w"), indent=1)
+print(json.dumps(out["launches"]))
