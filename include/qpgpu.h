@@ -67,7 +67,8 @@ enum {
 /*
  * Batched transform of `batch` polynomials of 2^log_n elements, polynomial c at data + c*2^log_n.
  * coset_shift: 0 or 1 = plain; otherwise forward = coset_fft(shift) (coefficients scaled by
- * shift^i first). Replaces fft_with_options / ifft_with_options / coset_fft.
+ * shift^i first). Replaces fft_with_options / ifft_with_options / coset_fft. log_n <= 23; an LDE beyond 2^20 points
+ * needs rate_bits <= 3 (the input must be at least 1/8 of the output).
  * Host-buffer form (copies in and out):
  */
 int qpgpu_ntt_batch(qpgpu_ctx *ctx, uint64_t *data, unsigned log_n, size_t batch, int flags,

@@ -9,6 +9,8 @@
 
 using gl::u64;
 
+#define QP_TRY_NTT(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
 struct NttTables {
     uint64_t *d = nullptr;  // device table
 };
@@ -66,16 +68,91 @@ int pick_log_t(int ka, int kb, u64 lanes_total) {
 
 }  // namespace
 
+namespace {
+// Where a transform of at most 2^20 points reads and writes when it is one block of a larger one (ntt_run, L > 20)
+struct Geom {
+    u64 in_col_stride = 0, out_col_stride = 0;   // 0: the transform's own sizes
+    u64 out_mul = 1;          // natural-order output: element k goes to k * out_mul
+    u64 scale = 0;            // inverse: overrides 1/N
+    u64 scratch_off = 0;      // words into ctx->scratch the natural-order intermediate may use
+};
+int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
+             size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift, const Geom &g);
+}  // namespace
+
 // Forward / inverse / coset-LDE transform. log_n_in <= log_n_out; inputs beyond 2^log_n_in are zero.
 int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
             size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift) {
-    if (log_n_out > 20) return ctx->fail(QPGPU_EINVAL, "ntt: log_n > 20 not supported yet");
+    if (log_n_out > 23) return ctx->fail(QPGPU_EINVAL, "ntt: log_n > 23 not supported");
     if (log_n_in > log_n_out) return ctx->fail(QPGPU_EINVAL, "ntt: log_n_in > log_n_out");
     if (batch == 0) return QPGPU_OK;
+    if (coset_shift > 1 && inverse) return ctx->fail(QPGPU_EINVAL, "ntt: coset inverse is ifft + scale; not a single call");
+    if (log_n_out <= 20) return ntt_core(ctx, d_in, d_out, log_n_in, log_n_out, batch, inverse, out_bitrev, coset_shift, Geom());
+
+    // ---- three passes: N = 8 * M0. Pass 0 transforms the top three index bits (stride M0) and applies the twiddle
+    // w_N^(m k); the eight blocks are then independent M0-point transforms (two passes each) whose outputs interleave
+    // (natural order: X[k0 + 8 k']) or land in bit-reversed block order (leaf order). ----
+    const unsigned L = log_n_out, L0 = 3, Li = L - L0;
+    const u64 N = 1ull << L, M0 = 1ull << Li, n_in = 1ull << log_n_in;
+    if (log_n_in < Li) return ctx->fail(QPGPU_EINVAL, "lde: for 2^21..2^23 outputs the input must be at least 1/8 of the output");
+    {
+        static std::once_flag once;
+        static hipError_t init_err = hipSuccess;
+        std::call_once(once, [] { init_err = ntt_pass_init(); });
+        QP_HIP(ctx, init_err);
+    }
+    const std::string dir = inverse ? "i" : "f";
+    const u64 wN = inverse ? gl::inv(gl::root_of_unity(L)) : gl::root_of_unity(L);
+    QP_TRY_NTT(ctx->ensure_scratch((batch * N + (out_bitrev ? 0 : batch * M0)) * sizeof(u64)));
+    uint64_t *mid0 = ctx->scratch;
+    {
+        Split s = split_round((int)L0);
+        NttPassArgs p{};
+        p.inverse = inverse ? 1 : 0;
+        p.ka = s.ka; p.kb = s.kb;
+        p.in = d_in; p.out = mid0;
+        p.in_col_stride = n_in; p.out_col_stride = N;
+        p.log_m = Li; p.lanes_total = M0;
+        p.in_row_stride = 0; p.in_l_stride = 1; p.in_p_stride = M0;
+        p.out_row_stride = 0; p.out_l_stride = 1; p.out_p_stride = M0;
+        p.log_t = pick_log_t(s.ka, s.kb, M0);
+        p.p_valid = (uint32_t)(n_in / M0);
+        p.load_lane_fast = 1; p.store_lane_fast = 1;
+        p.out_bitrev = 0; p.has_out_scale = 0;
+        QP_TRY_NTT(cached(ctx, "in" + dir + std::to_string(L0), gl::pow(wN, M0), 1ull << L0, (uint64_t **)&p.tw_inner));
+        p.tw_lo_bits = (L + 1) / 2;
+        QP_TRY_NTT(cached(ctx, "lo" + dir + std::to_string(L), wN, 1ull << p.tw_lo_bits, (uint64_t **)&p.tw_lo));
+        QP_TRY_NTT(cached(ctx, "hi" + dir + std::to_string(L), gl::pow(wN, 1ull << p.tw_lo_bits), 1ull << (L - p.tw_lo_bits), (uint64_t **)&p.tw_hi));
+        if (coset_shift > 1) {
+            const std::string k = std::to_string(coset_shift) + "_" + std::to_string(Li);
+            QP_TRY_NTT(cached(ctx, "csA" + k + "_" + std::to_string(p.p_valid), gl::pow(coset_shift, M0), p.p_valid, (uint64_t **)&p.in_scale_a));
+            QP_TRY_NTT(cached(ctx, "csB" + k, coset_shift, M0, (uint64_t **)&p.in_scale_b));
+        }
+        const u64 tiles = (M0 + (1ull << p.log_t) - 1) >> p.log_t;
+        ctx->prof_begin("ntt_pass_outer");
+        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream);
+        ctx->prof_end();
+        QP_HIP(ctx, le);
+    }
+    for (unsigned k0 = 0; k0 < (1u << L0); k0++) {
+        Geom g;
+        g.in_col_stride = N; g.out_col_stride = N;
+        g.scale = inverse ? gl::inv(gl::canon(N % gl::P)) : 0;
+        g.scratch_off = batch * N;
+        const unsigned rk = ((k0 & 1) << 2) | (k0 & 2) | (k0 >> 2);
+        uint64_t *out = out_bitrev ? d_out + (u64)rk * M0 : d_out + k0;
+        if (!out_bitrev) g.out_mul = 1ull << L0;
+        QP_TRY_NTT(ntt_core(ctx, mid0 + (u64)k0 * M0, out, Li, Li, batch, inverse, out_bitrev, 0, g));
+    }
+    return QPGPU_OK;
+}
+
+namespace {
+int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
+             size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift, const Geom &g) {
     const unsigned L = log_n_out;
     const u64 N = 1ull << L, n_in = 1ull << log_n_in;
     const bool coset = coset_shift > 1;
-    if (coset && inverse) return ctx->fail(QPGPU_EINVAL, "ntt: coset inverse is ifft + scale; not a single call");
     if (L == 0) {
         if (d_in != d_out) QP_HIP(ctx, hipMemcpyAsync(d_out, d_in, batch * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         return QPGPU_OK;
@@ -90,7 +167,7 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
     const std::string dir = inverse ? "i" : "f";
     const u64 wN = inverse ? gl::inv(gl::root_of_unity(L)) : gl::root_of_unity(L);
     u64 out_scale = 1;
-    if (inverse) out_scale = gl::inv(gl::canon(N % gl::P));
+    if (inverse) out_scale = g.scale ? g.scale : gl::inv(gl::canon(N % gl::P));
 
     const int n_pass = (L <= 10) ? 1 : 2;
     const int L1 = (n_pass == 1) ? (int)L : (int)(L + 1) / 2;
@@ -135,18 +212,20 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
 
     // ---- two passes: N = R1 * M1, pass 1 over the top L1 bits (stride M1), pass 2 on contiguous rows ----
     const u64 R1 = 1ull << L1, M1 = 1ull << L2;
+    const u64 in_cs = g.in_col_stride ? g.in_col_stride : n_in, out_cs = g.out_col_stride ? g.out_col_stride : N;
     uint64_t *mid = d_out;
+    u64 mid_cs = out_cs;
     if (!out_bitrev) {
-        int rc = ctx->ensure_scratch(batch * N * sizeof(u64));
+        int rc = ctx->ensure_scratch((g.scratch_off + batch * N) * sizeof(u64));
         if (rc) return rc;
-        mid = ctx->scratch;
+        mid = ctx->scratch + g.scratch_off; mid_cs = N;
     }
     {
         Split s = split_round(L1);
         NttPassArgs p = a;
         p.ka = s.ka; p.kb = s.kb;
         p.in = d_in; p.out = mid;
-        p.in_col_stride = n_in; p.out_col_stride = N;
+        p.in_col_stride = in_cs; p.out_col_stride = mid_cs;
         p.log_m = L2; p.lanes_total = M1;
         p.in_row_stride = 0; p.in_l_stride = 1; p.in_p_stride = M1;
         p.out_row_stride = 0; p.out_l_stride = 1; p.out_p_stride = M1;
@@ -184,14 +263,14 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
         NttPassArgs p = a;
         p.ka = s.ka; p.kb = s.kb;
         p.in = mid; p.out = d_out;
-        p.in_col_stride = N; p.out_col_stride = N;
+        p.in_col_stride = mid_cs; p.out_col_stride = out_cs;
         p.log_m = 0; p.lanes_total = R1;
         p.in_row_stride = M1; p.in_l_stride = 0; p.in_p_stride = 1;
         p.log_t = pick_log_t(s.ka, s.kb, R1);
         p.p_valid = (uint32_t)M1;
         p.load_lane_fast = 0;
         if (out_bitrev) { p.out_row_stride = M1; p.out_p_stride = 1; p.store_lane_fast = 0; p.out_bitrev = 1; }
-        else { p.out_row_stride = 1; p.out_p_stride = R1; p.store_lane_fast = 1; p.out_bitrev = 0; }
+        else { p.out_row_stride = g.out_mul; p.out_p_stride = R1 * g.out_mul; p.store_lane_fast = 1; p.out_bitrev = 0; }
         p.out_l_stride = 0;
         p.has_out_scale = inverse ? 1 : 0; p.out_scale = out_scale;
         if (s.kb > 0) {
@@ -206,3 +285,4 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
     }
     return QPGPU_OK;
 }
+}  // namespace

@@ -38,7 +38,8 @@ int qpgpu_oracle_commit(qpgpu_ctx *ctx, const uint64_t *polys, uint32_t num_poly
     QP_DEV(ctx);
     *out = nullptr;
     if (!polys || num_polys == 0) return ctx->fail(QPGPU_EINVAL, "oracle_commit: no polynomials");
-    if (degree_bits + rate_bits > 20 || degree_bits < 1) return ctx->fail(QPGPU_EINVAL, "oracle_commit: 2 <= 2^(degree_bits+rate_bits) <= 2^20 supported");
+    if (degree_bits + rate_bits > 23 || degree_bits < 1 || (degree_bits + rate_bits > 20 && rate_bits > 3))
+        return ctx->fail(QPGPU_EINVAL, "oracle_commit: LDE sizes up to 2^23 (rate_bits <= 3 above 2^20) supported");
     if (cap_height > degree_bits + rate_bits) return ctx->fail(QPGPU_EINVAL, "oracle_commit: cap_height exceeds the tree height");
     if (flags & ~7u) return ctx->fail(QPGPU_EINVAL, "oracle_commit: unknown flags");
     QP_TRY(merkle_ensure_constants(ctx));

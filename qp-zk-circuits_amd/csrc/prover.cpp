@@ -110,7 +110,7 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
     if (!err.empty()) { delete c; return ctx->fail(QPGPU_EINVAL, "circuit_load: " + err); }
     const CircuitPack &p = c->pack;
     if (p.num_chunks() > 16 || p.num_challenges > 4) { delete c; return ctx->fail(QPGPU_EINVAL, "circuit_load: too many chunks/challenges"); }
-    if (p.degree_bits + p.rate_bits > 20) { delete c; return ctx->fail(QPGPU_EINVAL, "circuit_load: LDE larger than 2^20 not supported yet"); }
+    if (p.degree_bits + p.rate_bits > 23) { delete c; return ctx->fail(QPGPU_EINVAL, "circuit_load: LDE larger than 2^23 not supported"); }
     const u64 n = p.n(), lde_n = n << p.rate_bits, R = p.num_routed_wires, nch = p.num_challenges;
     const unsigned d = (unsigned)p.degree_bits, L = (unsigned)(p.degree_bits + p.rate_bits);
     int rc = QPGPU_OK;

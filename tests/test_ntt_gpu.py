@@ -128,7 +128,52 @@ def test_baseline_size_properties(gpu, orc):
     d_a.free(); d_f.free()
 
 
+@pytest.mark.parametrize("log_n", [21, 22, 23])
+def test_three_pass_sizes_vs_oracle(gpu, orc, log_n):
+    """2^21..2^23 points (private batches of 9..64 leaves reach an LDE of 2^22): outer pass over the top three index bits,
+    then eight two-pass transforms. Forward, inverse, bit-reversed order and the in-place round trip against the oracle."""
+    batch = 2
+    rng = np.random.default_rng(300 + log_n)
+    a = rng.integers(0, P, (batch, 1 << log_n), dtype=np.uint64)
+    a[1, ::3] = P - 1
+    want = orc.fft_batch(a, log_n)
+    d_a = gpu.to_device(a)
+    d_f = gpu.alloc(a.nbytes)
+    gpu.ntt_dev(d_a, d_f, log_n, batch)
+    gpu.sync()
+    f = d_f.download().reshape(batch, -1)
+    assert np.array_equal(f, want)
+    gpu.ntt_dev(d_a, d_f, log_n, batch, bitrev=True)
+    gpu.sync()
+    assert np.array_equal(d_f.download().reshape(batch, -1), want[:, bitrev_perm(log_n)])
+    gpu.ntt_dev(d_a, d_f, log_n, batch, inverse=True)
+    gpu.sync()
+    assert np.array_equal(d_f.download().reshape(batch, -1), orc.fft_batch(a, log_n, inverse=True))
+    d_f.upload(want)
+    gpu.ntt_dev(d_f, d_f, log_n, batch, inverse=True)          # in place
+    gpu.sync()
+    assert np.array_equal(d_f.download().reshape(batch, -1), a)
+    d_a.free(); d_f.free()
+
+
+@pytest.mark.parametrize("log_n,batch", [(18, 3), (19, 2)])
+def test_three_pass_lde_vs_oracle(gpu, orc, log_n, batch):
+    rate_bits = 3
+    rng = np.random.default_rng(400 + log_n)
+    vals = rng.integers(0, P, (batch, 1 << log_n), dtype=np.uint64)
+    coeffs_want, lde_want = orc.lde_batch(vals, log_n, rate_bits, MULT_GEN)
+    d_coeffs = gpu.to_device(coeffs_want)
+    d_lde = gpu.alloc(vals.nbytes << rate_bits)
+    gpu.lde_dev(d_coeffs, d_lde, log_n, rate_bits, batch, coset_shift=MULT_GEN)
+    gpu.sync()
+    assert np.array_equal(d_lde.download().reshape(batch, -1), lde_want)
+    gpu.lde_dev(d_coeffs, d_lde, log_n, rate_bits, batch, coset_shift=MULT_GEN, bitrev=True)
+    gpu.sync()
+    assert np.array_equal(d_lde.download().reshape(batch, -1), lde_want[:, bitrev_perm(log_n + rate_bits)])
+    d_coeffs.free(); d_lde.free()
+
+
 def test_empty_and_bad_arguments(gpu, pkg):
     assert gpu.ntt_host(np.zeros((0, 8), dtype=np.uint64), 3).shape == (0, 8)
     with pytest.raises(pkg.QpGpuError):
-        gpu.ntt_host(np.zeros((1, 1 << 21), dtype=np.uint64), 21)  # beyond the supported size: loud error
+        gpu.ntt_host(np.zeros((1, 1 << 24), dtype=np.uint64), 24)  # beyond the supported size: loud error

@@ -134,6 +134,39 @@ def test_private_batch_sized_trace_verifies(pkg, gpu, orc):
     oc.close()
 
 
+def test_trace_beyond_2p17_rows(pkg, gpu, orc):
+    """2^18 rows: the LDE is 2^21 points, past the two-pass NTT (private batches of more than 8 leaves get there,
+    reference common/src/circuit.rs:393-395 and wormhole/inputs/src/lib.rs:46). Narrow rows keep the CPU restatement
+    affordable; bytes are compared and the restated verifier accepts."""
+    pack, wires, pis = pkg.synth_circuit(18, num_wires=24, num_routed=16, num_public_inputs=2, seed=43, base_sum=True)
+    circ = pkg.Circuit(gpu, pack)
+    proof = circ.prove(wires, pis)
+    circ.close()
+    oc = OracleCircuit(orc, pack)
+    assert proof == oc.prove(wires, pis)
+    assert oc.verify(proof) == 0
+    oc.close()
+
+
+def test_largest_private_batch_shape(pkg, gpu, orc):
+    """2^19 rows, 135 wires / 60 routed, zero-knowledge, all fourteen gate types: the shape of a 64-leaf private batch (the
+    reference's maximum, wormhole/inputs/src/lib.rs:46); LDE 2^22. The size-independent property: the restated verifier
+    accepts the proof and rejects it after a one-bit change."""
+    pack, wires, pis = pkg.synth_circuit(19, num_routed=60, num_public_inputs=29, seed=44, poseidon=True, base_sum=True,
+                                         ext_arith=True, recursion=True)
+    pack[14] = 1
+    circ = pkg.Circuit(gpu, pack)
+    proof = circ.prove(wires, pis)
+    circ.close()
+    del wires
+    oc = OracleCircuit(orc, pack)
+    assert len(proof) == oc.proof_size()
+    assert oc.verify(proof) == 0
+    bad = bytearray(proof); bad[len(bad) // 3] ^= 2
+    assert oc.verify(bytes(bad)) != 0
+    oc.close()
+
+
 def test_c_example_runs(pkg):
     """The same flow from plain C through the C ABI (no Python in the loop)."""
     import os, subprocess, tempfile
