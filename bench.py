@@ -357,7 +357,7 @@ def main():
         ok = ok and oc.verify(proof) == 0
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
-            threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+            threads = oracle_binding.usable_cpus(16)
             orc.set_threads(threads)
             reps = 0
             t1 = time.perf_counter()

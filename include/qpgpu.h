@@ -58,6 +58,19 @@ int qpgpu_free(qpgpu_ctx *ctx, void *dptr);
 int qpgpu_memcpy_h2d(qpgpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int qpgpu_memcpy_d2h(qpgpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
+/* ---- proof-system hasher -------------------------------------------------------------------------------------
+ * Which permutation backs the fork's `PoseidonGoldilocksConfig` hasher (Merkle trees, Fiat-Shamir challenger, public-input
+ * hash, proof of work) cannot be told from the reference, so it is a process-wide plug:
+ * kind 0 = plonky2's Poseidon (default; constants derived at start-up), kind 1 = Poseidon2 (width 12, x^7, 4+22+4 rounds)
+ * with caller-supplied parameters: 96 external round constants (round major), 22 internal round constants, the 12
+ * diagonal entries d of the internal matrix J + diag(d), and the 4x4 block M4 (row major) of the external matrix
+ * circ(2 M4, M4, M4) — 146 words. Select it before creating circuits or oracles and not while proofs are running. */
+#define QPGPU_HASH_POSEIDON 0
+#define QPGPU_HASH_POSEIDON2 1
+#define QPGPU_POSEIDON2_PARAM_WORDS 146
+int qpgpu_set_hasher(int kind, const uint64_t *params, size_t n_words);
+int qpgpu_get_hasher(void);
+
 /* ---- stage s2: plonky2::field::fft ---- */
 enum {
     QPGPU_NTT_FORWARD = 0,        /* fft:  out[i] = P(w^i), natural order in and out */

@@ -123,7 +123,13 @@ void orc_poseidon_permute_naive(gl_t s[12]) {
         mds_layer_naive(s);
     }
 }
+/* the proof-system permutation is a plug: when a Poseidon2 parameter block has been selected,
+   every sponge, Merkle node, challenger duplexing and proof-of-work evaluation of the oracle uses it instead */
+static const void *g_p2_plug = 0;
+void orc_p2_permute(const void *p, gl_t s[12]);
+void orc_select_hasher_p2(const void *params) { g_p2_plug = params; }   /* NULL: back to Poseidon */
 void orc_poseidon_permute(gl_t s[12]) {
+    if (g_p2_plug) { orc_p2_permute(g_p2_plug, s); return; }
     init_rc();
     int rc = 0;
     for (int r = 0; r < N_FULL_HALF; r++, rc++) {

@@ -67,6 +67,8 @@ def load_library():
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_poseidon_constants": (c.c_size_t, [u64p, u64p, c.c_size_t]),
+        "qpgpu_set_hasher": (c.c_int, [c.c_int, u64p, c.c_size_t]),
+        "qpgpu_get_hasher": (c.c_int, []),
         "qpgpu_witness_info": (c.c_int, [vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)]),
         "qpgpu_witness_free_mask": (c.c_int, [vp, vp, c.c_size_t]),
         "qpgpu_generate_witness_dev": (c.c_int, [vp, u64p, u64p]),
@@ -106,6 +108,21 @@ def exported_symbols():
     hdr = os.path.join(os.path.dirname(_HERE), "include", "qpgpu.h")
     text = open(hdr).read()
     return sorted(set(re.findall(r"\b(qpgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def set_hasher_poseidon():
+    """Process-wide: plonky2's Poseidon backs Merkle trees, challenger, public-input hash and proof of work (the default)."""
+    load_library().qpgpu_set_hasher(0, None, 0)
+
+
+def set_hasher_poseidon2(rc_ext, rc_int, diag_m1, m4):
+    """Process-wide: Poseidon2 with the given parameters (external round constants [8][12], internal [22], diagonal [12],
+    4x4 block) backs the proof-system hasher. Select before loading circuits."""
+    flat = np.concatenate([np.asarray(rc_ext, dtype=np.uint64).ravel(), np.asarray(rc_int, dtype=np.uint64).ravel(),
+                           np.asarray(diag_m1, dtype=np.uint64).ravel(), np.asarray(m4, dtype=np.uint64).ravel()])
+    rc = load_library().qpgpu_set_hasher(1, flat.ctypes.data, flat.size)
+    if rc != 0:
+        raise QpGpuError(rc, "qpgpu_set_hasher: bad Poseidon2 parameter block")
 
 
 def poseidon_constants():

@@ -20,7 +20,7 @@ struct qpgpu_ctx {
     size_t scratch_bytes = 0;
     std::map<std::string, std::shared_ptr<NttTables>> ntt_tables;
     std::vector<void *> owned;  // table allocations freed at destroy
-    bool poseidon_ready = false;  // round constants uploaded to __constant__ memory
+    unsigned hasher_generation = 0;  // hasher::generation() whose constants this ctx last uploaded to __constant__ memory
 
     // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)
     struct KStat { double ms = 0; uint64_t launches = 0; };

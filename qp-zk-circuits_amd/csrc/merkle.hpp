@@ -13,6 +13,8 @@ struct MerkleLeafArgs {
 };
 
 hipError_t merkle_upload_constants(const uint64_t *rc360);
+namespace poseidon2 { struct Params; }
+hipError_t merkle_select_hasher(int kind, const poseidon2::Params *p2);   // which permutation the hashing kernels run
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, hipStream_t st);
 hipError_t merkle_leaf_hash_rows(const uint64_t *rows, uint64_t n_leaves, uint32_t width, uint64_t *digests, hipStream_t st);
 hipError_t merkle_reduce_level(const uint64_t *in, uint64_t *out, uint64_t n_out, hipStream_t st);

@@ -6,11 +6,26 @@
 #include "poseidon.hpp"
 
 int merkle_ensure_constants(qpgpu_ctx *ctx) {
-    if (ctx->poseidon_ready) return QPGPU_OK;
+    if (ctx->hasher_generation == hasher::generation()) return QPGPU_OK;
     QP_HIP(ctx, merkle_upload_constants(poseidon::host_round_constants()));
-    ctx->poseidon_ready = true;
+    QP_HIP(ctx, merkle_select_hasher(hasher::kind(), &hasher::p2_params()));
+    ctx->hasher_generation = hasher::generation();
     return QPGPU_OK;
 }
+
+extern "C" int qpgpu_set_hasher(int kind, const uint64_t *params, size_t n_words) {
+    if (kind == hasher::POSEIDON) { hasher::set(hasher::POSEIDON, nullptr); return QPGPU_OK; }
+    if (kind != hasher::POSEIDON2 || !params || n_words != (size_t)poseidon2::PARAM_WORDS) return QPGPU_EINVAL;
+    poseidon2::Params p;
+    const uint64_t *w = params;
+    for (int i = 0; i < 96; i++) p.rc_ext[i] = gl::canon(*w++);
+    for (int i = 0; i < 22; i++) p.rc_int[i] = gl::canon(*w++);
+    for (int i = 0; i < 12; i++) p.diag_m1[i] = gl::canon(*w++);
+    for (int i = 0; i < 16; i++) p.m4[i] = gl::canon(*w++);
+    hasher::set(hasher::POSEIDON2, &p);
+    return QPGPU_OK;
+}
+extern "C" int qpgpu_get_hasher(void) { return hasher::kind(); }
 
 // digests: level 0 (n_leaves) then each parent level down to the cap level, concatenated.
 int merkle_build(qpgpu_ctx *ctx, const MerkleLeafArgs &leaf, unsigned log_leaves, unsigned cap_height, uint64_t *d_digests) {

@@ -18,14 +18,28 @@ using gl::u64;
 
 __constant__ u64 c_poseidon_rc[poseidon::ROUNDS * poseidon::WIDTH];
 
+__constant__ poseidon2::Params c_p2;
+static int g_dev_kind = 0;     // which permutation the launch wrappers instantiate (hasher::Kind), set with the constants
+
 hipError_t merkle_upload_constants(const u64 *rc360) {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
+}
+hipError_t merkle_select_hasher(int kind, const poseidon2::Params *p2) {
+    if (kind == hasher::POSEIDON2 && p2) {
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_p2), p2, sizeof(poseidon2::Params));
+        if (e != hipSuccess) return e;
+    }
+    g_dev_kind = kind;
+    return hipSuccess;
 }
 
 namespace {
 
 struct PoseidonV1 {
     static __device__ __forceinline__ void permute(u64 (&s)[12]) { poseidon::permute(s, c_poseidon_rc); }
+};
+struct Poseidon2P {   // the parameter plug: same sponge and tree code, other permutation
+    static __device__ __forceinline__ void permute(u64 (&s)[12]) { poseidon2::permute(s, c_p2); }
 };
 
 // leaf j = [src0 cols..., src1 cols...] at slot j (each source column-major with its own stride).
@@ -192,6 +206,7 @@ __global__ void permute_kernel(u64 *states, u64 n) {
 
 // s10 fri_proof_of_work: candidate nonce at `pos` of the pre-absorbed duplex state; accept when the last rate
 // element has >= pow_bits leading zeros; result = minimum accepted nonce in [base, base + count).
+template <class Perm>
 __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
     const u64 idx = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (idx >= a.count) return;
@@ -199,7 +214,7 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = (i == (int)a.pos) ? nonce : a.state[i];
-    poseidon::permute(s, c_poseidon_rc);
+    Perm::permute(s);
     if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin((unsigned long long *)a.result, (unsigned long long)nonce);
 }
 
@@ -208,7 +223,8 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
 hipError_t pk_pow(const PowArgs &a, hipStream_t st) {
     if (a.count == 0) return hipSuccess;
     dim3 b(256), g((unsigned)((a.count + 255) / 256));
-    hipLaunchKernelGGL(pow_kernel, g, b, 0, st, a);
+    if (g_dev_kind == hasher::POSEIDON2) hipLaunchKernelGGL((pow_kernel<Poseidon2P>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((pow_kernel<PoseidonV1>), g, b, 0, st, a);
     return hipGetLastError();
 }
 
@@ -223,41 +239,48 @@ static const u64 COOP_MAX = coop_max_init();
 
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, hipStream_t st) {
     if (a.n_leaves == 0) return hipSuccess;
-    if (a.n_leaves <= COOP_MAX / 2) {
+    const bool p2 = g_dev_kind == hasher::POSEIDON2;   // the lane-cooperative kernels exist for Poseidon only
+    if (!p2 && a.n_leaves <= COOP_MAX / 2) {
         dim3 block(256), grid((unsigned)((a.n_leaves * 16 + 255) / 256));
         hipLaunchKernelGGL(leaf_cols_coop_kernel, grid, block, 0, st, a);
         return hipGetLastError();
     }
     dim3 block(256), grid((unsigned)((a.n_leaves + 255) / 256));
-    hipLaunchKernelGGL((leaf_hash_kernel<PoseidonV1>), grid, block, 0, st, a);
+    if (p2) hipLaunchKernelGGL((leaf_hash_kernel<Poseidon2P>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((leaf_hash_kernel<PoseidonV1>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, hipStream_t st) {
     if (n_leaves == 0) return hipSuccess;
-    if (n_leaves <= COOP_MAX) {
+    const bool p2 = g_dev_kind == hasher::POSEIDON2;
+    if (!p2 && n_leaves <= COOP_MAX) {
         dim3 block(256), grid((unsigned)((n_leaves * 16 + 255) / 256));
         hipLaunchKernelGGL(leaf_rows_coop_kernel, grid, block, 0, st, rows, n_leaves, width, digests);
         return hipGetLastError();
     }
     dim3 block(256), grid((unsigned)((n_leaves + 255) / 256));
-    hipLaunchKernelGGL((leaf_hash_rows_kernel<PoseidonV1>), grid, block, 0, st, rows, n_leaves, width, digests);
+    if (p2) hipLaunchKernelGGL((leaf_hash_rows_kernel<Poseidon2P>), grid, block, 0, st, rows, n_leaves, width, digests);
+    else hipLaunchKernelGGL((leaf_hash_rows_kernel<PoseidonV1>), grid, block, 0, st, rows, n_leaves, width, digests);
     return hipGetLastError();
 }
 hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, hipStream_t st) {
     if (n_out == 0) return hipSuccess;
-    if (n_out <= COOP_MAX) {
+    const bool p2 = g_dev_kind == hasher::POSEIDON2;
+    if (!p2 && n_out <= COOP_MAX) {
         dim3 block(256), grid((unsigned)((n_out * 16 + 255) / 256));
         hipLaunchKernelGGL(node_coop_kernel, grid, block, 0, st, in, out, n_out);
         return hipGetLastError();
     }
     unsigned threads = n_out >= 256 ? 256 : 64;
     dim3 block(threads), grid((unsigned)((n_out + threads - 1) / threads));
-    hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out);
+    if (p2) hipLaunchKernelGGL((node_kernel<Poseidon2P>), grid, block, 0, st, in, out, n_out);
+    else hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out);
     return hipGetLastError();
 }
 hipError_t poseidon_permute_batch(u64 *states, u64 n, hipStream_t st) {
     if (n == 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL((permute_kernel<PoseidonV1>), grid, block, 0, st, states, n);
+    if (g_dev_kind == hasher::POSEIDON2) hipLaunchKernelGGL((permute_kernel<Poseidon2P>), grid, block, 0, st, states, n);
+    else hipLaunchKernelGGL((permute_kernel<PoseidonV1>), grid, block, 0, st, states, n);
     return hipGetLastError();
 }

@@ -146,3 +146,71 @@ void derive_round_constants(u64 *out360);
 const u64 *host_round_constants();
 
 }  // namespace poseidon
+
+// ---- Poseidon2 (width 12, x^7, 4 + 22 + 4 rounds) as a parameter plug ----
+// The qp fork ships a second hash family whose constants (qp-poseidon-core 3.1.0) are not available offline, and which
+// permutation backs the proof-system hasher of the fork cannot be told from the reference: the
+// Merkle / challenger permutation is therefore selectable, with the Poseidon2 parameters injected by the caller.
+namespace poseidon2 {
+using gl::u64;
+struct Params {
+    u64 rc_ext[8 * 12];   // external (full) round constants
+    u64 rc_int[22];       // internal (partial) round constants, element 0 only
+    u64 diag_m1[12];      // internal matrix = J + diag(diag_m1)
+    u64 m4[16];           // 4x4 block of the external matrix circ(2 M4, M4, M4), row major
+};
+constexpr int PARAM_WORDS = 96 + 22 + 12 + 16;
+
+GL_HD void ext_layer(u64 (&s)[12], const Params &p) {
+    u64 t[12];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            u64 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = gl::add(acc, gl::mul(p.m4[4 * i + j], s[4 * b + j]));
+            t[4 * b + i] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 sum = gl::add(gl::add(t[i], t[4 + i]), t[8 + i]);
+#pragma unroll
+        for (int b = 0; b < 3; b++) s[4 * b + i] = gl::add(t[4 * b + i], sum);
+    }
+}
+GL_HD void permute(u64 (&s)[12], const Params &p) {
+    ext_layer(s, p);
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = poseidon::sbox7(gl::add(s[i], p.rc_ext[r * 12 + i]));
+        ext_layer(s, p);
+    }
+    for (int r = 0; r < 22; r++) {
+        s[0] = poseidon::sbox7(gl::add(s[0], p.rc_int[r]));
+        u64 sum = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) sum = gl::add(sum, s[i]);
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl::add(gl::mul(s[i], p.diag_m1[i]), sum);
+    }
+    for (int r = 4; r < 8; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = poseidon::sbox7(gl::add(s[i], p.rc_ext[r * 12 + i]));
+        ext_layer(s, p);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+}
+}  // namespace poseidon2
+
+// ---- process-wide choice of the proof-system permutation (Merkle trees, challenger, public-input hash, PoW) ----
+namespace hasher {
+enum Kind : int { POSEIDON = 0, POSEIDON2 = 1 };
+int kind();
+unsigned generation();                        // bumped by every change; device copies are refreshed lazily
+const poseidon2::Params &p2_params();
+void set(int kind, const poseidon2::Params *p);
+// the selected permutation on the host (challenger, small hashes)
+void host_permute(gl::u64 (&s)[12]);
+}  // namespace hasher

@@ -31,7 +31,7 @@ void host_hash_no_pad(const u64 *in, size_t n, u64 out[4]) {
     for (size_t i = 0; i < n; i += 8) {
         size_t len = std::min<size_t>(8, n - i);
         for (size_t k = 0; k < len; k++) st[k] = gl::canon(in[i + k]);
-        poseidon::permute(st, poseidon::host_round_constants());
+        hasher::host_permute(st);
     }
     std::memcpy(out, st, 32);
 }

@@ -15,6 +15,19 @@ def _vp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def usable_cpus(cap=16):
+    """Threads worth starting: the affinity mask, the cgroup CPU quota when there is one, and a cap. OpenMP's default
+    (every CPU of the host) oversubscribes a container with a CPU quota and makes the spin-waiting runtime crawl."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 class Oracle:
     def __init__(self):
         so = os.path.join(ORACLE_DIR, "liboracle.so")
@@ -65,13 +78,25 @@ class Oracle:
         L.orc_trace_get.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
         L.orc_poseidon_fast_partial.restype = ctypes.c_size_t; L.orc_poseidon_fast_partial.argtypes = [ctypes.c_void_p]
         L.orc_p2_params_size.restype = ctypes.c_size_t
+        L.orc_select_hasher_p2.argtypes = [ctypes.c_void_p]
         L.orc_p2_permute.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_p2_hash_pad10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.orc_bytes_to_u64s.restype = ctypes.c_size_t
         L.orc_bytes_to_u64s.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         L.orc_bytes_to_digest.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
         L.orc_digest_to_bytes.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.orc_set_threads(usable_cpus())
 
+    def select_poseidon2(self, rc_ext, rc_int, diag_m1, m4):
+        """Proof-system permutation := Poseidon2 with these parameters (kept alive here); select_poseidon() undoes it."""
+        buf = np.zeros(self.lib.orc_p2_params_size() // 8, dtype=np.uint64)
+        flat = np.concatenate([np.asarray(rc_ext, dtype=np.uint64).ravel(), np.asarray(rc_int, dtype=np.uint64).ravel(),
+                               np.asarray(diag_m1, dtype=np.uint64).ravel(), np.asarray(m4, dtype=np.uint64).ravel()])
+        buf[:flat.size] = flat
+        self._p2 = buf
+        self.lib.orc_select_hasher_p2(_vp(buf))
+    def select_poseidon(self):
+        self.lib.orc_select_hasher_p2(None); self._p2 = None
     def set_threads(self, n): self.lib.orc_set_threads(int(n))
     def max_threads(self): return int(self.lib.orc_max_threads())
 
