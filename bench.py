@@ -143,15 +143,6 @@ def main():
     pool_gen = ThreadPoolExecutor(max_workers=1)
     gathered = None
 
-    def step():
-        # S independent proofs in flight on this GPU (ctypes releases the GIL inside the C ABI)
-        futs = [pool.submit(circs[i].prove_dev, w_t, pis, outs[i]) for i in range(S)]
-        proofs = [f.result() for f in futs]
-        if world > 1:   # aggregation step's input: every rank's proof bytes gathered over xGMI (RCCL)
-            nonlocal gathered
-            gathered = pkg.sharding.gather_proof_bytes(proofs, dist, coll_dev)
-        return proofs[0]
-
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -160,28 +151,25 @@ def main():
 
     import queue
 
-    def run_steps(k):
-        """k steps = k proofs on each of the S streams. The streams are independent pipelines: a worker never waits for
-        the others. The main thread closes step j when every stream has delivered its j-th proof and, with several
-        ranks, gathers that step's proof bytes over RCCL while the workers are already proving step j+1."""
-        qs = [queue.Queue() for _ in range(S)]
+    prover_pool = pkg.ProvingPool(pack, workers=S, device=local_rank)   # S proofs in flight: streams, circuit copies and
+                                                                        # transcript threads live inside the library
 
-        def worker(i):
-            for _ in range(k):
-                qs[i].put(circs[i].prove_dev(w_t, pis, outs[i]))
-        futs = [pool.submit(worker, i) for i in range(S)]
+    def run_steps(k):
+        """k steps = k*S proofs through the library's proving pool. All jobs are queued at once and the workers free-run;
+        the main thread closes step j when its S proofs are written and, with several ranks, gathers that step's proof
+        bytes over RCCL while the workers are already proving step j+1."""
+        bufs = [np.empty(proof_len, dtype=np.uint8) for _ in range(k * S)]
+        tickets = [prover_pool.submit(w_t, pis, bufs[i]) for i in range(k * S)]
         last = None
         nonlocal gathered
-        for _ in range(k):
-            proofs = [q.get() for q in qs]
+        for j in range(k):
+            proofs = [prover_pool.wait(t) for t in tickets[j * S:(j + 1) * S]]
             if world > 1:
                 gathered = pkg.sharding.gather_proof_bytes(proofs, dist, coll_dev)
             last = proofs[0]
-        for f in futs:
-            f.result()
         return last
 
-    proof = run_steps(args.warmup) if args.warmup > 0 else step()
+    proof = run_steps(max(args.warmup, 1))
     barrier()
     t0 = time.perf_counter()
     proof = run_steps(args.steps)
@@ -380,7 +368,8 @@ def main():
             ok = ok and ntt_ok and bool(np.array_equal(col_out, orc.fft(col_in, 20)))
             extra["roofline"] = roof
             extra["ntt_2p20_fwd_inv_GBps"] = round(gbs, 1)
-    pool.shutdown()
+    pool.shutdown(); pool_gen.shutdown()
+    prover_pool.close()
     for c_ in circs:
         c_.close()
     for g_ in gpus:

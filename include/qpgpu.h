@@ -223,6 +223,21 @@ int qpgpu_fri_prove(qpgpu_ctx *ctx, qpgpu_oracle *const *oracles, uint32_t num_o
                     uint32_t num_batches, const qpgpu_fri_params *params, qpgpu_challenger *challenger,
                     uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* ---- proving pool: several proofs of one circuit in flight on one GPU ------------------------------------------
+ * The native counterpart of the reference's dedicated proving worker (wormhole/aggregator/src/aggregator.rs:14-43):
+ * `workers` host threads, each with its own context (HIP stream) and loaded copy of the circuit, fed from one queue.
+ * One proof leaves most of the GPU idle between its latency-bound stages; four workers reach the throughput plateau.
+ * submit() never blocks; wait() blocks until that proof is written (tickets may be waited for in any order, once). The
+ * witness matrices and output buffers must stay valid until their ticket has been waited for. */
+typedef struct qpgpu_pool qpgpu_pool;
+int qpgpu_pool_create(int device, const uint64_t *pack_words, size_t n_words, unsigned workers, qpgpu_pool **out);
+void qpgpu_pool_destroy(qpgpu_pool *p);          /* drains the queue first */
+size_t qpgpu_pool_proof_size(const qpgpu_pool *p);
+unsigned qpgpu_pool_workers(const qpgpu_pool *p);
+const char *qpgpu_pool_last_error(const qpgpu_pool *p);
+int qpgpu_pool_submit(qpgpu_pool *p, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, uint64_t *ticket);
+int qpgpu_pool_wait(qpgpu_pool *p, uint64_t ticket, size_t *out_len);
+
 /* Hash constants the library derives at start-up (host only, no GPU): the 360 Poseidon round constants and plonky2's
  * FAST_PARTIAL_* tables flattened as FIRST[12] | RC[22] | VS[22][11] | W_HATS[22][11] | INIT[11][11] (row c of INIT
  * produces element 1+c). Returns the number of words of the second table. */

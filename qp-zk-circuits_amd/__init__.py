@@ -8,5 +8,5 @@ The directory name carries a hyphen (it mirrors the reference repository's name)
 imported through `__graft_entry__.load_package()` under the module name `qp_zk_circuits_amd`.
 """
 from .binding import poseidon_constants, synth_circuit, Circuit, QpGpu, QpGpuError, lib_path, load_library, P, MULT_GEN  # noqa: F401
-from .binding import PolyOracle, Challenger, fri_prove, set_hasher_poseidon, set_hasher_poseidon2  # noqa: F401
+from .binding import PolyOracle, Challenger, fri_prove, set_hasher_poseidon, set_hasher_poseidon2, ProvingPool  # noqa: F401
 from . import sharding  # noqa: F401,E402

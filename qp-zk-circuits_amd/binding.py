@@ -67,6 +67,13 @@ def load_library():
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_poseidon_constants": (c.c_size_t, [u64p, u64p, c.c_size_t]),
+        "qpgpu_pool_create": (c.c_int, [c.c_int, u64p, c.c_size_t, c.c_uint, c.POINTER(vp)]),
+        "qpgpu_pool_destroy": (None, [vp]),
+        "qpgpu_pool_proof_size": (c.c_size_t, [vp]),
+        "qpgpu_pool_workers": (c.c_uint, [vp]),
+        "qpgpu_pool_last_error": (c.c_char_p, [vp]),
+        "qpgpu_pool_submit": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
+        "qpgpu_pool_wait": (c.c_int, [vp, c.c_uint64, c.POINTER(c.c_size_t)]),
         "qpgpu_set_hasher": (c.c_int, [c.c_int, u64p, c.c_size_t]),
         "qpgpu_get_hasher": (c.c_int, []),
         "qpgpu_witness_info": (c.c_int, [vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)]),
@@ -364,6 +371,49 @@ def fri_prove(gpu, oracles, batches, challenger, reduction_arity_bits, rate_bits
     gpu._check(gpu.lib.qpgpu_fri_prove(gpu.ctx, hs, len(oracles), ctypes.byref(bs), len(batches), ctypes.byref(prm),
                                        ctypes.byref(challenger.state), out.ctypes.data, out.size, ctypes.byref(ln)))
     return out[:ln.value].tobytes()
+
+
+class ProvingPool:
+    """Several proofs of one circuit in flight on one GPU (qpgpu_pool_*): worker threads, streams and circuit copies live
+    inside the library."""
+
+    def __init__(self, pack_words, workers=4, device=0):
+        self.lib = load_library()
+        pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
+        h = ctypes.c_void_p()
+        rc = self.lib.qpgpu_pool_create(device, pw.ctypes.data, pw.size, workers, ctypes.byref(h))
+        if rc != 0:
+            raise QpGpuError(rc, "qpgpu_pool_create failed")
+        self.h = h
+        self._keep = {}
+
+    def close(self):
+        if self.h:
+            self.lib.qpgpu_pool_destroy(self.h)
+            self.h = None
+
+    def proof_size(self):
+        return self.lib.qpgpu_pool_proof_size(self.h)
+
+    def submit(self, d_wires, public_inputs, out=None):
+        """Queue one proof of a device-resident witness; returns a ticket for wait()."""
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        if out is None:
+            out = np.empty(self.proof_size(), dtype=np.uint8)
+        t = ctypes.c_uint64()
+        rc = self.lib.qpgpu_pool_submit(self.h, _ptr(d_wires), p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(t))
+        if rc != 0:
+            raise QpGpuError(rc, self.lib.qpgpu_pool_last_error(self.h).decode())
+        self._keep[t.value] = (p, out, d_wires)
+        return t.value
+
+    def wait(self, ticket):
+        ln = ctypes.c_size_t()
+        rc = self.lib.qpgpu_pool_wait(self.h, ticket, ctypes.byref(ln))
+        p, out, _ = self._keep.pop(ticket, (None, None, None))
+        if rc != 0:
+            raise QpGpuError(rc, self.lib.qpgpu_pool_last_error(self.h).decode())
+        return out[:ln.value].tobytes()
 
 
 class _Stage3:

@@ -246,3 +246,40 @@ def test_witness_check_reports_unsat(pkg, gpu, orc):
     circ.set_witness_check(False)
     assert oc.verify(circ.prove(w, pis)) != 0     # without the check the proof is produced and simply does not verify
     circ.close(); oc.close()
+
+
+def test_proving_pool(pkg, gpu, orc):
+    """qpgpu_pool_*: twelve proofs (three different witnesses / public inputs) over four workers, waited for out of
+    order; every proof equals the CPU restatement's; errors surface per ticket."""
+    pack, wires, pis = pkg.synth_circuit(9, seed=91, poseidon=True, base_sum=True)
+    oc = OracleCircuit(orc, pack)
+    circ = pkg.Circuit(gpu, pack)
+    mask = circ.witness_free_mask(*wires.shape)
+    variants = []
+    for b in range(3):
+        part = np.where(mask == 1, wires, 0).astype(np.uint64)
+        if b:
+            col = next(c for c in (0, 1, 2, 4, 5, 6) if mask[c, 3])
+            part[col, 3] = np.uint64(1000 + b)
+        p_b = (pis + np.uint64(b)) % np.uint64(0xFFFFFFFF00000001)
+        full = circ.generate_witness(part, p_b)
+        variants.append((gpu.to_device(full), p_b, oc.prove(full, p_b)))
+    circ.close()
+    pool = pkg.ProvingPool(pack, workers=4)
+    try:
+        assert pool.proof_size() == oc.proof_size()
+        tickets = [(pool.submit(variants[i % 3][0], variants[i % 3][1]), i % 3) for i in range(12)]
+        for t, v in reversed(tickets):
+            assert pool.wait(t) == variants[v][2]
+        with pytest.raises(pkg.QpGpuError):
+            pool.wait(tickets[0][0])                       # a ticket is waited for once
+        small = np.empty(16, dtype=np.uint8)
+        t = pool.submit(variants[0][0], variants[0][1], out=small)
+        with pytest.raises(pkg.QpGpuError):
+            pool.wait(t)                                   # output buffer too small: reported on the ticket
+        assert pool.wait(pool.submit(variants[1][0], variants[1][1])) == variants[1][2]    # the pool keeps working
+    finally:
+        pool.close()
+        for d, _, _ in variants:
+            d.free()
+        oc.close()
