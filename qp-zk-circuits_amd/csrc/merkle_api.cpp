@@ -7,7 +7,7 @@
 
 int merkle_ensure_constants(qpgpu_ctx *ctx) {
     if (ctx->hasher_generation == hasher::generation()) return QPGPU_OK;
-    QP_HIP(ctx, merkle_upload_constants(poseidon::host_round_constants()));
+    QP_HIP(ctx, merkle_upload_constants(poseidon::host_hash_round_constants()));
     QP_HIP(ctx, merkle_select_hasher(hasher::kind(), &hasher::p2_params()));
     ctx->hasher_generation = hasher::generation();
     return QPGPU_OK;

@@ -91,7 +91,11 @@ GL_HD void mds_layer(u64 (&s)[WIDTH]) {
     }
 }
 
-// rc: 360 canonical round constants
+// rc: the 360-entry table of host_hash_round_constants(): same layout as the round constants, with the partial rounds'
+// constants pushed onto lane 0. In a partial round lanes 1..11 skip the S-box, so the lane-1..11 part of a round's
+// constant vector commutes with it and can be carried through the MDS matrix into the next round: only the first
+// partial round adds a full vector, the others add one scalar, and what is left over after the last partial round is
+// folded into the constants of the following full round. Same function, 231 fewer modular additions.
 GL_HD void permute(u64 (&s)[WIDTH], const u64 *rc) {
     int r = 0;
     for (int k = 0; k < HALF_FULL; k++, r++) {
@@ -99,10 +103,10 @@ GL_HD void permute(u64 (&s)[WIDTH], const u64 *rc) {
         for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add_canonical(s[i], rc[r * WIDTH + i]));
         mds_layer(s);
     }
-    for (int k = 0; k < PARTIAL; k++, r++) {
 #pragma unroll
-        for (int i = 0; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
-        s[0] = sbox7(s[0]);
+    for (int i = 1; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
+    for (int k = 0; k < PARTIAL; k++, r++) {
+        s[0] = sbox7(gl::add_canonical(s[0], rc[r * WIDTH]));
         mds_layer(s);
     }
     for (int k = 0; k < HALF_FULL; k++, r++) {
@@ -111,6 +115,17 @@ GL_HD void permute(u64 (&s)[WIDTH], const u64 *rc) {
         mds_layer(s);
     }
 #pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
+}
+// the textbook schedule on the plain round constants (cross-check of the table above)
+GL_HD void permute_textbook(u64 (&s)[WIDTH], const u64 *rc) {
+    int r = 0;
+    for (int k = 0; k < ROUNDS; k++, r++) {
+        const bool full = k < HALF_FULL || k >= HALF_FULL + PARTIAL;
+        for (int i = 0; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
+        for (int i = 0; i < (full ? WIDTH : 1); i++) s[i] = sbox7(s[i]);
+        mds_layer_naive(s);
+    }
     for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
 }
 
@@ -143,7 +158,8 @@ const u64 *host_fast_partial();   // FP_WORDS entries, derived at start-up (pose
 
 // host: derive the 360 round constants (ChaCha8, seed 0, rand 0.8 gen_range(0..p))
 void derive_round_constants(u64 *out360);
-const u64 *host_round_constants();
+const u64 *host_round_constants();        // plonky2's ALL_ROUND_CONSTANTS (PoseidonGate, fast-partial derivation)
+const u64 *host_hash_round_constants();   // the table permute() takes (see there)
 
 }  // namespace poseidon
 

@@ -65,6 +65,44 @@ const u64 *host_round_constants() {
     return g_rc;
 }
 
+// ---- the hashing kernels' table: partial-round constants pushed onto lane 0 (poseidon.hpp: permute) ----
+namespace {
+u64 g_rc_hash[ROUNDS * WIDTH];
+std::once_flag g_hash_once;
+void derive_hash_constants() {
+    const u64 *rc = host_round_constants();
+    std::memcpy(g_rc_hash, rc, sizeof g_rc_hash);
+    // x_r = s_r + c_r. With u_r = s_r + b_r - d_r (b_r = c_r without lane 0, d_r the carried vector, d_0 = 0):
+    //   u_{r+1} = M sbox0(u_r + k_r e0) + alpha_{r+1} e0,   M d_r + b_{r+1} = alpha_{r+1} e0 + d_{r+1},   k_r = c_r[0] + alpha_r
+    u64 d[WIDTH] = {0};
+    u64 alpha = 0;
+    for (int r = 0; r < PARTIAL; r++) {
+        u64 *row = g_rc_hash + (HALF_FULL + r) * WIDTH;
+        const u64 *c = rc + (HALF_FULL + r) * WIDTH;
+        row[0] = gl::canon(gl::add(c[0], alpha));
+        for (int i = 1; i < WIDTH; i++) row[i] = r == 0 ? c[i] : 0;
+        // M d_r + b_{r+1}
+        u64 md[WIDTH];
+        for (int i = 0; i < WIDTH; i++) md[i] = d[i];
+        mds_layer_naive(md);
+        if (r + 1 < PARTIAL) {
+            const u64 *cn = rc + (HALF_FULL + r + 1) * WIDTH;
+            alpha = gl::canon(md[0]);
+            d[0] = 0;
+            for (int i = 1; i < WIDTH; i++) d[i] = gl::canon(gl::add(md[i], cn[i]));
+        } else {
+            // s after the last partial round = M sbox0(..) + M d_21: fold M d_21 into the next full round's constants
+            u64 *nxt = g_rc_hash + (HALF_FULL + PARTIAL) * WIDTH;
+            for (int i = 0; i < WIDTH; i++) nxt[i] = gl::canon(gl::add(nxt[i], gl::canon(md[i])));
+        }
+    }
+}
+}  // namespace
+const u64 *host_hash_round_constants() {
+    std::call_once(g_hash_once, derive_hash_constants);
+    return g_rc_hash;
+}
+
 // ---- fast partial rounds: the published HADES optimisation, written for column vectors ----
 namespace {
 typedef std::vector<std::vector<u64>> Mat;
@@ -163,6 +201,6 @@ void set(int k, const poseidon2::Params *p) {
 }
 void host_permute(gl::u64 (&s)[12]) {
     if (g_kind == POSEIDON2) poseidon2::permute(s, g_p2);
-    else poseidon::permute(s, poseidon::host_round_constants());
+    else poseidon::permute(s, poseidon::host_hash_round_constants());
 }
 }  // namespace hasher
