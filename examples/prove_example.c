@@ -1,6 +1,7 @@
 /*
  * prove_example.c — the C ABI used from plain C, the way a Rust `extern "C"` block would use it
- * (INTEGRATION.md): build a synthetic leaf-shaped circuit, load it, prove twice, check determinism.
+ * (INTEGRATION.md): build a synthetic leaf-shaped circuit, load it, prove twice, check determinism; then regenerate the
+ * witness on the device from its free cells and push eight proofs through a four-worker proving pool.
  *
  *   gcc -O2 -I include examples/prove_example.c -L qp-zk-circuits_amd -lqpgpu -Wl,-rpath,$PWD/qp-zk-circuits_amd -o /tmp/prove_example
  */
@@ -30,6 +31,37 @@ int main(int argc, char **argv) {
     if (len1 != cap || len2 != cap || memcmp(p1, p2, cap)) { fprintf(stderr, "non-deterministic proof\n"); return 3; }
     /* a too-small buffer is an error, not an overrun */
     if (qpgpu_prove(circuit, wires, pis, p2, cap - 1, &len2) != QPGPU_EBUFSIZE) { fprintf(stderr, "missing EBUFSIZE\n"); return 4; }
+    /* stage s1 on the device: keep only the caller-supplied cells, regenerate the rest, same proof */
+    {
+        const size_t cells = (size_t)num_wires << degree_bits;
+        uint8_t *mask = malloc(cells);
+        uint64_t *partial = malloc(cells * 8);
+        CHECK(qpgpu_witness_free_mask(circuit, mask, cells));
+        for (size_t i = 0; i < cells; i++) partial[i] = mask[i] ? wires[i] : 0;
+        CHECK(qpgpu_generate_witness(circuit, partial, pis));
+        if (memcmp(partial, wires, cells * 8)) { fprintf(stderr, "generated witness differs\n"); return 5; }
+        free(mask); free(partial);
+    }
+    /* throughput: eight proofs through a pool of four workers (own streams and circuit copies inside the library) */
+    {
+        qpgpu_pool *pool = NULL;
+        void *d_wires = NULL;
+        const size_t bytes = (size_t)num_wires * 8 << degree_bits;
+        CHECK(qpgpu_malloc(ctx, bytes, &d_wires));
+        CHECK(qpgpu_memcpy_h2d(ctx, d_wires, wires, bytes));
+        if (qpgpu_pool_create(0, pack, got, 4, &pool)) { fprintf(stderr, "pool_create failed\n"); return 6; }
+        uint8_t *outs = malloc(8 * cap);
+        uint64_t tickets[8];
+        for (int i = 0; i < 8; i++)
+            if (qpgpu_pool_submit(pool, d_wires, pis, outs + (size_t)i * cap, cap, &tickets[i])) { fprintf(stderr, "submit: %s\n", qpgpu_pool_last_error(pool)); return 6; }
+        for (int i = 0; i < 8; i++) {
+            size_t len = 0;
+            if (qpgpu_pool_wait(pool, tickets[i], &len) || len != cap || memcmp(outs + (size_t)i * cap, p1, cap)) { fprintf(stderr, "pool proof %d differs: %s\n", i, qpgpu_pool_last_error(pool)); return 7; }
+        }
+        qpgpu_pool_destroy(pool);
+        CHECK(qpgpu_free(ctx, d_wires));
+        free(outs);
+    }
     uint64_t h = 1469598103934665603ull;
     for (size_t i = 0; i < cap; i++) h = (h ^ p1[i]) * 1099511628211ull;
     printf("ok degree_bits=%u proof_bytes=%zu fnv1a=%016llx\n", degree_bits, cap, (unsigned long long)h);
