@@ -102,7 +102,7 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
     c->num_selectors = w[p++]; c->num_challenges = w[p++]; c->qdf = w[p++]; c->num_pp = w[p++]; c->num_pis = w[p++];
     c->rate_bits = w[p++]; c->cap_height = w[p++]; c->pow_bits = w[p++]; c->num_queries = w[p++]; c->zk = w[p++];
     c->num_gate_constraints = w[p++]; c->n_gates = w[p++]; c->n_arity = w[p++];
-    if (c->n_arity > 16 || c->num_challenges > MAXC) { free(c); return NULL; }
+    if (c->n_arity > 16 || c->num_challenges > MAXC || c->cap_height > 8) { free(c); return NULL; }
     for (size_t i = 0; i < c->n_arity; i++) c->arity[i] = w[p++];
     c->gates = (orc_gate *)malloc(sizeof(orc_gate) * c->n_gates);
     memcpy(c->gates, w + p, sizeof(orc_gate) * c->n_gates); p += 8 * c->n_gates;
@@ -747,7 +747,7 @@ int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public
         size_t nl = cur_len >> ab;
         gl_t *leaves = (gl_t *)malloc(sizeof(gl_t) * cur_len * 2);
         for (size_t j = 0; j < cur_len; j++) { gl2_t v = values[bitrev32((uint32_t)j, logc)]; leaves[2 * j] = v.c[0]; leaves[2 * j + 1] = v.c[1]; }
-        gl_t *dig = (gl_t *)malloc(sizeof(gl_t) * 4 * 2 * nl), capv[64 * 4];
+        gl_t *dig = (gl_t *)malloc(sizeof(gl_t) * 4 * 2 * nl), capv[256 * 4];   /* cap_height <= 8 (reference common/src/circuit.rs:455-470) */
         orc_merkle_build(leaves, nl, 2 * arity, ch_h, dig, capv);
         tree_digests[r] = dig; tree_leaves[r] = leaves; tree_nleaves[r] = nl;
         w_vec(&fri_caps, capv, cap_words);

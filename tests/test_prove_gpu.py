@@ -283,3 +283,47 @@ def test_proving_pool(pkg, gpu, orc):
         for d, _, _ in variants:
             d.free()
         oc.close()
+
+
+@pytest.mark.parametrize("nch", [1, 3, 4])
+def test_other_challenge_counts(pkg, gpu, orc, nch):
+    """num_challenges other than the production 2 (a memprof sweep knob, reference wormhole/memprof/src/config.rs:36-50)."""
+    pack, wires, pis = pkg.synth_circuit(7, seed=95, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+    pack[6] = nch
+    oc = OracleCircuit(orc, pack); circ = pkg.Circuit(gpu, pack)
+    try:
+        got = circ.prove(wires, pis)
+        assert got == oc.prove(wires, pis) and oc.verify(got) == 0
+    finally:
+        circ.close(); oc.close()
+
+
+def _with_fri_config(pack, cap_height=None, pow_bits=None, num_queries=None):
+    """Rewrite the FRI knobs of a circuit pack (header words 11..13) and the ConstantArityBits(4, 5) reduction schedule
+    that depends on the cap height."""
+    pack = np.array(pack, dtype=np.uint64)
+    d, rate, n_ar = int(pack[1]), int(pack[10]), int(pack[17])
+    head, rest = pack[:18].copy(), pack[18 + n_ar:]
+    if cap_height is not None: head[11] = cap_height
+    if pow_bits is not None: head[12] = pow_bits
+    if num_queries is not None: head[13] = num_queries
+    cap, arity, dd = int(head[11]), [], d
+    while dd > 5 and dd + rate >= cap + 4:
+        arity.append(4); dd -= 4
+    head[17] = len(arity)
+    return np.concatenate([head, np.array(arity, dtype=np.uint64), rest])
+
+
+@pytest.mark.parametrize("knobs", [dict(cap_height=0), dict(cap_height=2, num_queries=1), dict(cap_height=6, pow_bits=0),
+                                   dict(cap_height=8, pow_bits=8, num_queries=40), dict(pow_bits=18, num_queries=3)])
+def test_fri_configuration_knobs(pkg, gpu, orc, knobs):
+    """cap_height 0..8, proof-of-work bits and query counts away from the production values (the memprof sweep knobs and
+    the profile configurations of the reference, wormhole/circuit/src/profile.rs:135-174, common/src/circuit.rs:455-470)."""
+    pack, wires, pis = pkg.synth_circuit(9, seed=96, poseidon=True, base_sum=True)
+    pack = _with_fri_config(pack, **knobs)
+    oc = OracleCircuit(orc, pack); circ = pkg.Circuit(gpu, pack)
+    try:
+        got = circ.prove(wires, pis)
+        assert got == oc.prove(wires, pis) and oc.verify(got) == 0
+    finally:
+        circ.close(); oc.close()
