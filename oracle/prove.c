@@ -102,7 +102,7 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
     c->num_selectors = w[p++]; c->num_challenges = w[p++]; c->qdf = w[p++]; c->num_pp = w[p++]; c->num_pis = w[p++];
     c->rate_bits = w[p++]; c->cap_height = w[p++]; c->pow_bits = w[p++]; c->num_queries = w[p++]; c->zk = w[p++];
     c->num_gate_constraints = w[p++]; c->n_gates = w[p++]; c->n_arity = w[p++];
-    if (c->n_arity > 16 || c->num_challenges > MAXC || c->cap_height > 8) { free(c); return NULL; }
+    if (c->n_arity > 16 || c->num_challenges > MAXC || c->cap_height > 8 || c->rate_bits > 8 || c->qdf > ((uint64_t)1 << c->rate_bits)) { free(c); return NULL; }
     for (size_t i = 0; i < c->n_arity; i++) c->arity[i] = w[p++];
     c->gates = (orc_gate *)malloc(sizeof(orc_gate) * c->n_gates);
     memcpy(c->gates, w + p, sizeof(orc_gate) * c->n_gates); p += 8 * c->n_gates;
@@ -604,13 +604,15 @@ int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public
     orc_challenger_get_n(&ch, alphas, nch);
     trace_put("alphas", alphas, nch);
 
-    /* s6: quotient polynomials on the coset g<w_{8n}> */
+    /* s6: quotient polynomials on the coset g<w_{n qdf}>: every `step`-th point of the LDE (compute_quotient_polys) */
+    unsigned qbits = 0; while (((uint64_t)1 << qbits) < c->qdf) qbits++;
+    const size_t q_n = n << qbits, step = (size_t)1 << (rb - qbits);
     gl_t *quot = (gl_t *)malloc(sizeof(gl_t) * nch * lde_n);
     {
-        gl_t zh_inv[64];
+        gl_t zh_inv[256];
         gl_t gn = gl_pow(GL_MULT_GEN, n), wr = gl_root_of_unity(rb);
         size_t rate = (size_t)1 << rb;
-        gl_t zh[64];
+        gl_t zh[256];
         for (size_t i = 0; i < rate; i++) { zh[i] = gl_sub(gl_mul(gn, gl_pow(wr, i)), 1); zh_inv[i] = gl_inv(zh[i]); }
         gl_t wl = gl_root_of_unity(L), n_f = (gl_t)n;
         const size_t nterms = nch + nch * nchunks + c->num_gate_constraints;
@@ -618,7 +620,8 @@ int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public
         {
             gl_t *terms = (gl_t *)malloc(sizeof(gl_t) * nterms), *num = (gl_t *)malloc(sizeof(gl_t) * R), *den = (gl_t *)malloc(sizeof(gl_t) * R);
 #pragma omp for schedule(static)
-            for (long i = 0; i < (long)lde_n; i++) {
+            for (long iq = 0; iq < (long)q_n; iq++) {
+                const size_t i = (size_t)iq * step;   /* index on the LDE domain */
                 gl_t x = gl_mul(GL_MULT_GEN, gl_pow(wl, (uint64_t)i));
                 const gl_t *w_row = batch_lde_row(&wb, i), *cs_row = batch_lde_row(&c->cs, i), *z_row = batch_lde_row(&zb, i);
                 const gl_t *z_next = batch_lde_row(&zb, (i + rate) % lde_n);
@@ -643,15 +646,15 @@ int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public
                 for (size_t k = 0; k < nch; k++) {
                     gl_t acc = 0;   /* reduce_with_powers: sum terms[j] * alpha^j */
                     for (size_t j = nterms; j-- > 0;) acc = gl_add(gl_mul(acc, alphas[k]), terms[j]);
-                    quot[k * lde_n + i] = gl_mul(acc, zh_inv[i % rate]);
+                    quot[k * q_n + (size_t)iq] = gl_mul(acc, zh_inv[i % rate]);
                 }
             }
             free(terms); free(num); free(den);
         }
     }
-    trace_put("quotient_values", quot, nch * lde_n);
+    trace_put("quotient_values", quot, nch * q_n);
 #pragma omp parallel for
-    for (long k = 0; k < (long)nch; k++) orc_coset_ifft(quot + (size_t)k * lde_n, L, GL_MULT_GEN);
+    for (long k = 0; k < (long)nch; k++) orc_coset_ifft(quot + (size_t)k * q_n, d + qbits, GL_MULT_GEN);
     /* each quotient poly (8n coefficients) is split into qdf chunks of n: contiguous => nch*qdf columns of n */
     const size_t nq = nch * c->qdf;
     orc_batch qb;

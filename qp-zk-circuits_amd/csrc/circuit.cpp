@@ -54,7 +54,8 @@ std::string CircuitPack::validate() const {
     if (num_routed_wires > num_wires) return "num_routed_wires > num_wires";
     if (num_challenges == 0 || num_challenges > 4) return "unsupported num_challenges";
     if (quotient_degree_factor == 0 || (quotient_degree_factor & (quotient_degree_factor - 1))) return "quotient_degree_factor must be a power of two";
-    if ((1ull << rate_bits) != quotient_degree_factor) return "this backend requires quotient_degree_factor == 2^rate_bits";
+    if (quotient_degree_factor > (1ull << rate_bits)) return "quotient_degree_factor exceeds the blowup 2^rate_bits";
+    if (rate_bits > 8) return "rate_bits above 8";
     if (num_partial_products + 1 != (num_routed_wires + quotient_degree_factor - 1) / quotient_degree_factor) return "num_partial_products inconsistent";
     if (cap_height > degree_bits + rate_bits) return "cap_height above tree height";
     if (zero_knowledge > 1) return "zero_knowledge must be 0 or 1";

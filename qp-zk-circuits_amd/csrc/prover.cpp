@@ -231,6 +231,10 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     const size_t ncs = p.num_cs_cols(), NW = p.num_wires, nzp = p.num_zs_pp_cols(), nq = p.num_quotient_cols();
     const size_t sig0 = p.num_selectors + p.num_constants, cap_words = (1ull << cap_h) * 4;
     const size_t nterms = nch + nch * nchunks + p.num_gate_constraints;
+    // the quotient lives on the coset of size n * quotient_degree_factor: every 2^q_shift-th point of the LDE, i.e. its first q_n slots
+    unsigned qbits = 0; while ((1ull << qbits) < p.quotient_degree_factor) qbits++;
+    const unsigned Lq = d + qbits, q_shift = (unsigned)p.rate_bits - qbits;
+    const u64 q_n = 1ull << Lq;
 
     c->stage.pos = 0;
     u64 pih[4];
@@ -288,7 +292,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
         QuotientArgs ta{};
         ta.wires = d_wires; ta.cs = c->d_cs_values; ta.alpha_pows = d_apow; ta.pi_hash = d_pih; ta.gates = c->d_gates;
         ta.acc = c->d_qacc; ta.out = c->d_qacc; ta.poseidon_rc = c->d_poseidon_rc; ta.poseidon_fast = c->d_poseidon_fast;
-        ta.zh_inv = c->d_zh_inv; ta.lde_n = n; ta.log_lde = d; ta.rate = 1; ta.nch = nch; ta.num_routed = (uint32_t)R;
+        ta.zh_inv = c->d_zh_inv; ta.lde_n = n; ta.q_n = n; ta.q_shift = 0; ta.log_lde = d; ta.rate = 1; ta.nch = nch; ta.num_routed = (uint32_t)R;
         ta.chunk = (uint32_t)p.quotient_degree_factor; ta.nchunks = nchunks; ta.sig0 = (uint32_t)sig0;
         ta.num_selectors = (uint32_t)p.num_selectors; ta.num_gates = (uint32_t)p.gates.size(); ta.nterms = (uint32_t)nterms;
         QP_HIP(ctx, hipMemsetAsync(c->d_qacc, 0, (size_t)nch * n * 8, st));
@@ -306,13 +310,14 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
     QuotientArgs qa{};
     qa.wires = c->wires.lde; qa.cs = c->cs.lde; qa.zs_pp = c->zs.lde; qa.x_coset = c->d_x_coset; qa.l0_coset = c->d_l0_coset;
     qa.zh_inv = c->d_zh_inv; qa.alpha_pows = d_apow; qa.beta_k_is = d_bk; qa.betas = d_betas; qa.gammas = d_gammas; qa.pi_hash = d_pih;
-    qa.gates = c->d_gates; qa.acc = c->d_qacc; qa.poseidon_rc = c->d_poseidon_rc; qa.poseidon_fast = c->d_poseidon_fast; qa.out = c->quot.coeffs; qa.lde_n = lde_n; qa.log_lde = L; qa.rate = 1u << p.rate_bits; qa.nch = nch;
+    qa.gates = c->d_gates; qa.acc = c->d_qacc; qa.poseidon_rc = c->d_poseidon_rc; qa.poseidon_fast = c->d_poseidon_fast; qa.out = c->quot.coeffs; qa.lde_n = lde_n; qa.q_n = q_n; qa.q_shift = q_shift; qa.log_lde = L; qa.rate = 1u << p.rate_bits; qa.nch = nch;
     qa.num_routed = (uint32_t)R; qa.chunk = (uint32_t)p.quotient_degree_factor; qa.nchunks = nchunks; qa.sig0 = (uint32_t)sig0;
     qa.num_selectors = (uint32_t)p.num_selectors; qa.num_gates = (uint32_t)p.gates.size(); qa.nterms = (uint32_t)nterms;
     QP_HIP(ctx, pk_quotient(qa, c->h_gates.data(), st));
-    // coset_ifft(g): ifft then scale coefficient i by g^-i; the 8n coefficients are the qdf chunks of n, contiguous
-    QP_TRY(ntt_run(ctx, c->quot.coeffs, c->quot.coeffs, L, L, nch, true, false, 0));
-    QP_HIP(ctx, pk_scale_powers(c->quot.coeffs, lde_n, nch, c->d_ginv_lo, c->d_ginv_hi, c->ginv_lo_bits, st));
+    // coset_ifft(g) on the quotient domain: ifft then scale coefficient i by g^-i; the qdf*n coefficients of a challenge
+    // are its qdf chunks of n, contiguous
+    QP_TRY(ntt_run(ctx, c->quot.coeffs, c->quot.coeffs, Lq, Lq, nch, true, false, 0));
+    QP_HIP(ctx, pk_scale_powers(c->quot.coeffs, q_n, nch, c->d_ginv_lo, c->d_ginv_hi, c->ginv_lo_bits, st));
     ctx->prof_end();
     ctx->prof_begin("prove_commit_quotient");
     QP_TRY(commit_coeffs(c, c->quot));

@@ -117,7 +117,7 @@ __device__ __forceinline__ u64 gate_filter(const QuotientArgs &a, u32 gi, u64 s)
 template <int NCH>
 __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (j >= a.lde_n) return;
+    if (j >= a.q_n) return;
     const u32 logL = a.log_lde, R = a.num_routed, chunk = a.chunk, nchunks = a.nchunks, npp = nchunks - 1;
     const u64 i = brev32((u32)j, logL);
     const u64 jn = brev32((u32)((i + a.rate) & (a.lde_n - 1)), logL);   // slot of the next row g*x
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
 template <int NCH>
 __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (j >= a.lde_n) return;
+    if (j >= a.q_n) return;
     const u64 S = a.lde_n;
     u64 acc[NCH];
 #pragma unroll
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
         const u64 i = brev32((u32)j, a.log_lde);
         const u64 zi = a.zh_inv[i & (a.rate - 1)];
 #pragma unroll
-        for (int c = 0; c < NCH; c++) a.out[(u64)c * S + i] = gl::canon(gl::mul(acc[c], zi));
+        for (int c = 0; c < NCH; c++) a.out[(u64)c * a.q_n + (i >> a.q_shift)] = gl::canon(gl::mul(acc[c], zi));
     } else {
 #pragma unroll
         for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = acc[c];
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
 template <int NCH>
 __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, u32 gi, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (j >= a.lde_n) return;
+    if (j >= a.q_n) return;
     const u64 S = a.lde_n;
     const u64 *ap = a.alpha_pows + t0;
     auto W = [&](u32 i) -> u64 { return a.wires[(u64)i * S + j]; };
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
         const u64 i = brev32((u32)j, a.log_lde);
         const u64 zi = a.zh_inv[i & (a.rate - 1)];
 #pragma unroll
-        for (int c = 0; c < NCH; c++) a.out[(u64)c * S + i] = gl::canon(gl::mul(gl::add(a.acc[(u64)c * S + j], gl::mul(f, sum[c])), zi));
+        for (int c = 0; c < NCH; c++) a.out[(u64)c * a.q_n + (i >> a.q_shift)] = gl::canon(gl::mul(gl::add(a.acc[(u64)c * S + j], gl::mul(f, sum[c])), zi));
     } else {
 #pragma unroll
         for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = gl::add(a.acc[(u64)c * S + j], gl::mul(f, sum[c]));
@@ -581,7 +581,7 @@ hipError_t pk_pp_finish(const PpArgs &a, const u64 *z, u64 *zs_pp, hipStream_t s
 }
 template <int NCH>
 static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
-    dim3 b(256), g((unsigned)((a.lde_n + 255) / 256));
+    dim3 b(256), g((unsigned)((a.q_n + 255) / 256));
     const u32 t0 = a.nch + a.nch * a.nchunks;
     // Poseidon gates (heavy, one launch each) come last; the final launch also applies 1/Z_H and stores
     int n_pos = 0;
@@ -599,7 +599,7 @@ static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gat
 // gate kernels only (no permutation terms, no 1/Z_H): used by the witness check on the trace rows
 template <int NCH>
 static hipError_t gates_only_launch(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
-    dim3 b(256), g((unsigned)((a.lde_n + 255) / 256));
+    dim3 b(256), g((unsigned)((a.q_n + 255) / 256));
     const u32 t0 = a.nch + a.nch * a.nchunks;
     hipLaunchKernelGGL((quotient_gates_kernel<NCH>), g, b, 0, st, a, t0, 0);
     for (u32 i = 0; i < a.num_gates; i++)
@@ -620,7 +620,7 @@ hipError_t pk_witness_check(const u64 *acc, u64 n, u32 nch, const u64 *z, const 
     return hipGetLastError();
 }
 hipError_t pk_quotient(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
-    if (a.lde_n == 0) return hipSuccess;
+    if (a.q_n == 0) return hipSuccess;
     switch (a.nch) {
         case 1: return quotient_launch<1>(a, host_gates, st);
         case 2: return quotient_launch<2>(a, host_gates, st);

@@ -29,7 +29,9 @@ struct QuotientArgs {
     const uint64_t *poseidon_fast;        // FAST_PARTIAL_* tables, poseidon::FP_WORDS entries
     uint64_t *acc;                        // [nch][lde_n] slot order: running alpha-weighted sums between the s6 kernels
     uint64_t *out;                        // [nch][lde_n] natural order
-    uint64_t lde_n;
+    uint64_t lde_n;                       // column stride of the LDE batches (slots)
+    uint64_t q_n;                         // points the quotient is evaluated on: the first q_n slots = the coset g<w_{n*qdf}>
+    uint32_t q_shift;                     // rate_bits - log2(quotient_degree_factor): natural LDE index >> q_shift = quotient index
     uint32_t log_lde, rate, nch, num_routed, chunk, nchunks, sig0, num_selectors, num_gates, nterms;
 };
 

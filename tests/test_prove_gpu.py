@@ -298,12 +298,14 @@ def test_other_challenge_counts(pkg, gpu, orc, nch):
         circ.close(); oc.close()
 
 
-def _with_fri_config(pack, cap_height=None, pow_bits=None, num_queries=None):
+def _with_fri_config(pack, cap_height=None, pow_bits=None, num_queries=None, rate_bits=None):
     """Rewrite the FRI knobs of a circuit pack (header words 11..13) and the ConstantArityBits(4, 5) reduction schedule
     that depends on the cap height."""
     pack = np.array(pack, dtype=np.uint64)
-    d, rate, n_ar = int(pack[1]), int(pack[10]), int(pack[17])
+    d, n_ar = int(pack[1]), int(pack[17])
     head, rest = pack[:18].copy(), pack[18 + n_ar:]
+    if rate_bits is not None: head[10] = rate_bits
+    rate = int(head[10])
     if cap_height is not None: head[11] = cap_height
     if pow_bits is not None: head[12] = pow_bits
     if num_queries is not None: head[13] = num_queries
@@ -321,6 +323,21 @@ def test_fri_configuration_knobs(pkg, gpu, orc, knobs):
     the profile configurations of the reference, wormhole/circuit/src/profile.rs:135-174, common/src/circuit.rs:455-470)."""
     pack, wires, pis = pkg.synth_circuit(9, seed=96, poseidon=True, base_sum=True)
     pack = _with_fri_config(pack, **knobs)
+    oc = OracleCircuit(orc, pack); circ = pkg.Circuit(gpu, pack)
+    try:
+        got = circ.prove(wires, pis)
+        assert got == oc.prove(wires, pis) and oc.verify(got) == 0
+    finally:
+        circ.close(); oc.close()
+
+
+@pytest.mark.parametrize("rate_bits,queries", [(4, 21), (5, 17), (6, 14)])
+def test_blowup_above_the_quotient_degree(pkg, gpu, orc, rate_bits, queries):
+    """rate_bits > log2(quotient_degree_factor): the quotient is evaluated on every 2^(rate_bits-3)-th point of the LDE
+    (plonky2's compute_quotient_polys `step`); the reference sweeps this knob with the query count adjusted
+    (wormhole/memprof/src/config.rs:60-75, 278-292)."""
+    pack, wires, pis = pkg.synth_circuit(9, seed=97, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+    pack = _with_fri_config(pack, rate_bits=rate_bits, num_queries=queries)
     oc = OracleCircuit(orc, pack); circ = pkg.Circuit(gpu, pack)
     try:
         got = circ.prove(wires, pis)
