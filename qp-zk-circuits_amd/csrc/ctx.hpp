@@ -39,6 +39,11 @@ struct qpgpu_ctx {
         return QPGPU_EDEVICE;
     }
     int ensure_scratch(size_t bytes);
+    // small device-to-host reads on the proving path (caps, openings, query data): through a pinned bounce buffer, then a
+    // stream sync — a pageable destination makes the runtime stage the copy itself, tens of microseconds per read
+    void *h_pin = nullptr;
+    size_t h_pin_bytes = 0;
+    int read_back(void *host_dst, const void *dev_src, size_t bytes);
     int upload(const std::vector<uint64_t> &host, uint64_t **dptr);
 };
 

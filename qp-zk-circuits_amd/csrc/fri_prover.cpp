@@ -39,8 +39,7 @@ int oracle_commit_coeffs(qpgpu_ctx *ctx, PolyOracle &o, u64 blinding_seed) {
     QP_TRY(merkle_build(ctx, a, L, o.cap_h, o.digests));
     const size_t total = digest_words(L, o.cap_h);
     o.cap.resize((1ull << o.cap_h) * 4);
-    QP_HIP(ctx, hipMemcpyAsync(o.cap.data(), o.digests + total - o.cap.size(), o.cap.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    QP_TRY(ctx->read_back(o.cap.data(), o.digests + total - o.cap.size(), o.cap.size() * 8));
     return QPGPU_OK;
 }
 
@@ -173,8 +172,7 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
             u64 cnt = 1ull << log_leaves; u64 *lvl = w.digests[r];
             while (cnt > (1ull << cap_h)) { QP_HIP(ctx, merkle_reduce_level(lvl, lvl + cnt * 4, cnt / 2, st)); lvl += cnt * 4; cnt >>= 1; }
             std::vector<u64> capv(cap_words);
-            QP_HIP(ctx, hipMemcpyAsync(capv.data(), lvl, cap_words * 8, hipMemcpyDeviceToHost, st));
-            QP_HIP(ctx, hipStreamSynchronize(st));
+            QP_TRY(ctx->read_back(capv.data(), lvl, cap_words * 8));
             fri_caps.push_back(capv);
         }
         tree_log_leaves.push_back(log_leaves);
@@ -191,8 +189,7 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
         }
     }
     std::vector<u64> final_coeffs(2 * valid);   // component arrays [a...][b...]
-    QP_HIP(ctx, hipMemcpyAsync(final_coeffs.data(), coef, final_coeffs.size() * 8, hipMemcpyDeviceToHost, st));
-    QP_HIP(ctx, hipStreamSynchronize(st));
+    QP_TRY(ctx->read_back(final_coeffs.data(), coef, final_coeffs.size() * 8));
     ctx->prof_end();
     std::vector<e2> final_poly(valid);
     for (u64 i = 0; i < valid; i++) final_poly[i] = gl::e2_make(final_coeffs[i], final_coeffs[valid + i]);
@@ -211,12 +208,11 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
         bool found = false;
         for (u64 base = 0; !found; base += batch) {
             const u64 sentinel = ~0ull;
-            QP_HIP(ctx, hipMemcpyAsync(w.pow, &sentinel, 8, hipMemcpyHostToDevice, st));
+            QP_HIP(ctx, hipMemsetAsync(w.pow, 0xFF, 8, st));
             pw.base = base; pw.count = batch;
             QP_HIP(ctx, pk_pow(pw, st));
             u64 res = 0;
-            QP_HIP(ctx, hipMemcpyAsync(&res, w.pow, 8, hipMemcpyDeviceToHost, st));
-            QP_HIP(ctx, hipStreamSynchronize(st));
+            QP_TRY(ctx->read_back(&res, w.pow, 8));
             if (res != sentinel) { pow_witness = res; found = true; }
             if (base > (1ull << 40)) return ctx->fail(QPGPU_EDEVICE, "prove: proof of work not found");
         }
@@ -260,8 +256,7 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
     }
     if (goff != w.gather_words) return ctx->fail(QPGPU_EDEVICE, "prove: internal gather size mismatch");
     std::vector<u64> gathered(goff);
-    QP_HIP(ctx, hipMemcpyAsync(gathered.data(), w.gather, goff * 8, hipMemcpyDeviceToHost, st));
-    QP_HIP(ctx, hipStreamSynchronize(st));
+    QP_TRY(ctx->read_back(gathered.data(), w.gather, goff * 8));
     ctx->prof_end();
 
     // ---- FriProof bytes (util::serialization write_fri_proof): caps, query rounds, final poly, pow witness ----

@@ -1,6 +1,7 @@
 // ntt_plan.cpp — host-side planning for the NTT passes: pass split, twiddle tables, launches.
 // Replaces the root-table / dispatch logic of plonky2::field::fft (fft_root_table, fft_dispatch).
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include "ctx.hpp"
@@ -20,6 +21,20 @@ int qpgpu_ctx::ensure_scratch(size_t bytes) {
     if (scratch) { QP_HIP(this, hipStreamSynchronize(stream)); QP_HIP(this, hipFree(scratch)); scratch = nullptr; scratch_bytes = 0; }
     QP_HIP(this, hipMalloc((void **)&scratch, bytes));
     scratch_bytes = bytes;
+    return QPGPU_OK;
+}
+
+int qpgpu_ctx::read_back(void *host_dst, const void *dev_src, size_t bytes) {
+    if (bytes == 0) return QPGPU_OK;
+    if (bytes > h_pin_bytes) {
+        if (h_pin) { QP_HIP(this, hipStreamSynchronize(stream)); (void)hipHostFree(h_pin); h_pin = nullptr; h_pin_bytes = 0; }
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        QP_HIP(this, hipHostMalloc(&h_pin, want, hipHostMallocDefault));
+        h_pin_bytes = want;
+    }
+    QP_HIP(this, hipMemcpyAsync(h_pin, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+    QP_HIP(this, hipStreamSynchronize(stream));
+    memcpy(host_dst, h_pin, bytes);
     return QPGPU_OK;
 }
 

@@ -344,8 +344,7 @@ static int prove_impl(qpgpu_circuit *c, const u64 *d_wires, const u64 *public_in
         QP_HIP(ctx, pk_poly_eval(c->zs.coeffs, n, nch, c->d_points + 1, 1, nullptr, c->d_open + n_open, st));
     }
     std::vector<e2> open(n_open + nch);
-    QP_HIP(ctx, hipMemcpyAsync(open.data(), c->d_open, open.size() * sizeof(e2), hipMemcpyDeviceToHost, st));
-    QP_HIP(ctx, hipStreamSynchronize(st));
+    QP_TRY(ctx->read_back(open.data(), c->d_open, open.size() * sizeof(e2)));
     ctx->prof_end();
     ch.observe((const u64 *)open.data(), n_open * 2);
     ch.observe((const u64 *)(open.data() + n_open), (size_t)nch * 2);

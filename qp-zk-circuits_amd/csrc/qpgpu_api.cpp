@@ -73,6 +73,7 @@ void qpgpu_ctx_destroy(qpgpu_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->owned) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
