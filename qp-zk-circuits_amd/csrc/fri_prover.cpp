@@ -170,7 +170,8 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
         QP_HIP(ctx, merkle_leaf_hash_rows(rows, 1ull << log_leaves, (uint32_t)(2 * arity), w.digests[r], st));
         {
             u64 cnt = 1ull << log_leaves; u64 *lvl = w.digests[r];
-            while (cnt > (1ull << cap_h)) { QP_HIP(ctx, merkle_reduce_level(lvl, lvl + cnt * 4, cnt / 2, st)); lvl += cnt * 4; cnt >>= 1; }
+            QP_HIP(ctx, merkle_reduce_to_cap(lvl, cnt, 1ull << cap_h, st));
+            while (cnt > (1ull << cap_h)) { lvl += cnt * 4; cnt >>= 1; }
             std::vector<u64> capv(cap_words);
             QP_TRY(ctx->read_back(capv.data(), lvl, cap_words * 8));
             fri_caps.push_back(capv);

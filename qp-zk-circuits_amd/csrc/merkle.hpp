@@ -18,4 +18,5 @@ hipError_t merkle_select_hasher(int kind, const poseidon2::Params *p2);   // whi
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, hipStream_t st);
 hipError_t merkle_leaf_hash_rows(const uint64_t *rows, uint64_t n_leaves, uint32_t width, uint64_t *digests, hipStream_t st);
 hipError_t merkle_reduce_level(const uint64_t *in, uint64_t *out, uint64_t n_out, hipStream_t st);
+hipError_t merkle_reduce_to_cap(uint64_t *levels, uint64_t cnt, uint64_t cap_n, hipStream_t st);   // all levels above `levels`, the top fused
 hipError_t poseidon_permute_batch(uint64_t *states, uint64_t n, hipStream_t st);

@@ -36,15 +36,8 @@ int merkle_build(qpgpu_ctx *ctx, const MerkleLeafArgs &leaf, unsigned log_leaves
     hipError_t e = merkle_leaf_hash(leaf, ctx->stream);
     ctx->prof_end();
     QP_HIP(ctx, e);
-    uint64_t cnt = 1ull << log_leaves;
-    uint64_t *lvl = d_digests;
     ctx->prof_begin("merkle_nodes");
-    while (cnt > (1ull << cap_height)) {
-        uint64_t *next = lvl + cnt * 4;
-        e = merkle_reduce_level(lvl, next, cnt / 2, ctx->stream);
-        if (e != hipSuccess) break;
-        lvl = next; cnt >>= 1;
-    }
+    e = merkle_reduce_to_cap(d_digests, 1ull << log_leaves, 1ull << cap_height, ctx->stream);
     ctx->prof_end();
     QP_HIP(ctx, e);
     return QPGPU_OK;
@@ -86,12 +79,9 @@ int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t
     if (rc) return rc;
     uint64_t cnt = 1ull << log_leaves;
     QP_HIP(ctx, merkle_leaf_hash_rows(d_rows, cnt, width, d_digests, ctx->stream));
+    QP_HIP(ctx, merkle_reduce_to_cap(d_digests, cnt, 1ull << cap_height, ctx->stream));
     uint64_t *lvl = d_digests;
-    while (cnt > (1ull << cap_height)) {
-        uint64_t *next = lvl + cnt * 4;
-        QP_HIP(ctx, merkle_reduce_level(lvl, next, cnt / 2, ctx->stream));
-        lvl = next; cnt >>= 1;
-    }
+    while (cnt > (1ull << cap_height)) { lvl += cnt * 4; cnt >>= 1; }
     if (h_cap_out) {
         size_t cap_n = (size_t)1 << cap_height;
         QP_HIP(ctx, hipMemcpyAsync(h_cap_out, lvl, cap_n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

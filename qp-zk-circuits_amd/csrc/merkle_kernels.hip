@@ -112,6 +112,33 @@ __global__ void __launch_bounds__(256) node_coop_kernel(const u64 *in, u64 *out,
     if (live && g < 4) out[grp * 4 + g] = s;
 }
 
+// The top of a tree in one launch: workgroup b owns the subtree under cap entry b (m <= 32 digests of the input level),
+// keeps the current level in LDS and walks up to its root, one lane-cooperative permutation deep per level (at most one
+// wave per SIMD, waves without a live node only wait at the barrier); every level is also written to the digest array
+// (Merkle paths read it). Replaces up to five latency-bound launches.
+__global__ void __launch_bounds__(256) tree_top_kernel(u64 *levels, u64 cnt, u32 m) {
+    __shared__ u64 buf[2][32 * 4];
+    const u32 t = threadIdx.x, b = blockIdx.x;
+    const int lane = t & 63, g = lane & 15, base = lane & 48;
+    const u32 grp = t >> 4, wave_first = (t >> 6) << 2;
+    for (u32 i = t; i < m * 4; i += blockDim.x) buf[0][i] = levels[(u64)b * m * 4 + i];
+    __syncthreads();
+    u64 *out = levels + cnt * 4;          // next level in the digest array
+    u64 level_cnt = cnt / 2;
+    int cur = 0;
+    for (u32 nodes = m / 2; nodes >= 1; nodes >>= 1) {
+        if (wave_first < nodes) {
+            const bool live = grp < nodes;
+            u64 s = (live && g < 8) ? buf[cur][grp * 8 + g] : 0;
+            s = coop_permute(s, g, base);
+            if (live && g < 4) { buf[cur ^ 1][grp * 4 + g] = s; out[((u64)b * nodes + grp) * 4 + g] = s; }
+        }
+        __syncthreads();
+        cur ^= 1;
+        out += level_cnt * 4; level_cnt >>= 1;
+    }
+}
+
 // one 16-lane group per row-major leaf
 __global__ void __launch_bounds__(256) leaf_rows_coop_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests) {
     const u64 grp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
@@ -276,6 +303,23 @@ hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, hipStream_t s
     if (p2) hipLaunchKernelGGL((node_kernel<Poseidon2P>), grid, block, 0, st, in, out, n_out);
     else hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out);
     return hipGetLastError();
+}
+// every level from `cnt` digests (at `levels`, the following levels stored behind it) down to the cap
+hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, hipStream_t st) {
+    u64 *lvl = levels;
+    while (cnt > cap_n) {
+        const u64 m = cnt / cap_n;
+        // latency knob: the fused top saves ~0.1 ms of a single 2^13-row proof and costs ~3 % of the four-in-flight throughput
+        static const bool fuse_top = [] { const char *e = getenv("QPGPU_TREE_TOP"); return e ? atoi(e) != 0 : false; }();
+        if (fuse_top && g_dev_kind != hasher::POSEIDON2 && m <= 32 && cap_n <= 65535 && COOP_MAX >= 64) {
+            hipLaunchKernelGGL(tree_top_kernel, dim3((unsigned)cap_n), dim3(256), 0, st, lvl, cnt, (u32)m);
+            return hipGetLastError();
+        }
+        hipError_t e = merkle_reduce_level(lvl, lvl + cnt * 4, cnt / 2, st);
+        if (e != hipSuccess) return e;
+        lvl += cnt * 4; cnt >>= 1;
+    }
+    return hipSuccess;
 }
 hipError_t poseidon_permute_batch(u64 *states, u64 n, hipStream_t st) {
     if (n == 0) return hipSuccess;
