@@ -91,8 +91,8 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree-bits", type=int, default=13)
     ap.add_argument("--streams", type=int, default=4, help="proofs in flight per GPU (one HIP stream + workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
