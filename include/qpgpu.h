@@ -6,7 +6,7 @@
  *   wormhole/aggregator/src/private_batch/prover/lib.rs:326-330 (private batch prove)
  *   wormhole/aggregator/src/public_batch/prover/lib.rs:301-305  (public batch prove)
  * The entry points below are what a patched qp-plonky2 `plonk::prover::prove` would bind, stage by
- * stage (SURVEY.md §8a rows s2..s12), plus the all-in-one qpgpu_prove. INTEGRATION.md shows the
+ * stage (SURVEY.md §8a rows s1..s12), plus the all-in-one qpgpu_prove. INTEGRATION.md shows the
  * Rust `extern "C"` block. Plain pointers and sizes only; the caller owns every host buffer; device
  * memory is owned by the library behind opaque handles (or raw device pointers the caller got from
  * qpgpu_malloc / its own allocator). All field elements are little-endian u64; inputs may be any

@@ -344,3 +344,17 @@ def test_blowup_above_the_quotient_degree(pkg, gpu, orc, rate_bits, queries):
         assert got == oc.prove(wires, pis) and oc.verify(got) == 0
     finally:
         circ.close(); oc.close()
+
+
+def test_quotient_degree_factor_16(pkg, gpu, orc):
+    """max_quotient_degree_factor 16 (another memprof sweep knob): permutation chunks of 16 wires, 16 quotient chunks per
+    challenge, blowup 2^4."""
+    pack, wires, pis = pkg.synth_circuit(8, seed=98, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+    pack = _with_fri_config(pack, rate_bits=4, num_queries=21)
+    pack[7] = 16; pack[8] = (int(pack[3]) + 15) // 16 - 1          # quotient_degree_factor, num_partial_products
+    oc = OracleCircuit(orc, pack); circ = pkg.Circuit(gpu, pack)
+    try:
+        got = circ.prove(wires, pis)
+        assert got == oc.prove(wires, pis) and oc.verify(got) == 0
+    finally:
+        circ.close(); oc.close()
