@@ -142,6 +142,7 @@ def main():
     pool = ThreadPoolExecutor(max_workers=S)
     pool_gen = ThreadPoolExecutor(max_workers=1)
     gathered = None
+    step_layout = {}
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -162,10 +163,11 @@ def main():
         tickets = [prover_pool.submit(w_t, pis, bufs[i]) for i in range(k * S)]
         last = None
         nonlocal gathered
+        layout = step_layout          # proofs of one circuit have one size: metadata collectives run once
         for j in range(k):
             proofs = [prover_pool.wait(t) for t in tickets[j * S:(j + 1) * S]]
             if world > 1:
-                gathered = pkg.sharding.gather_proof_bytes(proofs, dist, coll_dev)
+                gathered = pkg.sharding.gather_proof_bytes(proofs, dist, coll_dev, layout)
             last = proofs[0]
         return last
 

@@ -31,24 +31,35 @@ def aggregation_schedule(num_leaves=64, leaves_per_private_batch=8, world=8):
     return plan
 
 
-def gather_proof_bytes(proofs, dist=None, device=None):
+def gather_proof_bytes(proofs, dist=None, device=None, layout=None):
     """All ranks contribute a list of proofs (bytes); every rank receives the list of all ranks' lists, in rank
-    order. Fixed-size padded uint8 buffers + a length vector, one all_gather each (payload is latency-bound)."""
+    order. Fixed-size padded uint8 buffers + a length vector, one all_gather each (payload is latency-bound).
+    `layout`: a dict the caller keeps between calls when every call has the same proof counts and sizes on every rank
+    (proofs of one circuit have a fixed size): the two metadata collectives then run once, not per call."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [list(proofs)]
     world = dist.get_world_size()
     dev = device if device is not None else torch.device("cpu")
-    lens = torch.tensor([len(p) for p in proofs], dtype=torch.int64, device=dev)
-    count = torch.tensor([len(proofs)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(count) for _ in range(world)]
-    dist.all_gather(counts, count)
-    max_count = max(int(c.item()) for c in counts)
-    lens_pad = torch.zeros(max_count, dtype=torch.int64, device=dev)
-    lens_pad[:len(proofs)] = lens
-    all_lens = [torch.zeros_like(lens_pad) for _ in range(world)]
-    dist.all_gather(all_lens, lens_pad)
-    max_len = max(int(l.max().item()) if l.numel() else 0 for l in all_lens)
+    if layout is not None and "counts" in layout:
+        counts, all_lens, max_count, max_len = layout["counts"], layout["all_lens"], layout["max_count"], layout["max_len"]
+        if len(proofs) != counts[dist.get_rank()] or any(len(p) != n for p, n in zip(proofs, all_lens[dist.get_rank()])):
+            raise ValueError("gather_proof_bytes: proofs do not match the cached layout")
+    else:
+        lens = torch.tensor([len(p) for p in proofs], dtype=torch.int64, device=dev)
+        count = torch.tensor([len(proofs)], dtype=torch.int64, device=dev)
+        counts_t = [torch.zeros_like(count) for _ in range(world)]
+        dist.all_gather(counts_t, count)
+        counts = [int(c.item()) for c in counts_t]
+        max_count = max(counts)
+        lens_pad = torch.zeros(max_count, dtype=torch.int64, device=dev)
+        lens_pad[:len(proofs)] = lens
+        all_lens_t = [torch.zeros_like(lens_pad) for _ in range(world)]
+        dist.all_gather(all_lens_t, lens_pad)
+        all_lens = [[int(x) for x in l.cpu().tolist()] for l in all_lens_t]
+        max_len = max([max(l) if l else 0 for l in all_lens] + [0])
+        if layout is not None:
+            layout.update(counts=counts, all_lens=all_lens, max_count=max_count, max_len=max_len)
     payload = torch.zeros(max_count * max_len, dtype=torch.uint8, device=dev)
     for i, p in enumerate(proofs):
         payload[i * max_len:i * max_len + len(p)] = torch.from_numpy(np.frombuffer(p, dtype=np.uint8).copy()).to(dev)
@@ -57,6 +68,5 @@ def gather_proof_bytes(proofs, dist=None, device=None):
     out = []
     for r in range(world):
         buf = recv[r].cpu().numpy()
-        cnt = int(counts[r].item())
-        out.append([buf[i * max_len:i * max_len + int(all_lens[r][i].item())].tobytes() for i in range(cnt)])
+        out.append([buf[i * max_len:i * max_len + all_lens[r][i]].tobytes() for i in range(counts[r])])
     return out

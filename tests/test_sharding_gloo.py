@@ -30,6 +30,16 @@ def _worker(rank, world, port, ret):
     # a rank with nothing to contribute still takes part
     g2 = sh.gather_proof_bytes(mine if rank == 0 else [], dist)
     ok = ok and g2 == [all_proofs[0:3], []] if rank == 0 else ok and g2[1] == []
+    # cached layout: metadata exchanged on the first call only; a changed size is refused rather than mis-sliced
+    layout = {}
+    for _ in range(3):
+        ok = ok and [p for r in sh.gather_proof_bytes(mine, dist, None, layout) for p in r] == all_proofs
+    ok = ok and layout["counts"] == [3, 2]
+    try:
+        sh.gather_proof_bytes([mine[0] + b"x"] + mine[1:], dist, None, dict(layout))
+        ok = False
+    except ValueError:
+        pass
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
