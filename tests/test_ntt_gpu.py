@@ -173,6 +173,26 @@ def test_three_pass_lde_vs_oracle(gpu, orc, log_n, batch):
     d_coeffs.free(); d_lde.free()
 
 
+def test_baseline_size_edge_vectors(gpu, orc):
+    """BASELINE config 2 at B = 1 and the edge inputs SURVEY 8(d) lists, at the full 2^20 points: all-zero, all p-1,
+    delta, constant, and a splitmix column; forward bit for bit against the oracle, inverse back to the input."""
+    log_n = 20
+    n = 1 << log_n
+    cols = {"zero": np.zeros(n, dtype=np.uint64), "p_minus_1": np.full(n, P - 1, dtype=np.uint64),
+            "delta": np.zeros(n, dtype=np.uint64), "constant": np.full(n, 0x123456789ABCDEF, dtype=np.uint64),
+            "splitmix": splitmix_columns(log_n, 1)[0]}
+    cols["delta"][1] = 1
+    for name, a in cols.items():
+        f = gpu.ntt_host(a[None, :], log_n)[0]                    # B = 1
+        assert np.array_equal(f, orc.fft(a, log_n)), name
+        assert np.array_equal(gpu.ntt_host(f[None, :], log_n, inverse=True)[0], a), name
+    assert not cols["zero"].any() and not gpu.ntt_host(cols["zero"][None, :], log_n)[0].any()
+    # delta at index 1 transforms to the powers of the primitive 2^20-th root of unity
+    f = gpu.ntt_host(cols["delta"][None, :], log_n)[0]
+    w = orc.root(log_n)
+    assert int(f[0]) == 1 and int(f[1]) == w and int(f[2]) == orc.mul(w, w)
+
+
 def test_empty_and_bad_arguments(gpu, pkg):
     assert gpu.ntt_host(np.zeros((0, 8), dtype=np.uint64), 3).shape == (0, 8)
     with pytest.raises(pkg.QpGpuError):
