@@ -272,6 +272,22 @@ def main():
         extra["single_proof_latency_ms"] = round(sum(stages.values()), 4)
         extra["proof_stage_ms"] = stages
         extra["merkle_leaf_hash_avg_ms"] = round(leaf_ms / max(leaf_n, 1), 4)
+        # the kernel that dominates a proof is integer-ALU-bound, not HBM-bound: its rate next to the bytes it moves
+        st_ = np.random.default_rng(3).integers(0, pkg.P, (1 << 20, 12), dtype=np.uint64)
+        d_st = gpu.to_device(st_)
+        gpu._check(gpu.lib.qpgpu_poseidon_permute_dev(gpu.ctx, d_st.ptr, 1 << 20)); gpu.sync()
+        tp = time.perf_counter()
+        for _ in range(5):
+            gpu._check(gpu.lib.qpgpu_poseidon_permute_dev(gpu.ctx, d_st.ptr, 1 << 20))
+        gpu.sync()
+        perm_rate = 5 * (1 << 20) / (time.perf_counter() - tp)
+        d_st.free()
+        lde_leaves = 1 << (d + 3)
+        extra["poseidon_hashing"] = {"bound": "valu", "permutations_per_s": round(perm_rate / 1e9, 3), "unit": "G/s",
+                                     "valu_instructions_per_permutation": 20000,
+                                     "wires_leaf_hash_algorithmic_GBps": round(8.0 * 135 * lde_leaves / 1e9 / (17 * lde_leaves / perm_rate), 1),
+                                     "note": "leaf hashing reads 8*W bytes per leaf and runs ceil(W/8) permutations: at the permutation "
+                                             "rate above the wires oracle streams this many GB/s, far below HBM"}
 
         # stage s1 on the device (separate leg, not part of the headline: the metric is quoted with the witness resident):
         # regenerate the witness from its free cells alone, one at a time and 16 per pass
