@@ -66,3 +66,34 @@ def test_schedule_and_shards(pkg):
     assert [len(plan2["ranks"][r]["private_batches"]) for r in range(2)] == [4, 4]
     # single process: gather is the identity
     assert sh.gather_proof_bytes([b"ab", b"c"]) == [[b"ab", b"c"]]
+
+
+def _tree_worker(rank, world, port, ret):
+    """The aggregation-tree dataflow of bench.py's `aggregation_tree` leg with stand-in proofs (sha256 of the inputs):
+    leaves per rank -> gather -> private batches per rank -> gather -> root proves the public batch."""
+    import hashlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = ge.load_package().sharding
+    plan = sh.aggregation_schedule(64, 8, world)
+    mine = plan["ranks"][rank]
+    leaf = lambda i: hashlib.sha256(b"leaf%d" % i).digest() * 4
+    g0 = sh.gather_proof_bytes([leaf(i) for i in mine["leaves"]], dist)
+    all_leaves = [p for r in g0 for p in r]
+    ok = all_leaves == [leaf(i) for i in range(64)]                       # rank order = leaf order
+    batch = lambda b: hashlib.sha256(b"".join(all_leaves[8 * b:8 * b + 8])).digest() * 5
+    g1 = sh.gather_proof_bytes([batch(b) for b in mine["private_batches"]], dist)
+    all_batches = [p for r in g1 for p in r]
+    ok = ok and all_batches == [batch(b) for b in range(8)]
+    root = hashlib.sha256(b"".join(all_batches)).digest() if rank == plan["root"] else None
+    want = hashlib.sha256(b"".join(hashlib.sha256(b"".join(leaf(i) for i in range(8 * b, 8 * b + 8))).digest() * 5 for b in range(8))).digest()
+    ret[rank] = ok and (root is None or root == want)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_aggregation_tree_dataflow_four_ranks_gloo():
+    world, port = 4, _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_tree_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))
