@@ -156,8 +156,9 @@ int qpgpu_prove_dev(qpgpu_circuit *c, const uint64_t *d_wires, const uint64_t *p
  * from the pack (copy classes are the cycles of the sigma permutation); generation is one kernel launch per dependency
  * level. The caller supplies the cells no generator produces — plonky2's PartialWitness; qpgpu_witness_free_mask marks
  * them (1 byte per cell, num_wires x 2^degree_bits, column-major like the wire matrix) — every other cell is
- * overwritten. Generators that are not attached to a gate (hints such as inverse / is_equal / split across gates) are
- * not part of a circuit pack yet: their outputs count as caller-supplied cells. */
+ * overwritten. Generators that are not attached to a gate (Copy, Equality, WireSplit, extension Quotient, Constant,
+ * NonzeroTest, LowHigh) run too when the pack carries them in its hint trailer (csrc/circuit.hpp); outputs of generators
+ * the pack does not describe count as caller-supplied cells. */
 int qpgpu_witness_info(qpgpu_circuit *c, uint64_t *num_generators, uint64_t *num_levels, uint64_t *num_free_cells);
 int qpgpu_witness_free_mask(qpgpu_circuit *c, uint8_t *mask, size_t mask_len);
 /* in place on a device-resident wire matrix / on a host matrix (uploaded, generated, downloaded, device copy scrubbed) */
@@ -256,7 +257,9 @@ size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned
  * circuit's range checks, reference wormhole/circuit/src/zk_merkle_proof.rs:486-504). bit 2: every 8th row alternates
  * ArithmeticExtensionGate / MulExtensionGate (quadratic-extension arithmetic of the recursive verifier circuits).
  * bit 3: every 8th row cycles through ReducingGate, ReducingExtensionGate, RandomAccessGate(4 bits), ExponentiationGate
- * and PoseidonMdsGate, the rest of the gates plonky2's in-circuit verifier uses (needs >= 48 routed wires). */
+ * and PoseidonMdsGate, the rest of the gates plonky2's in-circuit verifier uses (needs >= 48 routed wires). bit 4: some
+ * operation inputs come from generators that are not attached to a gate (Equality, LowHigh, NonzeroTest, Constant, Copy,
+ * WireSplit, extension quotient): the pack gets a hint trailer (circuit.hpp) and qpgpu_synth_pack_words_ex is an upper bound. */
 size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags);
 int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                            uint64_t seed, unsigned flags, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,

@@ -142,13 +142,13 @@ def poseidon_constants():
 
 
 def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=21, seed=1, poseidon=False, base_sum=False,
-                  ext_arith=False, recursion=False):
+                  ext_arith=False, recursion=False, hints=False):
     """Synthetic satisfied circuit: returns (pack_words, wires[num_wires, n], public_inputs). Host only.
     poseidon=True adds PoseidonGate rows (needs 135 wires), base_sum=True BaseSumGate<2> rows, ext_arith=True
     ArithmeticExtensionGate and MulExtensionGate rows, recursion=True Reducing / ReducingExtension / RandomAccess /
-    Exponentiation / PoseidonMds rows."""
+    Exponentiation / PoseidonMds rows, hints=True free-standing witness generators (a hint trailer in the pack)."""
     lib = load_library()
-    flags = (1 if poseidon else 0) | (2 if base_sum else 0) | (4 if ext_arith else 0) | (8 if recursion else 0)
+    flags = (1 if poseidon else 0) | (2 if base_sum else 0) | (4 if ext_arith else 0) | (8 if recursion else 0) | (16 if hints else 0)
     words = lib.qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, flags)
     pack = np.empty(words, dtype=np.uint64)
     wires = np.empty((num_wires, 1 << degree_bits), dtype=np.uint64)
@@ -156,9 +156,9 @@ def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=2
     got = ctypes.c_size_t()
     rc = lib.qpgpu_synth_circuit_ex(degree_bits, num_wires, num_routed, num_public_inputs, seed, flags, pack.ctypes.data,
                                     words, ctypes.byref(got), wires.ctypes.data, pis.ctypes.data)
-    if rc != 0 or got.value != words:
+    if rc != 0 or got.value > words or (not hints and got.value != words):
         raise QpGpuError(rc, f"synth_circuit failed (words {got.value} vs {words})")
-    return pack, wires, pis
+    return pack[:got.value].copy() if got.value != words else pack, wires, pis
 
 
 class DeviceBuffer:

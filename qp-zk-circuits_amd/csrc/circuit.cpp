@@ -17,6 +17,10 @@ std::vector<uint64_t> CircuitPack::serialize() const {
     w.insert(w.end(), k_is.begin(), k_is.end());
     w.insert(w.end(), circuit_digest, circuit_digest + 4);
     w.insert(w.end(), constants_sigmas.begin(), constants_sigmas.end());
+    if (!hints.empty()) {
+        w.push_back(QPCP_HINT_MAGIC); w.push_back(hints.size());
+        for (const auto &h : hints) w.insert(w.end(), h.w, h.w + 8);
+    }
     return w;
 }
 
@@ -46,7 +50,16 @@ std::string CircuitPack::parse(const uint64_t *words, size_t n_words) {
     const size_t cs = (size_t)num_cs_cols() << degree_bits;
     if (!need(cs)) return "truncated constants_sigmas";
     constants_sigmas.assign(words + pos, words + pos + cs); pos += cs;
-    if (pos != n_words) return "trailing data";
+    hints.clear();
+    if (pos != n_words) {
+        if (!need(2) || words[pos] != QPCP_HINT_MAGIC) return "trailing data";
+        const uint64_t nh = words[pos + 1];
+        pos += 2;
+        if (nh > (1ull << 28) || !need(nh * 8)) return "truncated hint list";
+        hints.resize(nh);
+        for (auto &h : hints) { for (int i = 0; i < 8; i++) h.w[i] = words[pos + i]; pos += 8; }
+        if (pos != n_words) return "trailing data";
+    }
     return validate();
 }
 
@@ -90,6 +103,15 @@ std::string CircuitPack::validate() const {
             if (start_int > num_routed_wires || start_int + 2 * (2 * ni + 1) > num_wires || g.num_constraints != 2 * (2 + 2 * ni)) return "bad coset-interpolation gate";
         }
         if (g.type == GATE_POSEIDON && (num_wires < 135 || num_routed_wires < 25 || g.num_constraints != 123)) return "bad poseidon gate";
+    }
+    const uint64_t n_cells = num_wires << degree_bits;
+    auto routed_cell = [&](uint64_t c) { return c < n_cells && c % num_wires < num_routed_wires; };
+    for (const auto &h : hints) {
+        static const int n_cells_of[8] = {0, 2, 4, 2, 6, 1, 2, 3};   // leading arguments that are cells, per opcode
+        if (h.w[0] < HINT_COPY || h.w[0] > HINT_LOW_HIGH) return "unknown hint opcode";
+        for (int i = 0; i < n_cells_of[h.w[0]]; i++) if (!routed_cell(h.w[1 + i])) return "hint cell is not a routed wire of the trace";
+        if (h.w[0] == HINT_WIRE_SPLIT && (h.w[3] > 63 || h.w[4] == 0 || h.w[4] > 63)) return "bad wire-split hint";
+        if (h.w[0] == HINT_LOW_HIGH && (h.w[4] == 0 || h.w[4] > 63)) return "bad low-high hint";
     }
     return "";
 }

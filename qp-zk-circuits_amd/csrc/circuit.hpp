@@ -20,6 +20,14 @@
 //   constants_sigmas values: (num_selectors + num_constants + num_routed_wires) columns x 2^degree_bits,
 //           column-major, natural subgroup order (column order = plonky2's constants_sigmas oracle:
 //           selectors, constants, sigmas)
+//   optional trailer: witness hints = the generators that are not attached to a gate (stage s1 only; the prover
+//           ignores them): magic 0x00000031544E4948 ("HINT1"), count, count x 8 words {opcode, a, b, c, d, e, f, 0}.
+//           A cell is row * num_wires + column and must be a routed wire. Opcodes (plonky2 generator, arguments):
+//           1 CopyGenerator (dst a <- src b); 2 EqualityGenerator (x a, y b -> equal c, inv d);
+//           3 WireSplitGenerator, one BaseSum gate (integer a -> sum wire b = (a >> c) & (2^d - 1));
+//           4 QuotientGeneratorExtension (numerator a,b / denominator c,d -> quotient e,f);
+//           5 ConstantGenerator (a <- value b); 6 NonzeroTestGenerator (x a -> b = x == 0 ? 1 : 1/x);
+//           7 LowHighGenerator (integer a -> low b, high c, split at bit d)
 #pragma once
 #include <stdint.h>
 #include <string>
@@ -32,6 +40,11 @@ struct GateInfo {
     uint64_t type, param0, param1, selector_index, group_start, group_end, num_constraints, param2;
 };
 
+enum HintOpcode : uint64_t { HINT_COPY = 1, HINT_EQUALITY = 2, HINT_WIRE_SPLIT = 3, HINT_QUOTIENT_EXT = 4, HINT_CONSTANT = 5,
+                             HINT_NONZERO_TEST = 6, HINT_LOW_HIGH = 7 };
+struct HintOp { uint64_t w[8]; };
+constexpr uint64_t QPCP_HINT_MAGIC = 0x00000031544E4948ull;
+
 struct CircuitPack {
     uint64_t degree_bits = 0, num_wires = 0, num_routed_wires = 0, num_constants = 0, num_selectors = 0,
              num_challenges = 0, quotient_degree_factor = 0, num_partial_products = 0, num_public_inputs = 0,
@@ -42,6 +55,7 @@ struct CircuitPack {
     std::vector<uint64_t> k_is;
     uint64_t circuit_digest[4] = {0, 0, 0, 0};
     std::vector<uint64_t> constants_sigmas;  // column-major values
+    std::vector<HintOp> hints;               // optional: free-standing witness generators (stage s1)
 
     uint64_t n() const { return 1ull << degree_bits; }
     uint64_t num_cs_cols() const { return num_selectors + num_constants + num_routed_wires; }

@@ -96,11 +96,14 @@ void synth_public_inputs_hash(const u64 *pis, size_t n, u64 out[4]) { host_hash_
 
 // flags: bit 0 PoseidonGate rows, bit 1 BaseSumGate<2> rows, bit 2 ArithmeticExtension + MulExtension rows,
 // bit 3 Reducing / ReducingExtension / RandomAccess / Exponentiation / PoseidonMds / CosetInterpolation rows (the
-// recursive verifier's set).
+// recursive verifier's set), bit 4 free-standing witness hints (Equality / LowHigh / NonzeroTest / Constant / Copy outputs
+// feeding arithmetic operations, WireSplit feeding BaseSum rows, extension quotients feeding extension multiplications):
+// the pack then carries a hint trailer and those cells are produced by stage s1 instead of being caller inputs.
 // Builds the pack and the witness. wires: num_wires x n column-major. Returns "" or an error.
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         u64 seed, unsigned flags, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
     const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0, with_rec = (flags & 8) != 0;
+    const bool with_hints = (flags & 16) != 0;
     if (degree_bits < 3 || degree_bits > 20) return "degree_bits out of range";
     if (num_routed < 8 || num_routed > num_wires || num_routed % 4) return "num_routed_wires must be a multiple of 4, >= 8";
     if (with_poseidon && (num_wires < 135 || num_routed < 28)) return "poseidon gates need 135 wires";
@@ -179,6 +182,55 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
         if (pool.size() > 4096) pool.erase(pool.begin(), pool.begin() + 2048);
     };
 
+    // hint plumbing: a pool entry as a hint cell (row * num_wires + column) and its value
+    auto pool_pick = [&]() -> uint32_t { return pool[rng.below(pool.size())]; };
+    auto hint_cell = [&](uint32_t pc) -> u64 { return (u64)(pc / num_routed) * num_wires + pc % num_routed; };
+    auto pool_val = [&](uint32_t pc) -> u64 { return wires[(size_t)(pc % num_routed) * n + pc / num_routed]; };
+    auto own_cell = [&](u64 r, u64 col) -> u64 { return r * num_wires + col; };
+    auto add_hint = [&](u64 op, u64 a, u64 b, u64 c_, u64 d, u64 e, u64 f) { pack.hints.push_back({{op, a, b, c_, d, e, f, 0}}); };
+    // feeds the two multiplicand cells (col, col + 1) of an arithmetic operation from a hint; returns false to use plain inputs
+    auto hinted_pair = [&](u64 r, u64 col) -> bool {
+        if (!with_hints || pool.size() < 8 || rng.below(8) != 0) return false;
+        const uint32_t px = pool_pick();
+        const u64 x = pool_val(px);
+        switch (rng.below(5)) {
+        case 0: {   // EqualityGenerator: equal, inv
+            const uint32_t py = rng.below(4) == 0 ? px : pool_pick();
+            const u64 y = pool_val(py);
+            W(r, col) = x == y ? 1 : 0; W(r, col + 1) = x == y ? 0 : gl::inv(gl::sub(x, y));
+            add_hint(HINT_EQUALITY, hint_cell(px), hint_cell(py), own_cell(r, col), own_cell(r, col + 1), 0, 0);
+            break;
+        }
+        case 1: {   // LowHighGenerator
+            const u64 bits = 1 + rng.below(40);
+            W(r, col) = x & ((1ull << bits) - 1); W(r, col + 1) = x >> bits;
+            add_hint(HINT_LOW_HIGH, hint_cell(px), own_cell(r, col), own_cell(r, col + 1), bits, 0, 0);
+            break;
+        }
+        case 2: {   // NonzeroTestGenerator + ConstantGenerator
+            const u64 cst = rng.felt();
+            W(r, col) = x == 0 ? 1 : gl::inv(x); W(r, col + 1) = cst;
+            add_hint(HINT_NONZERO_TEST, hint_cell(px), own_cell(r, col), 0, 0, 0, 0);
+            add_hint(HINT_CONSTANT, own_cell(r, col + 1), cst, 0, 0, 0, 0);
+            break;
+        }
+        case 3: {   // CopyGenerator twice (a copy made by a generator instead of a copy constraint)
+            const uint32_t py = pool_pick();
+            W(r, col) = x; W(r, col + 1) = pool_val(py);
+            add_hint(HINT_COPY, own_cell(r, col), hint_cell(px), 0, 0, 0, 0);
+            add_hint(HINT_COPY, own_cell(r, col + 1), hint_cell(py), 0, 0, 0, 0);
+            break;
+        }
+        default: {  // equality of a value with itself: equal = 1, inv = 0
+            W(r, col) = 1; W(r, col + 1) = 0;
+            add_hint(HINT_EQUALITY, hint_cell(px), hint_cell(px), own_cell(r, col), own_cell(r, col + 1), 0, 0);
+            break;
+        }
+        }
+        for (u64 k = 0; k < 2; k++) W(r, col + k) = gl::canon(W(r, col + k));
+        return true;
+    };
+
     for (u64 r = 0; r < n; r++) {
         const u64 kind = row_gate[r];
         for (u64 s = 0; s < sel_cols; s++) CS(r, s) = sel_of[kind] == s ? idx_of[kind] : UNUSED;   // selector polynomials
@@ -190,7 +242,10 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
             const u64 c0 = (r & 1) ? rng.felt() : 1, c1 = (r & 2) ? rng.felt() : 1;
             CS(r, sel_cols) = c0; CS(r, sel_cols + 1) = c1;
             for (u64 op = 0; op < num_ops; op++) {
-                const u64 m0 = input(r, 4 * op), m1 = input(r, 4 * op + 1), ad = input(r, 4 * op + 2);
+                u64 m0, m1;
+                if (hinted_pair(r, 4 * op)) { m0 = W(r, 4 * op); m1 = W(r, 4 * op + 1); }
+                else { m0 = input(r, 4 * op); m1 = input(r, 4 * op + 1); }
+                const u64 ad = input(r, 4 * op + 2);
                 output(r, 4 * op + 3, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1)));
             }
         } else if (kind == GATE_ARITHMETIC_EXT || kind == GATE_MUL_EXT) {
@@ -201,7 +256,17 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
             for (u64 op = 0; op < ops; op++) {
                 const u64 b = stride * op;
                 u64 in[6] = {0, 0, 0, 0, 0, 0};
-                for (u64 k = 0; k < stride - 2; k++) in[k] = input(r, b + k);   // in wire order: the rng stream is part of the fixture
+                u64 k0 = 0;
+                if (with_hints && pool.size() >= 8 && rng.below(4) == 0) {   // QuotientGeneratorExtension feeds the first multiplicand
+                    const uint32_t pn0 = pool_pick(), pn1 = pool_pick(), pd0 = pool_pick(), pd1 = pool_pick();
+                    e2 den = gl::e2_make(pool_val(pd0), pool_val(pd1));
+                    if (gl::canon(den.a) != 0 || gl::canon(den.b) != 0) {
+                        const e2 q = gl::e2_canon(gl::e2_mul(gl::e2_make(pool_val(pn0), pool_val(pn1)), gl::e2_inv(den)));
+                        W(r, b) = q.a; W(r, b + 1) = q.b; in[0] = q.a; in[1] = q.b; k0 = 2;
+                        add_hint(HINT_QUOTIENT_EXT, hint_cell(pn0), hint_cell(pn1), hint_cell(pd0), hint_cell(pd1), own_cell(r, b), own_cell(r, b + 1));
+                    }
+                }
+                for (u64 k = k0; k < stride - 2; k++) in[k] = input(r, b + k);   // in wire order: the rng stream is part of the fixture
                 e2 res = gl::e2_scale(gl::e2_mul(gl::e2_make(in[0], in[1]), gl::e2_make(in[2], in[3])), c0);
                 if (!mul_only) res = gl::e2_add(res, gl::e2_scale(gl::e2_make(in[4], in[5]), c1));
                 output(r, b + stride - 2, res.a); output(r, b + stride - 1, res.b);
@@ -285,7 +350,13 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
             output(r, s_ev, ev.a); output(r, s_ev + 1, ev.b);
         } else if (kind == GATE_BASE_SUM) {
             // BaseSumGate<2> row: a value below 2^num_limbs and its bits
-            const u64 v = rng.next() & ((1ull << num_limbs) - 1);
+            u64 v = rng.next() & ((1ull << num_limbs) - 1);
+            if (with_hints && pool.size() >= 8 && rng.below(2) == 0) {   // WireSplitGenerator: this gate's chunk of an earlier value
+                const uint32_t px = pool_pick();
+                const u64 shift = rng.below(64 - num_limbs + 1);
+                v = (pool_val(px) >> shift) & ((1ull << num_limbs) - 1);
+                add_hint(HINT_WIRE_SPLIT, hint_cell(px), own_cell(r, 0), shift, num_limbs, 0, 0);
+            }
             output(r, 0, v);
             for (u64 i = 0; i < num_limbs; i++) W(r, 1 + i) = (v >> i) & 1;
         } else if (kind == GATE_POSEIDON) {

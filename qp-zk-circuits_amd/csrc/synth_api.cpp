@@ -25,7 +25,10 @@ size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsig
     CircuitPack p;
     p.degree_bits = degree_bits; p.num_routed_wires = num_routed; p.num_selectors = sels; p.num_constants = 2;
     size_t arity = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5).size();
-    return 18 + arity + gates.size() * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits);
+    // with hints (flag bit 4) the trailer's length depends on the seed: an upper bound is returned and
+    // qpgpu_synth_circuit_ex reports the exact count
+    const size_t hint_cap = (flags & 16) ? 2 + 8 * (((size_t)num_routed / 2 + 2) << degree_bits) : 0;
+    return 18 + arity + gates.size() * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits) + hint_cap;
 }
 size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed) {
     return qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, 0);

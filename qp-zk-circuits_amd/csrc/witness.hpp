@@ -8,7 +8,8 @@
 
 // one generator instance = one gate generator of plonky2 (a whole row for most gates, one operation of the row for
 // Arithmetic / ArithmeticExtension / MulExtension / RandomAccess copies / Constant wires)
-struct WitnessInst { uint32_t row, gate, op; };
+struct WitnessInst { uint32_t row, gate, op; };   // gate == WITNESS_HINT: `row` indexes the hint list, `op` is its opcode
+constexpr uint32_t WITNESS_HINT = 0xFFFFFFFFu;
 
 struct WitnessArgs {
     uint64_t *wires;            // [num_wires][n] in place
@@ -17,6 +18,8 @@ struct WitnessArgs {
     const GateDev *gates;
     const uint64_t *cs;         // constants_sigmas VALUES [ncs][n] (constants of the row)
     const uint64_t *poseidon_rc, *poseidon_fast;
+    const uint64_t *hints;      // [n_hints][8]: the pack's free-standing generators (circuit.hpp)
+    uint32_t num_wires;
     const uint64_t *pi_hash;    // [batch][4]: PublicInputGate wires
     uint64_t n;
     uint64_t batch_stride;      // words between the wire matrices of a batch (blockIdx.y = witness index)

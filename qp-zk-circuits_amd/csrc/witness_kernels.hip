@@ -22,10 +22,30 @@ __global__ void __launch_bounds__(128) witness_level_kernel(WitnessArgs a, u32 f
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const WitnessInst in = a.insts[first + t];
-    const GateDev g = a.gates[in.gate];
     const u64 n = a.n;
     a.wires += (u64)blockIdx.y * a.batch_stride;        // one wire matrix per witness of the batch
     a.pi_hash += 4 * blockIdx.y;
+    if (in.gate == WITNESS_HINT) {
+        // a generator that is not attached to a gate: cells are named explicitly (routed wires), read through their copy class
+        const u64 *h = a.hints + (u64)in.row * 8;
+        const u32 NWc = a.num_wires, Rr = a.num_routed;
+        auto RDc = [&](u64 cell) -> u64 { const u32 r = (u32)(cell / NWc), c = (u32)(cell % NWc); return gl::canon(a.wires[a.src_of[(u64)r * Rr + c]]); };
+        auto WRc = [&](u64 cell, u64 v) { const u32 r = (u32)(cell / NWc), c = (u32)(cell % NWc); a.wires[(u64)c * n + r] = gl::canon(v); };
+        switch (h[0]) {
+        case 1: WRc(h[1], RDc(h[2])); break;                                                          // CopyGenerator
+        case 2: { const u64 x = RDc(h[1]), y = RDc(h[2]);                                             // EqualityGenerator
+                  WRc(h[3], x == y ? 1 : 0); WRc(h[4], x == y ? 0 : gl::inv(gl::sub(x, y))); break; }
+        case 3: WRc(h[2], (RDc(h[1]) >> h[3]) & ((1ull << h[4]) - 1)); break;                         // WireSplitGenerator (one gate)
+        case 4: { const e2 num = gl::e2_make(RDc(h[1]), RDc(h[2])), den = gl::e2_make(RDc(h[3]), RDc(h[4]));   // QuotientGeneratorExtension
+                  const e2 q = gl::e2_mul(num, gl::e2_inv(den)); WRc(h[5], q.a); WRc(h[6], q.b); break; }
+        case 5: WRc(h[1], h[2]); break;                                                               // ConstantGenerator
+        case 6: { const u64 x = RDc(h[1]); WRc(h[2], x == 0 ? 1 : gl::inv(x)); break; }               // NonzeroTestGenerator
+        case 7: { const u64 x = RDc(h[1]); WRc(h[2], x & ((1ull << h[4]) - 1)); WRc(h[3], x >> h[4]); break; }   // LowHighGenerator
+        default: break;
+        }
+        return;
+    }
+    const GateDev g = a.gates[in.gate];
     const u32 R = a.num_routed, row = in.row, op = in.op;
     auto RD = [&](u32 col) -> u64 { return col < R ? a.wires[a.src_of[(u64)row * R + col]] : a.wires[(u64)col * n + row]; };
     auto WR = [&](u32 col, u64 v) { a.wires[(u64)col * n + row] = gl::canon(v); };

@@ -27,6 +27,7 @@ struct WitnessPlan {
     uint32_t *d_src_of = nullptr;
     WitnessInst *d_insts = nullptr;
     u64 *d_pi_hash = nullptr;
+    u64 *d_hints = nullptr;
     uint32_t pi_cap = 0;                     // witnesses d_pi_hash has room for
 };
 
@@ -35,12 +36,15 @@ void witness_plan_free(WitnessPlan *p) {
     if (p->d_src_of) (void)hipFree(p->d_src_of);
     if (p->d_insts) (void)hipFree(p->d_insts);
     if (p->d_pi_hash) (void)hipFree(p->d_pi_hash);
+    if (p->d_hints) (void)hipFree(p->d_hints);
     delete p;
 }
 
 namespace {
 
-struct IO { std::vector<uint32_t> in, out; };
+struct IO { std::vector<uint32_t> in, out; };                                   // wire columns of the instance's own row
+struct Cell { uint32_t row, col; };
+struct CellIO { std::vector<Cell> in, out; };
 
 // the cells (wire columns of its row) a generator instance reads and writes; must match witness_level_kernel
 void describe(const GateInfo &g, uint32_t op, IO &io) {
@@ -91,6 +95,29 @@ uint32_t num_instances(const GateInfo &g) {
     }
 }
 
+// cells of any generator instance: a gate generator works on its row, a hint on the cells it names
+void describe_any(const CircuitPack &p, const WitnessInst &w, IO &tmp, CellIO &io) {
+    io.in.clear(); io.out.clear();
+    if (w.gate != WITNESS_HINT) {
+        describe(p.gates[w.gate], w.op, tmp);
+        for (uint32_t c : tmp.in) io.in.push_back({w.row, c});
+        for (uint32_t c : tmp.out) io.out.push_back({w.row, c});
+        return;
+    }
+    const HintOp &h = p.hints[w.row];
+    auto cell = [&](uint64_t x) { return Cell{(uint32_t)(x / p.num_wires), (uint32_t)(x % p.num_wires)}; };
+    switch (h.w[0]) {
+    case HINT_COPY: io.out = {cell(h.w[1])}; io.in = {cell(h.w[2])}; break;
+    case HINT_EQUALITY: io.in = {cell(h.w[1]), cell(h.w[2])}; io.out = {cell(h.w[3]), cell(h.w[4])}; break;
+    case HINT_WIRE_SPLIT: io.in = {cell(h.w[1])}; io.out = {cell(h.w[2])}; break;
+    case HINT_QUOTIENT_EXT: io.in = {cell(h.w[1]), cell(h.w[2]), cell(h.w[3]), cell(h.w[4])}; io.out = {cell(h.w[5]), cell(h.w[6])}; break;
+    case HINT_CONSTANT: io.out = {cell(h.w[1])}; break;
+    case HINT_NONZERO_TEST: io.in = {cell(h.w[1])}; io.out = {cell(h.w[2])}; break;
+    case HINT_LOW_HIGH: io.in = {cell(h.w[1])}; io.out = {cell(h.w[2]), cell(h.w[3])}; break;
+    default: break;
+    }
+}
+
 std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     const CircuitPack &p = c->pack;
     const u64 n = p.n(), R = p.num_routed_wires, NW = p.num_wires;
@@ -137,20 +164,22 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
         const GateInfo &g = p.gates[gate_of_row[r]];
         for (uint32_t op = 0, k = num_instances(g); op < k; op++) insts.push_back({(uint32_t)r, (uint32_t)gate_of_row[r], op});
     }
+    for (size_t hi = 0; hi < p.hints.size(); hi++) insts.push_back({(uint32_t)hi, WITNESS_HINT, (uint32_t)p.hints[hi].w[0]});
     // producer of each copy class (by class root), and the source cell every member reads
     std::vector<int32_t> producer(n * R, -1);           // indexed by class root: instance id
     std::vector<uint32_t> source(n * R);                // indexed by class root: cell (row * R + col)
     for (uint32_t i = 0; i < n * R; i++) source[i] = i;
     plan.free_mask.assign(NW * n, 1);
-    IO io;
+    IO tmp;
+    CellIO io;
     for (size_t id = 0; id < insts.size(); id++) {
-        describe(p.gates[insts[id].gate], insts[id].op, io);
-        for (uint32_t col : io.out) {
-            if (col >= NW) return "witness plan: generator output beyond num_wires";
-            plan.free_mask[(u64)col * n + insts[id].row] = 0;
-            if (col >= R) continue;
-            const uint32_t cell = (uint32_t)((u64)insts[id].row * R + col), root = find(cell);
-            if (producer[root] >= 0) return "witness plan: two generators write one copy class (row " + std::to_string(insts[id].row) + ")";
+        describe_any(p, insts[id], tmp, io);
+        for (const Cell &oc : io.out) {
+            if (oc.col >= NW) return "witness plan: generator output beyond num_wires";
+            plan.free_mask[(u64)oc.col * n + oc.row] = 0;
+            if (oc.col >= R) continue;
+            const uint32_t cell = (uint32_t)((u64)oc.row * R + oc.col), root = find(cell);
+            if (producer[root] >= 0) return "witness plan: two generators write one copy class (row " + std::to_string(oc.row) + ")";
             producer[root] = (int32_t)id; source[root] = cell;
         }
     }
@@ -168,10 +197,10 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     std::vector<std::pair<uint32_t, uint32_t>> stack;   // (instance, next input position)
     std::vector<std::vector<uint32_t>> deps(insts.size());
     for (size_t id = 0; id < insts.size(); id++) {
-        describe(p.gates[insts[id].gate], insts[id].op, io);
-        for (uint32_t col : io.in) {
-            if (col >= R) continue;
-            const int32_t pr = producer[find((uint32_t)((u64)insts[id].row * R + col))];
+        describe_any(p, insts[id], tmp, io);
+        for (const Cell &ic : io.in) {
+            if (ic.col >= R) continue;
+            const int32_t pr = producer[find((uint32_t)((u64)ic.row * R + ic.col))];
             if (pr >= 0 && (size_t)pr != id) deps[id].push_back((uint32_t)pr);
         }
     }
@@ -196,7 +225,7 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     for (int32_t l : level) max_level = std::max(max_level, l);
     std::vector<uint32_t> order(insts.size());
     std::iota(order.begin(), order.end(), 0u);
-    auto is_pos = [&](uint32_t i) { return p.gates[insts[i].gate].type == GATE_POSEIDON ? 1 : 0; };
+    auto is_pos = [&](uint32_t i) { return insts[i].gate != WITNESS_HINT && p.gates[insts[i].gate].type == GATE_POSEIDON ? 1 : 0; };
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return level[a] != level[b] ? level[a] < level[b] : is_pos(a) < is_pos(b); });
     plan.insts.resize(insts.size());
     plan.level_start.assign(max_level + 1, 0);
@@ -209,7 +238,7 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     plan.level_poseidon.assign(max_level, 0);
     for (int32_t l = 0; l < max_level; l++) {
         uint32_t k = plan.level_start[l];
-        while (k < plan.level_start[l + 1] && p.gates[plan.insts[k].gate].type != GATE_POSEIDON) k++;
+        while (k < plan.level_start[l + 1] && (plan.insts[k].gate == WITNESS_HINT || p.gates[plan.insts[k].gate].type != GATE_POSEIDON)) k++;
         plan.level_poseidon[l] = k;
     }
 
@@ -221,6 +250,7 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     };
     if (!up(src_of.data(), src_of.size() * 4, (void **)&plan.d_src_of)) return "witness plan: device allocation failed";
     if (!up(plan.insts.data(), plan.insts.size() * sizeof(WitnessInst), (void **)&plan.d_insts)) return "witness plan: device allocation failed";
+    if (!p.hints.empty() && !up(p.hints.data(), p.hints.size() * sizeof(HintOp), (void **)&plan.d_hints)) return "witness plan: device allocation failed";
     return "";
 }
 
@@ -285,6 +315,7 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
     WitnessArgs a{};
     a.wires = d_wires; a.src_of = plan.d_src_of; a.insts = plan.d_insts; a.gates = c->d_gates; a.cs = c->d_cs_values;
     a.poseidon_rc = c->d_poseidon_rc; a.poseidon_fast = c->d_poseidon_fast; a.pi_hash = plan.d_pi_hash;
+    a.hints = plan.d_hints; a.num_wires = (uint32_t)c->pack.num_wires;
     a.n = c->pack.n(); a.batch_stride = c->pack.num_wires * c->pack.n();
     a.num_routed = (uint32_t)c->pack.num_routed_wires; a.num_selectors = (uint32_t)c->pack.num_selectors;
     ctx->prof_begin("witness_generate");

@@ -13,6 +13,8 @@ CASES = [
     dict(degree_bits=8, seed=72, poseidon=True, base_sum=True),
     dict(degree_bits=9, seed=73, poseidon=True, base_sum=True, ext_arith=True, recursion=True),
     dict(degree_bits=7, num_wires=80, num_routed=48, num_public_inputs=0, seed=74, recursion=True),
+    dict(degree_bits=9, seed=78, poseidon=True, base_sum=True, ext_arith=True, recursion=True, hints=True),
+    dict(degree_bits=6, num_wires=24, num_routed=16, num_public_inputs=2, seed=79, base_sum=True, hints=True),
 ]
 
 
@@ -106,5 +108,41 @@ def test_batched_generation(pkg, gpu):
                 assert (got[b] != wires).any()
                 assert (got[b] == circ.generate_witness(partials[b], all_pis[b])).all()    # same as one at a time
             circ.prove(got[b], all_pis[b])             # every witness satisfies the circuit
+    finally:
+        circ.close()
+
+
+def test_hint_trailer(pkg, gpu, orc):
+    """Generators that are not attached to a gate travel in the pack's hint trailer: their output cells are produced by
+    stage s1 (not caller-supplied), chains through them resolve, and the prover ignores the trailer."""
+    kw = dict(seed=80, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+    plain, _, _ = pkg.synth_circuit(8, **kw)
+    pack, wires, pis = pkg.synth_circuit(8, hints=True, **kw)
+    n, NW = 1 << 8, 135
+    body = plain.size                                   # same shape without hints: the trailer starts here
+    assert int(pack[body]) == 0x31544E4948 and pack.size == body + 2 + 8 * int(pack[body + 1])
+    hints = pack[body + 2:].reshape(-1, 8)
+    assert set(int(h[0]) for h in hints) == {1, 2, 3, 4, 5, 6, 7}
+    circ = pkg.Circuit(gpu, pack)
+    try:
+        mask = circ.witness_free_mask(NW, n)
+        outs = {1: [1], 2: [3, 4], 3: [2], 4: [5, 6], 5: [1], 6: [2], 7: [2, 3]}
+        for h in hints:
+            for k in outs[int(h[0])]:
+                row, col = divmod(int(h[k]), NW)
+                assert mask[col, row] == 0, (list(map(int, h)), k)
+        full = circ.generate_witness(np.where(mask == 1, wires, 0).astype(np.uint64), pis)
+        assert (full == wires).all()
+        circ.set_witness_check(True)
+        proof = circ.prove(full, pis)
+        oc = OracleCircuit(orc, pack)
+        assert proof == oc.prove(wires, pis)
+        oc.close()
+        # a truncated or foreign trailer is refused
+        with pytest.raises(pkg.QpGpuError):
+            pkg.Circuit(gpu, pack[:-3])
+        bad = pack.copy(); bad[body + 2] = 99
+        with pytest.raises(pkg.QpGpuError):
+            pkg.Circuit(gpu, bad)
     finally:
         circ.close()
