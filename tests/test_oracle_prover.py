@@ -135,3 +135,18 @@ def test_recursion_gate_set_circuit(pkg, orc):
     oc = OracleCircuit(orc, pack)
     assert oc.verify(oc.prove(wires, pis)) == 0
     oc.close()
+
+
+def test_hint_trailer_is_ignored_by_the_prover(pkg, orc):
+    """A pack with a witness-hint trailer (stage s1 only) loads in the restatement, and the circuit whose operation inputs
+    come from those generators is satisfied by the generator's witness."""
+    kw = dict(seed=11, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+    plain, _, _ = pkg.synth_circuit(7, **kw)
+    pack, wires, pis = pkg.synth_circuit(7, hints=True, **kw)
+    assert pack.size > plain.size and int(pack[plain.size]) == 0x31544E4948
+    oc = OracleCircuit(orc, pack)
+    assert oc.verify(oc.prove(wires, pis)) == 0
+    oc.close()
+    import pytest
+    with pytest.raises(ValueError):
+        OracleCircuit(orc, pack[:-1])                    # a torn trailer is refused
