@@ -1,0 +1,46 @@
+"""Randomised differential run: circuit shapes, gate mixes, FRI knobs, zero knowledge and witness hints drawn at random;
+GPU proof bytes against the CPU restatement, the restated verifier, and device witness generation against the full witness.
+usage: fuzz_shapes.py [cases] [seed]"""
+import sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+import __graft_entry__ as g
+pkg = g.load_package()
+import oracle_binding
+from test_prove_gpu import _with_fri_config
+orc = oracle_binding.Oracle()
+gpu = pkg.QpGpu(0)
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+for i in range(cases):
+    d = int(rng.integers(3, 12))
+    big = bool(rng.integers(0, 2))
+    routed = int(rng.integers(12, 21)) * 4 if big else int(rng.integers(2, 12)) * 4
+    wires_n = max(135 if big else routed + int(rng.integers(0, 20)), routed)
+    kw = dict(num_wires=wires_n, num_routed=routed, num_public_inputs=int(rng.integers(0, 9)), seed=1000 + i,
+              poseidon=big and bool(rng.integers(0, 2)), base_sum=bool(rng.integers(0, 2)), ext_arith=routed >= 8 and bool(rng.integers(0, 2)),
+              recursion=routed >= 48 and wires_n >= 64 and bool(rng.integers(0, 2)), hints=bool(rng.integers(0, 2)))
+    pack, wires, pis = pkg.synth_circuit(d, **kw)
+    rate = int(rng.choice([3, 3, 3, 4, 5]))
+    knobs = dict(cap_height=int(rng.integers(0, min(7, d + rate) + 1)), pow_bits=int(rng.choice([0, 4, 12, 16])),
+                 num_queries=int(rng.integers(1, 32)), rate_bits=rate)
+    pack = _with_fri_config(pack, **knobs)
+    pack[6] = int(rng.integers(1, 5))                  # num_challenges
+    zk = bool(rng.integers(0, 2)); pack[14] = 1 if zk else 0
+    desc = f"case {i}: d={d} {kw} {knobs} nch={int(pack[6])} zk={zk}"
+    try:
+        circ = pkg.Circuit(gpu, pack)
+    except pkg.QpGpuError as e:
+        print("skip (rejected at load):", desc, e); continue
+    oc = oracle_binding.OracleCircuit(orc, pack)
+    circ.set_blinding_seed(7 + i)
+    got = circ.prove(wires, pis)
+    want = oc.prove(wires, pis, seed=7 + i)
+    assert got == want, "BYTES DIFFER " + desc
+    assert oc.verify(got) == 0, "REJECTED " + desc
+    mask = circ.witness_free_mask(*wires.shape)
+    full = circ.generate_witness(np.where(mask == 1, wires, 0).astype(np.uint64), pis)
+    assert (full == wires).all(), "WITNESS DIFFERS " + desc
+    circ.close(); oc.close()
+print(f"{cases} cases ok in {time.time()-t0:.1f} s")
