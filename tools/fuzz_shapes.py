@@ -1,6 +1,6 @@
 """Randomised differential run: circuit shapes, gate mixes, FRI knobs, zero knowledge and witness hints drawn at random;
 GPU proof bytes against the CPU restatement, the restated verifier, and device witness generation against the full witness.
-usage: fuzz_shapes.py [cases] [seed]"""
+usage: fuzz_shapes.py [cases] [seed] [max degree_bits]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -11,10 +11,11 @@ from test_prove_gpu import _with_fri_config
 orc = oracle_binding.Oracle()
 gpu = pkg.QpGpu(0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+max_d = int(sys.argv[3]) if len(sys.argv) > 3 else 11
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 for i in range(cases):
-    d = int(rng.integers(3, 12))
+    d = int(rng.integers(3, max_d + 1))
     big = bool(rng.integers(0, 2))
     routed = int(rng.integers(12, 21)) * 4 if big else int(rng.integers(2, 12)) * 4
     wires_n = max(135 if big else routed + int(rng.integers(0, 20)), routed)
