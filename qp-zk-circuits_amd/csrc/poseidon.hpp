@@ -48,6 +48,8 @@ GL_HD void mds_layer_naive(u64 (&s)[WIDTH]) {
 // kernel's images are powers of two: 64*(1,2,1), 4*(-1,-8,2), 2*(2+i, -4-i, 16-i); three 3-term twisted
 // convolutions with shifts only; inverse FFT. All in signed 64-bit integers (|values| < 2^42).
 typedef long long i64;
+// left shift of a possibly negative value, as two's-complement arithmetic (signed << of a negative is not defined before C++20)
+GL_HD i64 shl(i64 x, int k) { return (i64)((u64)x << k); }
 GL_HD void mds_circulant_half(const i64 (&x)[WIDTH], i64 (&o)[WIDTH]) {
     i64 U1[3], Um[3], F[3], H[3];
 #pragma unroll
@@ -57,19 +59,19 @@ GL_HD void mds_circulant_half(const i64 (&x)[WIDTH], i64 (&o)[WIDTH]) {
     }
     const i64 T = U1[0] + U1[1] + U1[2];
     const i64 A[3] = {T + U1[2], T + U1[0], T + U1[1]};                       // V_1 / 64
-    const i64 B[3] = {(Um[2] << 3) - Um[0] - (Um[1] << 1),                    // V_-1 / 4
-                      -((Um[0] << 3) + Um[1] + (Um[2] << 1)),
-                      (Um[0] << 1) - (Um[1] << 3) - Um[2]};
+    const i64 B[3] = {shl(Um[2], 3) - Um[0] - shl(Um[1], 1),                    // V_-1 / 4
+                      -(shl(Um[0], 3) + Um[1] + shl(Um[2], 1)),
+                      shl(Um[0], 1) - shl(Um[1], 3) - Um[2]};
     const i64 f0 = F[0], f1 = F[1], f2 = F[2], h0 = H[0], h1 = H[1], h2 = H[2];
-    const i64 R[3] = {(f0 << 1) - h0 + f1 - (h1 << 4) + f2 + (h2 << 2),       // Re(V_i / 2)
-                      -(f0 << 2) + h0 + (f1 << 1) - h1 + f2 - (h2 << 4),
-                      (f0 << 4) + h0 - (f1 << 2) + h1 + (f2 << 1) - h2};
-    const i64 I[3] = {f0 + (h0 << 1) + (f1 << 4) + h1 - (f2 << 2) + h2,       // Im(V_i / 2)
-                      -f0 - (h0 << 2) + f1 + (h1 << 1) + (f2 << 4) + h2,
-                      -f0 + (h0 << 4) - f1 - (h1 << 2) + f2 + (h2 << 1)};
+    const i64 R[3] = {shl(f0, 1) - h0 + f1 - shl(h1, 4) + f2 + shl(h2, 2),       // Re(V_i / 2)
+                      -shl(f0, 2) + h0 + shl(f1, 1) - h1 + f2 - shl(h2, 4),
+                      shl(f0, 4) + h0 - shl(f1, 2) + h1 + shl(f2, 1) - h2};
+    const i64 I[3] = {f0 + shl(h0, 1) + shl(f1, 4) + h1 - shl(f2, 2) + h2,       // Im(V_i / 2)
+                      -f0 - shl(h0, 2) + f1 + shl(h1, 1) + shl(f2, 4) + h2,
+                      -f0 + shl(h0, 4) - f1 - shl(h1, 2) + f2 + shl(h2, 1)};
 #pragma unroll
     for (int b = 0; b < 3; b++) {
-        const i64 a16 = A[b] << 4, p = a16 + B[b], q = a16 - B[b];
+        const i64 a16 = shl(A[b], 4), p = a16 + B[b], q = a16 - B[b];
         o[b] = p + R[b]; o[b + 3] = q + I[b]; o[b + 6] = p - R[b]; o[b + 9] = q - I[b];
     }
 }
@@ -81,7 +83,7 @@ GL_HD void mds_layer(u64 (&s)[WIDTH]) {
     for (int i = 0; i < WIDTH; i++) { lo[i] = (i64)(u32)s[i]; hi[i] = (i64)(s[i] >> 32); }
     mds_circulant_half(lo, ol);
     mds_circulant_half(hi, oh);
-    ol[0] += lo[0] << 3; oh[0] += hi[0] << 3;   // the diagonal term 8 * s[0]
+    ol[0] += shl(lo[0], 3); oh[0] += shl(hi[0], 3);   // the diagonal term 8 * s[0]
 #pragma unroll
     for (int r = 0; r < WIDTH; r++) {
         const u64 al = (u64)ol[r], ah = (u64)oh[r];   // both in [0, 2^42)

@@ -57,7 +57,7 @@ int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned nu
         std::memcpy(pack_out, words.data(), words.size() * 8);
     }
     if (wires_out) std::memcpy(wires_out, wires.data(), wires.size() * 8);
-    if (pis_out) std::memcpy(pis_out, pis.data(), pis.size() * 8);
+    if (pis_out && !pis.empty()) std::memcpy(pis_out, pis.data(), pis.size() * 8);
     return QPGPU_OK;
 }
 
