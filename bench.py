@@ -88,17 +88,62 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
     return gbs, roof, ok, x[0].cpu().numpy().view(np.uint64), y[0].cpu().numpy().view(np.uint64)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, created before this
+    process makes any GPU or torch.cuda call), one per GPU, with the torchrun environment; rank 0 prints the JSON line.
+    Returns the exit code."""
+    import socket
+    import subprocess
+    import torch     # device_count() does not initialise the GPU
+    backend = os.environ.get("QPGPU_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {ndev} (QPGPU_BENCH_BACKEND=gloo rehearses several "
+              "ranks on fewer GPUs)", file=sys.stderr)
+        return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            failed = [p.returncode for p in procs if p.poll() is not None and p.returncode]
+            if failed:                # a failed rank strands the others in a collective: stop exactly those we started
+                rc = failed[0]
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+                break
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        rc = 130
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree-bits", type=int, default=13)
+    ap.add_argument("--batch-degree-bits", type=int, default=16, help="rows of the private / public batch circuits of the tree leg")
     ap.add_argument("--streams", type=int, default=4, help="proofs in flight per GPU (one HIP stream + workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-tree", action="store_true", help="skip the 64-leaf aggregation-tree leg (BASELINE configs[4])")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))       # this process never touches a GPU: the ranks are fresh interpreters
 
     import torch
     import torch.distributed as dist
@@ -106,8 +151,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if os.environ.get("QPGPU_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < (int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible (one rank per GPU)")
     # rehearsal on a one-GPU box: QPGPU_BENCH_BACKEND=gloo puts every rank on the visible GPUs round-robin and does
     # the gather on host tensors; the driver's multi-GPU runs use the default (nccl = RCCL over xGMI)
     backend = os.environ.get("QPGPU_BENCH_BACKEND", "nccl")
@@ -194,64 +243,63 @@ def main():
     # circuit of the level's size and configuration; what is real: the sharding, the per-level gather of proof bytes and
     # the proving work per level. Witness generation of the recursive verifiers (host work in the reference) is not included.
     tree = None
+    tree_check = None
     if not args.no_tree:
-        plan = pkg.sharding.aggregation_schedule(64, 8, world)
-        mine = plan["ranks"][rank]
+        agg = pkg.aggregation
         # recursive-verifier gate mix (Poseidon, extension arithmetic, Reducing*, RandomAccess, Exponentiation, PoseidonMds,
         # CosetInterpolation); private batch: standard_recursion_zk_config with 60 routed wires
         # (reference common/src/circuit.rs:396-402), public batch: standard_recursion_config
         rec = dict(poseidon=True, base_sum=True, ext_arith=True, recursion=True)
-        zpack, zwires, zpis = pkg.synth_circuit(16, num_wires=135, num_routed=60, num_public_inputs=21 * 8 + 8, seed=78, **rec)
-        zpack[14] = 1
-        zw_t = torch.from_numpy(zwires.view(np.int64)).to(dev)
-        priv = pkg.Circuit(gpus[0], zpack)
-        pub = None
-        if rank == plan["root"]:
-            bpack, bwires, bpis = pkg.synth_circuit(16, num_wires=135, num_routed=80, num_public_inputs=21 * 8 + 8, seed=77, **rec)
-            bw_t = torch.from_numpy(bwires.view(np.int64)).to(dev)
-            pub = pkg.Circuit(gpus[1 % S], bpack)
-        priv_out = np.empty(priv.proof_size(), dtype=np.uint8)
-
-        def tree_once():
-            # level 0: this rank's leaf proofs, S in flight
-            leaves = list(mine["leaves"])
-            leaf_proofs = []
-            for i in range(0, len(leaves), S):
-                futs = [pool.submit(circs[j].prove_dev, w_t, pis, outs[j]) for j in range(min(S, len(leaves) - i))]
-                leaf_proofs += [f.result() for f in futs]
-            g0 = pkg.sharding.gather_proof_bytes(leaf_proofs, dist if world > 1 else None, coll_dev)
-            # level 1: this rank's private batches
-            pb = [priv.prove_dev(zw_t, zpis, priv_out) for _ in mine["private_batches"]]
-            g1 = pkg.sharding.gather_proof_bytes(pb, dist if world > 1 else None, coll_dev)
-            # level 2: the root proves the public batch over the gathered private-batch proofs
-            root_proof = pub.prove_dev(bw_t, bpis) if pub is not None else None
-            return sum(len(x) for x in g0), sum(len(x) for x in g1), root_proof
-
-        tree_once()
+        NB_PIS = 21 * 8 + 8
+        tleaf = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000, poseidon=True, base_sum=True)
+        tpriv = pkg.synth_circuit(args.batch_degree_bits, num_wires=135, num_routed=60, num_public_inputs=NB_PIS, seed=78, **rec)
+        tpriv[0][14] = 1
+        tpub = None
+        if rank == 0:
+            tpub = pkg.synth_circuit(args.batch_degree_bits, num_wires=135, num_routed=80, num_public_inputs=NB_PIS * 8 + 8, seed=77, **rec)
+        atree = agg.AggregationTree(pkg, gpus[0], rank, world, tleaf, tpriv, tpub)
+        dd = dist if world > 1 else None
+        atree.run(dd, coll_dev)
         barrier()
         t2 = time.perf_counter()
-        n_leaf, n_priv, root_proof = tree_once()
+        t_leaves, t_batches, t_root = atree.run(dd, coll_dev)
         barrier()
         tdt = time.perf_counter() - t2
         if world > 1:
             tt = torch.tensor([tdt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tdt = float(tt.item())
-        assert n_leaf == 64 and n_priv == 8
+        assert len(t_leaves) == 64 and len(t_batches) == 8
         tree = {"leaves": 64, "private_batches": 8, "public_batches": 1, "seconds": round(tdt, 4),
                 "trees_per_s": round(1.0 / tdt, 3),
-                "shape": "leaf 2^13 rows (80 routed); private batch 2^16 rows zero-knowledge, 60 routed wires; public batch 2^16 rows, "
-                         "80 routed; 135 wires; batches carry the 14-gate recursive-verifier mix",
-                "note": "shape-equivalent synthetic circuits per level; sharding + RCCL gathers + proving are real, recursive "
-                        "witness generation is not included; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
-                        "sequential on an M2 Max including witness generation"}
-        priv.close()
-        del zw_t
-        if pub is not None:
-            pub.close()
-            del bw_t
+                "shape": f"leaf 2^{d} rows (80 routed); private batch 2^{args.batch_degree_bits} rows zero-knowledge, 60 routed wires; "
+                         f"public batch 2^{args.batch_degree_bits} rows, 80 routed; 135 wires; batches carry the 14-gate recursive-verifier mix",
+                "note": "shape-equivalent synthetic circuits per level; each level parses the previous level's gathered proof bytes, "
+                        "derives its public inputs from them, generates its witness on the device (stage s1) and proves; the inner "
+                        "proofs are not verified in-circuit; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
+                        "sequential on an M2 Max"}
+        if rank == 0:
+            # checker, untimed: the oracle verifies the root and one proof per level, and the root's public inputs hold the 8
+            # batch proofs' public inputs in rank order (they in turn the leaves')
+            import oracle_binding as ob
+            orc_t = ob.Oracle()
+            ok_t = True
+            for pk, pf in ((tleaf[0], t_leaves[63]), (tpriv[0], t_batches[7]), (tpub[0], t_root)):
+                oc_t = ob.OracleCircuit(orc_t, pk)
+                ok_t = ok_t and oc_t.verify(pf) == 0
+                oc_t.close()
+            rp = agg.proof_public_inputs(t_root, NB_PIS * 8 + 8)
+            for b in range(8):
+                bp = agg.proof_public_inputs(t_batches[b], NB_PIS)
+                ok_t = ok_t and bool(np.array_equal(rp[b * NB_PIS:(b + 1) * NB_PIS], bp))
+                for j in range(8):
+                    ok_t = ok_t and bool(np.array_equal(bp[21 * j:21 * j + 21], agg.proof_public_inputs(t_leaves[8 * b + j], 21)))
+            tree["checked"] = "oracle verifier accepts leaf 63, private batch 7 and the root; root public inputs = the 8 batch proofs' in rank order" if ok_t else "FAILED"
+            tree_check = ok_t
+        atree.close()
     if rank == 0:
         extra["aggregation_tree"] = tree
+        ok = ok and tree_check is not False
         # per-stage breakdown (HIP events recorded by the library on the launch stream; separate leg)
         gpu.profile(True)
         for _ in range(5):

@@ -168,6 +168,15 @@ int qpgpu_generate_witness(qpgpu_circuit *c, uint64_t *wires, const uint64_t *pu
  * levels are walked once for all of them, which is how the device pays off — a single witness is latency-bound by the
  * circuit's dependency depth, exactly the part a host core does well. */
 int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs);
+/* The same from a sparse PartialWitness: `count` assignments (cell = row * num_wires + wire, value), as the reference
+ * builds them with `pw.set_target` (wormhole/prover/src/lib.rs:187-221). d_wires (num_wires x 2^degree_bits, device) is
+ * cleared, the assignments and the public inputs (at the pack's public-input cells, trailer "PUBI1") are written, the
+ * generators run. A target set twice with different values — two assignments inside one copy class, or an assignment that
+ * disagrees with the value a generator or the public-input argument gives that target — returns QPGPU_EUNSAT and names
+ * the target in qpgpu_last_error: plonky2's "set twice with different values" panic, which six reference tests expect
+ * (wormhole/tests/src/circuit/block_header_tests.rs:34-95, nullifier_tests.rs:53-58). Unassigned free cells stay zero. */
+int qpgpu_generate_witness_partial_dev(qpgpu_circuit *c, const uint64_t *cells, const uint64_t *values, size_t count,
+                                       const uint64_t *public_inputs, uint64_t *d_wires);
 
 /* ---- stage-level entry points: the circuit-independent parts of prove() ---------------------------------------
  * For a patched `qp-plonky2::plonk::prover::prove` that keeps witness generation, partial products and the quotient

@@ -113,8 +113,20 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
     memcpy(c->k_is, w + p, sizeof(gl_t) * c->num_routed); p += c->num_routed;
     memcpy(c->digest, w + p, 32); p += 4;
     size_t n = (size_t)1 << c->degree_bits, ncs = c->num_selectors + c->num_constants + c->num_routed;
-    /* an optional trailer of witness hints (stage s1; magic "HINT1") is of no concern to the prover */
-    if (p + ncs * n != nw && !(p + ncs * n + 2 <= nw && w[p + ncs * n] == 0x00000031544E4948ULL && p + ncs * n + 2 + 8 * w[p + ncs * n + 1] == nw)) { free(c->gates); free(c->k_is); free(c); return NULL; }
+    /* optional trailers are of no concern to the prover: witness hints (stage s1; magic "HINT1", 8 words per entry) and
+     * the public-input cells (magic "PUBI1", one word per entry); they are only checked for being well formed */
+    {
+        size_t q = p + ncs * n;
+        int ok = q <= nw;
+        while (ok && q != nw) {
+            if (q + 2 > nw) { ok = 0; break; }
+            const uint64_t magic = w[q], cnt = w[q + 1];
+            const uint64_t per = magic == 0x00000031544E4948ULL ? 8 : magic == 0x0000003149425550ULL ? 1 : 0;
+            if (!per || cnt > (nw - q - 2) / per) { ok = 0; break; }
+            q += 2 + per * cnt;
+        }
+        if (!ok) { free(c->gates); free(c->k_is); free(c); return NULL; }
+    }
     c->cs_values = (gl_t *)malloc(sizeof(gl_t) * ncs * n);
     memcpy(c->cs_values, w + p, sizeof(gl_t) * ncs * n);
     g_blind = 0;

@@ -81,6 +81,7 @@ def load_library():
         "qpgpu_generate_witness_dev": (c.c_int, [vp, u64p, u64p]),
         "qpgpu_generate_witness": (c.c_int, [vp, u64p, u64p]),
         "qpgpu_generate_witness_batch_dev": (c.c_int, [vp, u64p, c.c_uint32, u64p]),
+        "qpgpu_generate_witness_partial_dev": (c.c_int, [vp, u64p, u64p, c.c_size_t, u64p, u64p]),
         "qpgpu_oracle_commit": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint32,
                                           c.POINTER(vp)]),
         "qpgpu_oracle_free": (None, [vp]),
@@ -149,16 +150,41 @@ def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=2
     Exponentiation / PoseidonMds rows, hints=True free-standing witness generators (a hint trailer in the pack)."""
     lib = load_library()
     flags = (1 if poseidon else 0) | (2 if base_sum else 0) | (4 if ext_arith else 0) | (8 if recursion else 0) | (16 if hints else 0)
-    words = lib.qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, flags)
+    # with Poseidon rows the pack also carries the public-input cell trailer (2 + num_public_inputs words, circuit.hpp)
+    words = lib.qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, flags) + 2 + num_public_inputs
     pack = np.empty(words, dtype=np.uint64)
     wires = np.empty((num_wires, 1 << degree_bits), dtype=np.uint64)
     pis = np.empty(num_public_inputs, dtype=np.uint64)
     got = ctypes.c_size_t()
     rc = lib.qpgpu_synth_circuit_ex(degree_bits, num_wires, num_routed, num_public_inputs, seed, flags, pack.ctypes.data,
                                     words, ctypes.byref(got), wires.ctypes.data, pis.ctypes.data)
-    if rc != 0 or got.value > words or (not hints and got.value != words):
+    if rc != 0 or got.value > words:
         raise QpGpuError(rc, f"synth_circuit failed (words {got.value} vs {words})")
     return pack[:got.value].copy() if got.value != words else pack, wires, pis
+
+
+def pack_header(pack_words):
+    """The fixed header of a circuit pack (csrc/circuit.hpp) as a dict. Host only."""
+    names = ["degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_selectors", "num_challenges",
+             "quotient_degree_factor", "num_partial_products", "num_public_inputs", "rate_bits", "cap_height",
+             "proof_of_work_bits", "num_query_rounds", "zero_knowledge", "num_gate_constraints", "num_gates", "num_arity_rounds"]
+    return {k: int(v) for k, v in zip(names, pack_words[1:18])}
+
+
+def pack_public_input_cells(pack_words):
+    """Cells (row * num_wires + wire) of the public inputs from the pack's "PUBI1" trailer, or None."""
+    h = pack_header(pack_words)
+    pos = 18 + h["num_arity_rounds"] + 8 * h["num_gates"] + h["num_routed_wires"] + 4
+    pos += (h["num_selectors"] + h["num_constants"] + h["num_routed_wires"]) << h["degree_bits"]
+    while pos + 2 <= len(pack_words):
+        magic, cnt = int(pack_words[pos]), int(pack_words[pos + 1])
+        if magic == 0x31544E4948:
+            pos += 2 + 8 * cnt
+        elif magic == 0x3149425550:
+            return np.array(pack_words[pos + 2:pos + 2 + cnt], dtype=np.uint64)
+        else:
+            break
+    return None
 
 
 class DeviceBuffer:
@@ -242,6 +268,15 @@ class Circuit:
         """In place on `batch` device-resident wire matrices laid out back to back; public_inputs [batch, num_pis]."""
         p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         self.gpu._check(self.gpu.lib.qpgpu_generate_witness_batch_dev(self.h, _ptr(d_wires), batch, p.ctypes.data))
+
+    def generate_witness_partial_dev(self, cells, values, public_inputs, d_wires):
+        """plonky2's PartialWitness as (cell = row * num_wires + wire, value) assignments -> full witness in d_wires.
+        Raises QpGpuError(-4) when a target is set twice with different values."""
+        cl = np.ascontiguousarray(cells, dtype=np.uint64); vl = np.ascontiguousarray(values, dtype=np.uint64)
+        assert cl.shape == vl.shape
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_generate_witness_partial_dev(self.h, cl.ctypes.data, vl.ctypes.data, cl.size,
+                                                                        p.ctypes.data, _ptr(d_wires)))
 
     def prove(self, wires, public_inputs):
         """wires: host array [num_wires, n]; returns proof bytes."""

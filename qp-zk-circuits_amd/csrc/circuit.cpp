@@ -21,20 +21,36 @@ std::vector<uint64_t> CircuitPack::serialize() const {
         w.push_back(QPCP_HINT_MAGIC); w.push_back(hints.size());
         for (const auto &h : hints) w.insert(w.end(), h.w, h.w + 8);
     }
+    if (!pi_cells.empty()) {
+        w.push_back(QPCP_PUBI_MAGIC); w.push_back(pi_cells.size());
+        w.insert(w.end(), pi_cells.begin(), pi_cells.end());
+    }
     return w;
 }
 
 std::string CircuitPack::parse(const uint64_t *words, size_t n_words) {
     size_t pos = 0;
-    auto need = [&](size_t k) { return pos + k <= n_words; };
-    if (!need(18) || words[0] != QPCP_MAGIC) return "bad magic or truncated header";
+    // `k` words left from `pos`? written so that neither side can wrap
+    auto need = [&](uint64_t k) { return k <= (uint64_t)(n_words - pos); };
+    if (n_words < 18 || words[0] != QPCP_MAGIC) return "bad magic or truncated header";
     pos = 1;
     uint64_t *fields[] = {&degree_bits, &num_wires, &num_routed_wires, &num_constants, &num_selectors, &num_challenges,
                           &quotient_degree_factor, &num_partial_products, &num_public_inputs, &rate_bits, &cap_height,
                           &proof_of_work_bits, &num_query_rounds, &zero_knowledge, &num_gate_constraints};
     for (auto f : fields) *f = words[pos++];
     uint64_t ng = words[pos++], na = words[pos++];
-    if (degree_bits > 24 || ng > 4096 || na > 16 || num_routed_wires > 4096 || num_wires > 4096) return "header field out of range";
+    // every header word is bounded before it is used in a size, a shift or an index (a corrupt pack must fail here, not in
+    // a host read past the buffer or a kernel indexing outside its allocation)
+    if (degree_bits > 24 || ng == 0 || ng > 4096 || na > 16 || num_routed_wires == 0 || num_routed_wires > 4096 || num_wires == 0 || num_wires > 4096) return "header field out of range";
+    if (num_selectors == 0 || num_selectors > 4096 || num_constants > 4096) return "header field out of range: num_selectors / num_constants";
+    if (num_public_inputs > (1ull << 20)) return "header field out of range: num_public_inputs";
+    if (rate_bits == 0 || rate_bits > 8) return "header field out of range: rate_bits";
+    if (cap_height > 16) return "header field out of range: cap_height";
+    if (proof_of_work_bits > 40) return "header field out of range: proof_of_work_bits";
+    if (num_query_rounds == 0 || num_query_rounds > 4096) return "header field out of range: num_query_rounds";
+    if (num_challenges == 0 || num_challenges > 4) return "unsupported num_challenges";
+    if (quotient_degree_factor == 0 || quotient_degree_factor > 256) return "header field out of range: quotient_degree_factor";
+    if (num_partial_products > 4096 || num_gate_constraints > (1ull << 20)) return "header field out of range";
     if (!need(na)) return "truncated arity list";
     arity_bits.assign(words + pos, words + pos + na); pos += na;
     if (!need(ng * 8)) return "truncated gate list";
@@ -47,18 +63,25 @@ std::string CircuitPack::parse(const uint64_t *words, size_t n_words) {
     if (!need(num_routed_wires + 4)) return "truncated k_is";
     k_is.assign(words + pos, words + pos + num_routed_wires); pos += num_routed_wires;
     for (int i = 0; i < 4; i++) circuit_digest[i] = words[pos++];
-    const size_t cs = (size_t)num_cs_cols() << degree_bits;
+    const uint64_t cs = num_cs_cols() << degree_bits;          // <= 3 * 4096 * 2^24: no overflow
     if (!need(cs)) return "truncated constants_sigmas";
     constants_sigmas.assign(words + pos, words + pos + cs); pos += cs;
-    hints.clear();
-    if (pos != n_words) {
-        if (!need(2) || words[pos] != QPCP_HINT_MAGIC) return "trailing data";
-        const uint64_t nh = words[pos + 1];
+    hints.clear(); pi_cells.clear();
+    bool seen_hints = false, seen_pubi = false;
+    while (pos != n_words) {   // optional trailers, each at most once
+        if (!need(2)) return "trailing data";
+        const uint64_t magic = words[pos], cnt = words[pos + 1];
         pos += 2;
-        if (nh > (1ull << 28) || !need(nh * 8)) return "truncated hint list";
-        hints.resize(nh);
-        for (auto &h : hints) { for (int i = 0; i < 8; i++) h.w[i] = words[pos + i]; pos += 8; }
-        if (pos != n_words) return "trailing data";
+        if (magic == QPCP_HINT_MAGIC && !seen_hints && !seen_pubi) {
+            seen_hints = true;
+            if (cnt > (1ull << 28) || !need(cnt * 8)) return "truncated hint list";
+            hints.resize(cnt);
+            for (auto &h : hints) { for (int i = 0; i < 8; i++) h.w[i] = words[pos + i]; pos += 8; }
+        } else if (magic == QPCP_PUBI_MAGIC && !seen_pubi) {
+            seen_pubi = true;
+            if (cnt != num_public_inputs || !need(cnt)) return "public-input cell list does not match num_public_inputs";
+            pi_cells.assign(words + pos, words + pos + cnt); pos += cnt;
+        } else return "trailing data";
     }
     return validate();
 }
@@ -67,8 +90,9 @@ std::string CircuitPack::validate() const {
     if (num_routed_wires > num_wires) return "num_routed_wires > num_wires";
     if (num_challenges == 0 || num_challenges > 4) return "unsupported num_challenges";
     if (quotient_degree_factor == 0 || (quotient_degree_factor & (quotient_degree_factor - 1))) return "quotient_degree_factor must be a power of two";
+    if (rate_bits == 0 || rate_bits > 8) return "rate_bits outside 1..8";
     if (quotient_degree_factor > (1ull << rate_bits)) return "quotient_degree_factor exceeds the blowup 2^rate_bits";
-    if (rate_bits > 8) return "rate_bits above 8";
+    if (degree_bits > 24 || proof_of_work_bits > 40 || cap_height > 16) return "header field out of range";
     if (num_partial_products + 1 != (num_routed_wires + quotient_degree_factor - 1) / quotient_degree_factor) return "num_partial_products inconsistent";
     if (cap_height > degree_bits + rate_bits) return "cap_height above tree height";
     if (zero_knowledge > 1) return "zero_knowledge must be 0 or 1";
@@ -104,7 +128,11 @@ std::string CircuitPack::validate() const {
         }
         if (g.type == GATE_POSEIDON && (num_wires < 135 || num_routed_wires < 25 || g.num_constraints != 123)) return "bad poseidon gate";
     }
+    if (constants_sigmas.size() != (num_cs_cols() << degree_bits)) return "constants_sigmas has the wrong size";
+    if (k_is.size() != num_routed_wires) return "k_is has the wrong size";
     const uint64_t n_cells = num_wires << degree_bits;
+    if (!pi_cells.empty() && pi_cells.size() != num_public_inputs) return "public-input cell list does not match num_public_inputs";
+    for (uint64_t c : pi_cells) if (c >= n_cells || c % num_wires >= num_routed_wires) return "public-input cell is not a routed wire of the trace";
     auto routed_cell = [&](uint64_t c) { return c < n_cells && c % num_wires < num_routed_wires; };
     for (const auto &h : hints) {
         static const int n_cells_of[8] = {0, 2, 4, 2, 6, 1, 2, 3};   // leading arguments that are cells, per opcode

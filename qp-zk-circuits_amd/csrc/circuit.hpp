@@ -28,6 +28,10 @@
 //           4 QuotientGeneratorExtension (numerator a,b / denominator c,d -> quotient e,f);
 //           5 ConstantGenerator (a <- value b); 6 NonzeroTestGenerator (x a -> b = x == 0 ? 1 : 1/x);
 //           7 LowHighGenerator (integer a -> low b, high c, split at bit d)
+//   optional trailer after it: public-input cells = where `prover_only.public_inputs` (the registered targets) sit in
+//           the trace: magic 0x0000003149425550 ("PUBI1"), count (= num_public_inputs), count cells. Stage s1 writes the
+//           caller's public inputs there (PartialWitness::set_target for each public-input target); in plonky2 those
+//           cells feed the PoseidonGate rows whose output is copy-connected to the PublicInputGate's wires.
 #pragma once
 #include <stdint.h>
 #include <string>
@@ -44,6 +48,7 @@ enum HintOpcode : uint64_t { HINT_COPY = 1, HINT_EQUALITY = 2, HINT_WIRE_SPLIT =
                              HINT_NONZERO_TEST = 6, HINT_LOW_HIGH = 7 };
 struct HintOp { uint64_t w[8]; };
 constexpr uint64_t QPCP_HINT_MAGIC = 0x00000031544E4948ull;
+constexpr uint64_t QPCP_PUBI_MAGIC = 0x0000003149425550ull;   // "PUBI1"
 
 struct CircuitPack {
     uint64_t degree_bits = 0, num_wires = 0, num_routed_wires = 0, num_constants = 0, num_selectors = 0,
@@ -56,6 +61,7 @@ struct CircuitPack {
     uint64_t circuit_digest[4] = {0, 0, 0, 0};
     std::vector<uint64_t> constants_sigmas;  // column-major values
     std::vector<HintOp> hints;               // optional: free-standing witness generators (stage s1)
+    std::vector<uint64_t> pi_cells;          // optional: the wire cell (row * num_wires + column) of every public input
 
     uint64_t n() const { return 1ull << degree_bits; }
     uint64_t num_cs_cols() const { return num_selectors + num_constants + num_routed_wires; }

@@ -173,11 +173,25 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) {
             const u32 ops = (u32)a.out_p_stride;
             const u32 obase = row * (u32)a.out_row_stride + mm * (u32)a.out_l_stride;
             const u32 ka = (u32)brev(j, KA);
+            if (a.tw_lo && a.tw_mode == 1) {
+                // inter-pass twiddle w^(mm*k), k = ka + (r << KA) for output r = brev(jb): w^(mm*ka) * (w^(mm << KA))^r. Two
+                // table lookups per thread and a running product instead of two scattered table reads per element.
+                const u32 lo_mask = (1u << a.tw_lo_bits) - 1;
+                const u32 e0 = mm * ka, es = mm << KA;
+                u64 t = gl::mul(a.tw_hi[e0 >> a.tw_lo_bits], a.tw_lo[e0 & lo_mask]);
+                const u64 step = gl::mul(a.tw_hi[es >> a.tw_lo_bits], a.tw_lo[es & lo_mask]);
+#pragma unroll
+                for (int r = 0; r < NB; r++) {
+                    const int jb = brev(r, KB);
+                    y[jb] = gl::mul(y[jb], t);
+                    if (r + 1 < NB) t = gl::mul(t, step);
+                }
+            }
 #pragma unroll
             for (int jb = 0; jb < NB; jb++) {
                 const u32 k = ka + ((u32)brev(jb, KB) << KA);
                 u64 v = y[jb];
-                if (a.tw_lo) {
+                if (a.tw_lo && a.tw_mode == 0) {
                     const u32 e = mm * k;
                     if (e) v = gl::mul(v, gl::mul(a.tw_hi[e >> a.tw_lo_bits], a.tw_lo[e & ((1u << a.tw_lo_bits) - 1)]));
                 }

@@ -1,6 +1,7 @@
 // ntt_plan.cpp — host-side planning for the NTT passes: pass split, twiddle tables, launches.
 // Replaces the root-table / dispatch logic of plonky2::field::fft (fft_root_table, fft_dispatch).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -72,7 +73,10 @@ int cached(qpgpu_ctx *ctx, const std::string &key, u64 base, u64 count, uint64_t
 struct Split { int ka, kb; };
 Split split_round(int l) { Split s; s.ka = (l + 1) / 2; s.kb = l / 2; if (l == 1) { s.ka = 1; s.kb = 0; } return s; }
 
+int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 int pick_log_t(int ka, int kb, u64 lanes_total) {
+    static const int force = env_int("QPGPU_NTT_LOGT", -1);   // tuning knob for the 2^10-point passes
+    if (force >= 0 && ka + kb == 10 && lanes_total >= (1ull << force)) return force;
     int log_t = 8 - ka;  // 256 threads per workgroup
     if (log_t < 3) log_t = 3;
     // keep LDS under ~72 KB so two workgroups share a CU
@@ -256,6 +260,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         if (rc) return rc;
         // inter-pass twiddle w_N^(mm*k): e < N, split at lo_bits
         p.tw_lo_bits = (L + 1) / 2;
+        { static const int tw_mode = env_int("QPGPU_NTT_TW", 0); p.tw_mode = (uint32_t)tw_mode; }
         rc = cached(ctx, "lo" + dir + std::to_string(L), wN, 1ull << p.tw_lo_bits, (uint64_t **)&p.tw_lo);
         if (rc) return rc;
         rc = cached(ctx, "hi" + dir + std::to_string(L), gl::pow(wN, 1ull << p.tw_lo_bits), 1ull << (L - p.tw_lo_bits), (uint64_t **)&p.tw_hi);

@@ -7,6 +7,7 @@
 // and grouped into selector polynomials with the builder's own rule. It plays the role of reference rows a1/a6
 // (witness + circuit shape providers).
 #include <algorithm>
+#include <map>
 #include <numeric>
 #include <string>
 #include "circuit.hpp"
@@ -152,6 +153,18 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
         for (u64 r = 7, k = 0; r + n_noop < n; r += 8, k++) row_gate[r] = cyc[k % 6];
     }
 
+    // the public-input hash in-circuit (plonky2's CircuitBuilder::build): ceil(npis / 8) chained PoseidonGate rows right
+    // after the constant rows; their last output is copy-connected to the PublicInputGate's wires. Without Poseidon rows
+    // (or without room) the PublicInputGate row holds the hash as a plain source, as the first synthetic circuits did.
+    std::map<u64, u64> pi_hash_row;      // row -> absorption index
+    {
+        const u64 chunks = (num_public_inputs + 7) / 8;
+        if (with_poseidon && chunks > 0 && 1 + n_const_rows + chunks + n_noop <= n) {
+            for (u64 k = 0; k < chunks; k++) { row_gate[1 + n_const_rows + k] = GATE_POSEIDON; pi_hash_row[1 + n_const_rows + k] = k; }
+            pack.pi_cells.assign(num_public_inputs, 0);
+        }
+    }
+
     wires.assign((size_t)num_wires * n, 0);
     auto W = [&](u64 row, u64 col) -> u64 & { return wires[col * n + row]; };
     for (u64 c = 0; c < num_wires; c++) for (u64 r = 0; r < n; r++) W(r, c) = rng.felt();  // unconstrained cells
@@ -231,13 +244,56 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
         return true;
     };
 
+    // fills the swap bit, deltas and recorded S-box inputs of a PoseidonGate row; st receives the permutation output
+    auto poseidon_row = [&](u64 r, const u64 (&in)[12], u64 swap, u64 (&st)[12]) {
+        const u64 *rcs = poseidon::host_round_constants();
+        W(r, 24) = swap;
+        for (int i = 0; i < 4; i++) {
+            u64 delta = swap ? gl::canon(gl::sub(in[i + 4], in[i])) : 0;
+            W(r, 25 + i) = delta;
+            st[i] = gl::canon(gl::add(in[i], delta)); st[i + 4] = gl::canon(gl::sub(in[i + 4], delta));
+        }
+        for (int i = 8; i < 12; i++) st[i] = in[i];
+        int rc = 0;
+        for (int rr = 0; rr < 4; rr++, rc++) {
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
+            if (rr) for (int i = 0; i < 12; i++) W(r, 29 + 12 * (rr - 1) + i) = st[i];
+            for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+            poseidon::mds_layer(st);
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+        }
+        // partial rounds in plonky2's fast basis: the S-box input wires are state[0] of that formulation
+        const u64 *fpt = poseidon::host_fast_partial();
+        poseidon::fast_partial_enter(st, fpt);
+        for (int rr = 0; rr < 22; rr++) {
+            st[0] = gl::canon(st[0]);
+            W(r, 65 + rr) = st[0];
+            st[0] = poseidon::sbox7(st[0]);
+            poseidon::fast_partial_linear(st, fpt, rr);
+        }
+        for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+        rc += 22;
+        for (int rr = 0; rr < 4; rr++, rc++) {
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
+            for (int i = 0; i < 12; i++) W(r, 87 + 12 * rr + i) = st[i];
+            for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+            poseidon::mds_layer(st);
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+        }
+    };
+
     for (u64 r = 0; r < n; r++) {
         const u64 kind = row_gate[r];
         for (u64 s = 0; s < sel_cols; s++) CS(r, s) = sel_of[kind] == s ? idx_of[kind] : UNUSED;   // selector polynomials
         if (kind == GATE_PUBLIC_INPUT) {
             for (int i = 0; i < 4; i++) W(r, i) = pih[i];
         } else if (kind == GATE_CONSTANT) {
-            for (int i = 0; i < 2; i++) { u64 c = rng.felt(); CS(r, sel_cols + i) = c; output(r, i, c); }
+            for (int i = 0; i < 2; i++) {
+                u64 c = rng.felt();
+                // builder.zero(): the constant the unused inputs of the public-input hash are wired to (kept out of the copy pool)
+                if (r == 1 && i == 0 && !pi_hash_row.empty()) { CS(r, sel_cols) = 0; W(r, 0) = 0; continue; }
+                CS(r, sel_cols + i) = c; output(r, i, c);
+            }
         } else if (kind == GATE_ARITHMETIC) {
             const u64 c0 = (r & 1) ? rng.felt() : 1, c1 = (r & 2) ? rng.felt() : 1;
             CS(r, sel_cols) = c0; CS(r, sel_cols + 1) = c1;
@@ -360,46 +416,28 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
             output(r, 0, v);
             for (u64 i = 0; i < num_limbs; i++) W(r, 1 + i) = (v >> i) & 1;
         } else if (kind == GATE_POSEIDON) {
-            // PoseidonGate row: inputs (some copied), swap bit, deltas, recorded S-box inputs, outputs
-            const u64 *rcs = poseidon::host_round_constants();
-            u64 in[12];
-            for (int k = 0; k < 12; k++) in[k] = input(r, k);
-            const u64 swap = rng.below(2);
-            W(r, 24) = swap;
-            u64 st[12];
-            for (int i = 0; i < 4; i++) {
-                u64 delta = swap ? gl::canon(gl::sub(in[i + 4], in[i])) : 0;
-                W(r, 25 + i) = delta;
-                st[i] = gl::canon(gl::add(in[i], delta)); st[i + 4] = gl::canon(gl::sub(in[i + 4], delta));
+            u64 in[12], st[12];
+            if (pi_hash_row.count(r)) {
+                // one absorption of the public-input hash, wired the way CircuitBuilder::build does it: the chunk's public
+                // inputs are this row's own cells (free: the PartialWitness sets them), every other input is copy-connected
+                // to the previous absorption's output (overwrite-mode sponge; zero for the first), swap = 0
+                const u64 k = pi_hash_row[r], lo = 8 * k, len = std::min<u64>(8, num_public_inputs - lo);
+                for (u64 j = 0; j < 12; j++) {
+                    if (j < len) { W(r, j) = pis[lo + j]; pack.pi_cells[lo + j] = own_cell(r, j); }
+                    else if (k == 0) { W(r, j) = 0; const uint32_t a = find(cell(1, 0)), b = find(cell(r, j)); if (a != b) parent[b] = a; }
+                    else { W(r, j) = W(r - 1, 12 + j); const uint32_t a = find(cell(r - 1, 12 + j)), b = find(cell(r, j)); if (a != b) parent[b] = a; }
+                    in[j] = W(r, j);
+                }
+                poseidon_row(r, in, 0, st);
+                for (int i = 0; i < 12; i++) W(r, 12 + i) = st[i];          // sponge state: not offered to the copy pool
+                if (lo + len == num_public_inputs)
+                    for (int i = 0; i < 4; i++) { W(0, i) = st[i]; const uint32_t a = find(cell(r, 12 + i)), b = find(cell(0, i)); if (a != b) parent[b] = a; }
+            } else {
+                // PoseidonGate row: inputs (some copied), swap bit, deltas, recorded S-box inputs, outputs
+                for (int k = 0; k < 12; k++) in[k] = input(r, k);
+                poseidon_row(r, in, rng.below(2), st);
+                for (int i = 0; i < 12; i++) output(r, 12 + i, st[i]);
             }
-            for (int i = 8; i < 12; i++) st[i] = in[i];
-            int rc = 0;
-            for (int rr = 0; rr < 4; rr++, rc++) {
-                for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
-                if (rr) for (int i = 0; i < 12; i++) W(r, 29 + 12 * (rr - 1) + i) = st[i];
-                for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
-                poseidon::mds_layer(st);
-                for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
-            }
-            // partial rounds in plonky2's fast basis: the S-box input wires are state[0] of that formulation
-            const u64 *fpt = poseidon::host_fast_partial();
-            poseidon::fast_partial_enter(st, fpt);
-            for (int rr = 0; rr < 22; rr++) {
-                st[0] = gl::canon(st[0]);
-                W(r, 65 + rr) = st[0];
-                st[0] = poseidon::sbox7(st[0]);
-                poseidon::fast_partial_linear(st, fpt, rr);
-            }
-            for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
-            rc += 22;
-            for (int rr = 0; rr < 4; rr++, rc++) {
-                for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], rcs[rc * 12 + i]));
-                for (int i = 0; i < 12; i++) W(r, 87 + 12 * rr + i) = st[i];
-                for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
-                poseidon::mds_layer(st);
-                for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
-            }
-            for (int i = 0; i < 12; i++) output(r, 12 + i, st[i]);
         }
     }
     // sigma: cycle through each copy class

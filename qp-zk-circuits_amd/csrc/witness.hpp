@@ -29,3 +29,6 @@ struct WitnessArgs {
 hipError_t wk_run_level(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st);
 hipError_t wk_run_poseidon(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st);   // PoseidonGate instances, 16 lanes each
 hipError_t wk_fill_copies(const WitnessArgs &a, uint32_t batch, hipStream_t st);
+// wires[b * batch_stride + idx[i]] = vals[b * val_stride + i] (flat cell index = column * n + row); out[i] = wires[idx[i]]
+hipError_t wk_scatter(uint64_t *wires, const uint32_t *idx, const uint64_t *vals, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t val_stride, hipStream_t st);
+hipError_t wk_gather(const uint64_t *wires, const uint32_t *idx, uint64_t *out, uint32_t count, hipStream_t st);

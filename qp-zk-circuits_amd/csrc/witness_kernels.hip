@@ -241,8 +241,29 @@ __global__ void __launch_bounds__(256) witness_fill_kernel(WitnessArgs a) {
     if (src != own) a.wires[own] = a.wires[src];
 }
 
+// wires[b][idx[i]] = vals[b][i]: the caller's assignments (PartialWitness::set_target) and the public-input cells
+__global__ void __launch_bounds__(256) witness_scatter_kernel(u64 *wires, const u32 *idx, const u64 *vals, u32 count, u64 batch_stride, u32 val_stride) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    wires[(u64)blockIdx.y * batch_stride + idx[i]] = gl::canon(vals[(u64)blockIdx.y * val_stride + i]);
+}
+__global__ void __launch_bounds__(256) witness_gather_kernel(const u64 *wires, const u32 *idx, u64 *out, u32 count) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = gl::canon(wires[idx[i]]);
+}
+
 }  // namespace
 
+hipError_t wk_scatter(uint64_t *wires, const uint32_t *idx, const uint64_t *vals, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t val_stride, hipStream_t st) {
+    if (count == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(witness_scatter_kernel, dim3((count + 255) / 256, batch), dim3(256), 0, st, wires, idx, vals, count, batch_stride, val_stride);
+    return hipGetLastError();
+}
+hipError_t wk_gather(const uint64_t *wires, const uint32_t *idx, uint64_t *out, uint32_t count, hipStream_t st) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(witness_gather_kernel, dim3((count + 255) / 256), dim3(256), 0, st, wires, idx, out, count);
+    return hipGetLastError();
+}
 hipError_t wk_run_level(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st) {
     if (count == 0 || batch == 0) return hipSuccess;
     hipLaunchKernelGGL(witness_level_kernel, dim3((count + 127) / 128, batch), dim3(128), 0, st, a, first, count);

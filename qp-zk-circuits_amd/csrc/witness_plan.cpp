@@ -29,6 +29,13 @@ struct WitnessPlan {
     u64 *d_pi_hash = nullptr;
     u64 *d_hints = nullptr;
     uint32_t pi_cap = 0;                     // witnesses d_pi_hash has room for
+    // public-input cells (pack trailer "PUBI1"): stage s1 writes the caller's public inputs there
+    uint32_t *d_pi_idx = nullptr;            // flat cell (column * n + row) of public input i
+    u64 *d_pi_vals = nullptr;                // [pi_cap][num_public_inputs]
+    // partial-witness entry: host view of the copy classes and growable device staging
+    std::vector<uint32_t> h_src_of;          // [n][num_routed] -> flat source cell of the copy class
+    std::vector<uint8_t> generated;          // [num_wires][n]: 1 = a generator produces this cell (or its copy class)
+    uint32_t *d_pair_idx = nullptr; u64 *d_pair_val = nullptr; size_t pair_cap = 0;
 };
 
 void witness_plan_free(WitnessPlan *p) {
@@ -37,6 +44,10 @@ void witness_plan_free(WitnessPlan *p) {
     if (p->d_insts) (void)hipFree(p->d_insts);
     if (p->d_pi_hash) (void)hipFree(p->d_pi_hash);
     if (p->d_hints) (void)hipFree(p->d_hints);
+    if (p->d_pi_idx) (void)hipFree(p->d_pi_idx);
+    if (p->d_pi_vals) (void)hipFree(p->d_pi_vals);
+    if (p->d_pair_idx) (void)hipFree(p->d_pair_idx);
+    if (p->d_pair_val) (void)hipFree(p->d_pair_val);
     delete p;
 }
 
@@ -172,16 +183,36 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     plan.free_mask.assign(NW * n, 1);
     IO tmp;
     CellIO io;
-    for (size_t id = 0; id < insts.size(); id++) {
-        describe_any(p, insts[id], tmp, io);
-        for (const Cell &oc : io.out) {
-            if (oc.col >= NW) return "witness plan: generator output beyond num_wires";
-            plan.free_mask[(u64)oc.col * n + oc.row] = 0;
-            if (oc.col >= R) continue;
-            const uint32_t cell = (uint32_t)((u64)oc.row * R + oc.col), root = find(cell);
-            if (producer[root] >= 0) return "witness plan: two generators write one copy class (row " + std::to_string(oc.row) + ")";
-            producer[root] = (int32_t)id; source[root] = cell;
+    // PublicInputGate has no generator in plonky2: CircuitBuilder::build hashes the public-input targets with PoseidonGate
+    // rows and copy-connects that hash to the gate's wires, so in an exported circuit those four cells are filled by the copy
+    // pass. Only where nothing else produces them (the first synthetic circuits) does the row take the host-computed hash.
+    auto is_pi = [&](const WitnessInst &w) { return w.gate != WITNESS_HINT && p.gates[w.gate].type == GATE_PUBLIC_INPUT; };
+    std::vector<uint8_t> dropped(insts.size(), 0);
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t id = 0; id < insts.size(); id++) {
+            if ((is_pi(insts[id]) ? 1 : 0) != pass) continue;
+            describe_any(p, insts[id], tmp, io);
+            if (pass == 1) {
+                size_t taken = 0;
+                for (const Cell &oc : io.out) if (oc.col < R && producer[find((uint32_t)((u64)oc.row * R + oc.col))] >= 0) taken++;
+                if (taken == io.out.size()) { dropped[id] = 1; continue; }
+                if (taken) return "witness plan: PublicInputGate wires are only partly connected to a hash output (row " + std::to_string(insts[id].row) + ")";
+            }
+            for (const Cell &oc : io.out) {
+                if (oc.col >= NW) return "witness plan: generator output beyond num_wires";
+                plan.free_mask[(u64)oc.col * n + oc.row] = 0;
+                if (oc.col >= R) continue;
+                const uint32_t cell = (uint32_t)((u64)oc.row * R + oc.col), root = find(cell);
+                if (producer[root] >= 0) return "witness plan: two generators write one copy class (row " + std::to_string(oc.row) + ")";
+                producer[root] = (int32_t)id; source[root] = cell;
+            }
         }
+    if (std::count(dropped.begin(), dropped.end(), 1)) {   // compact, keeping producer ids valid
+        std::vector<int32_t> remap(insts.size(), -1);
+        std::vector<WitnessInst> kept;
+        for (size_t id = 0; id < insts.size(); id++) if (!dropped[id]) { remap[id] = (int32_t)kept.size(); kept.push_back(insts[id]); }
+        for (auto &pr : producer) if (pr >= 0) pr = remap[pr];
+        insts.swap(kept);
     }
     std::vector<uint32_t> src_of(n * R);
     for (uint32_t cell = 0; cell < n * R; cell++) {
@@ -191,6 +222,11 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     }
     plan.num_free = 0;
     for (uint8_t m : plan.free_mask) plan.num_free += m;
+    plan.generated.assign(NW * n, 0);
+    for (u64 col = 0; col < NW; col++)
+        for (u64 r = 0; r < n; r++)
+            plan.generated[col * n + r] = col < R ? (producer[find((uint32_t)(r * R + col))] >= 0) : (plan.free_mask[col * n + r] == 0);
+    plan.h_src_of = src_of;
 
     // ---- levels: 1 + the deepest producer among the inputs (iterative depth-first, cycles rejected) ----
     std::vector<int32_t> level(insts.size(), 0);        // 0 = unvisited, -1 = on the stack
@@ -251,6 +287,11 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     if (!up(src_of.data(), src_of.size() * 4, (void **)&plan.d_src_of)) return "witness plan: device allocation failed";
     if (!up(plan.insts.data(), plan.insts.size() * sizeof(WitnessInst), (void **)&plan.d_insts)) return "witness plan: device allocation failed";
     if (!p.hints.empty() && !up(p.hints.data(), p.hints.size() * sizeof(HintOp), (void **)&plan.d_hints)) return "witness plan: device allocation failed";
+    if (!p.pi_cells.empty()) {
+        std::vector<uint32_t> flat(p.pi_cells.size());
+        for (size_t i = 0; i < flat.size(); i++) flat[i] = (uint32_t)((p.pi_cells[i] % NW) * n + p.pi_cells[i] / NW);
+        if (!up(flat.data(), flat.size() * 4, (void **)&plan.d_pi_idx)) return "witness plan: device allocation failed";
+    }
     return "";
 }
 
@@ -303,10 +344,19 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
     if (!d_wires || batch == 0 || batch > 65535 || (!public_inputs && c->pack.num_public_inputs)) return ctx->fail(QPGPU_EINVAL, "generate_witness: bad argument");
     QP_TRY(ensure_plan(c));
     WitnessPlan &plan = *c->wplan;
+    const size_t npis = c->pack.num_public_inputs;
     if (plan.pi_cap < batch) {
-        if (plan.d_pi_hash) { QP_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(plan.d_pi_hash); plan.d_pi_hash = nullptr; plan.pi_cap = 0; }
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (plan.d_pi_hash) { (void)hipFree(plan.d_pi_hash); plan.d_pi_hash = nullptr; }
+        if (plan.d_pi_vals) { (void)hipFree(plan.d_pi_vals); plan.d_pi_vals = nullptr; }
+        plan.pi_cap = 0;
         QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_hash, (size_t)batch * 32));
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_vals, std::max<size_t>((size_t)batch * npis * 8, 8)));
         plan.pi_cap = batch;
+    }
+    if (plan.d_pi_idx && npis) {   // PartialWitness::set_target for every public-input target
+        QP_HIP(ctx, hipMemcpyAsync(plan.d_pi_vals, public_inputs, (size_t)batch * npis * 8, hipMemcpyHostToDevice, ctx->stream));
+        QP_HIP(ctx, wk_scatter(d_wires, plan.d_pi_idx, plan.d_pi_vals, (uint32_t)npis, batch, c->pack.num_wires * c->pack.n(), (uint32_t)npis, ctx->stream));
     }
     std::vector<u64> pih((size_t)batch * 4);
     for (uint32_t b = 0; b < batch; b++) host_pi_hash(public_inputs + (size_t)b * c->pack.num_public_inputs, c->pack.num_public_inputs, pih.data() + 4 * b);
@@ -331,6 +381,75 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
 
 int qpgpu_generate_witness_dev(qpgpu_circuit *c, uint64_t *d_wires, const uint64_t *public_inputs) {
     return qpgpu_generate_witness_batch_dev(c, d_wires, 1, public_inputs);
+}
+
+// plonky2's generate_partial_witness on a sparse PartialWitness: (cell, value) assignments instead of a wire matrix.
+// A target that is set twice with different values — two assignments in one copy class, or an assignment that disagrees
+// with what a generator (or the public-input argument) produces for that target — is the reference's
+// "set twice with different values" panic (wormhole/tests/src/circuit/block_header_tests.rs:34-95); here QPGPU_EUNSAT.
+int qpgpu_generate_witness_partial_dev(qpgpu_circuit *c, const uint64_t *cells, const uint64_t *values, size_t count,
+                                       const uint64_t *public_inputs, uint64_t *d_wires) {
+    if (!c) return QPGPU_EINVAL;
+    qpgpu_ctx *ctx = c->ctx;
+    QP_DEV(ctx);
+    const CircuitPack &p = c->pack;
+    if (!d_wires || (count && (!cells || !values)) || (!public_inputs && p.num_public_inputs)) return ctx->fail(QPGPU_EINVAL, "generate_witness_partial: null argument");
+    QP_TRY(ensure_plan(c));
+    WitnessPlan &plan = *c->wplan;
+    const u64 n = p.n(), NW = p.num_wires, R = p.num_routed_wires;
+    auto name = [&](u64 cell) { return "target (row " + std::to_string(cell / NW) + ", wire " + std::to_string(cell % NW) + ")"; };
+    // key = the slot plonky2's PartitionWitness would use: the copy class's source cell for routed wires, else the cell
+    struct Slot { u64 value, cell; };
+    std::unordered_map<uint32_t, Slot> set;
+    set.reserve((count + p.num_public_inputs) * 2);
+    std::vector<uint32_t> idx; std::vector<u64> val;          // scatter list (flat cells)
+    std::vector<uint32_t> chk_idx; std::vector<u64> chk_val, chk_cell;   // generator-produced targets to compare afterwards
+    auto assign = [&](u64 cell, u64 v, std::string &err) {
+        if (cell >= NW * n) { err = "generate_witness_partial: cell " + std::to_string(cell) + " is outside the trace"; return; }
+        const u64 row = cell / NW, col = cell % NW;
+        const uint32_t own = (uint32_t)(col * n + row), key = col < R ? plan.h_src_of[row * R + col] : own;
+        v = gl::canon(v);
+        auto it = set.find(key);
+        if (it != set.end()) {
+            if (it->second.value != v) err = name(cell) + " set twice with different values (" + std::to_string(v) + " here, " + std::to_string(it->second.value) + " through " + name(it->second.cell) + ")";
+            return;
+        }
+        set.emplace(key, Slot{v, cell});
+        if (plan.generated[own]) { chk_idx.push_back(key); chk_val.push_back(v); chk_cell.push_back(cell); return; }
+        idx.push_back(key); val.push_back(v);     // a free class is read through its source cell; the copy pass fills the members
+    };
+    std::string err;
+    for (size_t i = 0; i < p.pi_cells.size() && err.empty(); i++) assign(p.pi_cells[i], public_inputs[i], err);
+    for (size_t i = 0; i < count && err.empty(); i++) assign(cells[i], values[i], err);
+    if (!err.empty()) return ctx->fail(err.rfind("generate_witness_partial", 0) == 0 ? QPGPU_EINVAL : QPGPU_EUNSAT, err);
+    const size_t need = std::max(idx.size(), chk_idx.size());
+    if (plan.pair_cap < need) {
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (plan.d_pair_idx) (void)hipFree(plan.d_pair_idx);
+        if (plan.d_pair_val) (void)hipFree(plan.d_pair_val);
+        plan.d_pair_idx = nullptr; plan.d_pair_val = nullptr; plan.pair_cap = 0;
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_pair_idx, need * 4));
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_pair_val, need * 8));
+        plan.pair_cap = need;
+    }
+    QP_HIP(ctx, hipMemsetAsync(d_wires, 0, NW * n * 8, ctx->stream));
+    if (!idx.empty()) {
+        QP_HIP(ctx, hipMemcpyAsync(plan.d_pair_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        QP_HIP(ctx, hipMemcpyAsync(plan.d_pair_val, val.data(), val.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        QP_HIP(ctx, wk_scatter(d_wires, plan.d_pair_idx, plan.d_pair_val, (uint32_t)idx.size(), 1, 0, 0, ctx->stream));
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    QP_TRY(qpgpu_generate_witness_batch_dev(c, d_wires, 1, public_inputs));
+    if (!chk_idx.empty()) {
+        std::vector<u64> got(chk_idx.size());
+        QP_HIP(ctx, hipMemcpyAsync(plan.d_pair_idx, chk_idx.data(), chk_idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        QP_HIP(ctx, wk_gather(d_wires, plan.d_pair_idx, plan.d_pair_val, (uint32_t)chk_idx.size(), ctx->stream));
+        QP_TRY(ctx->read_back(got.data(), plan.d_pair_val, got.size() * 8));
+        for (size_t i = 0; i < got.size(); i++)
+            if (got[i] != chk_val[i])
+                return ctx->fail(QPGPU_EUNSAT, name(chk_cell[i]) + " set twice with different values (" + std::to_string(chk_val[i]) + " supplied, " + std::to_string(got[i]) + " generated)");
+    }
+    return QPGPU_OK;
 }
 
 int qpgpu_generate_witness(qpgpu_circuit *c, uint64_t *wires, const uint64_t *public_inputs) {

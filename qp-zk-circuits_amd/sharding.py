@@ -43,8 +43,12 @@ def gather_proof_bytes(proofs, dist=None, device=None, layout=None):
     dev = device if device is not None else torch.device("cpu")
     if layout is not None and "counts" in layout:
         counts, all_lens, max_count, max_len = layout["counts"], layout["all_lens"], layout["max_count"], layout["max_len"]
-        if len(proofs) != counts[dist.get_rank()] or any(len(p) != n for p, n in zip(proofs, all_lens[dist.get_rank()])):
-            raise ValueError("gather_proof_bytes: proofs do not match the cached layout")
+        bad = len(proofs) != counts[dist.get_rank()] or any(len(p) != n for p, n in zip(proofs, all_lens[dist.get_rank()]))
+        # every rank must leave together: a rank raising on its own would strand the others inside all_gather
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise ValueError("gather_proof_bytes: proofs do not match the cached layout" + ("" if bad else " on another rank"))
     else:
         lens = torch.tensor([len(p) for p in proofs], dtype=torch.int64, device=dev)
         count = torch.tensor([len(proofs)], dtype=torch.int64, device=dev)

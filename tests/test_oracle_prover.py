@@ -143,7 +143,9 @@ def test_hint_trailer_is_ignored_by_the_prover(pkg, orc):
     kw = dict(seed=11, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
     plain, _, _ = pkg.synth_circuit(7, **kw)
     pack, wires, pis = pkg.synth_circuit(7, hints=True, **kw)
-    assert pack.size > plain.size and int(pack[plain.size]) == 0x31544E4948
+    body = plain.size - (2 + pis.size)                   # both packs end with the public-input cell trailer ("PUBI1")
+    assert int(plain[body]) == 0x3149425550 and int(plain[body + 1]) == pis.size
+    assert pack.size > plain.size and int(pack[body]) == 0x31544E4948 and int(pack[-pis.size - 2]) == 0x3149425550
     oc = OracleCircuit(orc, pack)
     assert oc.verify(oc.prove(wires, pis)) == 0
     oc.close()

@@ -35,11 +35,12 @@ def _worker(rank, world, port, ret):
     for _ in range(3):
         ok = ok and [p for r in sh.gather_proof_bytes(mine, dist, None, layout) for p in r] == all_proofs
     ok = ok and layout["counts"] == [3, 2]
-    try:
-        sh.gather_proof_bytes([mine[0] + b"x"] + mine[1:], dist, None, dict(layout))
+    try:   # only rank 0 breaks the layout: both ranks must raise, neither may hang in the collective
+        sh.gather_proof_bytes(([mine[0] + b"x"] + mine[1:]) if rank == 0 else mine, dist, None, dict(layout))
         ok = False
     except ValueError:
         pass
+    ok = ok and [p for r in sh.gather_proof_bytes(mine, dist, None, layout) for p in r] == all_proofs   # still usable
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
