@@ -136,7 +136,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree-bits", type=int, default=13)
     ap.add_argument("--batch-degree-bits", type=int, default=16, help="rows of the private / public batch circuits of the tree leg")
-    ap.add_argument("--streams", type=int, default=4, help="proofs in flight per GPU (one HIP stream + workspace each)")
+    ap.add_argument("--streams", type=int, default=2, help="proving workers per GPU (one HIP stream + host transcript thread each)")
+    ap.add_argument("--batch", type=int, default=8, help="proofs a worker proves in lockstep (qpgpu_prove_batch_dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-tree", action="store_true", help="skip the 64-leaf aggregation-tree leg (BASELINE configs[4])")
@@ -174,10 +175,11 @@ def main():
     import __graft_entry__ as ge
     pkg = ge.load_package()
     from concurrent.futures import ThreadPoolExecutor
-    S = max(1, args.streams)
+    WORKERS, LOCKSTEP = max(1, args.streams), max(1, args.batch)
+    S = WORKERS * LOCKSTEP                                          # proofs in flight per GPU = proofs per step per GPU
     stream = torch.cuda.current_stream(dev)
-    gpu = pkg.QpGpu(local_rank, stream=stream.cuda_stream)          # stream 0 shares torch's stream (NTT leg, profiling)
-    gpus = [gpu] + [pkg.QpGpu(local_rank) for _ in range(S - 1)]    # the others own a HIP stream each
+    gpu = pkg.QpGpu(local_rank, stream=stream.cuda_stream)          # shares torch's stream (NTT leg, profiling)
+    gpus = [gpu]
 
     # ---- synthetic leaf-shaped circuit + witness (setup, untimed: reference builds the circuit in the bench's
     # setup closure too, wormhole/prover/benches/prover.rs:35-37) ----
@@ -188,7 +190,7 @@ def main():
     w_t = torch.from_numpy(wires.view(np.int64)).to(dev)            # witness resident in HBM
     proof_len = circ.proof_size()
     outs = [np.empty(proof_len, dtype=np.uint8) for _ in range(S)]
-    pool = ThreadPoolExecutor(max_workers=S)
+    pool = ThreadPoolExecutor(max_workers=1)
     pool_gen = ThreadPoolExecutor(max_workers=1)
     gathered = None
     step_layout = {}
@@ -201,15 +203,29 @@ def main():
 
     import queue
 
-    prover_pool = pkg.ProvingPool(pack, workers=S, device=local_rank)   # S proofs in flight: streams, circuit copies and
-                                                                        # transcript threads live inside the library
+    # WORKERS lockstep batches of LOCKSTEP proofs in flight: streams, circuit workspaces and transcript threads live inside
+    # the library (qpgpu_pool_create_batched)
+    prover_pool = pkg.ProvingPool(pack, workers=WORKERS, device=local_rank, max_batch=LOCKSTEP)
+    # S different witnesses of the circuit resident in HBM (setup, untimed): witness 0 is the generator's own, the others
+    # come from its free cells with other public inputs, completed by stage s1 on the device
+    agg = pkg.aggregation
+    mat_bytes = wires.size * 8
+    w_all = gpu.alloc(S * mat_bytes)
+    pis_all = [pis] + [agg.leaf_public_inputs(1000 * rank + i) for i in range(1, S)]
+    tp_ = agg.TemplateProver(gpu, pack, wires, max_batch=min(S, 16))
+    for k0 in range(0, S, tp_.max_batch):
+        chunk = pis_all[k0:k0 + tp_.max_batch]
+        tp_.commit_many(chunk)
+        gpu._check(gpu.lib.qpgpu_memcpy_d2d(gpu.ctx, w_all.ptr + k0 * mat_bytes, tp_.d_wires.ptr, len(chunk) * mat_bytes))
+    gpu.sync()
+    tp_.close()
 
     def run_steps(k):
         """k steps = k*S proofs through the library's proving pool. All jobs are queued at once and the workers free-run;
         the main thread closes step j when its S proofs are written and, with several ranks, gathers that step's proof
         bytes over RCCL while the workers are already proving step j+1."""
         bufs = [np.empty(proof_len, dtype=np.uint8) for _ in range(k * S)]
-        tickets = [prover_pool.submit(w_t, pis, bufs[i]) for i in range(k * S)]
+        tickets = [prover_pool.submit(w_all.ptr + (i % S) * mat_bytes, pis_all[i % S], bufs[i]) for i in range(k * S)]
         last = None
         nonlocal gathered
         layout = step_layout          # proofs of one circuit have one size: metadata collectives run once
@@ -455,7 +471,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]/[3]: full proof (LDE + Poseidon Merkle commit + quotient + FRI) of a "
                                    "shape-equivalent synthetic leaf circuit, one proof per GPU per step, witness resident in HBM",
                        "degree_bits": d, "gates": "PublicInput, Constant, BaseSum<2>(63 limbs), Arithmetic(20 ops), Poseidon(123 constraints), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
-                       "num_query_rounds": 28, "proof_of_work_bits": 16, "fri_arity_bits": 4, "proof_bytes": proof_len, "proofs_in_flight_per_gpu": S, "proofs_per_step_per_gpu": S,
+                       "num_query_rounds": 28, "proof_of_work_bits": 16, "fri_arity_bits": 4, "proof_bytes": proof_len, "proofs_in_flight_per_gpu": S, "proofs_per_step_per_gpu": S, "workers": WORKERS, "lockstep_batch": LOCKSTEP,
                        "multi_gpu": "independent proofs per rank + RCCL all_gather of proof bytes" if world > 1 else "single GPU"},
         }
         line.update(extra)

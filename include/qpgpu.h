@@ -57,17 +57,24 @@ int qpgpu_malloc(qpgpu_ctx *ctx, size_t bytes, void **dptr);
 int qpgpu_free(qpgpu_ctx *ctx, void *dptr);
 int qpgpu_memcpy_h2d(qpgpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int qpgpu_memcpy_d2h(qpgpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int qpgpu_memcpy_d2d(qpgpu_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);   /* asynchronous on the ctx stream */
 
 /* ---- proof-system hasher -------------------------------------------------------------------------------------
  * Which permutation backs the fork's `PoseidonGoldilocksConfig` hasher (Merkle trees, Fiat-Shamir challenger, public-input
- * hash, proof of work) cannot be told from the reference, so it is a process-wide plug:
- * kind 0 = plonky2's Poseidon (default; constants derived at start-up), kind 1 = Poseidon2 (width 12, x^7, 4+22+4 rounds)
- * with caller-supplied parameters: 96 external round constants (round major), 22 internal round constants, the 12
+ * hash, proof of work) cannot be told from the reference, so it is a plug, and a property of the
+ * context: kind 0 = plonky2's Poseidon (default; constants derived at start-up), kind 1 = Poseidon2 (width 12, x^7, 4+22+4
+ * rounds) with caller-supplied parameters: 96 external round constants (round major), 22 internal round constants, the 12
  * diagonal entries d of the internal matrix J + diag(d), and the 4x4 block M4 (row major) of the external matrix
- * circ(2 M4, M4, M4) — 146 words. Select it before creating circuits or oracles and not while proofs are running. */
+ * circ(2 M4, M4, M4) — 146 words. qpgpu_ctx_set_hasher must come before the first circuit or oracle is created on the
+ * context (QPGPU_EINVAL afterwards); everything created on the context then hashes with it, and contexts with different
+ * hashers coexist in one process. */
 #define QPGPU_HASH_POSEIDON 0
 #define QPGPU_HASH_POSEIDON2 1
 #define QPGPU_POSEIDON2_PARAM_WORDS 146
+int qpgpu_ctx_set_hasher(qpgpu_ctx *ctx, int kind, const uint64_t *params, size_t n_words);
+int qpgpu_ctx_get_hasher(const qpgpu_ctx *ctx);
+/* Deprecated process-wide default: what a new context (and the context-free helpers: synthetic circuits,
+ * qpgpu_challenger_*, the workers of a proving pool) starts with. Existing contexts are not affected. */
 int qpgpu_set_hasher(int kind, const uint64_t *params, size_t n_words);
 int qpgpu_get_hasher(void);
 
@@ -124,12 +131,23 @@ int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t
  * wormhole/circuit/src/circuit.rs:210-212 (`builder.build_prover()`).
  */
 int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_words, qpgpu_circuit **out);
+/* The same with a per-proof workspace for up to max_batch proofs proven in lockstep (qpgpu_prove_batch_dev): about
+ * 260 MB per proof at 2^13 rows x 135 wires. The constants/sigmas commitment is shared by the batch. */
+int qpgpu_circuit_load_batch(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_words, unsigned max_batch, qpgpu_circuit **out);
+unsigned qpgpu_circuit_max_batch(const qpgpu_circuit *c);
+/* Releases the handle; every device region that held witness-derived data is overwritten first. */
 void qpgpu_circuit_free(qpgpu_circuit *c);
+/* Overwrites the witness-derived workspace now (witness copy, Z / quotient values, coefficients, LDEs, salts, FRI
+ * workspace, openings). qpgpu_prove does this after every proof; the _dev and pool entries leave the workspace as it is
+ * until the next proof or the free (the caller owns the witness buffer it passed and clears that itself). */
+int qpgpu_circuit_scrub(qpgpu_circuit *c);
 int qpgpu_circuit_constants_sigmas_cap(const qpgpu_circuit *c, uint64_t *out, size_t out_words);
 /* Zero-knowledge packs (standard_recursion_zk_config, reference common/src/circuit.rs:396-402): the wires,
- * Z/partial-products and quotient oracles carry 4 salt columns per leaf. By default they are drawn from the OS
- * entropy source per proof (the reference uses thread_rng); a seed set here applies to the NEXT prove call only and
- * makes its bytes reproducible. */
+ * Z/partial-products and quotient oracles carry 4 salt columns per leaf: a ChaCha20 stream keyed with 256 bits that are
+ * drawn from the OS entropy source (getrandom) for every proof (the reference uses thread_rng, also a CSPRNG): opened
+ * salts say nothing about unopened ones. TEST HOOK: a seed set here applies to the NEXT prove call only (proof b of a
+ * batch derives its key from seed + b) and makes its bytes reproducible; a proof made under a known seed is not
+ * zero-knowledge against whoever knows the seed. */
 int qpgpu_circuit_set_blinding_seed(qpgpu_circuit *c, uint64_t seed);
 /* Optional witness check (off by default): before the quotient stage, evaluate every filtered gate constraint on the
  * trace rows and the closing of the permutation product; a violation makes qpgpu_prove* return QPGPU_EUNSAT with the
@@ -148,6 +166,13 @@ size_t qpgpu_proof_size(const qpgpu_circuit *c);   /* bytes written by qpgpu_pro
  */
 int qpgpu_prove(qpgpu_circuit *c, const uint64_t *wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len);
 int qpgpu_prove_dev(qpgpu_circuit *c, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, size_t *out_len);
+/* `batch` (<= the handle's max_batch) independent proofs of the circuit in lockstep: every stage is launched once for all
+ * of them, the Fiat-Shamir transcripts advance together on the host, one stream synchronisation per stage for the batch.
+ * d_wires[b] / public_inputs[b] / outs[b] (each out_cap bytes) / out_lens[b] belong to proof b; witnesses laid out back to
+ * back are used in place, others are gathered into the workspace first. Each proof's bytes equal what qpgpu_prove_dev
+ * gives for the same witness. An error concerns the whole batch (an unsatisfied witness names its proof). */
+int qpgpu_prove_batch_dev(qpgpu_circuit *c, const uint64_t *const *d_wires, uint32_t batch, const uint64_t *const *public_inputs,
+                          uint8_t *const *outs, size_t out_cap, size_t *out_lens);
 
 /* ---- stage s1: witness generation on the device ------------------------------------------------------------------
  * `iop::generator::generate_partial_witness` for the gate-attached generators of the supported gate set (Constant,
@@ -194,8 +219,10 @@ typedef struct qpgpu_oracle qpgpu_oracle;
 #define QPGPU_ORACLE_COEFFS 1u        /* input polynomials are coefficients (from_coeffs) */
 #define QPGPU_ORACLE_BLINDING 2u      /* append 4 salt elements to every leaf (zero-knowledge configs) */
 #define QPGPU_ORACLE_DEVICE_INPUT 4u  /* `polys` is a device pointer */
-/* polys: num_polys x 2^degree_bits, column-major (polynomial j at polys + j*2^degree_bits). blinding_stream selects
- * the salt stream derived from blinding_seed (the all-in-one prover uses 1, 2, 3 for wires, Z/partial products, quotient). */
+/* polys: num_polys x 2^degree_bits, column-major (polynomial j at polys + j*2^degree_bits). With QPGPU_ORACLE_BLINDING the
+ * salts are a ChaCha20 stream: blinding_seed 0 = keyed with 256 fresh bits from the OS entropy source (production);
+ * non-zero = key derived from the seed (reproducible, tests only). blinding_stream selects the stream under the key
+ * (the all-in-one prover uses 1, 2, 3 for wires, Z/partial products, quotient). */
 int qpgpu_oracle_commit(qpgpu_ctx *ctx, const uint64_t *polys, uint32_t num_polys, unsigned degree_bits, unsigned rate_bits,
                         unsigned cap_height, unsigned flags, uint64_t blinding_seed, uint32_t blinding_stream, qpgpu_oracle **out);
 void qpgpu_oracle_free(qpgpu_oracle *o);   /* overwrites the device copies before releasing them */
@@ -216,6 +243,10 @@ typedef struct {
     uint32_t input_len, output_len;
 } qpgpu_challenger;
 void qpgpu_challenger_init(qpgpu_challenger *c);
+/* under the context's hasher; QPGPU_EINVAL for a state plonky2 cannot be in (input_len >= 8 or output_len > 8) */
+int qpgpu_ctx_challenger_observe(const qpgpu_ctx *ctx, qpgpu_challenger *c, const uint64_t *elements, size_t n);
+int qpgpu_ctx_challenger_get(const qpgpu_ctx *ctx, qpgpu_challenger *c, uint64_t *out);
+/* under the process-default hasher (first ABI); an invalid state is left untouched and get returns 0 */
 void qpgpu_challenger_observe(qpgpu_challenger *c, const uint64_t *elements, size_t n);
 uint64_t qpgpu_challenger_get(qpgpu_challenger *c);
 
@@ -241,6 +272,9 @@ int qpgpu_fri_prove(qpgpu_ctx *ctx, qpgpu_oracle *const *oracles, uint32_t num_o
  * witness matrices and output buffers must stay valid until their ticket has been waited for. */
 typedef struct qpgpu_pool qpgpu_pool;
 int qpgpu_pool_create(int device, const uint64_t *pack_words, size_t n_words, unsigned workers, qpgpu_pool **out);
+/* Workers that prove in lockstep: each takes up to max_batch queued proofs at once (qpgpu_prove_batch_dev). Two workers of
+ * eight keep the GPU busy while one of them is in a host-side stage. The workers' contexts use the process-default hasher. */
+int qpgpu_pool_create_batched(int device, const uint64_t *pack_words, size_t n_words, unsigned workers, unsigned max_batch, qpgpu_pool **out);
 void qpgpu_pool_destroy(qpgpu_pool *p);          /* drains the queue first */
 size_t qpgpu_pool_proof_size(const qpgpu_pool *p);
 unsigned qpgpu_pool_workers(const qpgpu_pool *p);

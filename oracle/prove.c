@@ -41,12 +41,35 @@ int orc_trace_get(const char *name, uint64_t *out) {
 static void batch_free(orc_batch *b) { free(b->coeffs); free(b->leaves); free(b->digests); free(b->cap); memset(b, 0, sizeof *b); }
 
 /* PolynomialBatch::from_coeffs (no blinding): LDE each column on the coset g<w>, transpose, bit-reverse rows, Merkle */
-/* salt for leaf `leaf` of a blinded oracle: splitmix64 in counter mode, reduced into the field */
+/* salt for leaf `leaf` of a blinded oracle. The reference draws salts from thread_rng (upstream PolynomialBatch::from_coeffs
+ * with blinding), so there is nothing to restate; for byte parity under an injected seed this follows the product's stream
+ * (csrc/prover_kernels.hip salt_kernel): ChaCha20 (RFC 8439 block function, 64-bit block counter), key = (seed lo, seed hi,
+ * "QPGP", "SALT", 0, 0, 0, 0), nonce = (oracle_index, column), block = leaf >> 1 holding four 64-bit candidates per leaf,
+ * the first one below p taken. */
+#define ROTL32(x, k) (((x) << (k)) | ((x) >> (32 - (k))))
+static void salt_chacha20_block(const uint32_t key[8], uint64_t counter, uint32_t n0, uint32_t n1, uint32_t out[16]) {
+    uint32_t x[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), n0, n1}, w[16];
+    memcpy(w, x, sizeof w);
+#define QR(a, b, c, d) w[a] += w[b]; w[d] = ROTL32(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = ROTL32(w[b] ^ w[c], 12); \
+                       w[a] += w[b]; w[d] = ROTL32(w[d] ^ w[a], 8);  w[c] += w[d]; w[b] = ROTL32(w[b] ^ w[c], 7);
+    for (int r = 0; r < 10; r++) {
+        QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
+        QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
+    }
+#undef QR
+    for (int i = 0; i < 16; i++) out[i] = w[i] + x[i];
+}
 gl_t orc_salt_value(uint64_t seed, unsigned oracle_index, unsigned column, uint64_t leaf) {
-    uint64_t ctr = ((uint64_t)(oracle_index * 4 + column) << 40) | leaf;
-    uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (ctr + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
-    return z >= GL_P ? z - GL_P : z;
+    const uint32_t key[8] = {(uint32_t)seed, (uint32_t)(seed >> 32), 0x51504750u, 0x53414c54u, 0, 0, 0, 0};
+    uint32_t blk[16];
+    salt_chacha20_block(key, leaf >> 1, oracle_index, column, blk);
+    const unsigned h = (unsigned)(leaf & 1) * 8;
+    for (int k = 0; k < 4; k++) {
+        const uint64_t cand = ((uint64_t)blk[h + 2 * k + 1] << 32) | blk[h + 2 * k];
+        if (cand < GL_P) return cand;
+    }
+    return (((uint64_t)blk[h + 7] << 32) | blk[h + 6]) - GL_P;
 }
 static uint64_t g_seed = 0;
 static int g_blind = 0;

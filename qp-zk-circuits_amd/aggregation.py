@@ -48,10 +48,11 @@ class TemplateProver:
     (its free cells other than the public-input cells) plus the given public inputs; the full witness is generated on the
     device. Stands in for WormholeProver::commit / prove (wormhole/prover/src/lib.rs:156-175) on a synthetic leaf circuit."""
 
-    def __init__(self, gpu, pack, template_wires):
+    def __init__(self, gpu, pack, template_wires, max_batch=1):
         self.gpu, self.pack = gpu, pack
         self.hdr = pack_header(pack)
-        self.circ = Circuit(gpu, pack)
+        self.max_batch = max_batch
+        self.circ = Circuit(gpu, pack, max_batch=max_batch)
         nw, n = self.hdr["num_wires"], 1 << self.hdr["degree_bits"]
         pi_cells = pack_public_input_cells(pack)
         if pi_cells is None:
@@ -62,8 +63,10 @@ class TemplateProver:
         keep = ~np.isin(cells, pi_cells)
         self.cells = cells[keep]
         self.values = np.asarray(template_wires, dtype=np.uint64)[col[keep], row[keep]]
-        self.d_wires = gpu.alloc(nw * n * 8)
+        self.mat_bytes = nw * n * 8
+        self.d_wires = gpu.alloc(self.mat_bytes * max_batch)
         self.pis = None
+        self.batch_pis = None
 
     def close(self):
         if self.circ is not None:
@@ -88,9 +91,33 @@ class TemplateProver:
         self.pis = pis
         return pis
 
+    def commit_many(self, public_inputs_list):
+        """Witnesses for up to max_batch public-input vectors at once: the PartialWitness of the first is expanded on the
+        device, copied, and one batched generation pass (stage s1, all dependency levels walked once) rewrites the public-input
+        cells and everything that depends on them in every copy."""
+        nb = len(public_inputs_list)
+        if nb == 0 or nb > self.max_batch:
+            raise ValueError("batch size outside 1..max_batch")
+        pis = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.uint64) for p in public_inputs_list]))
+        self.circ.generate_witness_partial_dev(self.cells, self.values, pis[0], self.d_wires)
+        if nb > 1:
+            for b in range(1, nb):
+                self.gpu._check(self.gpu.lib.qpgpu_memcpy_d2d(self.gpu.ctx, self.d_wires.ptr + b * self.mat_bytes, self.d_wires.ptr, self.mat_bytes))
+            self.circ.generate_witness_dev(self.d_wires, pis, batch=nb)
+        self.batch_pis = pis
+        return pis
+
+    def prove_many(self):
+        """The committed batch in lockstep (qpgpu_prove_batch_dev); returns the list of proofs."""
+        if self.batch_pis is None:
+            raise RuntimeError("prove_many() before commit_many()")
+        pis = self.batch_pis
+        self.batch_pis = None
+        return self.circ.prove_batch_dev([self.d_wires.ptr + b * self.mat_bytes for b in range(len(pis))], list(pis))
+
     def witness(self):
         """The committed full witness [num_wires, n] (host copy; tests compare it with the oracle's view)."""
-        return self.d_wires.download().reshape(self.hdr["num_wires"], 1 << self.hdr["degree_bits"])
+        return self.d_wires.download(count=self.mat_bytes // 8).reshape(self.hdr["num_wires"], 1 << self.hdr["degree_bits"])
 
     def prove(self, out=None):
         if self.pis is None:
@@ -134,14 +161,15 @@ class AggregationTree:
     gathered (sharding.gather_proof_bytes: RCCL on GPUs, gloo in rehearsals) and consumed by the next level.
     Reference call stack SURVEY.md 3.4; partitioning SURVEY.md 8e."""
 
-    def __init__(self, pkg, gpu, rank, world, leaf, private, public, num_leaves=64, slots=8):
+    def __init__(self, pkg, gpu, rank, world, leaf, private, public, num_leaves=64, slots=8, leaf_batch=8):
         """leaf / private / public: (pack, template_wires, template_pis) of the level's circuit (public only on the root)."""
         from . import sharding
         self.sharding, self.rank, self.world, self.slots = sharding, rank, world, slots
         self.plan = sharding.aggregation_schedule(num_leaves, slots, world)
         self.mine = self.plan["ranks"][rank]
         self.num_batches = num_leaves // slots
-        self.leaf = TemplateProver(gpu, leaf[0], leaf[1])
+        self.leaf_batch = max(1, min(leaf_batch, len(self.mine["leaves"]))) if self.mine["leaves"] else 1
+        self.leaf = TemplateProver(gpu, leaf[0], leaf[1], max_batch=self.leaf_batch)
         self.private = BatchProver(gpu, private[0], private[1], private[2], LEAF_PUBLIC_INPUTS, slots)
         self.public = None
         if rank == self.plan["root"]:
@@ -158,11 +186,15 @@ class AggregationTree:
         rank's (index, public inputs, full witness) triples for an external checker (costs a device download each)."""
         d = dist if self.world > 1 else None
         mine_leaf = []
-        for i in self.mine["leaves"]:
-            pis = self.leaf.commit(leaf_public_inputs(i))
+        ids = list(self.mine["leaves"])
+        for k in range(0, len(ids), self.leaf_batch):   # this rank's leaves, leaf_batch at a time in lockstep
+            chunk = ids[k:k + self.leaf_batch]
+            pis = self.leaf.commit_many([leaf_public_inputs(i) for i in chunk])
             if keep is not None:
-                keep.setdefault("leaf", []).append((i, pis.copy(), self.leaf.witness()))
-            mine_leaf.append(self.leaf.prove())
+                all_w = self.leaf.d_wires.download(count=len(chunk) * self.leaf.mat_bytes // 8).reshape(len(chunk), self.leaf.hdr["num_wires"], -1)
+                for j, i in enumerate(chunk):
+                    keep.setdefault("leaf", []).append((i, pis[j].copy(), all_w[j].copy()))
+            mine_leaf += self.leaf.prove_many()
         leaves = [p for r in self.sharding.gather_proof_bytes(mine_leaf, d, device) for p in r]
         mine_priv = []
         for b in self.mine["private_batches"]:

@@ -51,6 +51,7 @@ def load_library():
         "qpgpu_free": (c.c_int, [vp, vp]),
         "qpgpu_memcpy_h2d": (c.c_int, [vp, vp, vp, c.c_size_t]),
         "qpgpu_memcpy_d2h": (c.c_int, [vp, vp, vp, c.c_size_t]),
+        "qpgpu_memcpy_d2d": (c.c_int, [vp, vp, vp, c.c_size_t]),
         "qpgpu_ntt_batch": (c.c_int, [vp, u64p, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
         "qpgpu_ntt_batch_dev": (c.c_int, [vp, u64p, u64p, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
         "qpgpu_lde_batch_dev": (c.c_int, [vp, u64p, u64p, c.c_uint, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
@@ -59,6 +60,15 @@ def load_library():
         "qpgpu_merkle_build_dev": (c.c_int, [vp, u64p, c.c_uint64, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
         "qpgpu_merkle_build_rows_dev": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
         "qpgpu_circuit_load": (c.c_int, [vp, u64p, c.c_size_t, c.POINTER(vp)]),
+        "qpgpu_circuit_load_batch": (c.c_int, [vp, u64p, c.c_size_t, c.c_uint, c.POINTER(vp)]),
+        "qpgpu_circuit_max_batch": (c.c_uint, [vp]),
+        "qpgpu_circuit_scrub": (c.c_int, [vp]),
+        "qpgpu_prove_batch_dev": (c.c_int, [vp, vp, c.c_uint32, vp, vp, c.c_size_t, vp]),
+        "qpgpu_ctx_set_hasher": (c.c_int, [vp, c.c_int, u64p, c.c_size_t]),
+        "qpgpu_ctx_get_hasher": (c.c_int, [vp]),
+        "qpgpu_ctx_challenger_observe": (c.c_int, [vp, vp, u64p, c.c_size_t]),
+        "qpgpu_ctx_challenger_get": (c.c_int, [vp, vp, c.POINTER(c.c_uint64)]),
+        "qpgpu_pool_create_batched": (c.c_int, [c.c_int, u64p, c.c_size_t, c.c_uint, c.c_uint, c.POINTER(vp)]),
         "qpgpu_circuit_free": (None, [vp]),
         "qpgpu_circuit_constants_sigmas_cap": (c.c_int, [vp, u64p, c.c_size_t]),
         "qpgpu_proof_size": (c.c_size_t, [vp]),
@@ -119,15 +129,19 @@ def exported_symbols():
 
 
 def set_hasher_poseidon():
-    """Process-wide: plonky2's Poseidon backs Merkle trees, challenger, public-input hash and proof of work (the default)."""
+    """Process default (what NEW contexts and the context-free helpers use): plonky2's Poseidon."""
     load_library().qpgpu_set_hasher(0, None, 0)
 
 
-def set_hasher_poseidon2(rc_ext, rc_int, diag_m1, m4):
-    """Process-wide: Poseidon2 with the given parameters (external round constants [8][12], internal [22], diagonal [12],
-    4x4 block) backs the proof-system hasher. Select before loading circuits."""
-    flat = np.concatenate([np.asarray(rc_ext, dtype=np.uint64).ravel(), np.asarray(rc_int, dtype=np.uint64).ravel(),
+def _p2_block(rc_ext, rc_int, diag_m1, m4):
+    return np.concatenate([np.asarray(rc_ext, dtype=np.uint64).ravel(), np.asarray(rc_int, dtype=np.uint64).ravel(),
                            np.asarray(diag_m1, dtype=np.uint64).ravel(), np.asarray(m4, dtype=np.uint64).ravel()])
+
+
+def set_hasher_poseidon2(rc_ext, rc_int, diag_m1, m4):
+    """Process default: Poseidon2 with the given parameters (external round constants [8][12], internal [22], diagonal
+    [12], 4x4 block). Contexts that already exist keep their hasher; QpGpu(hasher=...) sets one context's."""
+    flat = _p2_block(rc_ext, rc_int, diag_m1, m4)
     rc = load_library().qpgpu_set_hasher(1, flat.ctypes.data, flat.size)
     if rc != 0:
         raise QpGpuError(rc, "qpgpu_set_hasher: bad Poseidon2 parameter block")
@@ -217,12 +231,31 @@ class DeviceBuffer:
 class Circuit:
     """A circuit pack loaded on the GPU (constants/sigmas committed, workspace allocated)."""
 
-    def __init__(self, gpu, pack_words):
+    def __init__(self, gpu, pack_words, max_batch=1):
         self.gpu = gpu
         pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
         h = ctypes.c_void_p()
-        gpu._check(gpu.lib.qpgpu_circuit_load(gpu.ctx, pw.ctypes.data, pw.size, ctypes.byref(h)))
+        gpu._check(gpu.lib.qpgpu_circuit_load_batch(gpu.ctx, pw.ctypes.data, pw.size, max_batch, ctypes.byref(h)))
         self.h = h
+        self.max_batch = max_batch
+
+    def scrub(self):
+        """Overwrite every witness-derived device region of the workspace now."""
+        self.gpu._check(self.gpu.lib.qpgpu_circuit_scrub(self.h))
+
+    def prove_batch_dev(self, d_wires_list, public_inputs_list, outs=None):
+        """Lockstep batch: one device witness and one public-input vector per proof; returns the list of proof bytes."""
+        nb = len(d_wires_list)
+        ptrs = (ctypes.c_void_p * nb)(*[_ptr(w) for w in d_wires_list])
+        pis = [np.ascontiguousarray(p, dtype=np.uint64) for p in public_inputs_list]
+        pip = (ctypes.c_void_p * nb)(*[p.ctypes.data for p in pis])
+        size = self.proof_size()
+        if outs is None:
+            outs = [np.empty(size, dtype=np.uint8) for _ in range(nb)]
+        op = (ctypes.c_void_p * nb)(*[o.ctypes.data for o in outs])
+        lens = (ctypes.c_size_t * nb)()
+        self.gpu._check(self.gpu.lib.qpgpu_prove_batch_dev(self.h, ptrs, nb, pip, op, size, lens))
+        return [outs[i][:lens[i]].tobytes() for i in range(nb)]
 
     def close(self):
         if self.h:
@@ -307,17 +340,31 @@ class ChallengerState(ctypes.Structure):
 
 
 class Challenger:
-    def __init__(self):
+    """gpu=None: the process-default hasher (first ABI); gpu=QpGpu: that context's hasher."""
+
+    def __init__(self, gpu=None):
         self.lib = load_library()
+        self.gpu = gpu
         self.state = ChallengerState()
         self.lib.qpgpu_challenger_init(ctypes.byref(self.state))
 
     def observe(self, xs):
         x = np.ascontiguousarray(xs, dtype=np.uint64).ravel()
-        self.lib.qpgpu_challenger_observe(ctypes.byref(self.state), x.ctypes.data, x.size)
+        if self.gpu is None:
+            self.lib.qpgpu_challenger_observe(ctypes.byref(self.state), x.ctypes.data, x.size)
+        else:
+            rc = self.lib.qpgpu_ctx_challenger_observe(self.gpu.ctx, ctypes.byref(self.state), x.ctypes.data, x.size)
+            if rc != 0:
+                raise QpGpuError(rc, "invalid challenger state")
 
     def get(self):
-        return int(self.lib.qpgpu_challenger_get(ctypes.byref(self.state)))
+        if self.gpu is None:
+            return int(self.lib.qpgpu_challenger_get(ctypes.byref(self.state)))
+        v = ctypes.c_uint64()
+        rc = self.lib.qpgpu_ctx_challenger_get(self.gpu.ctx, ctypes.byref(self.state), ctypes.byref(v))
+        if rc != 0:
+            raise QpGpuError(rc, "invalid challenger state")
+        return int(v.value)
 
     def get_n(self, n):
         return [self.get() for _ in range(n)]
@@ -412,11 +459,11 @@ class ProvingPool:
     """Several proofs of one circuit in flight on one GPU (qpgpu_pool_*): worker threads, streams and circuit copies live
     inside the library."""
 
-    def __init__(self, pack_words, workers=4, device=0):
+    def __init__(self, pack_words, workers=4, device=0, max_batch=1):
         self.lib = load_library()
         pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
         h = ctypes.c_void_p()
-        rc = self.lib.qpgpu_pool_create(device, pw.ctypes.data, pw.size, workers, ctypes.byref(h))
+        rc = self.lib.qpgpu_pool_create_batched(device, pw.ctypes.data, pw.size, workers, max_batch, ctypes.byref(h))
         if rc != 0:
             raise QpGpuError(rc, "qpgpu_pool_create failed")
         self.h = h
@@ -481,13 +528,20 @@ class _Stage3:
 class QpGpu(_Stage3):
     """One context = one GPU + one HIP stream."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, hasher=None):
+        """hasher: None = the process default; "poseidon"; or the Poseidon2 block (rc_ext, rc_int, diag_m1, m4)."""
         self.lib = load_library()
         ctx = ctypes.c_void_p()
         rc = self.lib.qpgpu_ctx_create(device, ctypes.byref(ctx))
         if rc != 0:
             raise QpGpuError(rc, "qpgpu_ctx_create failed (no gfx950 device visible?)")
         self.ctx = ctx
+        if hasher is not None:
+            if isinstance(hasher, str):
+                self._check(self.lib.qpgpu_ctx_set_hasher(self.ctx, 0, None, 0))
+            else:
+                flat = _p2_block(*hasher)
+                self._check(self.lib.qpgpu_ctx_set_hasher(self.ctx, 1, flat.ctypes.data, flat.size))
         if stream is not None:
             self._check(self.lib.qpgpu_ctx_set_stream(self.ctx, ctypes.c_void_p(stream)))
 

@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 #include "../../include/qpgpu.h"
+#include "merkle.hpp"
+#include "poseidon.hpp"
 
 struct NttTables;  // ntt_plan.cpp
 
@@ -20,7 +22,12 @@ struct qpgpu_ctx {
     size_t scratch_bytes = 0;
     std::map<std::string, std::shared_ptr<NttTables>> ntt_tables;
     std::vector<void *> owned;  // table allocations freed at destroy
-    unsigned hasher_generation = 0;  // hasher::generation() whose constants this ctx last uploaded to __constant__ memory
+    // the proof-system hasher of everything created on this context (copied from the process default at creation,
+    // changed by qpgpu_ctx_set_hasher until the first circuit or oracle is created here)
+    hasher::Config hasher;
+    poseidon2::Params *d_p2 = nullptr;       // device copy of hasher.p2 (Poseidon2 only)
+    bool hasher_in_use = false;
+    HasherDev hasher_dev() const { HasherDev h; h.kind = hasher.kind; h.p2 = d_p2; return h; }
 
     // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)
     struct KStat { double ms = 0; uint64_t launches = 0; };
@@ -44,6 +51,8 @@ struct qpgpu_ctx {
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     int read_back(void *host_dst, const void *dev_src, size_t bytes);
+    // `rows` pieces of `width` bytes, `src_pitch` bytes apart on the device, packed back to back on the host
+    int read_back_2d(void *host_dst, const void *dev_src, size_t src_pitch, size_t width, size_t rows);
     int upload(const std::vector<uint64_t> &host, uint64_t **dptr);
 };
 
@@ -51,8 +60,10 @@ struct qpgpu_ctx {
 #define QP_DEV(ctx) do { hipError_t _e = hipSetDevice((ctx)->device); if (_e != hipSuccess) return (ctx)->hip_fail(_e, "hipSetDevice"); } while (0)
 #define QP_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->hip_fail(_e, #call); } while (0)
 
-struct MerkleLeafArgs;
-int merkle_ensure_constants(qpgpu_ctx *ctx);
+int merkle_ensure_constants(qpgpu_ctx *ctx);   // Poseidon round constants on the device, the context's Poseidon2 block uploaded
+// leaf hashing + all levels down to the cap for `leaf.batch` trees (digest arrays at d_digests + b * leaf.ps_digests)
 int merkle_build(qpgpu_ctx *ctx, const MerkleLeafArgs &leaf, unsigned log_leaves, unsigned cap_height, uint64_t *d_digests);
+// `batch` columns per proof; with nproofs > 1 proof b reads at d_in + b * in_ps and writes at d_out + b * out_ps (words)
+struct NttProofs { uint32_t nproofs = 1; uint64_t in_ps = 0, out_ps = 0; };
 int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
-            size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift);
+            size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift, NttProofs np = NttProofs());

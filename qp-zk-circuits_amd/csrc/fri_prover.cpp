@@ -3,7 +3,10 @@
 // through the C ABI (oracle_api.cpp). Follows qp-plonky2 1.5.5 `fri::oracle::PolynomialBatch::{from_values,
 // from_coeffs, prove_openings}` and `fri::prover::{fri_proof, fri_committed_trees, fri_proof_of_work,
 // fri_prover_query_rounds}` as reached from the reference's `prove()` call (wormhole/prover/src/lib.rs:171-175).
+//
+// All of it runs on a lockstep batch of nb proofs (prover_host.hpp): one launch per stage, nb transcripts on the host.
 #include <hip/hip_runtime.h>
+#include <sys/random.h>
 #include <algorithm>
 #include <string>
 #include "merkle.hpp"
@@ -27,34 +30,57 @@ int Stager::put(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return QPGPU_OK;
 }
 
-int oracle_commit_coeffs(qpgpu_ctx *ctx, PolyOracle &o, u64 blinding_seed) {
+int salt_key_random(uint32_t key[8]) {
+    size_t got = 0;
+    while (got < 32) {
+        const ssize_t r = getrandom((uint8_t *)key + got, 32 - got, 0);
+        if (r <= 0) return QPGPU_EDEVICE;
+        got += (size_t)r;
+    }
+    return QPGPU_OK;
+}
+void salt_key_from_seed(uint64_t seed, uint32_t key[8]) {
+    key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
+    key[2] = 0x51504750u; key[3] = 0x53414c54u;   // "QPGP" "SALT"
+    key[4] = key[5] = key[6] = key[7] = 0;
+}
+
+int oracle_commit_coeffs(qpgpu_ctx *ctx, PolyOracle &o, const uint32_t *d_keys) {
     const unsigned L = o.log_lde();
-    QP_TRY(ntt_run(ctx, o.coeffs, o.lde, o.log_n, L, o.ncols, false, true, gl::MULT_GEN));
+    const uint32_t nb = o.nb;
+    if (nb > 1 && (o.ps_coeffs != ((u64)o.ncols << o.log_n) || o.ps_lde != ((u64)o.ncols << L)))
+        return ctx->fail(QPGPU_EINVAL, "oracle_commit: batched oracles are dense arrays");
+    // the nb * ncols columns of the batch are one column batch for the transform
+    QP_TRY(ntt_run(ctx, o.coeffs, o.lde, o.log_n, L, (size_t)nb * o.ncols, false, true, gl::MULT_GEN));
     MerkleLeafArgs a{};
     a.src0 = o.lde; a.stride0 = 1ull << L; a.ncols0 = o.ncols; a.n_leaves = 1ull << L; a.digests = o.digests;
+    a.batch = nb; a.ps_src0 = o.ps_lde; a.ps_digests = o.ps_digests;
     if (o.salt) {
-        QP_HIP(ctx, pk_salt(blinding_seed, o.oracle_index, 1ull << L, o.salt, ctx->stream));
-        a.src1 = o.salt; a.stride1 = 1ull << L; a.ncols1 = 4;
+        if (!d_keys) return ctx->fail(QPGPU_EINVAL, "oracle_commit: a blinded oracle needs salt keys");
+        QP_HIP(ctx, pk_salt(d_keys, o.oracle_index, 1ull << L, o.salt, nb, ctx->stream));
+        a.src1 = o.salt; a.stride1 = 1ull << L; a.ncols1 = 4; a.ps_src1 = o.ps_salt;
     }
     QP_TRY(merkle_build(ctx, a, L, o.cap_h, o.digests));
-    const size_t total = digest_words(L, o.cap_h);
-    o.cap.resize((1ull << o.cap_h) * 4);
-    QP_TRY(ctx->read_back(o.cap.data(), o.digests + total - o.cap.size(), o.cap.size() * 8));
+    const size_t total = digest_words(L, o.cap_h), cw = o.cap_words();
+    o.cap.resize(cw * nb);
+    QP_TRY(ctx->read_back_2d(o.cap.data(), o.digests + total - cw, o.ps_digests * 8, cw * 8, nb));
     return QPGPU_OK;
 }
 
-int oracle_commit_values(qpgpu_ctx *ctx, const u64 *d_values, PolyOracle &o, u64 blinding_seed) {
-    QP_TRY(ntt_run(ctx, d_values, o.coeffs, o.log_n, o.log_n, o.ncols, true, false, 0));
-    return oracle_commit_coeffs(ctx, o, blinding_seed);
+int oracle_commit_values(qpgpu_ctx *ctx, const u64 *d_values, PolyOracle &o, const uint32_t *d_keys) {
+    QP_TRY(ntt_run(ctx, d_values, o.coeffs, o.log_n, o.log_n, (size_t)o.nb * o.ncols, true, false, 0));
+    return oracle_commit_coeffs(ctx, o, d_keys);
 }
 
 namespace {
 struct Layout {
-    size_t comp, fin, vals, coeffs0, coeffs1, pow, qidx, gather, alpha, total;
+    size_t comp, fin, vals, coeffs0, coeffs1, gather, alpha, ws;
     std::vector<size_t> digests, leafrows;
     size_t gather_words;
+    // batch-level tables, offsets from the end of the per-proof blocks
+    size_t t_points, t_shifts, t_betas, pow_states, pow_bases, pow_results, qidx, total;
 };
-Layout layout(const FriParams &p, const std::vector<size_t> &leaf_widths, size_t max_batch_polys) {
+Layout layout(const FriParams &p, const std::vector<size_t> &leaf_widths, size_t max_batch_polys, uint32_t nb) {
     Layout l;
     const size_t n = 1ull << p.degree_bits, lde_n = n << p.rate_bits;
     const unsigned L = p.degree_bits + p.rate_bits;
@@ -71,23 +97,30 @@ Layout layout(const FriParams &p, const std::vector<size_t> &leaf_widths, size_t
         gw += (2ull << a) + (size_t)(lvl - p.cap_h) * 4;
     }
     l.gather_words = gw * p.num_queries;
-    l.pow = take(2); l.qidx = take(p.num_queries); l.gather = take(l.gather_words); l.alpha = take(2 * max_batch_polys);
+    l.gather = take(l.gather_words); l.alpha = take(2 * max_batch_polys);
+    l.ws = off;
+    off = l.ws * nb;
+    l.t_points = take(2 * (size_t)nb); l.t_shifts = take(2 * (size_t)nb); l.t_betas = take(2 * (size_t)nb);
+    l.pow_states = take(12 * (size_t)nb); l.pow_bases = take(nb); l.pow_results = take(nb); l.qidx = take((size_t)nb * p.num_queries);
     l.total = off;
     return l;
 }
 }  // namespace
 
-size_t FriWork::words(const FriParams &p, const std::vector<size_t> &leaf_widths, size_t max_batch_polys) {
-    return layout(p, leaf_widths, max_batch_polys).total;
+size_t FriWork::words(const FriParams &p, const std::vector<size_t> &leaf_widths, size_t max_batch_polys, uint32_t nb) {
+    return layout(p, leaf_widths, max_batch_polys, nb).total;
 }
-void FriWork::bind(u64 *base, const FriParams &p, const std::vector<size_t> &leaf_widths, size_t mbp) {
-    const Layout l = layout(p, leaf_widths, mbp);
+void FriWork::bind(u64 *base, const FriParams &p, const std::vector<size_t> &leaf_widths, size_t mbp, uint32_t nb) {
+    const Layout l = layout(p, leaf_widths, mbp, nb);
+    ws = l.ws; nb_cap = nb;
     comp = base + l.comp; fin = base + l.fin; vals = base + l.vals; coeffs[0] = base + l.coeffs0; coeffs[1] = base + l.coeffs1;
     digests.clear(); leafrows.clear();
     for (size_t o : l.digests) digests.push_back(base + o);
     for (size_t o : l.leafrows) leafrows.push_back(base + o);
-    pow = base + l.pow; qidx = base + l.qidx; gather = base + l.gather; alpha_ext = (e2 *)(base + l.alpha);
+    gather = base + l.gather; alpha_ext = (e2 *)(base + l.alpha);
     gather_words = l.gather_words; max_batch_polys = mbp;
+    t_points = (e2 *)(base + l.t_points); t_shifts = (e2 *)(base + l.t_shifts); t_betas = (e2 *)(base + l.t_betas);
+    pow_states = base + l.pow_states; pow_bases = base + l.pow_bases; pow_results = base + l.pow_results; qidx = base + l.qidx;
 }
 
 size_t fri_proof_bytes(const FriParams &p, const std::vector<size_t> &leaf_widths) {
@@ -99,23 +132,30 @@ size_t fri_proof_bytes(const FriParams &p, const std::vector<size_t> &leaf_width
 }
 
 int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracles, size_t n_oracles,
-              const std::vector<FriBatch> &batches, Challenger &ch, FriWork &w, Stager &stage, ByteWriter &out) {
+              const std::vector<FriBatch> &batches, uint32_t nb, Challenger *chs, FriWork &w, Stager &stage, ByteWriter *outs) {
     hipStream_t st = ctx->stream;
+    const HasherDev hd = ctx->hasher_dev();
     const unsigned d = p.degree_bits, L = d + p.rate_bits, cap_h = p.cap_h;
     const u64 n = 1ull << d, lde_n = n << p.rate_bits;
     const size_t cap_words = (1ull << cap_h) * 4;
-    for (size_t i = 0; i < n_oracles; i++)
+    if (nb == 0 || nb > w.nb_cap) return ctx->fail(QPGPU_EINVAL, "fri_prove: batch larger than the workspace");
+    for (size_t i = 0; i < n_oracles; i++) {
         if (oracles[i]->log_n != d || oracles[i]->rate_bits != p.rate_bits || oracles[i]->cap_h != cap_h)
             return ctx->fail(QPGPU_EINVAL, "fri_prove: oracle " + std::to_string(i) + " does not match the FRI parameters");
+        if (oracles[i]->nb != 1 && oracles[i]->nb < nb) return ctx->fail(QPGPU_EINVAL, "fri_prove: oracle committed for fewer proofs than the batch");
+    }
     { unsigned tot = 0; for (unsigned a : p.arity_bits) { tot += a; if (a == 0 || a > 8) return ctx->fail(QPGPU_EINVAL, "fri_prove: bad reduction arity"); }
       if (tot > d || L - tot < cap_h) return ctx->fail(QPGPU_EINVAL, "fri_prove: reduction schedule does not fit the degree / cap height"); }
+    if (p.pow_bits > 40) return ctx->fail(QPGPU_EINVAL, "fri_prove: proof_of_work_bits above 40");
 
-    const e2 fri_alpha = ch.get_ext();
+    std::vector<e2> fri_alpha(nb);
+    for (uint32_t b = 0; b < nb; b++) fri_alpha[b] = chs[b].get_ext();
 
     // ---- s8 batched opening polynomial: final = sum over batches, each shifted by alpha^(#polys of the later ones) ----
     size_t max_count = 0;
     for (const FriBatch &fb : batches) {
         if (fb.ranges.empty() || fb.ranges.size() > 8) return ctx->fail(QPGPU_EINVAL, "fri_prove: a batch needs 1..8 polynomial ranges");
+        if (fb.points.size() != nb) return ctx->fail(QPGPU_EINVAL, "fri_prove: one opening point per proof expected");
         size_t cnt = 0;
         for (const FriRange &rg : fb.ranges) {
             if (rg.oracle >= n_oracles || (size_t)rg.first + rg.count > oracles[rg.oracle]->ncols || rg.count == 0)
@@ -126,122 +166,152 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
     }
     if (max_count == 0 || max_count > w.max_batch_polys) return ctx->fail(QPGPU_EINVAL, "fri_prove: empty batch or workspace too small");
     ctx->prof_begin("prove_fri_batch");
-    {   // alpha powers always start at 1: one table, every batch reads a prefix
+    {   // alpha powers always start at 1: one table per proof, every batch reads a prefix
         std::vector<e2> apw(max_count);
-        e2 a = gl::e2_from(1);
-        for (size_t i = 0; i < max_count; i++) { apw[i] = gl::e2_canon(a); a = gl::e2_mul(a, fri_alpha); }
-        QP_TRY(stage.put(ctx, w.alpha_ext, apw.data(), apw.size() * sizeof(e2)));
+        for (uint32_t b = 0; b < nb; b++) {
+            e2 a = gl::e2_from(1);
+            for (size_t i = 0; i < max_count; i++) { apw[i] = gl::e2_canon(a); a = gl::e2_mul(a, fri_alpha[b]); }
+            QP_TRY(stage.put(ctx, (u64 *)w.alpha_ext + (size_t)b * w.ws, apw.data(), apw.size() * sizeof(e2)));
+        }
     }
-    for (size_t b = 0; b < batches.size(); b++) {
-        const FriBatch &fb = batches[b];
+    for (size_t bi = 0; bi < batches.size(); bi++) {
+        const FriBatch &fb = batches[bi];
         ReduceArgs ra{};
         size_t count = 0;
         for (size_t r = 0; r < fb.ranges.size(); r++) {
             const FriRange &rg = fb.ranges[r];
-            ra.src[r] = oracles[rg.oracle]->coeffs + (size_t)rg.first * n; ra.ncols[r] = rg.count;
+            const PolyOracle *o = oracles[rg.oracle];
+            ra.src[r] = o->coeffs + (size_t)rg.first * n; ra.ps_src[r] = o->ps_coeffs; ra.ncols[r] = rg.count;
             count += rg.count;
         }
         ra.nsrc = (uint32_t)fb.ranges.size();
         ra.alpha_pows = w.alpha_ext; ra.comp_a = w.comp; ra.comp_b = w.comp + n; ra.n = n;
+        ra.batch = nb; ra.ps_alpha = w.ws / 2; ra.ps_comp = w.ws;      // alpha table in e2 units (ws is even)
         QP_HIP(ctx, pk_reduce_polys(ra, st));
         // alpha.shift_poly(final) multiplies what is there by alpha^count of THIS batch, then the quotient is added
-        QP_HIP(ctx, pk_divide_linear(w.comp, w.comp + n, n, gl::e2_canon(fb.point), b == 0 ? gl::e2_from(1) : gl::e2_canon(gl::e2_pow(fri_alpha, count)),
-                                     b == 0 ? 0 : 1, w.fin, w.fin + n, st));
+        std::vector<e2> pts(nb), shifts(nb);
+        for (uint32_t b = 0; b < nb; b++) {
+            pts[b] = gl::e2_canon(fb.points[b]);
+            shifts[b] = bi == 0 ? gl::e2_from(1) : gl::e2_canon(gl::e2_pow(fri_alpha[b], count));
+        }
+        QP_TRY(stage.put(ctx, w.t_points, pts.data(), nb * sizeof(e2)));
+        QP_TRY(stage.put(ctx, w.t_shifts, shifts.data(), nb * sizeof(e2)));
+        QP_HIP(ctx, pk_divide_linear(w.comp, w.comp + n, n, w.t_points, w.t_shifts, bi == 0 ? 0 : 1, w.fin, w.fin + n, nb, w.ws, w.ws, st));
     }
     ctx->prof_end();
 
     // ---- s9 FRI commit phase ----
     ctx->prof_begin("prove_fri_commit");
-    std::vector<std::vector<u64>> fri_caps;
+    std::vector<std::vector<u64>> fri_caps;     // per round: [nb][cap_words]
     std::vector<unsigned> tree_log_leaves;
     u64 shift = gl::MULT_GEN;
-    u64 *coef = w.fin;           // [2][valid]
+    u64 *coef = w.fin;           // [2][valid] per proof
     u64 valid = n; unsigned log_len = L;
     size_t slot = 0;
+    NttProofs np; np.nproofs = nb; np.in_ps = w.ws; np.out_ps = w.ws;
     // values of the first layer: LDE of the two component columns, leaf order
-    QP_TRY(ntt_run(ctx, coef, w.vals, d, L, 2, false, true, shift));
+    QP_TRY(ntt_run(ctx, coef, w.vals, d, L, 2, false, true, shift, np));
     for (size_t r = 0; r < p.arity_bits.size(); r++) {
         const unsigned ab = p.arity_bits[r];
         const u64 len = 1ull << log_len, arity = 1ull << ab;
         const unsigned log_leaves = log_len - ab;
         u64 *rows = w.leafrows[r];
-        QP_HIP(ctx, pk_interleave_ext(w.vals, w.vals + len, len, rows, st));
+        QP_HIP(ctx, pk_interleave_ext(w.vals, w.vals + len, len, rows, nb, w.ws, w.ws, st));
         // leaves = chunks of `arity` extension values = 2*arity consecutive felts
-        QP_HIP(ctx, merkle_leaf_hash_rows(rows, 1ull << log_leaves, (uint32_t)(2 * arity), w.digests[r], st));
+        QP_HIP(ctx, merkle_leaf_hash_rows(rows, 1ull << log_leaves, (uint32_t)(2 * arity), w.digests[r], nb, w.ws, w.ws, hd, st));
         {
             u64 cnt = 1ull << log_leaves; u64 *lvl = w.digests[r];
-            QP_HIP(ctx, merkle_reduce_to_cap(lvl, cnt, 1ull << cap_h, st));
+            QP_HIP(ctx, merkle_reduce_to_cap(lvl, cnt, 1ull << cap_h, nb, w.ws, hd, st));
             while (cnt > (1ull << cap_h)) { lvl += cnt * 4; cnt >>= 1; }
-            std::vector<u64> capv(cap_words);
-            QP_TRY(ctx->read_back(capv.data(), lvl, cap_words * 8));
+            std::vector<u64> capv(cap_words * nb);
+            QP_TRY(ctx->read_back_2d(capv.data(), lvl, w.ws * 8, cap_words * 8, nb));
             fri_caps.push_back(capv);
         }
         tree_log_leaves.push_back(log_leaves);
-        ch.observe(fri_caps.back().data(), cap_words);
-        const e2 beta = ch.get_ext();
+        std::vector<e2> betas(nb);
+        for (uint32_t b = 0; b < nb; b++) {
+            chs[b].observe(fri_caps.back().data() + (size_t)b * cap_words, cap_words);
+            betas[b] = gl::e2_canon(chs[b].get_ext());
+        }
+        QP_TRY(stage.put(ctx, w.t_betas, betas.data(), nb * sizeof(e2)));
         const u64 new_valid = valid >> ab;
         u64 *ncoef = w.coeffs[slot]; slot ^= 1;
-        QP_HIP(ctx, pk_fri_fold(coef, coef + valid, new_valid, (uint32_t)arity, beta, ncoef, ncoef + new_valid, st));
+        QP_HIP(ctx, pk_fri_fold(coef, coef + valid, new_valid, (uint32_t)arity, w.t_betas, ncoef, ncoef + new_valid, nb, w.ws, w.ws, st));
         coef = ncoef; valid = new_valid; log_len -= ab;
         shift = gl::pow(shift, arity);
         if (r + 1 < p.arity_bits.size()) {
             unsigned lv = 0; while ((1ull << lv) < valid) lv++;
-            QP_TRY(ntt_run(ctx, coef, w.vals, lv, log_len, 2, false, true, shift));
+            QP_TRY(ntt_run(ctx, coef, w.vals, lv, log_len, 2, false, true, shift, np));
         }
     }
-    std::vector<u64> final_coeffs(2 * valid);   // component arrays [a...][b...]
-    QP_TRY(ctx->read_back(final_coeffs.data(), coef, final_coeffs.size() * 8));
+    std::vector<u64> final_coeffs(2 * valid * nb);   // per proof: component arrays [a...][b...]
+    QP_TRY(ctx->read_back_2d(final_coeffs.data(), coef, w.ws * 8, 2 * valid * 8, nb));
     ctx->prof_end();
-    std::vector<e2> final_poly(valid);
-    for (u64 i = 0; i < valid; i++) final_poly[i] = gl::e2_make(final_coeffs[i], final_coeffs[valid + i]);
-    ch.observe((const u64 *)final_poly.data(), 2 * valid);
+    std::vector<std::vector<e2>> final_poly(nb, std::vector<e2>(valid));
+    for (uint32_t b = 0; b < nb; b++) {
+        const u64 *fc = final_coeffs.data() + (size_t)b * 2 * valid;
+        for (u64 i = 0; i < valid; i++) final_poly[b][i] = gl::e2_make(fc[i], fc[valid + i]);
+        chs[b].observe((const u64 *)final_poly[b].data(), 2 * valid);
+    }
 
-    // ---- s10 proof of work: minimum nonce ----
+    // ---- s10 proof of work: minimum nonce per proof ----
     ctx->prof_begin("prove_pow");
-    u64 pow_witness = 0;
+    std::vector<u64> pow_witness(nb, 0);
     if (p.pow_bits > 0) {
+        std::vector<u64> states(12 * (size_t)nb);
+        for (uint32_t b = 0; b < nb; b++) {
+            std::memcpy(states.data() + 12 * (size_t)b, chs[b].state, 12 * 8);
+            for (int i = 0; i < chs[b].n_in; i++) states[12 * (size_t)b + i] = chs[b].in[i];
+            if (chs[b].n_in != chs[0].n_in) return ctx->fail(QPGPU_EDEVICE, "prove: transcripts of a batch diverged in length");
+        }
+        QP_TRY(stage.put(ctx, w.pow_states, states.data(), states.size() * 8));
         PowArgs pw{};
-        std::memcpy(pw.state, ch.state, sizeof pw.state);
-        for (int i = 0; i < ch.n_in; i++) pw.state[i] = ch.in[i];
-        pw.pos = (uint32_t)ch.n_in; pw.pow_bits = p.pow_bits; pw.result = w.pow;
+        pw.states = w.pow_states; pw.bases = w.pow_bases; pw.results = w.pow_results;
+        pw.pos = (uint32_t)chs[0].n_in; pw.pow_bits = p.pow_bits; pw.batch = nb;
         // expected 2^pow_bits candidates; a batch of 2x that finds it 86% of the time and costs one wave per SIMD
-        const u64 batch = std::max<u64>(1ull << 16, 2ull << pw.pow_bits);
-        bool found = false;
-        for (u64 base = 0; !found; base += batch) {
-            const u64 sentinel = ~0ull;
-            QP_HIP(ctx, hipMemsetAsync(w.pow, 0xFF, 8, st));
-            pw.base = base; pw.count = batch;
-            QP_HIP(ctx, pk_pow(pw, st));
-            u64 res = 0;
-            QP_TRY(ctx->read_back(&res, w.pow, 8));
-            if (res != sentinel) { pow_witness = res; found = true; }
-            if (base > (1ull << 40)) return ctx->fail(QPGPU_EDEVICE, "prove: proof of work not found");
+        const u64 span = std::max<u64>(1ull << 16, 2ull << pw.pow_bits);
+        pw.count = span;
+        std::vector<u64> bases(nb, 0), res(nb);
+        std::vector<char> found(nb, 0);
+        uint32_t n_found = 0;
+        QP_HIP(ctx, hipMemsetAsync(w.pow_results, 0xFF, 8 * (size_t)nb, st));
+        for (u64 round = 0; n_found < nb; round++) {
+            for (uint32_t b = 0; b < nb; b++) bases[b] = found[b] ? ~0ull : round * span;
+            QP_TRY(stage.put(ctx, w.pow_bases, bases.data(), 8 * (size_t)nb));
+            QP_HIP(ctx, pk_pow(pw, hd, st));
+            QP_TRY(ctx->read_back(res.data(), w.pow_results, 8 * (size_t)nb));
+            for (uint32_t b = 0; b < nb; b++)
+                if (!found[b] && res[b] != ~0ull) { pow_witness[b] = res[b]; found[b] = 1; n_found++; }
+            if (round * span > (1ull << 41)) return ctx->fail(QPGPU_EDEVICE, "prove: proof of work not found");
         }
     }
     ctx->prof_end();
-    ch.observe(&pow_witness, 1);
-    (void)ch.get();   // the response, re-derived by the verifier
+    for (uint32_t b = 0; b < nb; b++) {
+        chs[b].observe(&pow_witness[b], 1);
+        (void)chs[b].get();   // the response, re-derived by the verifier
+    }
 
     // ---- s11 queries ----
     ctx->prof_begin("prove_queries");
     const uint32_t nqr = p.num_queries;
-    std::vector<u64> qidx(nqr);
-    for (auto &x : qidx) x = ch.get() % lde_n;
-    QP_TRY(stage.put(ctx, w.qidx, qidx.data(), nqr * 8));
+    std::vector<u64> qidx((size_t)nqr * nb);
+    for (uint32_t b = 0; b < nb; b++)
+        for (uint32_t q = 0; q < nqr; q++) qidx[(size_t)b * nqr + q] = chs[b].get() % lde_n;
+    QP_TRY(stage.put(ctx, w.qidx, qidx.data(), qidx.size() * 8));
     // gather layout (per section, all queries contiguous): for each oracle rows then paths; for each FRI round evals then paths
     struct Sec { size_t off, words; bool is_path; };
     std::vector<Sec> secs;
     size_t goff = 0;
     const uint32_t plen0 = L - cap_h;
     for (size_t i = 0; i < n_oracles; i++) {
-        const PolyOracle *b = oracles[i];
-        QP_HIP(ctx, pk_gather_rows(b->lde, lde_n, b->ncols, w.qidx, nqr, w.gather + goff, st));
-        secs.push_back({goff, b->ncols, false}); goff += (size_t)b->ncols * nqr;
-        if (b->salt) {
-            QP_HIP(ctx, pk_gather_rows(b->salt, lde_n, 4, w.qidx, nqr, w.gather + goff, st));
+        const PolyOracle *o = oracles[i];
+        QP_HIP(ctx, pk_gather_rows(o->lde, lde_n, o->ncols, w.qidx, nqr, w.gather + goff, nb, o->ps_lde, w.ws, st));
+        secs.push_back({goff, o->ncols, false}); goff += (size_t)o->ncols * nqr;
+        if (o->salt) {
+            QP_HIP(ctx, pk_gather_rows(o->salt, lde_n, 4, w.qidx, nqr, w.gather + goff, nb, o->ps_salt, w.ws, st));
             secs.push_back({goff, 4, false}); goff += (size_t)4 * nqr;
         }
-        QP_HIP(ctx, pk_gather_paths(b->digests, lde_n, plen0, w.qidx, 0, nqr, w.gather + goff, st));
+        QP_HIP(ctx, pk_gather_paths(o->digests, lde_n, plen0, w.qidx, 0, nqr, w.gather + goff, nb, o->ps_digests, w.ws, st));
         secs.push_back({goff, (size_t)plen0 * 4, true}); goff += (size_t)plen0 * 4 * nqr;
     }
     {
@@ -249,26 +319,30 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
         for (size_t r = 0; r < p.arity_bits.size(); r++) {
             const uint32_t ab = p.arity_bits[r], width = 2u << ab, pl = tree_log_leaves[r] - cap_h;
             sh += ab;
-            QP_HIP(ctx, pk_gather_leaf_rows(w.leafrows[r], width, w.qidx, sh, nqr, w.gather + goff, st));
+            QP_HIP(ctx, pk_gather_leaf_rows(w.leafrows[r], width, w.qidx, sh, nqr, w.gather + goff, nb, w.ws, w.ws, st));
             secs.push_back({goff, width, false}); goff += (size_t)width * nqr;
-            QP_HIP(ctx, pk_gather_paths(w.digests[r], 1ull << tree_log_leaves[r], pl, w.qidx, sh, nqr, w.gather + goff, st));
+            QP_HIP(ctx, pk_gather_paths(w.digests[r], 1ull << tree_log_leaves[r], pl, w.qidx, sh, nqr, w.gather + goff, nb, w.ws, w.ws, st));
             secs.push_back({goff, (size_t)pl * 4, true}); goff += (size_t)pl * 4 * nqr;
         }
     }
     if (goff != w.gather_words) return ctx->fail(QPGPU_EDEVICE, "prove: internal gather size mismatch");
-    std::vector<u64> gathered(goff);
-    QP_TRY(ctx->read_back(gathered.data(), w.gather, goff * 8));
+    std::vector<u64> gathered(goff * nb);
+    QP_TRY(ctx->read_back_2d(gathered.data(), w.gather, w.ws * 8, goff * 8, nb));
     ctx->prof_end();
 
     // ---- FriProof bytes (util::serialization write_fri_proof): caps, query rounds, final poly, pow witness ----
-    for (auto &cp : fri_caps) out.vec(cp.data(), cap_words);
-    for (uint32_t q = 0; q < nqr; q++) {
-        for (const Sec &sc : secs) {
-            if (sc.is_path) out.u8((uint8_t)(sc.words / 4));   // write_merkle_proof: one-byte sibling count
-            out.vec(gathered.data() + sc.off + (size_t)q * sc.words, sc.words);
+    for (uint32_t b = 0; b < nb; b++) {
+        ByteWriter &out = outs[b];
+        const u64 *g = gathered.data() + (size_t)b * goff;
+        for (auto &cp : fri_caps) out.vec(cp.data() + (size_t)b * cap_words, cap_words);
+        for (uint32_t q = 0; q < nqr; q++) {
+            for (const Sec &sc : secs) {
+                if (sc.is_path) out.u8((uint8_t)(sc.words / 4));   // write_merkle_proof: one-byte sibling count
+                out.vec(g + sc.off + (size_t)q * sc.words, sc.words);
+            }
         }
+        for (u64 i = 0; i < valid; i++) out.ext(final_poly[b][i]);
+        out.u64le(pow_witness[b]);
     }
-    for (u64 i = 0; i < valid; i++) out.ext(final_poly[i]);
-    out.u64le(pow_witness);
     return QPGPU_OK;
 }

@@ -6,38 +6,75 @@
 #include "poseidon.hpp"
 
 int merkle_ensure_constants(qpgpu_ctx *ctx) {
-    if (ctx->hasher_generation == hasher::generation()) return QPGPU_OK;
-    QP_HIP(ctx, merkle_upload_constants(poseidon::host_hash_round_constants()));
-    QP_HIP(ctx, merkle_select_hasher(hasher::kind(), &hasher::p2_params()));
-    ctx->hasher_generation = hasher::generation();
+    // plonky2's Poseidon round constants live in __constant__ memory, the same for every context: once per device
+    static std::mutex mu;
+    static bool uploaded[64] = {false};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const int dev = ctx->device;
+        if (dev < 0 || dev >= 64) return ctx->fail(QPGPU_EINVAL, "device index out of range");
+        if (!uploaded[dev]) {
+            QP_HIP(ctx, merkle_upload_constants(poseidon::host_hash_round_constants()));
+            uploaded[dev] = true;
+        }
+    }
+    if (ctx->hasher.kind == hasher::POSEIDON2 && !ctx->d_p2) {   // the context's Poseidon2 parameter block
+        void *v = nullptr;
+        QP_HIP(ctx, hipMalloc(&v, sizeof(poseidon2::Params)));
+        ctx->d_p2 = (poseidon2::Params *)v;
+        QP_HIP(ctx, hipMemcpy(ctx->d_p2, &ctx->hasher.p2, sizeof(poseidon2::Params), hipMemcpyHostToDevice));
+    }
     return QPGPU_OK;
 }
 
-extern "C" int qpgpu_set_hasher(int kind, const uint64_t *params, size_t n_words) {
-    if (kind == hasher::POSEIDON) { hasher::set(hasher::POSEIDON, nullptr); return QPGPU_OK; }
-    if (kind != hasher::POSEIDON2 || !params || n_words != (size_t)poseidon2::PARAM_WORDS) return QPGPU_EINVAL;
-    poseidon2::Params p;
+static int parse_p2(const uint64_t *params, size_t n_words, poseidon2::Params &p) {
+    if (!params || n_words != (size_t)poseidon2::PARAM_WORDS) return QPGPU_EINVAL;
     const uint64_t *w = params;
     for (int i = 0; i < 96; i++) p.rc_ext[i] = gl::canon(*w++);
     for (int i = 0; i < 22; i++) p.rc_int[i] = gl::canon(*w++);
     for (int i = 0; i < 12; i++) p.diag_m1[i] = gl::canon(*w++);
     for (int i = 0; i < 16; i++) p.m4[i] = gl::canon(*w++);
-    hasher::set(hasher::POSEIDON2, &p);
+    return QPGPU_OK;
+}
+
+// process default (seeds new contexts; kept for callers of the first ABI)
+extern "C" int qpgpu_set_hasher(int kind, const uint64_t *params, size_t n_words) {
+    if (kind == hasher::POSEIDON) { hasher::set_process_default(hasher::POSEIDON, nullptr); return QPGPU_OK; }
+    if (kind != hasher::POSEIDON2) return QPGPU_EINVAL;
+    poseidon2::Params p;
+    if (parse_p2(params, n_words, p) != QPGPU_OK) return QPGPU_EINVAL;
+    hasher::set_process_default(hasher::POSEIDON2, &p);
     return QPGPU_OK;
 }
 extern "C" int qpgpu_get_hasher(void) { return hasher::kind(); }
 
-// digests: level 0 (n_leaves) then each parent level down to the cap level, concatenated.
+extern "C" int qpgpu_ctx_set_hasher(qpgpu_ctx *ctx, int kind, const uint64_t *params, size_t n_words) {
+    if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
+    if (ctx->hasher_in_use) return ctx->fail(QPGPU_EINVAL, "ctx_set_hasher: circuits or oracles already exist on this context; choose the hasher first");
+    if (kind == hasher::POSEIDON) { ctx->hasher.kind = hasher::POSEIDON; return QPGPU_OK; }
+    if (kind != hasher::POSEIDON2) return ctx->fail(QPGPU_EINVAL, "ctx_set_hasher: unknown hasher kind");
+    poseidon2::Params p;
+    if (parse_p2(params, n_words, p) != QPGPU_OK) return ctx->fail(QPGPU_EINVAL, "ctx_set_hasher: bad Poseidon2 parameter block");
+    ctx->hasher.kind = hasher::POSEIDON2; ctx->hasher.p2 = p;
+    if (ctx->d_p2) QP_HIP(ctx, hipMemcpy(ctx->d_p2, &ctx->hasher.p2, sizeof(poseidon2::Params), hipMemcpyHostToDevice));
+    return QPGPU_OK;
+}
+extern "C" int qpgpu_ctx_get_hasher(const qpgpu_ctx *ctx) { return ctx ? ctx->hasher.kind : QPGPU_EINVAL; }
+
+// digests: level 0 (n_leaves) then each parent level down to the cap level, concatenated; leaf.batch trees at once.
 int merkle_build(qpgpu_ctx *ctx, const MerkleLeafArgs &leaf, unsigned log_leaves, unsigned cap_height, uint64_t *d_digests) {
     int rc = merkle_ensure_constants(ctx);
     if (rc) return rc;
     if (cap_height > log_leaves) return ctx->fail(QPGPU_EINVAL, "merkle: cap_height exceeds tree height");
+    const HasherDev hd = ctx->hasher_dev();
+    const uint32_t nb = leaf.batch ? leaf.batch : 1;
     ctx->prof_begin("merkle_leaf_hash");
-    hipError_t e = merkle_leaf_hash(leaf, ctx->stream);
+    hipError_t e = merkle_leaf_hash(leaf, hd, ctx->stream);
     ctx->prof_end();
     QP_HIP(ctx, e);
     ctx->prof_begin("merkle_nodes");
-    e = merkle_reduce_to_cap(d_digests, 1ull << log_leaves, 1ull << cap_height, ctx->stream);
+    e = merkle_reduce_to_cap(d_digests, 1ull << log_leaves, 1ull << cap_height, nb, leaf.ps_digests, hd, ctx->stream);
     ctx->prof_end();
     QP_HIP(ctx, e);
     return QPGPU_OK;
@@ -58,7 +95,8 @@ int qpgpu_merkle_build_dev(qpgpu_ctx *ctx, const uint64_t *d_cols, uint64_t col_
     if (log_leaves > 40) return ctx->fail(QPGPU_EINVAL, "merkle: log_leaves out of range");
     MerkleLeafArgs a{};
     a.src0 = d_cols; a.stride0 = col_stride; a.ncols0 = n_cols; a.src1 = nullptr; a.ncols1 = 0; a.stride1 = 0;
-    a.n_leaves = 1ull << log_leaves; a.digests = d_digests;
+    a.n_leaves = 1ull << log_leaves; a.digests = d_digests; a.batch = 1;
+    ctx->hasher_in_use = true;
     int rc = merkle_build(ctx, a, log_leaves, cap_height, d_digests);
     if (rc) return rc;
     if (h_cap_out) {
@@ -78,8 +116,10 @@ int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t
     int rc = merkle_ensure_constants(ctx);
     if (rc) return rc;
     uint64_t cnt = 1ull << log_leaves;
-    QP_HIP(ctx, merkle_leaf_hash_rows(d_rows, cnt, width, d_digests, ctx->stream));
-    QP_HIP(ctx, merkle_reduce_to_cap(d_digests, cnt, 1ull << cap_height, ctx->stream));
+    ctx->hasher_in_use = true;
+    const HasherDev hd = ctx->hasher_dev();
+    QP_HIP(ctx, merkle_leaf_hash_rows(d_rows, cnt, width, d_digests, 1, 0, 0, hd, ctx->stream));
+    QP_HIP(ctx, merkle_reduce_to_cap(d_digests, cnt, 1ull << cap_height, 1, 0, hd, ctx->stream));
     uint64_t *lvl = d_digests;
     while (cnt > (1ull << cap_height)) { lvl += cnt * 4; cnt >>= 1; }
     if (h_cap_out) {
@@ -96,7 +136,8 @@ int qpgpu_poseidon_permute_dev(qpgpu_ctx *ctx, uint64_t *d_states, size_t n) {
     if (!d_states && n) return ctx->fail(QPGPU_EINVAL, "poseidon: null buffer");
     int rc = merkle_ensure_constants(ctx);
     if (rc) return rc;
-    QP_HIP(ctx, poseidon_permute_batch(d_states, n, ctx->stream));
+    ctx->hasher_in_use = true;
+    QP_HIP(ctx, poseidon_permute_batch(d_states, n, ctx->hasher_dev(), ctx->stream));
     return QPGPU_OK;
 }
 

@@ -18,35 +18,29 @@ using gl::u64;
 
 __constant__ u64 c_poseidon_rc[poseidon::ROUNDS * poseidon::WIDTH];
 
-__constant__ poseidon2::Params c_p2;
-static int g_dev_kind = 0;     // which permutation the launch wrappers instantiate (hasher::Kind), set with the constants
-
 hipError_t merkle_upload_constants(const u64 *rc360) {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
-}
-hipError_t merkle_select_hasher(int kind, const poseidon2::Params *p2) {
-    if (kind == hasher::POSEIDON2 && p2) {
-        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_p2), p2, sizeof(poseidon2::Params));
-        if (e != hipSuccess) return e;
-    }
-    g_dev_kind = kind;
-    return hipSuccess;
 }
 
 namespace {
 
 struct PoseidonV1 {
-    static __device__ __forceinline__ void permute(u64 (&s)[12]) { poseidon::permute(s, c_poseidon_rc); }
+    static __device__ __forceinline__ void permute(u64 (&s)[12], const poseidon2::Params *) { poseidon::permute(s, c_poseidon_rc); }
 };
-struct Poseidon2P {   // the parameter plug: same sponge and tree code, other permutation
-    static __device__ __forceinline__ void permute(u64 (&s)[12]) { poseidon2::permute(s, c_p2); }
+struct Poseidon2P {   // the parameter plug: same sponge and tree code, other permutation; parameters of the caller's context
+    static __device__ __forceinline__ void permute(u64 (&s)[12], const poseidon2::Params *p2) { poseidon2::permute(s, *p2); }
 };
+
+// tree of the batch a global leaf / node index belongs to (counts are powers of two)
+__device__ __forceinline__ u32 ilog2_64(u64 x) { return 63u - (u32)__clzll((long long)x); }
 
 // leaf j = [src0 cols..., src1 cols...] at slot j (each source column-major with its own stride).
 template <class Perm>
-__global__ void __launch_bounds__(256) leaf_hash_kernel(MerkleLeafArgs a) {
-    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (j >= a.n_leaves) return;
+__global__ void __launch_bounds__(256) leaf_hash_kernel(MerkleLeafArgs a, const poseidon2::Params *p2) {
+    const u64 gj = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (gj >= a.n_leaves * a.batch) return;
+    const u64 pr = gj >> ilog2_64(a.n_leaves), j = gj & (a.n_leaves - 1);
+    a.src0 += pr * a.ps_src0; a.src1 += pr * a.ps_src1; a.digests += pr * a.ps_digests;
     const u32 W = a.ncols0 + a.ncols1;
     u64 *out = a.digests + j * 4;
     auto elem = [&](u32 c) -> u64 {
@@ -64,7 +58,7 @@ __global__ void __launch_bounds__(256) leaf_hash_kernel(MerkleLeafArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if (c + i < W) s[i] = elem(c + i);
-        Perm::permute(s);
+        Perm::permute(s, p2);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) out[i] = s[i];
@@ -103,10 +97,12 @@ __device__ __forceinline__ u64 coop_permute(u64 s, const int g, const int lane_b
 }
 
 // one 16-lane group per node: out[i] = two_to_one(in[2i], in[2i+1])
-__global__ void __launch_bounds__(256) node_coop_kernel(const u64 *in, u64 *out, u64 n_out) {
-    const u64 grp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
+__global__ void __launch_bounds__(256) node_coop_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps) {
+    const u64 ggrp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
     const int lane = threadIdx.x & 63, g = lane & 15, base = lane & 48;
-    const bool live = grp < n_out;
+    const bool live = ggrp < n_out * batch;
+    const u64 pr = live ? ggrp >> ilog2_64(n_out) : 0, grp = ggrp & (n_out - 1);
+    in += pr * ps; out += pr * ps;
     u64 s = (live && g < 8) ? in[grp * 8 + g] : 0;
     s = coop_permute(s, g, base);
     if (live && g < 4) out[grp * 4 + g] = s;
@@ -116,9 +112,10 @@ __global__ void __launch_bounds__(256) node_coop_kernel(const u64 *in, u64 *out,
 // keeps the current level in LDS and walks up to its root, one lane-cooperative permutation deep per level (at most one
 // wave per SIMD, waves without a live node only wait at the barrier); every level is also written to the digest array
 // (Merkle paths read it). Replaces up to five latency-bound launches.
-__global__ void __launch_bounds__(256) tree_top_kernel(u64 *levels, u64 cnt, u32 m) {
+__global__ void __launch_bounds__(256) tree_top_kernel(u64 *levels, u64 cnt, u32 m, u64 ps) {
     __shared__ u64 buf[2][32 * 4];
     const u32 t = threadIdx.x, b = blockIdx.x;
+    levels += (u64)blockIdx.y * ps;
     const int lane = t & 63, g = lane & 15, base = lane & 48;
     const u32 grp = t >> 4, wave_first = (t >> 6) << 2;
     for (u32 i = t; i < m * 4; i += blockDim.x) buf[0][i] = levels[(u64)b * m * 4 + i];
@@ -140,10 +137,12 @@ __global__ void __launch_bounds__(256) tree_top_kernel(u64 *levels, u64 cnt, u32
 }
 
 // one 16-lane group per row-major leaf
-__global__ void __launch_bounds__(256) leaf_rows_coop_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests) {
-    const u64 grp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
+__global__ void __launch_bounds__(256) leaf_rows_coop_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests) {
+    const u64 ggrp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
     const int lane = threadIdx.x & 63, g = lane & 15, base = lane & 48;
-    const bool live = grp < n_leaves;
+    const bool live = ggrp < n_leaves * batch;
+    const u64 pr = live ? ggrp >> ilog2_64(n_leaves) : 0, grp = ggrp & (n_leaves - 1);
+    rows += pr * ps_rows; digests += pr * ps_digests;
     const u64 *row = rows + (live ? grp : 0) * width;
     if (width <= 4) {
         if (live && g < 4) digests[grp * 4 + g] = g < (int)width ? gl::canon(row[g]) : 0;
@@ -159,10 +158,11 @@ __global__ void __launch_bounds__(256) leaf_rows_coop_kernel(const u64 *rows, u6
 
 // one 16-lane group per column-major leaf (small LDEs)
 __global__ void __launch_bounds__(256) leaf_cols_coop_kernel(MerkleLeafArgs a) {
-    const u64 grp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
+    const u64 ggrp = (blockIdx.x * (u64)blockDim.x + threadIdx.x) >> 4;
     const int lane = threadIdx.x & 63, g = lane & 15, base = lane & 48;
-    const bool live = grp < a.n_leaves;
-    const u64 j = live ? grp : 0;
+    const bool live = ggrp < a.n_leaves * a.batch;
+    const u64 pr = live ? ggrp >> ilog2_64(a.n_leaves) : 0, j = ggrp & (a.n_leaves - 1);
+    a.src0 += pr * a.ps_src0; a.src1 += pr * a.ps_src1; a.digests += pr * a.ps_digests;
     const u32 W = a.ncols0 + a.ncols1;
     auto elem = [&](u32 c) -> u64 {
         return c < a.ncols0 ? a.src0[(u64)c * a.stride0 + j] : a.src1[(u64)(c - a.ncols0) * a.stride1 + j];
@@ -181,9 +181,11 @@ __global__ void __launch_bounds__(256) leaf_cols_coop_kernel(MerkleLeafArgs a) {
 
 // row-major leaves (FRI round trees: leaf = 2^arity ext values = contiguous felts)
 template <class Perm>
-__global__ void __launch_bounds__(256) leaf_hash_rows_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests) {
-    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (j >= n_leaves) return;
+__global__ void __launch_bounds__(256) leaf_hash_rows_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const poseidon2::Params *p2) {
+    const u64 gj = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (gj >= n_leaves * batch) return;
+    const u64 pr = gj >> ilog2_64(n_leaves), j = gj & (n_leaves - 1);
+    rows += pr * ps_rows; digests += pr * ps_digests;
     const u64 *row = rows + j * width;
     u64 *out = digests + j * 4;
     if (width <= 4) {
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(256) leaf_hash_rows_kernel(const u64 *rows, u6
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if (c + i < width) s[i] = row[c + i];
-        Perm::permute(s);
+        Perm::permute(s, p2);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) out[i] = s[i];
@@ -205,53 +207,59 @@ __global__ void __launch_bounds__(256) leaf_hash_rows_kernel(const u64 *rows, u6
 
 // one level: out[i] = two_to_one(in[2i], in[2i+1])
 template <class Perm>
-__global__ void __launch_bounds__(256) node_kernel(const u64 *in, u64 *out, u64 n_out) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
+__global__ void __launch_bounds__(256) node_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const poseidon2::Params *p2) {
+    const u64 gi = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (gi >= n_out * batch) return;
+    const u64 pr = gi >> ilog2_64(n_out), i = gi & (n_out - 1);
+    in += pr * ps; out += pr * ps;
     u64 s[12];
     const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(in + i * 8);
     ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
     s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = c.x; s[5] = c.y; s[6] = d.x; s[7] = d.y;
     s[8] = s[9] = s[10] = s[11] = 0;
-    Perm::permute(s);
+    Perm::permute(s, p2);
     ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + i * 4);
     o[0] = make_ulonglong2(s[0], s[1]);
     o[1] = make_ulonglong2(s[2], s[3]);
 }
 
 template <class Perm>
-__global__ void permute_kernel(u64 *states, u64 n) {
+__global__ void permute_kernel(u64 *states, u64 n, const poseidon2::Params *p2) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = gl::canon(states[i * 12 + k]);
-    Perm::permute(s);
+    Perm::permute(s, p2);
 #pragma unroll
     for (int k = 0; k < 12; k++) states[i * 12 + k] = s[k];
 }
 
 // s10 fri_proof_of_work: candidate nonce at `pos` of the pre-absorbed duplex state; accept when the last rate
-// element has >= pow_bits leading zeros; result = minimum accepted nonce in [base, base + count).
+// element has >= pow_bits leading zeros; result = minimum accepted nonce in [base, base + count). grid.y = proof.
 template <class Perm>
-__global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
+__global__ void __launch_bounds__(256) pow_kernel(PowArgs a, const poseidon2::Params *p2) {
     const u64 idx = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (idx >= a.count) return;
-    const u64 nonce = a.base + idx;
+    const u32 pr = blockIdx.y;
+    const u64 base = a.bases[pr];
+    if (base == ~0ull) return;                 // this proof already has its nonce
+    const u64 nonce = base + idx;
+    const u64 *st = a.states + 12 * (u64)pr;
     u64 s[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = (i == (int)a.pos) ? nonce : a.state[i];
-    Perm::permute(s);
-    if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin((unsigned long long *)a.result, (unsigned long long)nonce);
+    for (int i = 0; i < 12; i++) s[i] = (i == (int)a.pos) ? nonce : st[i];
+    Perm::permute(s, p2);
+    if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin((unsigned long long *)&a.results[pr], (unsigned long long)nonce);
 }
 
 }  // namespace
 
-hipError_t pk_pow(const PowArgs &a, hipStream_t st) {
-    if (a.count == 0) return hipSuccess;
-    dim3 b(256), g((unsigned)((a.count + 255) / 256));
-    if (g_dev_kind == hasher::POSEIDON2) hipLaunchKernelGGL((pow_kernel<Poseidon2P>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((pow_kernel<PoseidonV1>), g, b, 0, st, a);
+hipError_t pk_pow(const PowArgs &a, const HasherDev &h, hipStream_t st) {
+    if (a.count == 0 || a.batch == 0) return hipSuccess;
+    dim3 b(256), g((unsigned)((a.count + 255) / 256), a.batch);
+    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((pow_kernel<Poseidon2P>), g, b, 0, st, a, h.p2);
+    else hipLaunchKernelGGL((pow_kernel<PoseidonV1>), g, b, 0, st, a, h.p2);
     return hipGetLastError();
 }
 
@@ -264,67 +272,76 @@ static u64 coop_max_init() {
 }
 static const u64 COOP_MAX = coop_max_init();
 
-hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, hipStream_t st) {
+hipError_t merkle_leaf_hash(const MerkleLeafArgs &a0, const HasherDev &h, hipStream_t st) {
+    MerkleLeafArgs a = a0;
+    if (a.batch == 0) a.batch = 1;
     if (a.n_leaves == 0) return hipSuccess;
-    const bool p2 = g_dev_kind == hasher::POSEIDON2;   // the lane-cooperative kernels exist for Poseidon only
-    if (!p2 && a.n_leaves <= COOP_MAX / 2) {
-        dim3 block(256), grid((unsigned)((a.n_leaves * 16 + 255) / 256));
+    if (a.n_leaves & (a.n_leaves - 1)) return hipErrorInvalidValue;
+    const u64 total = a.n_leaves * a.batch;
+    const bool p2 = h.kind == hasher::POSEIDON2;   // the lane-cooperative kernels exist for Poseidon only
+    if (!p2 && total <= COOP_MAX / 2) {
+        dim3 block(256), grid((unsigned)((total * 16 + 255) / 256));
         hipLaunchKernelGGL(leaf_cols_coop_kernel, grid, block, 0, st, a);
         return hipGetLastError();
     }
-    dim3 block(256), grid((unsigned)((a.n_leaves + 255) / 256));
-    if (p2) hipLaunchKernelGGL((leaf_hash_kernel<Poseidon2P>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((leaf_hash_kernel<PoseidonV1>), grid, block, 0, st, a);
+    dim3 block(256), grid((unsigned)((total + 255) / 256));
+    if (p2) hipLaunchKernelGGL((leaf_hash_kernel<Poseidon2P>), grid, block, 0, st, a, h.p2);
+    else hipLaunchKernelGGL((leaf_hash_kernel<PoseidonV1>), grid, block, 0, st, a, h.p2);
     return hipGetLastError();
 }
-hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, hipStream_t st) {
-    if (n_leaves == 0) return hipSuccess;
-    const bool p2 = g_dev_kind == hasher::POSEIDON2;
-    if (!p2 && n_leaves <= COOP_MAX) {
-        dim3 block(256), grid((unsigned)((n_leaves * 16 + 255) / 256));
-        hipLaunchKernelGGL(leaf_rows_coop_kernel, grid, block, 0, st, rows, n_leaves, width, digests);
+hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st) {
+    if (n_leaves == 0 || batch == 0) return hipSuccess;
+    if (n_leaves & (n_leaves - 1)) return hipErrorInvalidValue;
+    const u64 total = n_leaves * batch;
+    const bool p2 = h.kind == hasher::POSEIDON2;
+    if (!p2 && total <= COOP_MAX) {
+        dim3 block(256), grid((unsigned)((total * 16 + 255) / 256));
+        hipLaunchKernelGGL(leaf_rows_coop_kernel, grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests);
         return hipGetLastError();
     }
-    dim3 block(256), grid((unsigned)((n_leaves + 255) / 256));
-    if (p2) hipLaunchKernelGGL((leaf_hash_rows_kernel<Poseidon2P>), grid, block, 0, st, rows, n_leaves, width, digests);
-    else hipLaunchKernelGGL((leaf_hash_rows_kernel<PoseidonV1>), grid, block, 0, st, rows, n_leaves, width, digests);
+    dim3 block(256), grid((unsigned)((total + 255) / 256));
+    if (p2) hipLaunchKernelGGL((leaf_hash_rows_kernel<Poseidon2P>), grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h.p2);
+    else hipLaunchKernelGGL((leaf_hash_rows_kernel<PoseidonV1>), grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h.p2);
     return hipGetLastError();
 }
-hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, hipStream_t st) {
+static hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const HasherDev &h, hipStream_t st) {
     if (n_out == 0) return hipSuccess;
-    const bool p2 = g_dev_kind == hasher::POSEIDON2;
-    if (!p2 && n_out <= COOP_MAX) {
-        dim3 block(256), grid((unsigned)((n_out * 16 + 255) / 256));
-        hipLaunchKernelGGL(node_coop_kernel, grid, block, 0, st, in, out, n_out);
+    const u64 total = n_out * batch;
+    const bool p2 = h.kind == hasher::POSEIDON2;
+    if (!p2 && total <= COOP_MAX) {
+        dim3 block(256), grid((unsigned)((total * 16 + 255) / 256));
+        hipLaunchKernelGGL(node_coop_kernel, grid, block, 0, st, in, out, n_out, batch, ps);
         return hipGetLastError();
     }
-    unsigned threads = n_out >= 256 ? 256 : 64;
-    dim3 block(threads), grid((unsigned)((n_out + threads - 1) / threads));
-    if (p2) hipLaunchKernelGGL((node_kernel<Poseidon2P>), grid, block, 0, st, in, out, n_out);
-    else hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out);
+    unsigned threads = total >= 256 ? 256 : 64;
+    dim3 block(threads), grid((unsigned)((total + threads - 1) / threads));
+    if (p2) hipLaunchKernelGGL((node_kernel<Poseidon2P>), grid, block, 0, st, in, out, n_out, batch, ps, h.p2);
+    else hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out, batch, ps, h.p2);
     return hipGetLastError();
 }
 // every level from `cnt` digests (at `levels`, the following levels stored behind it) down to the cap
-hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, hipStream_t st) {
+hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, u32 batch, u64 ps, const HasherDev &h, hipStream_t st) {
+    if (batch == 0) return hipSuccess;
+    if ((cnt & (cnt - 1)) || (cap_n & (cap_n - 1))) return hipErrorInvalidValue;
     u64 *lvl = levels;
     while (cnt > cap_n) {
         const u64 m = cnt / cap_n;
         // latency knob: the fused top saves ~0.1 ms of a single 2^13-row proof and costs ~3 % of the four-in-flight throughput
         static const bool fuse_top = [] { const char *e = getenv("QPGPU_TREE_TOP"); return e ? atoi(e) != 0 : false; }();
-        if (fuse_top && g_dev_kind != hasher::POSEIDON2 && m <= 32 && cap_n <= 65535 && COOP_MAX >= 64) {
-            hipLaunchKernelGGL(tree_top_kernel, dim3((unsigned)cap_n), dim3(256), 0, st, lvl, cnt, (u32)m);
+        if (fuse_top && h.kind != hasher::POSEIDON2 && m <= 32 && cap_n <= 65535 && batch <= 65535 && COOP_MAX >= 64) {
+            hipLaunchKernelGGL(tree_top_kernel, dim3((unsigned)cap_n, batch), dim3(256), 0, st, lvl, cnt, (u32)m, ps);
             return hipGetLastError();
         }
-        hipError_t e = merkle_reduce_level(lvl, lvl + cnt * 4, cnt / 2, st);
+        hipError_t e = merkle_reduce_level(lvl, lvl + cnt * 4, cnt / 2, batch, ps, h, st);
         if (e != hipSuccess) return e;
         lvl += cnt * 4; cnt >>= 1;
     }
     return hipSuccess;
 }
-hipError_t poseidon_permute_batch(u64 *states, u64 n, hipStream_t st) {
+hipError_t poseidon_permute_batch(u64 *states, u64 n, const HasherDev &h, hipStream_t st) {
     if (n == 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((n + 255) / 256));
-    if (g_dev_kind == hasher::POSEIDON2) hipLaunchKernelGGL((permute_kernel<Poseidon2P>), grid, block, 0, st, states, n);
-    else hipLaunchKernelGGL((permute_kernel<PoseidonV1>), grid, block, 0, st, states, n);
+    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((permute_kernel<Poseidon2P>), grid, block, 0, st, states, n, h.p2);
+    else hipLaunchKernelGGL((permute_kernel<PoseidonV1>), grid, block, 0, st, states, n, h.p2);
     return hipGetLastError();
 }

@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) {
     const u64 tile = blockIdx.x;
     const u64 lane0 = tile << a.log_t;          // first lane of this tile (global lane index)
     const u64 col = blockIdx.y;
-    const u64 *in = a.in + col * a.in_col_stride;
-    u64 *out = a.out + col * a.out_col_stride;
+    const u64 *in = a.in + col * a.in_col_stride + (u64)blockIdx.z * a.in_proof_stride;
+    u64 *out = a.out + col * a.out_col_stride + (u64)blockIdx.z * a.out_proof_stride;
 
     // ---------------- round A ----------------
     {

@@ -51,9 +51,10 @@ hipError_t ntt_pass_init() {
     return hipSuccess;
 }
 
-hipError_t ntt_pass_launch(const NttPassArgs &a, uint64_t n_tiles, uint64_t n_cols, hipStream_t st) {
+hipError_t ntt_pass_launch(const NttPassArgs &a, uint64_t n_tiles, uint64_t n_cols, hipStream_t st, uint32_t n_proofs) {
     const int ka = a.ka, kb = a.kb;
-    dim3 grid((unsigned)n_tiles, (unsigned)n_cols, 1);
+    if (n_cols > 65535 || n_proofs > 65535 || n_proofs == 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)n_tiles, (unsigned)n_cols, n_proofs);
     dim3 block((unsigned)(1u << (ka + a.log_t)), 1, 1);
     if (kb == 0) block.x = 1u << a.log_t;
     if (block.x < 64) block.x = 64;

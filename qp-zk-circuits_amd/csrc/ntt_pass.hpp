@@ -10,6 +10,7 @@ struct NttPassArgs {
     // geometry: a lane is (row, mm) with lane = row << log_m | mm; element (p, lane) of the input sits at
     //   in[col*in_col_stride + row*in_row_stride + mm*in_l_stride + p*in_p_stride]
     uint64_t in_col_stride, out_col_stride;
+    uint64_t in_proof_stride, out_proof_stride;   // grid.z = proof of a lockstep batch (0 when there is one proof)
     uint64_t in_row_stride, in_l_stride, in_p_stride;
     uint64_t out_row_stride, out_l_stride, out_p_stride;
     uint64_t lanes_total;      // lanes per column (rows << log_m)
@@ -34,4 +35,4 @@ struct NttPassArgs {
 
 size_t ntt_pass_lds_bytes(int ka, int kb, int log_t);
 hipError_t ntt_pass_init();
-hipError_t ntt_pass_launch(const NttPassArgs &a, uint64_t n_tiles, uint64_t n_cols, hipStream_t st);
+hipError_t ntt_pass_launch(const NttPassArgs &a, uint64_t n_tiles, uint64_t n_cols, hipStream_t st, uint32_t n_proofs = 1);

@@ -1,6 +1,7 @@
 // ntt_plan.cpp — host-side planning for the NTT passes: pass split, twiddle tables, launches.
 // Replaces the root-table / dispatch logic of plonky2::field::fft (fft_root_table, fft_dispatch).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -34,6 +35,21 @@ int qpgpu_ctx::read_back(void *host_dst, const void *dev_src, size_t bytes) {
         h_pin_bytes = want;
     }
     QP_HIP(this, hipMemcpyAsync(h_pin, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+    QP_HIP(this, hipStreamSynchronize(stream));
+    memcpy(host_dst, h_pin, bytes);
+    return QPGPU_OK;
+}
+
+int qpgpu_ctx::read_back_2d(void *host_dst, const void *dev_src, size_t src_pitch, size_t width, size_t rows) {
+    if (rows <= 1 || src_pitch == width) return read_back(host_dst, dev_src, width * rows);
+    const size_t bytes = width * rows;
+    if (bytes > h_pin_bytes) {
+        if (h_pin) { QP_HIP(this, hipStreamSynchronize(stream)); (void)hipHostFree(h_pin); h_pin = nullptr; h_pin_bytes = 0; }
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        QP_HIP(this, hipHostMalloc(&h_pin, want, hipHostMallocDefault));
+        h_pin_bytes = want;
+    }
+    QP_HIP(this, hipMemcpy2DAsync(h_pin, width, dev_src, src_pitch, width, rows, hipMemcpyDeviceToHost, stream));
     QP_HIP(this, hipStreamSynchronize(stream));
     memcpy(host_dst, h_pin, bytes);
     return QPGPU_OK;
@@ -94,6 +110,8 @@ struct Geom {
     u64 out_mul = 1;          // natural-order output: element k goes to k * out_mul
     u64 scale = 0;            // inverse: overrides 1/N
     u64 scratch_off = 0;      // words into ctx->scratch the natural-order intermediate may use
+    uint32_t nproofs = 1;     // lockstep batch: proof b at d_in + b * in_ps, d_out + b * out_ps
+    u64 in_ps = 0, out_ps = 0;
 };
 int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
              size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift, const Geom &g);
@@ -101,12 +119,33 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
 
 // Forward / inverse / coset-LDE transform. log_n_in <= log_n_out; inputs beyond 2^log_n_in are zero.
 int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n_in, unsigned log_n_out,
-            size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift) {
+            size_t batch, bool inverse, bool out_bitrev, uint64_t coset_shift, NttProofs np) {
     if (log_n_out > 23) return ctx->fail(QPGPU_EINVAL, "ntt: log_n > 23 not supported");
     if (log_n_in > log_n_out) return ctx->fail(QPGPU_EINVAL, "ntt: log_n_in > log_n_out");
-    if (batch == 0) return QPGPU_OK;
+    if (batch == 0 || np.nproofs == 0) return QPGPU_OK;
     if (coset_shift > 1 && inverse) return ctx->fail(QPGPU_EINVAL, "ntt: coset inverse is ifft + scale; not a single call");
-    if (log_n_out <= 20) return ntt_core(ctx, d_in, d_out, log_n_in, log_n_out, batch, inverse, out_bitrev, coset_shift, Geom());
+    // the column dimension rides on grid.y (<= 65535): wider batches go in slices (columns are contiguous, stride 2^log_n)
+    if (batch > 65535) {
+        if (np.nproofs > 1) return ctx->fail(QPGPU_EINVAL, "ntt: more than 65535 columns per proof");
+        for (size_t c0 = 0; c0 < batch; c0 += 32768) {
+            const size_t cnt = std::min<size_t>(32768, batch - c0);
+            int rc = ntt_run(ctx, d_in + (c0 << log_n_in), d_out + (c0 << log_n_out), log_n_in, log_n_out, cnt, inverse, out_bitrev, coset_shift);
+            if (rc) return rc;
+        }
+        return QPGPU_OK;
+    }
+    if (log_n_out <= 20) {
+        Geom g;
+        g.nproofs = np.nproofs; g.in_ps = np.in_ps; g.out_ps = np.out_ps;
+        return ntt_core(ctx, d_in, d_out, log_n_in, log_n_out, batch, inverse, out_bitrev, coset_shift, g);
+    }
+    if (np.nproofs > 1) {   // the three-pass sizes take the proofs one after the other
+        for (uint32_t b = 0; b < np.nproofs; b++) {
+            int rc = ntt_run(ctx, d_in + b * np.in_ps, d_out + b * np.out_ps, log_n_in, log_n_out, batch, inverse, out_bitrev, coset_shift);
+            if (rc) return rc;
+        }
+        return QPGPU_OK;
+    }
 
     // ---- three passes: N = 8 * M0. Pass 0 transforms the top three index bits (stride M0) and applies the twiddle
     // w_N^(m k); the eight blocks are then independent M0-point transforms (two passes each) whose outputs interleave
@@ -222,8 +261,9 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         // when in == out and the row strides differ (LDE in place) the caller must not alias; same size is safe
         // because a workgroup reads its whole tile before writing it.
         u64 tiles = (batch + (1ull << a.log_t) - 1) >> a.log_t;
+        a.in_proof_stride = g.in_ps; a.out_proof_stride = g.out_ps;
         ctx->prof_begin("ntt_pass_single");
-        hipError_t le = ntt_pass_launch(a, tiles, 1, ctx->stream);
+        hipError_t le = ntt_pass_launch(a, tiles, 1, ctx->stream, g.nproofs);
         ctx->prof_end();
         QP_HIP(ctx, le);
         return QPGPU_OK;
@@ -233,11 +273,11 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
     const u64 R1 = 1ull << L1, M1 = 1ull << L2;
     const u64 in_cs = g.in_col_stride ? g.in_col_stride : n_in, out_cs = g.out_col_stride ? g.out_col_stride : N;
     uint64_t *mid = d_out;
-    u64 mid_cs = out_cs;
+    u64 mid_cs = out_cs, mid_ps = g.out_ps;
     if (!out_bitrev) {
-        int rc = ctx->ensure_scratch((g.scratch_off + batch * N) * sizeof(u64));
+        int rc = ctx->ensure_scratch((g.scratch_off + (u64)g.nproofs * batch * N) * sizeof(u64));
         if (rc) return rc;
-        mid = ctx->scratch + g.scratch_off; mid_cs = N;
+        mid = ctx->scratch + g.scratch_off; mid_cs = N; mid_ps = batch * N;
     }
     {
         Split s = split_round(L1);
@@ -249,6 +289,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         p.in_row_stride = 0; p.in_l_stride = 1; p.in_p_stride = M1;
         p.out_row_stride = 0; p.out_l_stride = 1; p.out_p_stride = M1;
         p.log_t = pick_log_t(s.ka, s.kb, M1);
+        { static const int f = env_int("QPGPU_NTT_LOGT_S", -1); if (f >= 0 && s.ka + s.kb == 10) p.log_t = f; }
         if ((1ull << p.log_t) > M1) p.log_t = L2;
         // zero padding: coefficient index n = p*M1 + mm < n_in  <=>  p < n_in / M1 (n_in >= M1 required)
         if (n_in < M1) return ctx->fail(QPGPU_EINVAL, "lde: input shorter than one pass-1 row is not supported");
@@ -273,8 +314,9 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
             if (rc) return rc;
         }
         u64 tiles = (M1 + (1ull << p.log_t) - 1) >> p.log_t;
+        p.in_proof_stride = g.in_ps; p.out_proof_stride = mid_ps;
         ctx->prof_begin("ntt_pass_strided");
-        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream);
+        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream, g.nproofs);
         ctx->prof_end();
         QP_HIP(ctx, le);
     }
@@ -287,6 +329,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         p.log_m = 0; p.lanes_total = R1;
         p.in_row_stride = M1; p.in_l_stride = 0; p.in_p_stride = 1;
         p.log_t = pick_log_t(s.ka, s.kb, R1);
+        { static const int f = env_int("QPGPU_NTT_LOGT_R", -1); if (f >= 0 && s.ka + s.kb == 10) p.log_t = f; }
         p.p_valid = (uint32_t)M1;
         p.load_lane_fast = 0;
         if (out_bitrev) { p.out_row_stride = M1; p.out_p_stride = 1; p.store_lane_fast = 0; p.out_bitrev = 1; }
@@ -298,8 +341,9 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
             if (rc) return rc;
         }
         u64 tiles = (R1 + (1ull << p.log_t) - 1) >> p.log_t;
+        p.in_proof_stride = mid_ps; p.out_proof_stride = g.out_ps;
         ctx->prof_begin("ntt_pass_rows");
-        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream);
+        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream, g.nproofs);
         ctx->prof_end();
         QP_HIP(ctx, le);
     }

@@ -6,6 +6,7 @@
 // a small pool: each worker owns a context (HIP stream), a loaded copy of the circuit (constants/sigmas commitment,
 // workspace) and a host thread for the Fiat-Shamir transcript; jobs are taken from one queue.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -36,6 +37,7 @@ struct qpgpu_pool {
     std::vector<Done> done;          // ring indexed by ticket % size
     uint64_t next_ticket = 0, oldest_live = 0;
     bool stopping = false;
+    unsigned max_batch = 1;          // proofs a worker takes from the queue at once and proves in lockstep
     std::string err;
 };
 
@@ -43,20 +45,30 @@ namespace {
 void worker(qpgpu_pool *p, size_t w) {
     (void)hipSetDevice(p->device);
     for (;;) {
-        Job j;
+        std::vector<Job> js;
         {
             std::unique_lock<std::mutex> lk(p->mu);
             p->cv_job.wait(lk, [&] { return p->stopping || !p->queue.empty(); });
             if (p->queue.empty()) return;   // stopping and drained
-            j = p->queue.front(); p->queue.pop_front();
+            // whatever is queued, up to the lockstep width, split evenly when several workers wait for little work
+            size_t take = std::min<size_t>(p->max_batch, p->queue.size());
+            if (p->queue.size() < (size_t)p->max_batch * p->circuits.size()) take = std::min<size_t>(take, (p->queue.size() + p->circuits.size() - 1) / p->circuits.size());
+            for (size_t i = 0; i < take; i++) { js.push_back(p->queue.front()); p->queue.pop_front(); }
         }
-        size_t len = 0;
-        const int rc = qpgpu_prove_dev(p->circuits[w], j.d_wires, j.public_inputs, j.out, j.out_cap, &len);
+        const uint32_t nb = (uint32_t)js.size();
+        std::vector<const uint64_t *> wires(nb), pis(nb);
+        std::vector<uint8_t *> outs(nb);
+        std::vector<size_t> lens(nb, 0);
+        size_t cap = ~(size_t)0;
+        for (uint32_t i = 0; i < nb; i++) { wires[i] = js[i].d_wires; pis[i] = js[i].public_inputs; outs[i] = js[i].out; cap = std::min(cap, js[i].out_cap); }
+        const int rc = qpgpu_prove_batch_dev(p->circuits[w], wires.data(), nb, pis.data(), outs.data(), cap, lens.data());
         {
             std::lock_guard<std::mutex> lk(p->mu);
-            Done &d = p->done[j.ticket % p->done.size()];
-            d.rc = rc; d.len = len;
-            if (rc != QPGPU_OK) d.err = qpgpu_last_error(p->ctxs[w]);
+            for (uint32_t i = 0; i < nb; i++) {
+                Done &d = p->done[js[i].ticket % p->done.size()];
+                d.rc = rc; d.len = lens[i];
+                if (rc != QPGPU_OK) d.err = qpgpu_last_error(p->ctxs[w]);
+            }
         }
         p->cv_done.notify_all();
     }
@@ -76,10 +88,15 @@ void qpgpu_pool_destroy(qpgpu_pool *p) {
 }
 
 int qpgpu_pool_create(int device, const uint64_t *pack_words, size_t n_words, unsigned workers, qpgpu_pool **out) {
-    if (!out || !pack_words || workers == 0 || workers > 64) return QPGPU_EINVAL;
+    return qpgpu_pool_create_batched(device, pack_words, n_words, workers, 1, out);
+}
+
+int qpgpu_pool_create_batched(int device, const uint64_t *pack_words, size_t n_words, unsigned workers, unsigned max_batch, qpgpu_pool **out) {
+    if (!out || !pack_words || workers == 0 || workers > 64 || max_batch == 0 || max_batch > 1024) return QPGPU_EINVAL;
     *out = nullptr;
     qpgpu_pool *p = new qpgpu_pool();
     p->device = device;
+    p->max_batch = max_batch;
     p->done.resize(4096);
     for (unsigned w = 0; w < workers; w++) {
         qpgpu_ctx *ctx = nullptr;
@@ -87,7 +104,7 @@ int qpgpu_pool_create(int device, const uint64_t *pack_words, size_t n_words, un
         if (rc != QPGPU_OK) { qpgpu_pool_destroy(p); return rc; }
         p->ctxs.push_back(ctx);
         qpgpu_circuit *c = nullptr;
-        rc = qpgpu_circuit_load(ctx, pack_words, n_words, &c);
+        rc = qpgpu_circuit_load_batch(ctx, pack_words, n_words, max_batch, &c);
         if (rc != QPGPU_OK) { qpgpu_pool_destroy(p); return rc; }
         p->circuits.push_back(c);
     }

@@ -222,13 +222,19 @@ GL_HD void permute(u64 (&s)[12], const Params &p) {
 }
 }  // namespace poseidon2
 
-// ---- process-wide choice of the proof-system permutation (Merkle trees, challenger, public-input hash, PoW) ----
+// ---- choice of the proof-system permutation (Merkle trees, challenger, public-input hash, PoW) ----
+// A property of the context (qpgpu_ctx_set_hasher): two contexts of one process may prove under different hashers. The
+// process-wide default below only seeds new contexts and the host-only helpers that have no context (synthetic circuit
+// generator, qpgpu_challenger_*); qpgpu_set_hasher changes it and is kept for callers written against the first ABI.
 namespace hasher {
 enum Kind : int { POSEIDON = 0, POSEIDON2 = 1 };
-int kind();
-unsigned generation();                        // bumped by every change; device copies are refreshed lazily
-const poseidon2::Params &p2_params();
-void set(int kind, const poseidon2::Params *p);
-// the selected permutation on the host (challenger, small hashes)
-void host_permute(gl::u64 (&s)[12]);
+struct Config {
+    int kind = POSEIDON;
+    poseidon2::Params p2{};
+    void permute(gl::u64 (&s)[12]) const;     // the selected permutation on the host (challenger, small hashes)
+};
+const Config &process_default();
+void set_process_default(int kind, const poseidon2::Params *p);
+inline int kind() { return process_default().kind; }
+inline void host_permute(gl::u64 (&s)[12]) { process_default().permute(s); }
 }  // namespace hasher

@@ -187,20 +187,15 @@ const u64 *host_fast_partial() {
 // ---- hasher selection (see poseidon.hpp) ----
 namespace hasher {
 namespace {
-int g_kind = POSEIDON;
-unsigned g_generation = 1;
-poseidon2::Params g_p2{};
+Config g_default{};
 }  // namespace
-int kind() { return g_kind; }
-unsigned generation() { return g_generation; }
-const poseidon2::Params &p2_params() { return g_p2; }
-void set(int k, const poseidon2::Params *p) {
-    if (p) g_p2 = *p;
-    g_kind = k;
-    g_generation++;
+const Config &process_default() { return g_default; }
+void set_process_default(int k, const poseidon2::Params *p) {
+    if (p) g_default.p2 = *p;
+    g_default.kind = k;
 }
-void host_permute(gl::u64 (&s)[12]) {
-    if (g_kind == POSEIDON2) poseidon2::permute(s, g_p2);
+void Config::permute(gl::u64 (&s)[12]) const {
+    if (kind == POSEIDON2) poseidon2::permute(s, p2);
     else poseidon::permute(s, poseidon::host_hash_round_constants());
 }
 }  // namespace hasher

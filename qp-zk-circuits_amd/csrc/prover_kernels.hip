@@ -31,6 +31,9 @@ __global__ void __launch_bounds__(256) pp_rows_kernel(PpArgs a) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const u32 k = blockIdx.y;
+    { const u64 pr = blockIdx.z;   // proof of the batch
+      a.wires += pr * a.ps_wires; a.betas += pr * a.ps_small; a.gammas += pr * a.ps_small; a.beta_k_is += pr * a.ps_small;
+      a.qcp += pr * a.ps_qcp; a.rowprod += pr * a.ps_rowprod; }
     const u64 beta = a.betas[k], gamma = a.gammas[k];
     const u64 x = a.omega_pows[i];
     const u32 R = a.num_routed, chunk = a.chunk, nchunks = a.nchunks;
@@ -86,9 +89,10 @@ __global__ void __launch_bounds__(1024) pp_scan_kernel(const u64 *rowprod, u64 *
 }
 
 // zs_pp columns: [Z_0..Z_{nch-1}, pp_{0,*}, pp_{1,*}, ...]; pp_{k,c}(x_i) = Z_k(x_i) * prod_{c' <= c} qcp
-__global__ void __launch_bounds__(256) pp_finish_kernel(PpArgs a, const u64 *z, u64 *zs_pp) {
+__global__ void __launch_bounds__(256) pp_finish_kernel(PpArgs a, const u64 *z, u64 *zs_pp, u64 ps_z, u64 ps_zs) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= a.n) return;
+    { const u64 pr = blockIdx.z; a.qcp += pr * a.ps_qcp; z += pr * ps_z; zs_pp += pr * ps_zs; }
     const u32 k = blockIdx.y, npp = a.nchunks - 1;
     u64 acc = z[(u64)k * a.n + i];
     zs_pp[(u64)k * a.n + i] = acc;
@@ -113,11 +117,20 @@ __device__ __forceinline__ u64 gate_filter(const QuotientArgs &a, u32 gi, u64 s)
 // quotient values in natural order for the inverse NTT. NCH (number of challenges) is a compile-time constant so the
 // per-challenge accumulators live in registers.
 
+// proof blockIdx.z of a lockstep batch: move the per-proof pointers
+__device__ __forceinline__ void quotient_select_proof(QuotientArgs &a) {
+    const u64 pr = blockIdx.z;
+    a.wires += pr * a.ps_wires; a.zs_pp += pr * a.ps_zs;
+    a.alpha_pows += pr * a.ps_small; a.beta_k_is += pr * a.ps_small; a.betas += pr * a.ps_small; a.gammas += pr * a.ps_small; a.pi_hash += pr * a.ps_small;
+    a.acc += pr * a.ps_acc; a.out += pr * a.ps_out;
+}
+
 // (1) L_0(x)(Z(x) - 1) and the partial-product checks
 template <int NCH>
 __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (j >= a.q_n) return;
+    quotient_select_proof(a);
     const u32 logL = a.log_lde, R = a.num_routed, chunk = a.chunk, nchunks = a.nchunks, npp = nchunks - 1;
     const u64 i = brev32((u32)j, logL);
     const u64 jn = brev32((u32)((i + a.rate) & (a.lde_n - 1)), logL);   // slot of the next row g*x
@@ -162,6 +175,7 @@ template <int NCH>
 __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (j >= a.q_n) return;
+    quotient_select_proof(a);
     const u64 S = a.lde_n;
     u64 acc[NCH];
 #pragma unroll
@@ -326,6 +340,7 @@ template <int NCH>
 __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, u32 gi, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (j >= a.q_n) return;
+    quotient_select_proof(a);
     const u64 S = a.lde_n;
     const u64 *ap = a.alpha_pows + t0;
     auto W = [&](u32 i) -> u64 { return a.wires[(u64)i * S + j]; };
@@ -398,6 +413,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
 __global__ void __launch_bounds__(256) witness_check_kernel(const u64 *acc, u64 n, u32 nch, const u64 *z, const u64 *rowprod, u64 *result) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    { const u64 pr = blockIdx.z; acc += pr * nch * n; z += pr * nch * n; rowprod += pr * nch * n; result += pr * 2; }
     bool bad = false;
     for (u32 c = 0; c < nch; c++) bad |= gl::canon(acc[(u64)c * n + i]) != 0;
     if (bad) atomicMin((unsigned long long *)&result[0], (unsigned long long)i);
@@ -416,10 +432,11 @@ __global__ void __launch_bounds__(256) scale_powers_kernel(u64 *data, u64 n, u64
 
 // ---------------------------------------------------------------- s7
 // Evaluate polynomial p (n base-field coefficients) at an extension point. One workgroup per (poly, point).
-__global__ void __launch_bounds__(256) poly_eval_kernel(const u64 *coeffs, u64 n, const e2 *points, const u64 *poly_index, e2 *out) {
+__global__ void __launch_bounds__(256) poly_eval_kernel(const u64 *coeffs, u64 n, const e2 *points, e2 *out, u64 ps_coeffs, u64 ps_points, u64 ps_out) {
     __shared__ e2 part[256];
     const u32 t = threadIdx.x, T = blockDim.x;
-    const u64 p = poly_index ? poly_index[blockIdx.x] : blockIdx.x;
+    { const u64 pr = blockIdx.z; coeffs += pr * ps_coeffs; points += pr * ps_points; out += pr * ps_out; }
+    const u64 p = blockIdx.x;
     const e2 z = points[blockIdx.y];
     const u64 *f = coeffs + p * n;
     const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = lo + per < n ? lo + per : n;
@@ -441,10 +458,12 @@ __global__ void __launch_bounds__(256) poly_eval_kernel(const u64 *coeffs, u64 n
 __global__ void __launch_bounds__(256) reduce_polys_kernel(ReduceArgs a) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= a.n) return;
+    const u64 pr = blockIdx.z;
+    a.alpha_pows += pr * a.ps_alpha; a.comp_a += pr * a.ps_comp; a.comp_b += pr * a.ps_comp;
     e2 acc = gl::e2_from(0);
     u32 p = 0;
     for (u32 s = 0; s < a.nsrc; s++) {
-        const u64 *base = a.src[s];
+        const u64 *base = a.src[s] + pr * a.ps_src[s];
         for (u32 c = 0; c < a.ncols[s]; c++, p++) acc = gl::e2_add(acc, gl::e2_scale(a.alpha_pows[p], base[(u64)c * a.n + i]));
     }
     a.comp_a[i] = gl::canon(acc.a);
@@ -454,9 +473,13 @@ __global__ void __launch_bounds__(256) reduce_polys_kernel(ReduceArgs a) {
 // q = comp / (X - z) by synthetic division: b_{i-1} = b_i z + comp_i (from the top), quotient coefficient
 // q_{i-1} = b_i ... one workgroup, blocked linear-recurrence scan. final += handled by the caller's mode:
 // mode 0: final = q ; mode 1: final = final * shift + q.
-__global__ void __launch_bounds__(1024) divide_linear_kernel(const u64 *comp_a, const u64 *comp_b, u64 n, e2 z, e2 shift, int mode, u64 *fin_a, u64 *fin_b) {
+__global__ void __launch_bounds__(1024) divide_linear_kernel(const u64 *comp_a, const u64 *comp_b, u64 n, const e2 *zs, const e2 *shifts, int mode, u64 *fin_a, u64 *fin_b,
+                                                             u64 ps_comp, u64 ps_fin) {
     __shared__ e2 carry[1024];
     const u32 t = threadIdx.x, T = blockDim.x;
+    const u64 pr = blockIdx.x;   // one workgroup per proof of the batch
+    comp_a += pr * ps_comp; comp_b += pr * ps_comp; fin_a += pr * ps_fin; fin_b += pr * ps_fin;
+    const e2 z = zs[pr], shift = shifts[pr];
     const u64 per = (n + T - 1) / T;
     // thread t owns indices [lo, hi) counted from the TOP: index i = n-1-r
     const u64 rlo = (u64)t * per, rhi = rlo + per < n ? rlo + per : n;
@@ -499,15 +522,19 @@ __global__ void __launch_bounds__(1024) divide_linear_kernel(const u64 *comp_a, 
 
 // ---------------------------------------------------------------- s9
 // rows[j] = (va[j], vb[j]) interleaved: extension values in leaf order -> row-major leaves of 2*arity felts
-__global__ void __launch_bounds__(256) interleave_ext_kernel(const u64 *va, const u64 *vb, u64 n, u64 *rows) {
+__global__ void __launch_bounds__(256) interleave_ext_kernel(const u64 *va, const u64 *vb, u64 n, u64 *rows, u64 ps_vals, u64 ps_rows) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    { const u64 pr = blockIdx.z; va += pr * ps_vals; vb += pr * ps_vals; rows += pr * ps_rows; }
     reinterpret_cast<ulonglong2 *>(rows)[i] = make_ulonglong2(va[i], vb[i]);
 }
 // new[i] = sum_{k < arity} beta^k coeffs[arity*i + k]   (in place is safe: i <= arity*i; done out of place here)
-__global__ void __launch_bounds__(256) fri_fold_kernel(const u64 *ca, const u64 *cb, u64 new_n, u32 arity, e2 beta, u64 *oa, u64 *ob) {
+__global__ void __launch_bounds__(256) fri_fold_kernel(const u64 *ca, const u64 *cb, u64 new_n, u32 arity, const e2 *betas, u64 *oa, u64 *ob, u64 ps_in, u64 ps_out) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= new_n) return;
+    const u64 pr = blockIdx.z;
+    ca += pr * ps_in; cb += pr * ps_in; oa += pr * ps_out; ob += pr * ps_out;
+    const e2 beta = betas[pr];
     e2 acc = gl::e2_from(0);
     for (u32 k = arity; k-- > 0;) acc = gl::e2_add(gl::e2_mul(acc, beta), gl::e2_make(ca[(u64)arity * i + k], cb[(u64)arity * i + k]));
     oa[i] = gl::canon(acc.a); ob[i] = gl::canon(acc.b);
@@ -515,13 +542,15 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const u64 *ca, const u64 
 
 // ---------------------------------------------------------------- s11
 // out[q][c] = cols[c*stride + idx[q]]
-__global__ void gather_rows_kernel(const u64 *cols, u64 stride, u32 ncols, const u64 *idx, u32 nq, u64 *out) {
+__global__ void gather_rows_kernel(const u64 *cols, u64 stride, u32 ncols, const u64 *idx, u32 nq, u64 *out, u64 ps_cols, u64 ps_out) {
     const u32 q = blockIdx.x;
+    { const u64 pr = blockIdx.z; cols += pr * ps_cols; idx += pr * nq; out += pr * ps_out; }
     for (u32 c = threadIdx.x; c < ncols; c += blockDim.x) out[(u64)q * ncols + c] = cols[(u64)c * stride + idx[q]];
 }
 // Merkle authentication paths: out[q][lvl] = digests[level lvl][ (idx[q] >> lvl) ^ 1 ]
-__global__ void gather_paths_kernel(const u64 *digests, u64 n_leaves, u32 path_len, const u64 *idx, u32 shift, u64 *out) {
+__global__ void gather_paths_kernel(const u64 *digests, u64 n_leaves, u32 path_len, const u64 *idx, u32 shift, u64 *out, u32 nq, u64 ps_digests, u64 ps_out) {
     const u32 q = blockIdx.x, t = threadIdx.x;
+    { const u64 pr = blockIdx.z; digests += pr * ps_digests; idx += pr * nq; out += pr * ps_out; }
     if (t >= path_len * 4) return;
     const u32 lvl = t >> 2, e = t & 3;
     u64 off = 0, cnt = n_leaves;
@@ -530,22 +559,54 @@ __global__ void gather_paths_kernel(const u64 *digests, u64 n_leaves, u32 path_l
     out[((u64)q * path_len + lvl) * 4 + e] = digests[(off + node) * 4 + e];
 }
 // out[q][e] = rows[(idx[q] >> shift) * width + e]
-__global__ void gather_leaf_rows_kernel(const u64 *rows, u32 width, const u64 *idx, u32 shift, u64 *out) {
+__global__ void gather_leaf_rows_kernel(const u64 *rows, u32 width, const u64 *idx, u32 shift, u64 *out, u32 nq, u64 ps_rows, u64 ps_out) {
     const u32 q = blockIdx.x;
+    { const u64 pr = blockIdx.z; rows += pr * ps_rows; idx += pr * nq; out += pr * ps_out; }
     for (u32 e = threadIdx.x; e < width; e += blockDim.x) out[(u64)q * width + e] = rows[(idx[q] >> shift) * width + e];
 }
 
-// salt columns of a blinded oracle (PolynomialBatch::from_coeffs with blinding: SALT_SIZE = 4 random columns in
-// every leaf). The reference draws them from thread_rng; here a counter-mode splitmix64 keyed by the caller's seed,
-// so a proof is reproducible under an injected seed.
-__global__ void __launch_bounds__(256) salt_kernel(u64 seed, u32 oracle_index, u64 lde_n, u64 *out) {
+// salt columns of a blinded oracle (PolynomialBatch::from_coeffs with blinding: SALT_SIZE = 4 random columns in every
+// leaf). The reference draws them from thread_rng, a CSPRNG; every opened leaf publishes its salts, so they must not be
+// predictable from one another: ChaCha20 (RFC 8439 block function, 64-bit block counter) keyed with 256 bits per proof
+// from the OS entropy source (or from an injected seed, which makes a proof reproducible: SURVEY.md section 0.5).
+// Stream layout: nonce = (oracle_index, column); block (leaf >> 1) holds the candidates of leaves 2k and 2k+1, four 64-bit
+// words each; a leaf takes its first candidate below p (rejection sampling: uniform on [0, p)).
+__device__ __forceinline__ u32 rotl32(u32 x, int k) { return (x << k) | (x >> (32 - k)); }
+__device__ __forceinline__ void chacha20_block(const u32 *key, u64 counter, u32 n0, u32 n1, u32 (&out)[16]) {
+    u32 x[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                 (u32)counter, (u32)(counter >> 32), n0, n1};
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = x[i];
+#define QR(a, b, c, d) w[a] += w[b]; w[d] = rotl32(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = rotl32(w[b] ^ w[c], 12); \
+                       w[a] += w[b]; w[d] = rotl32(w[d] ^ w[a], 8);  w[c] += w[d]; w[b] = rotl32(w[b] ^ w[c], 7);
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {
+        QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
+        QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
+    }
+#undef QR
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = w[i] + x[i];
+}
+__global__ void __launch_bounds__(256) salt_kernel(const u32 *keys, u32 oracle_index, u64 lde_n, u64 *out) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (j >= lde_n) return;
+    const u32 *key = keys + 8 * blockIdx.z;
+    out += (u64)blockIdx.z * 4 * lde_n;
     for (u32 c = 0; c < 4; c++) {
-        const u64 ctr = ((u64)(oracle_index * 4 + c) << 40) | j;
-        u64 z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-        out[(u64)c * lde_n + j] = gl::canon(z);
+        u32 blk[16];
+        chacha20_block(key, j >> 1, oracle_index, c, blk);
+        const u32 h = (u32)(j & 1) * 8;
+        u64 v = 0;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u64 cand = ((u64)blk[h + 2 * k + 1] << 32) | blk[h + 2 * k];
+            if (!found && cand < gl::P) { v = cand; found = true; }
+        }
+        if (!found) v = (((u64)blk[h + 7] << 32) | blk[h + 6]) - gl::P;   // four rejections in a row: probability 2^-128
+        out[(u64)c * lde_n + j] = v;
     }
 }
 
@@ -564,24 +625,27 @@ __global__ void __launch_bounds__(256) coset_tables_kernel(u64 lde_n, u32 log_ld
 
 #define LAUNCH_1D(kern, count, threads, st, ...) \
     do { if ((count) > 0) { dim3 b(threads), g((unsigned)(((count) + (threads)-1) / (threads))); hipLaunchKernelGGL(kern, g, b, 0, st, __VA_ARGS__); } } while (0)
+// the same over a lockstep batch: grid.z = proof
+#define LAUNCH_1D_B(kern, count, threads, nbatch, st, ...) \
+    do { if ((count) > 0 && (nbatch) > 0) { dim3 b(threads), g((unsigned)(((count) + (threads)-1) / (threads)), 1, (unsigned)(nbatch)); hipLaunchKernelGGL(kern, g, b, 0, st, __VA_ARGS__); } } while (0)
 
 hipError_t pk_pp_rows(const PpArgs &a, hipStream_t st) {
-    dim3 b(256), g((unsigned)((a.n + 255) / 256), a.nch);
+    dim3 b(256), g((unsigned)((a.n + 255) / 256), a.nch, a.batch);
     hipLaunchKernelGGL(pp_rows_kernel, g, b, 0, st, a);
     return hipGetLastError();
 }
-hipError_t pk_pp_scan(const u64 *rowprod, u64 *z, u64 n, u32 nch, hipStream_t st) {
-    hipLaunchKernelGGL(pp_scan_kernel, dim3(nch), dim3(1024), 0, st, rowprod, z, n);
+hipError_t pk_pp_scan(const u64 *rowprod, u64 *z, u64 n, u32 nch_total, hipStream_t st) {
+    hipLaunchKernelGGL(pp_scan_kernel, dim3(nch_total), dim3(1024), 0, st, rowprod, z, n);
     return hipGetLastError();
 }
-hipError_t pk_pp_finish(const PpArgs &a, const u64 *z, u64 *zs_pp, hipStream_t st) {
-    dim3 b(256), g((unsigned)((a.n + 255) / 256), a.nch);
-    hipLaunchKernelGGL(pp_finish_kernel, g, b, 0, st, a, z, zs_pp);
+hipError_t pk_pp_finish(const PpArgs &a, const u64 *z, u64 *zs_pp, u64 ps_z, u64 ps_zs, hipStream_t st) {
+    dim3 b(256), g((unsigned)((a.n + 255) / 256), a.nch, a.batch);
+    hipLaunchKernelGGL(pp_finish_kernel, g, b, 0, st, a, z, zs_pp, ps_z, ps_zs);
     return hipGetLastError();
 }
 template <int NCH>
 static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
-    dim3 b(256), g((unsigned)((a.q_n + 255) / 256));
+    dim3 b(256), g((unsigned)((a.q_n + 255) / 256), 1, a.batch);
     const u32 t0 = a.nch + a.nch * a.nchunks;
     // Poseidon gates (heavy, one launch each) come last; the final launch also applies 1/Z_H and stores
     int n_pos = 0;
@@ -599,7 +663,7 @@ static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gat
 // gate kernels only (no permutation terms, no 1/Z_H): used by the witness check on the trace rows
 template <int NCH>
 static hipError_t gates_only_launch(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
-    dim3 b(256), g((unsigned)((a.q_n + 255) / 256));
+    dim3 b(256), g((unsigned)((a.q_n + 255) / 256), 1, a.batch);
     const u32 t0 = a.nch + a.nch * a.nchunks;
     hipLaunchKernelGGL((quotient_gates_kernel<NCH>), g, b, 0, st, a, t0, 0);
     for (u32 i = 0; i < a.num_gates; i++)
@@ -615,12 +679,12 @@ hipError_t pk_gate_sums(const QuotientArgs &a, const GateDev *host_gates, hipStr
         default: return hipErrorInvalidValue;
     }
 }
-hipError_t pk_witness_check(const u64 *acc, u64 n, u32 nch, const u64 *z, const u64 *rowprod, u64 *result, hipStream_t st) {
-    LAUNCH_1D(witness_check_kernel, n, 256, st, acc, n, nch, z, rowprod, result);
+hipError_t pk_witness_check(const u64 *acc, u64 n, u32 nch, const u64 *z, const u64 *rowprod, u64 *result, u32 batch, hipStream_t st) {
+    LAUNCH_1D_B(witness_check_kernel, n, 256, batch, st, acc, n, nch, z, rowprod, result);
     return hipGetLastError();
 }
 hipError_t pk_quotient(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
-    if (a.q_n == 0) return hipSuccess;
+    if (a.q_n == 0 || a.batch == 0) return hipSuccess;
     switch (a.nch) {
         case 1: return quotient_launch<1>(a, host_gates, st);
         case 2: return quotient_launch<2>(a, host_gates, st);
@@ -633,43 +697,47 @@ hipError_t pk_scale_powers(u64 *data, u64 n, u64 ncols, const u64 *pw_lo, const 
     LAUNCH_1D(scale_powers_kernel, n, 256, st, data, n, ncols, pw_lo, pw_hi, lo_bits);
     return hipGetLastError();
 }
-hipError_t pk_poly_eval(const u64 *coeffs, u64 n, u32 npolys, const e2 *points, u32 npoints, const u64 *poly_index, e2 *out, hipStream_t st) {
-    if (npolys == 0) return hipSuccess;
-    hipLaunchKernelGGL(poly_eval_kernel, dim3(npolys, npoints), dim3(256), 0, st, coeffs, n, points, poly_index, out);
+hipError_t pk_poly_eval(const u64 *coeffs, u64 n, u32 npolys, const e2 *points, u32 npoints, e2 *out, u32 batch, u64 ps_coeffs, u64 ps_points, u64 ps_out, hipStream_t st) {
+    if (npolys == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(poly_eval_kernel, dim3(npolys, npoints, batch), dim3(256), 0, st, coeffs, n, points, out, ps_coeffs, ps_points, ps_out);
     return hipGetLastError();
 }
 hipError_t pk_reduce_polys(const ReduceArgs &a, hipStream_t st) {
-    LAUNCH_1D(reduce_polys_kernel, a.n, 256, st, a);
+    LAUNCH_1D_B(reduce_polys_kernel, a.n, 256, a.batch, st, a);
     return hipGetLastError();
 }
-hipError_t pk_divide_linear(const u64 *comp_a, const u64 *comp_b, u64 n, e2 z, e2 shift, int mode, u64 *fin_a, u64 *fin_b, hipStream_t st) {
+hipError_t pk_divide_linear(const u64 *comp_a, const u64 *comp_b, u64 n, const e2 *zs, const e2 *shifts, int mode, u64 *fin_a, u64 *fin_b,
+                            u32 batch, u64 ps_comp, u64 ps_fin, hipStream_t st) {
+    if (batch == 0) return hipSuccess;
     unsigned threads = n >= 1024 ? 1024 : (n >= 64 ? (unsigned)n : 64);
-    hipLaunchKernelGGL(divide_linear_kernel, dim3(1), dim3(threads), 0, st, comp_a, comp_b, n, z, shift, mode, fin_a, fin_b);
+    hipLaunchKernelGGL(divide_linear_kernel, dim3(batch), dim3(threads), 0, st, comp_a, comp_b, n, zs, shifts, mode, fin_a, fin_b, ps_comp, ps_fin);
     return hipGetLastError();
 }
-hipError_t pk_interleave_ext(const u64 *va, const u64 *vb, u64 n, u64 *rows, hipStream_t st) {
-    LAUNCH_1D(interleave_ext_kernel, n, 256, st, va, vb, n, rows);
+hipError_t pk_interleave_ext(const u64 *va, const u64 *vb, u64 n, u64 *rows, u32 batch, u64 ps_vals, u64 ps_rows, hipStream_t st) {
+    LAUNCH_1D_B(interleave_ext_kernel, n, 256, batch, st, va, vb, n, rows, ps_vals, ps_rows);
     return hipGetLastError();
 }
-hipError_t pk_fri_fold(const u64 *ca, const u64 *cb, u64 new_n, u32 arity, e2 beta, u64 *oa, u64 *ob, hipStream_t st) {
-    LAUNCH_1D(fri_fold_kernel, new_n, 256, st, ca, cb, new_n, arity, beta, oa, ob);
+hipError_t pk_fri_fold(const u64 *ca, const u64 *cb, u64 new_n, u32 arity, const e2 *betas, u64 *oa, u64 *ob, u32 batch, u64 ps_in, u64 ps_out, hipStream_t st) {
+    LAUNCH_1D_B(fri_fold_kernel, new_n, 256, batch, st, ca, cb, new_n, arity, betas, oa, ob, ps_in, ps_out);
     return hipGetLastError();
 }
-hipError_t pk_gather_rows(const u64 *cols, u64 stride, u32 ncols, const u64 *idx, u32 nq, u64 *out, hipStream_t st) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nq), dim3(128), 0, st, cols, stride, ncols, idx, nq, out);
+hipError_t pk_gather_rows(const u64 *cols, u64 stride, u32 ncols, const u64 *idx, u32 nq, u64 *out, u32 batch, u64 ps_cols, u64 ps_out, hipStream_t st) {
+    if (nq == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nq, 1, batch), dim3(128), 0, st, cols, stride, ncols, idx, nq, out, ps_cols, ps_out);
     return hipGetLastError();
 }
-hipError_t pk_gather_paths(const u64 *digests, u64 n_leaves, u32 path_len, const u64 *idx, u32 shift, u32 nq, u64 *out, hipStream_t st) {
-    if (path_len == 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_paths_kernel, dim3(nq), dim3(256), 0, st, digests, n_leaves, path_len, idx, shift, out);
+hipError_t pk_gather_paths(const u64 *digests, u64 n_leaves, u32 path_len, const u64 *idx, u32 shift, u32 nq, u64 *out, u32 batch, u64 ps_digests, u64 ps_out, hipStream_t st) {
+    if (path_len == 0 || nq == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_paths_kernel, dim3(nq, 1, batch), dim3(256), 0, st, digests, n_leaves, path_len, idx, shift, out, nq, ps_digests, ps_out);
     return hipGetLastError();
 }
-hipError_t pk_gather_leaf_rows(const u64 *rows, u32 width, const u64 *idx, u32 shift, u32 nq, u64 *out, hipStream_t st) {
-    hipLaunchKernelGGL(gather_leaf_rows_kernel, dim3(nq), dim3(64), 0, st, rows, width, idx, shift, out);
+hipError_t pk_gather_leaf_rows(const u64 *rows, u32 width, const u64 *idx, u32 shift, u32 nq, u64 *out, u32 batch, u64 ps_rows, u64 ps_out, hipStream_t st) {
+    if (nq == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_leaf_rows_kernel, dim3(nq, 1, batch), dim3(64), 0, st, rows, width, idx, shift, out, nq, ps_rows, ps_out);
     return hipGetLastError();
 }
-hipError_t pk_salt(u64 seed, u32 oracle_index, u64 lde_n, u64 *out, hipStream_t st) {
-    LAUNCH_1D(salt_kernel, lde_n, 256, st, seed, oracle_index, lde_n, out);
+hipError_t pk_salt(const u32 *keys, u32 oracle_index, u64 lde_n, u64 *out, u32 batch, hipStream_t st) {
+    LAUNCH_1D_B(salt_kernel, lde_n, 256, batch, st, keys, oracle_index, lde_n, out);
     return hipGetLastError();
 }
 hipError_t pk_coset_tables(u64 lde_n, u32 log_lde, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits, const u64 *zh, u32 rate,

@@ -61,6 +61,7 @@ int qpgpu_ctx_create(int device, qpgpu_ctx **out) {
     qpgpu_ctx *c = new (std::nothrow) qpgpu_ctx();
     if (!c) return QPGPU_ENOMEM;
     c->device = device;
+    c->hasher = hasher::process_default();   // the context's proof-system hasher; qpgpu_ctx_set_hasher changes it
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return QPGPU_EDEVICE; }
     c->own_stream = true;
     *out = c;
@@ -73,6 +74,7 @@ void qpgpu_ctx_destroy(qpgpu_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->owned) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->d_p2) (void)hipFree(ctx->d_p2);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -124,6 +126,13 @@ int qpgpu_memcpy_d2h(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     QP_DEV(ctx);
     QP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return QPGPU_OK;
+}
+
+int qpgpu_memcpy_d2d(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return QPGPU_EINVAL;
+    QP_DEV(ctx);
+    QP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));   // asynchronous on the ctx stream
     return QPGPU_OK;
 }
 

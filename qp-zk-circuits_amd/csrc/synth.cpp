@@ -159,7 +159,9 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     std::map<u64, u64> pi_hash_row;      // row -> absorption index
     {
         const u64 chunks = (num_public_inputs + 7) / 8;
-        if (with_poseidon && chunks > 0 && 1 + n_const_rows + chunks + n_noop <= n) {
+        // (the PoseidonGate rows compute plonky2's Poseidon: only when that is also the proof-system hasher does their
+        // output equal the public-input hash the prover binds)
+        if (with_poseidon && !(flags & 32) && hasher::kind() == hasher::POSEIDON && chunks > 0 && 1 + n_const_rows + chunks + n_noop <= n) {
             for (u64 k = 0; k < chunks; k++) { row_gate[1 + n_const_rows + k] = GATE_POSEIDON; pi_hash_row[1 + n_const_rows + k] = k; }
             pack.pi_cells.assign(num_public_inputs, 0);
         }

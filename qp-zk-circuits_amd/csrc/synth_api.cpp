@@ -28,7 +28,10 @@ size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsig
     // with hints (flag bit 4) the trailer's length depends on the seed: an upper bound is returned and
     // qpgpu_synth_circuit_ex reports the exact count
     const size_t hint_cap = (flags & 16) ? 2 + 8 * (((size_t)num_routed / 2 + 2) << degree_bits) : 0;
-    return 18 + arity + gates.size() * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits) + hint_cap;
+    // with Poseidon rows (flag bit 0) the pack carries the public-input cell trailer: room for 4094 public inputs here; for
+    // more, qpgpu_synth_circuit_ex with pack_out = NULL reports the exact size
+    const size_t pubi_cap = (flags & 1) ? 4096 : 0;
+    return 18 + arity + gates.size() * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits) + hint_cap + pubi_cap;
 }
 size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed) {
     return qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, 0);

@@ -304,12 +304,12 @@ int ensure_plan(qpgpu_circuit *c) {
     return QPGPU_OK;
 }
 
-void host_pi_hash(const u64 *pis, size_t n, u64 out[4]) {
+void host_pi_hash(const hasher::Config &h, const u64 *pis, size_t n, u64 out[4]) {
     u64 st[12] = {0};
     for (size_t i = 0; i < n; i += 8) {
         const size_t len = std::min<size_t>(8, n - i);
         for (size_t k = 0; k < len; k++) st[k] = gl::canon(pis[i + k]);
-        hasher::host_permute(st);
+        h.permute(st);
     }
     std::memcpy(out, st, 32);
 }
@@ -359,7 +359,7 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
         QP_HIP(ctx, wk_scatter(d_wires, plan.d_pi_idx, plan.d_pi_vals, (uint32_t)npis, batch, c->pack.num_wires * c->pack.n(), (uint32_t)npis, ctx->stream));
     }
     std::vector<u64> pih((size_t)batch * 4);
-    for (uint32_t b = 0; b < batch; b++) host_pi_hash(public_inputs + (size_t)b * c->pack.num_public_inputs, c->pack.num_public_inputs, pih.data() + 4 * b);
+    for (uint32_t b = 0; b < batch; b++) host_pi_hash(ctx->hasher, public_inputs + (size_t)b * c->pack.num_public_inputs, c->pack.num_public_inputs, pih.data() + 4 * b);
     QP_HIP(ctx, hipMemcpyAsync(plan.d_pi_hash, pih.data(), pih.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));       // pih goes out of scope
     WitnessArgs a{};

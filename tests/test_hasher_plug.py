@@ -57,8 +57,17 @@ def test_selection_is_visible_and_reversible(pkg, orc):
     assert again.get() == v1 and lib.qpgpu_get_hasher() == 0
 
 
+@pytest.fixture()
+def gpu2(pkg, poseidon2_selected):
+    """A context created while Poseidon2 is the process default: the hasher is a property of the context."""
+    g = pkg.QpGpu(0)
+    yield g
+    g.close()
+
+
 @pytest.mark.gpu
-def test_hashing_kernels_under_poseidon2(pkg, gpu, orc, poseidon2_selected):
+def test_hashing_kernels_under_poseidon2(pkg, gpu2, orc, poseidon2_selected):
+    gpu = gpu2
     rng = np.random.default_rng(13)
     st = rng.integers(0, P, (300, 12), dtype=np.uint64)
     got = gpu.poseidon_permute(st)
@@ -72,9 +81,10 @@ def test_hashing_kernels_under_poseidon2(pkg, gpu, orc, poseidon2_selected):
 
 
 @pytest.mark.gpu
-def test_proofs_under_poseidon2(pkg, gpu, orc, poseidon2_selected):
+def test_proofs_under_poseidon2(pkg, gpu2, orc, poseidon2_selected):
     """Whole proofs with the plugged hasher: byte parity, verification, zero-knowledge salts, the (Poseidon) gate rows
     keep their own constants."""
+    gpu = gpu2
     for d, kw, zk in ((8, dict(seed=81, num_wires=24, num_routed=16, num_public_inputs=3), False),
                       (9, dict(seed=82, poseidon=True, base_sum=True, ext_arith=True, recursion=True), True)):
         pack, wires, pis = pkg.synth_circuit(d, **kw)
@@ -97,3 +107,38 @@ def test_back_to_poseidon_after_the_plug(pkg, gpu, orc):
     circ = pkg.Circuit(gpu, pack); oc = OracleCircuit(orc, pack)
     assert circ.prove(wires, pis) == oc.prove(wires, pis)
     circ.close(); oc.close()
+
+
+@pytest.mark.gpu
+def test_two_hashers_coexist_in_one_process(pkg, gpu, orc):
+    """The hasher belongs to the context (no global state): a Poseidon context and a Poseidon2 context prove
+    interleaved in one process, each byte-equal to the restatement under its own permutation."""
+    prm = placeholder_params()
+    g2 = pkg.QpGpu(0, hasher=prm)
+    lib = pkg.load_library()
+    assert lib.qpgpu_ctx_get_hasher(gpu.ctx) == 0 and lib.qpgpu_ctx_get_hasher(g2.ctx) == 1 and lib.qpgpu_get_hasher() == 0
+    # no public inputs: the public-input hash is the zero digest under every hasher, so one witness serves both contexts
+    pack, wires, pis = pkg.synth_circuit(7, num_wires=40, num_routed=24, num_public_inputs=0, seed=91, base_sum=True)
+    c1, c2 = pkg.Circuit(gpu, pack), pkg.Circuit(g2, pack)
+    try:
+        p1a = c1.prove(wires, pis); p2a = c2.prove(wires, pis); p1b = c1.prove(wires, pis); p2b = c2.prove(wires, pis)
+        assert p1a == p1b and p2a == p2b and p1a != p2a
+        oc = OracleCircuit(orc, pack)
+        assert p1a == oc.prove(wires, pis) and oc.verify(p1a) == 0 and oc.verify(p2a) != 0
+        oc.close()
+        orc.select_poseidon2(*prm)
+        try:
+            oc = OracleCircuit(orc, pack)
+            assert p2a == oc.prove(wires, pis) and oc.verify(p2a) == 0
+            oc.close()
+        finally:
+            orc.select_poseidon()
+        # the context's challenger follows the context's hasher
+        a, b = pkg.Challenger(gpu), pkg.Challenger(g2)
+        a.observe([1, 2, 3]); b.observe([1, 2, 3])
+        assert a.get() != b.get()
+        # choosing the hasher after a circuit exists is refused
+        with pytest.raises(pkg.QpGpuError):
+            g2._check(lib.qpgpu_ctx_set_hasher(g2.ctx, 0, None, 0))
+    finally:
+        c1.close(); c2.close(); g2.close()
