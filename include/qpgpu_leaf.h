@@ -1,0 +1,142 @@
+/*
+ * qpgpu_leaf.h — C ABI of the native leaf-witness front-end (host only, no GPU): what the reference does between
+ * `CircuitInputs` and the PartialWitness of the Wormhole leaf circuit, i.e. SURVEY.md section 8 row a1 / f2:
+ *
+ *   WormholeProver::commit -> fill_witness                     wormhole/prover/src/lib.rs:156-163,187-221
+ *     Nullifier::fill_targets                                   wormhole/circuit/src/nullifier.rs:345-354
+ *     UnspendableAccount::fill_targets                          wormhole/circuit/src/unspendable_account.rs:239-248
+ *     ZkMerkleProofData::try_from / fill_targets                wormhole/circuit/src/zk_merkle_proof.rs:424-470,628-700
+ *     DualExitAccount::fill_targets                             wormhole/circuit/src/substrate_account.rs:152-165
+ *     BlockHeader::fill_targets, HeaderInputs::new              wormhole/circuit/src/block_header/mod.rs:130-147, header.rs:110-131
+ *   byte <-> felt codecs                                        common/src/serialization.rs:62-247
+ *   public-input order (21 felts)                               wormhole/inputs/src/lib.rs:68-80
+ *
+ * fill_witness is pure encoding: every value it assigns is a re-encoding of an input field (the hashes are inputs; the
+ * circuit recomputes them). It is therefore pinned by the reference's encoding anchors alone
+ * (wormhole/prover/src/lib.rs:262-271, common/src/serialization.rs:92-97) and does not depend on the Poseidon2 constants.
+ *
+ * The helpers that DERIVE hashes natively (nullifier from its preimage, unspendable account from the secret, block hash,
+ * ZK-tree leaf and node hashes) run the fork's Poseidon2 sponge (`input || 1 || 0*` to a multiple of the rate 8,
+ * wormhole/circuit/tests/heap_zeroization.rs:133-160) on a caller-supplied parameter block — qp-poseidon-core 3.1.0's
+ * constants are not available offline. A parameter block is right iff it reproduces the
+ * reference's seven known-answer vectors (tests/golden/poseidon2_kats.json); until one does these helpers are
+ * PARITY-UNPINNED and say so in their names' documentation.
+ *
+ * Assignments are reported against LOGICAL targets of the leaf circuit (enum below), in the order fill_witness sets
+ * them; the circuit-pack exporter (integration/) records which wire cell each logical target became, and
+ * qpgpu_leaf_map_targets turns the pair list into the (cell, value) list qpgpu_generate_witness_partial_dev takes.
+ */
+#ifndef QPGPU_LEAF_H
+#define QPGPU_LEAF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPGPU_LEAF_PUBLIC_INPUTS 21          /* wormhole/inputs/src/lib.rs:33 */
+#define QPGPU_LEAF_MAX_DEPTH 16              /* common/src/zk_merkle.rs:65 */
+#define QPGPU_LEAF_DIGEST_LOGS_SIZE 110      /* wormhole/circuit/src/block_header/header.rs:14 */
+#define QPGPU_LEAF_DIGEST_LOGS_FELTS 28
+#define QPGPU_LEAF_ERR_CAP 160
+
+/* CircuitInputs = PublicCircuitInputs + PrivateCircuitInputs (wormhole/circuit/src/inputs.rs:30-83). 32-byte fields are
+ * BytesDigest: four little-endian 8-byte limbs, each below the Goldilocks modulus (wormhole/inputs/src/lib.rs:148-167). */
+typedef struct {
+    /* public */
+    uint32_t asset_id, output_amount_1, output_amount_2, volume_fee_bps;
+    uint8_t nullifier[32], exit_account_1[32], exit_account_2[32], block_hash[32];
+    uint32_t block_number;
+    /* private */
+    uint8_t secret[32];
+    uint64_t transfer_count;
+    uint8_t unspendable_account[32], parent_hash[32], state_root[32], extrinsics_root[32];
+    uint8_t digest[QPGPU_LEAF_DIGEST_LOGS_SIZE];
+    uint32_t input_amount;
+    uint8_t zk_tree_root[32];
+    uint32_t zk_merkle_depth;                                   /* siblings.len() == positions.len() */
+    uint8_t zk_merkle_siblings[QPGPU_LEAF_MAX_DEPTH][3][32];    /* sorted order, current hash excluded */
+    uint8_t zk_merkle_positions[QPGPU_LEAF_MAX_DEPTH];          /* 0..3 */
+} qpgpu_leaf_inputs;
+
+/* Logical targets of CircuitTargets, grouped as fill_witness visits them. A target id is base + index. */
+enum {
+    QPGPU_LT_NULLIFIER_HASH = 0,            /* 4  nullifier.rs:350 */
+    QPGPU_LT_NULLIFIER_SECRET = 4,          /* 4 */
+    QPGPU_LT_NULLIFIER_TRANSFER_COUNT = 8,  /* 2 */
+    QPGPU_LT_UNSPENDABLE_ACCOUNT_ID = 10,   /* 4  unspendable_account.rs:244 */
+    QPGPU_LT_UNSPENDABLE_SECRET = 14,       /* 4 */
+    QPGPU_LT_ZK_ROOT_HASH = 18,             /* 4  zk_merkle_proof.rs:654 */
+    QPGPU_LT_ZK_DEPTH = 22,                 /* 1 */
+    QPGPU_LT_ZK_SIBLINGS = 23,              /* 16 x 3 x 4, level major */
+    QPGPU_LT_ZK_POSITIONS = 215,            /* 16 */
+    QPGPU_LT_LEAF_TO_ACCOUNT = 231,         /* 4 */
+    QPGPU_LT_LEAF_TRANSFER_COUNT = 235,     /* 2 */
+    QPGPU_LT_LEAF_ASSET_ID = 237,
+    QPGPU_LT_LEAF_INPUT_AMOUNT = 238,
+    QPGPU_LT_LEAF_OUTPUT_AMOUNT_1 = 239,
+    QPGPU_LT_LEAF_OUTPUT_AMOUNT_2 = 240,
+    QPGPU_LT_LEAF_VOLUME_FEE_BPS = 241,
+    QPGPU_LT_EXIT_ACCOUNT_1 = 242,          /* 4  substrate_account.rs:157 */
+    QPGPU_LT_EXIT_ACCOUNT_2 = 246,          /* 4 */
+    QPGPU_LT_BLOCK_HASH = 250,              /* 4  block_header/mod.rs:135 */
+    QPGPU_LT_HEADER_PARENT_HASH = 254,      /* 4 */
+    QPGPU_LT_HEADER_BLOCK_NUMBER = 258,
+    QPGPU_LT_HEADER_STATE_ROOT = 259,       /* 4 */
+    QPGPU_LT_HEADER_EXTRINSICS_ROOT = 263,  /* 4 */
+    QPGPU_LT_HEADER_ZK_TREE_ROOT = 267,     /* 4 */
+    QPGPU_LT_HEADER_DIGEST = 271,           /* 28 */
+    QPGPU_LT_COUNT = 299
+};
+
+/* ---- codecs (common/src/serialization.rs) ---- */
+/* bytes_to_felts: 4 bytes per element little-endian after appending the terminator 0x01 and zero padding; returns the
+ * number of elements (len / 4 + 1), or 0 when out_cap is too small or len exceeds 1 MiB (MAX_SERIALIZED_BYTES). */
+size_t qpgpu_bytes_to_felts(const uint8_t *in, size_t len, uint64_t *out, size_t out_cap);
+/* inverse; returns the byte count, or (size_t)-1 for a missing / misplaced terminator or an element above 32 bits */
+size_t qpgpu_felts_to_bytes(const uint64_t *in, size_t n, uint8_t *out, size_t out_cap);
+/* 32 bytes <-> 4 elements, 8 bytes per element little-endian (from_noncanonical_u64: reduced mod p on the way in) */
+void qpgpu_bytes_to_digest(const uint8_t in[32], uint64_t out[4]);
+void qpgpu_digest_to_bytes(const uint64_t in[4], uint8_t out[32]);
+/* BytesDigest::try_from: 1 when every 8-byte limb is canonical (< p) */
+int qpgpu_bytes_digest_is_canonical(const uint8_t in[32]);
+/* u64 / u128 as 32-bit limbs, most significant first (u128: hi 64 bits then lo 64 bits) */
+void qpgpu_u64_to_felts(uint64_t v, uint64_t out[2]);
+void qpgpu_u128_to_felts(uint64_t hi, uint64_t lo, uint64_t out[4]);
+
+/* ---- fill_witness ---- */
+/* public_inputs_out: the 21 public inputs in registration order (asset_id, output_amount_1, output_amount_2,
+ * volume_fee_bps, nullifier x4, exit_account_1 x4, exit_account_2 x4, block_hash x4, block_number).
+ * targets_out / values_out: QPGPU_LT_COUNT (299) assignments in fill_witness order. Returns 0, or -1 with a message in
+ * err (QPGPU_LEAF_ERR_CAP bytes) for inputs the reference rejects: depth above 16, a position above 3, a 32-byte field
+ * with a non-canonical limb. */
+int qpgpu_leaf_fill_witness(const qpgpu_leaf_inputs *in, uint64_t public_inputs_out[QPGPU_LEAF_PUBLIC_INPUTS],
+                            uint32_t *targets_out, uint64_t *values_out, size_t cap, size_t *count, char *err);
+/* is_not_dummy as ZkMerkleProofData::try_from derives it (block_hash == 0 and both outputs == 0 mean dummy) */
+int qpgpu_leaf_is_not_dummy(const qpgpu_leaf_inputs *in);
+/* logical targets -> wire cells through the exporter's target map (target_map[id] = row * num_wires + wire, or
+ * UINT64_MAX for a target the builder optimised away); returns the number of (cell, value) pairs written */
+size_t qpgpu_leaf_map_targets(const uint32_t *targets, const uint64_t *values, size_t count, const uint64_t *target_map,
+                              size_t map_len, uint64_t *cells_out, uint64_t *cell_values_out);
+
+/* ---- Poseidon2 sponge of the fork on a caller-supplied parameter block (146 words, layout of qpgpu_ctx_set_hasher) ----
+ * PARITY-UNPINNED until a block reproduces tests/golden/poseidon2_kats.json. */
+int qpgpu_poseidon2_permute(const uint64_t *params, size_t n_words, uint64_t state[12]);
+/* Poseidon2Hash::hash_no_pad of the fork: pads `|| 1 || 0*` to a multiple of 8, overwrite-mode absorption, 4 outputs */
+int qpgpu_poseidon2_hash_pad10(const uint64_t *params, size_t n_words, const uint64_t *in, size_t n, uint64_t out[4]);
+/* hash_no_pad_bytes: the same, output as 32 bytes (digest_to_bytes) */
+int qpgpu_poseidon2_hash_bytes(const uint64_t *params, size_t n_words, const uint64_t *in, size_t n, uint8_t out[32]);
+/* H(H(felts("wormhole") || secret)): UnspendableAccount::from_secret (unspendable_account.rs:63-94) */
+int qpgpu_leaf_unspendable_account(const uint64_t *params, size_t n_words, const uint8_t secret[32], uint8_t out[32]);
+/* H(H(felts("~nullif~") || secret || transfer_count)): Nullifier::from_preimage (nullifier.rs:103-128) */
+int qpgpu_leaf_nullifier(const uint64_t *params, size_t n_words, const uint8_t secret[32], uint64_t transfer_count, uint8_t out[32]);
+/* HeaderInputs::block_hash over the 45-element preimage (block_header/header.rs:132-141) */
+int qpgpu_leaf_block_hash(const uint64_t *params, size_t n_words, const uint8_t parent_hash[32], uint32_t block_number,
+                          const uint8_t state_root[32], const uint8_t extrinsics_root[32], const uint8_t zk_tree_root[32],
+                          const uint8_t digest[QPGPU_LEAF_DIGEST_LOGS_SIZE], uint8_t out[32]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -122,10 +122,12 @@ def load_library():
 
 def exported_symbols():
     """Names include/qpgpu.h declares; tests check each resolves in the built library."""
+    import glob
     import re
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "qpgpu.h")
-    text = open(hdr).read()
-    return sorted(set(re.findall(r"\b(qpgpu_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for hdr in glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")):
+        names |= set(re.findall(r"\b(qpgpu_[a-z0-9_]+)\s*\(", open(hdr).read()))
+    return sorted(names)
 
 
 def set_hasher_poseidon():

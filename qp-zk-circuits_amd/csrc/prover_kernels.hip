@@ -169,9 +169,34 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
     for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = acc[c];
 }
 
+// One copy of a RandomAccessGate with 2^BITS list entries: out[0..BITS) the bit constraints, out[BITS] the index
+// reconstruction, out[BITS+1] the list folded by the bits against the claimed element. BITS is a compile-time constant so
+// the item array stays in registers (a dynamically indexed array went to scratch). The 32-entry form, which standard
+// configurations do not use (arity 16, cap height 4), lives in its own kernel instance (WIDE) so that it does not set the
+// register count of the common one.
+template <int BITS>
+__device__ __forceinline__ void random_access_values(const u64 *cw, const u64 *bw, u64 S, u64 *out) {
+    constexpr int VEC = 1 << BITS;
+    u64 items[VEC], bit[BITS];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) items[i] = cw[(u64)(2 + i) * S];
+#pragma unroll
+    for (int i = 0; i < BITS; i++) { bit[i] = bw[(u64)i * S]; out[i] = gl::mul(bit[i], gl::sub(bit[i], 1)); }
+    u64 idx = 0;
+#pragma unroll
+    for (int i = BITS - 1; i >= 0; i--) idx = gl::add(gl::add(idx, idx), bit[i]);
+    out[BITS] = gl::sub(idx, cw[0]);
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+#pragma unroll
+        for (int i = 0; i < (VEC >> (b + 1)); i++) items[i] = gl::add(items[2 * i], gl::mul(bit[b], gl::sub(items[2 * i + 1], items[2 * i])));
+    }
+    out[BITS + 1] = gl::sub(items[0], cw[S]);
+}
+
 // (2) every gate except PoseidonGate: Constant, PublicInput, BaseSum<2>, Arithmetic, the extension-arithmetic pair and the
 // recursion set (Reducing*, RandomAccess, Exponentiation, PoseidonMds, CosetInterpolation). t0 = index of the first gate constraint.
-template <int NCH>
+template <int NCH, bool WIDE>
 __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (j >= a.q_n) return;
@@ -242,19 +267,15 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
             u32 q = 0;
             for (u32 cp = 0; cp < copies; cp++) {
                 const u64 *cw = a.wires + (u64)((2 + vec) * cp) * S + j, *bw = a.wires + (u64)(routed + cp * bits) * S + j;
-                u64 items[32];
-                for (u32 i = 0; i < vec; i++) items[i] = cw[(u64)(2 + i) * S];
-                u64 idx = 0;
-                for (u32 i = 0; i < bits; i++) { const u64 b = bw[(u64)i * S]; emit(q++, gl::mul(b, gl::sub(b, 1))); }
-                for (u32 i = bits; i-- > 0;) idx = gl::add(gl::add(idx, idx), bw[(u64)i * S]);
-                emit(q++, gl::sub(idx, cw[0]));
-                u32 len = vec;
-                for (u32 b = 0; b < bits; b++) {
-                    const u64 bit = bw[(u64)b * S];
-                    for (u32 i = 0; i < len / 2; i++) items[i] = gl::add(items[2 * i], gl::mul(bit, gl::sub(items[2 * i + 1], items[2 * i])));
-                    len >>= 1;
+                u64 vals[7];
+                switch (bits) {
+                    case 1: random_access_values<1>(cw, bw, S, vals); break;
+                    case 2: random_access_values<2>(cw, bw, S, vals); break;
+                    case 3: random_access_values<3>(cw, bw, S, vals); break;
+                    case 4: random_access_values<4>(cw, bw, S, vals); break;
+                    default: if constexpr (WIDE) random_access_values<5>(cw, bw, S, vals); break;
                 }
-                emit(q++, gl::sub(items[0], cw[S]));
+                for (u32 i = 0; i < bits + 2; i++) emit(q++, vals[i]);
             }
             for (u32 i = 0; i < extra; i++) emit(q++, gl::sub(consts_base[(u64)i * S], a.wires[(u64)((2 + vec) * copies + i) * S + j]));
         } else if (g.type == 11) {    // ExponentiationGate: square-and-multiply chain over the power bits (big-endian walk)
@@ -643,6 +664,10 @@ hipError_t pk_pp_finish(const PpArgs &a, const u64 *z, u64 *zs_pp, u64 ps_z, u64
     hipLaunchKernelGGL(pp_finish_kernel, g, b, 0, st, a, z, zs_pp, ps_z, ps_zs);
     return hipGetLastError();
 }
+static bool wide_random_access(const QuotientArgs &a, const GateDev *host_gates) {
+    for (u32 i = 0; i < a.num_gates; i++) if (host_gates[i].type == 10 && host_gates[i].param0 > 4) return true;
+    return false;
+}
 template <int NCH>
 static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
     dim3 b(256), g((unsigned)((a.q_n + 255) / 256), 1, a.batch);
@@ -651,7 +676,8 @@ static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gat
     int n_pos = 0;
     for (u32 i = 0; i < a.num_gates; i++) if (host_gates[i].type == 4 && host_gates[i].num_constraints) n_pos++;
     hipLaunchKernelGGL((quotient_perm_kernel<NCH>), g, b, 0, st, a);
-    hipLaunchKernelGGL((quotient_gates_kernel<NCH>), g, b, 0, st, a, t0, n_pos == 0 ? 1 : 0);
+    if (wide_random_access(a, host_gates)) hipLaunchKernelGGL((quotient_gates_kernel<NCH, true>), g, b, 0, st, a, t0, n_pos == 0 ? 1 : 0);
+    else hipLaunchKernelGGL((quotient_gates_kernel<NCH, false>), g, b, 0, st, a, t0, n_pos == 0 ? 1 : 0);
     int seen = 0;
     for (u32 i = 0; i < a.num_gates; i++)
         if (host_gates[i].type == 4 && host_gates[i].num_constraints) {
@@ -665,7 +691,8 @@ template <int NCH>
 static hipError_t gates_only_launch(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {
     dim3 b(256), g((unsigned)((a.q_n + 255) / 256), 1, a.batch);
     const u32 t0 = a.nch + a.nch * a.nchunks;
-    hipLaunchKernelGGL((quotient_gates_kernel<NCH>), g, b, 0, st, a, t0, 0);
+    if (wide_random_access(a, host_gates)) hipLaunchKernelGGL((quotient_gates_kernel<NCH, true>), g, b, 0, st, a, t0, 0);
+    else hipLaunchKernelGGL((quotient_gates_kernel<NCH, false>), g, b, 0, st, a, t0, 0);
     for (u32 i = 0; i < a.num_gates; i++)
         if (host_gates[i].type == 4 && host_gates[i].num_constraints) hipLaunchKernelGGL((quotient_poseidon_kernel<NCH>), g, b, 0, st, a, i, t0, 0);
     return hipGetLastError();

@@ -1,0 +1,285 @@
+"""Native leaf-witness front-end (include/qpgpu_leaf.h, host only): codecs pinned by the reference's encoding anchors,
+fill_witness against an independent restatement in this file and against the oracle's codecs, the reference's input
+validation, and the hash-deriving helpers KAT-gated: they are reported UNPINNED until a Poseidon2 parameter block reproduces
+all seven reference known-answer vectors (tests/golden/poseidon2_kats.json, transcribed from
+wormhole/tests/src/circuit/unspendable_account_tests.rs:9-24 and wormhole/tests/test-helpers/src/lib.rs:210-273)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "poseidon2_kats.json")))
+P = 0xFFFFFFFF00000001
+MAX_DEPTH, DIGEST_LEN = 16, 110
+
+
+class LeafInputs(ctypes.Structure):
+    _fields_ = [("asset_id", ctypes.c_uint32), ("output_amount_1", ctypes.c_uint32), ("output_amount_2", ctypes.c_uint32),
+                ("volume_fee_bps", ctypes.c_uint32),
+                ("nullifier", ctypes.c_uint8 * 32), ("exit_account_1", ctypes.c_uint8 * 32), ("exit_account_2", ctypes.c_uint8 * 32),
+                ("block_hash", ctypes.c_uint8 * 32), ("block_number", ctypes.c_uint32),
+                ("secret", ctypes.c_uint8 * 32), ("transfer_count", ctypes.c_uint64),
+                ("unspendable_account", ctypes.c_uint8 * 32), ("parent_hash", ctypes.c_uint8 * 32), ("state_root", ctypes.c_uint8 * 32),
+                ("extrinsics_root", ctypes.c_uint8 * 32), ("digest", ctypes.c_uint8 * DIGEST_LEN), ("input_amount", ctypes.c_uint32),
+                ("zk_tree_root", ctypes.c_uint8 * 32), ("zk_merkle_depth", ctypes.c_uint32),
+                ("zk_merkle_siblings", ctypes.c_uint8 * (MAX_DEPTH * 3 * 32)), ("zk_merkle_positions", ctypes.c_uint8 * MAX_DEPTH)]
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    L = pkg.load_library()
+    L.qpgpu_bytes_to_felts.restype = ctypes.c_size_t
+    L.qpgpu_bytes_to_felts.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    L.qpgpu_felts_to_bytes.restype = ctypes.c_size_t
+    L.qpgpu_felts_to_bytes.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    L.qpgpu_bytes_to_digest.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    L.qpgpu_digest_to_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.qpgpu_bytes_digest_is_canonical.argtypes = [ctypes.c_char_p]
+    L.qpgpu_u64_to_felts.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+    L.qpgpu_u128_to_felts.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    L.qpgpu_leaf_fill_witness.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_char_p]
+    L.qpgpu_leaf_is_not_dummy.argtypes = [ctypes.c_void_p]
+    L.qpgpu_leaf_map_targets.restype = ctypes.c_size_t
+    L.qpgpu_leaf_map_targets.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    for name in ("qpgpu_leaf_unspendable_account",):
+        getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p]
+    L.qpgpu_leaf_nullifier.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
+    L.qpgpu_leaf_block_hash.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p,
+                                        ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
+    L.qpgpu_poseidon2_hash_pad10.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.qpgpu_poseidon2_permute.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    return L
+
+
+def b2f(lib, data):
+    out = np.zeros(len(data) // 4 + 2, dtype=np.uint64)
+    n = lib.qpgpu_bytes_to_felts(bytes(data), len(data), out.ctypes.data, out.size)
+    return out[:n]
+
+
+def b2d(lib, b32):
+    out = np.zeros(4, dtype=np.uint64)
+    lib.qpgpu_bytes_to_digest(bytes(b32), out.ctypes.data)
+    return out
+
+
+def header_digest():
+    return bytes.fromhex(KATS["digest_hex_head"]) + bytes(KATS["digest_zero_run"]) + bytes.fromhex(KATS["digest_hex_tail"])
+
+
+def dummy_fields():
+    """build_dummy_circuit_inputs (reference wormhole/aggregator/src/dummy_proof.rs:58-84,125-170), the bench input, as flat
+    fields. Its unspendable account is UnspendableAccount::from_secret(secret): the secret is the first address KAT's, so the
+    account is that KAT's address (a value the reference holds, no hashing needed here)."""
+    d = dict(KATS["dummy_leaf_inputs"])
+    d["output_amount_1"], d["output_amount_2"] = d["output_amounts"]
+    d["exit_account_1"], d["exit_account_2"] = d["exit_accounts"]
+    assert KATS["address_kats"][0]["secret"] == d["secret"]
+    d["unspendable_account"] = KATS["address_kats"][0]["address"]
+    return d
+
+
+def dummy_inputs():
+    d = dummy_fields()
+    x = LeafInputs()
+    x.asset_id, x.output_amount_1, x.output_amount_2, x.volume_fee_bps = d["asset_id"], d["output_amount_1"], d["output_amount_2"], d["volume_fee_bps"]
+    x.block_number, x.transfer_count, x.input_amount = d["block_number"], d["transfer_count"], d["input_amount"]
+    for name in ("nullifier", "exit_account_1", "exit_account_2", "block_hash", "secret", "unspendable_account", "parent_hash", "state_root",
+                 "extrinsics_root", "zk_tree_root"):
+        ctypes.memmove(getattr(x, name), bytes.fromhex(d[name]), 32)
+    ctypes.memmove(x.digest, header_digest(), DIGEST_LEN)
+    x.zk_merkle_depth = d["zk_merkle_depth"]
+    return x
+
+
+def fill(lib, x):
+    pis = np.zeros(21, dtype=np.uint64); t = np.zeros(299, dtype=np.uint32); v = np.zeros(299, dtype=np.uint64)
+    n = ctypes.c_size_t(); err = ctypes.create_string_buffer(160)
+    rc = lib.qpgpu_leaf_fill_witness(ctypes.byref(x), pis.ctypes.data, t.ctypes.data, v.ctypes.data, 299, ctypes.byref(n), err)
+    return rc, pis, t[:n.value], v[:n.value], err.value.decode()
+
+
+def test_codecs_against_reference_anchors(lib, orc):
+    a = KATS["encoding_anchors"]
+    # wormhole/prover/src/lib.rs:262-271
+    assert int(b2d(lib, [0xAB] * 32)[0]) == a["felt_of_ab_x8"] and int(b2d(lib, [0xCD] * 32)[0]) == a["felt_of_cd_x8"]
+    # common/src/serialization.rs:92-97: high limb first
+    out = np.zeros(2, dtype=np.uint64)
+    lib.qpgpu_u64_to_felts(int(a["u64_to_felts"]["value"], 16), out.ctypes.data)
+    assert out.tolist() == [a["u64_to_felts"]["hi"], a["u64_to_felts"]["lo"]]
+    o4 = np.zeros(4, dtype=np.uint64)
+    lib.qpgpu_u128_to_felts(0x0123456789ABCDEF, 0x0FEDCBA987654321, o4.ctypes.data)
+    assert o4.tolist() == [0x01234567, 0x89ABCDEF, 0x0FEDCBA9, 0x87654321]
+    # salt: 8 bytes -> 3 elements (nullifier.rs:57), 110-byte digest -> 28 (header.rs:16-17)
+    assert b2f(lib, b"wormhole").tolist() == [int.from_bytes(b"worm", "little"), int.from_bytes(b"hole", "little"), 1]
+    assert b2f(lib, header_digest()).size == a["digest_felts"] and len(header_digest()) == a["digest_bytes"]
+    # the same bytes through the oracle's independent restatement
+    rng = np.random.default_rng(1)
+    for ln in (0, 1, 3, 4, 5, 31, 110, 1000):
+        data = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        ref = np.zeros(ln // 4 + 2, dtype=np.uint64)
+        n = orc.lib.orc_bytes_to_u64s(data, ln, ref.ctypes.data_as(ctypes.c_void_p))
+        assert b2f(lib, data).tolist() == ref[:n].tolist()
+        # round trip (common/src/serialization.rs:301-313)
+        f = b2f(lib, data); back = np.zeros(ln + 8, dtype=np.uint8)
+        assert lib.qpgpu_felts_to_bytes(f.ctypes.data, f.size, back.ctypes.data, back.size) == ln and back[:ln].tobytes() == data
+    for case in ([], [0], [1, 2, 3], [255] * 32, list(b"hello world")):
+        f = b2f(lib, bytes(case)); back = np.zeros(len(case) + 8, dtype=np.uint8)
+        assert lib.qpgpu_felts_to_bytes(f.ctypes.data, f.size, back.ctypes.data, back.size) == len(case) and back[:len(case)].tolist() == case
+    # malformed element vectors are refused: no terminator, terminator not in the last element, element above 32 bits
+    for bad in ([0], [5, 0], [1, 1 << 32], [0x0100, 0]):
+        f = np.array(bad, dtype=np.uint64); back = np.zeros(64, dtype=np.uint8)
+        assert lib.qpgpu_felts_to_bytes(f.ctypes.data, f.size, back.ctypes.data, back.size) == 2**64 - 1, bad
+    # digest <-> bytes, canonical check (wormhole/inputs/src/lib.rs:148-167)
+    raw = rng.integers(0, 256, 32, dtype=np.uint8); raw[7::8] &= 0x7F
+    d = b2d(lib, raw.tobytes()); back = np.zeros(32, dtype=np.uint8)
+    lib.qpgpu_digest_to_bytes(d.ctypes.data, back.ctypes.data)
+    assert back.tobytes() == raw.tobytes() and lib.qpgpu_bytes_digest_is_canonical(raw.tobytes()) == 1
+    assert lib.qpgpu_bytes_digest_is_canonical(bytes([0xFF] * 8) + bytes(24)) == 0
+    assert int(b2d(lib, bytes([0xFF] * 8) + bytes(24))[0]) == 0xFFFFFFFFFFFFFFFF - P      # from_noncanonical_u64 reduces
+
+
+def test_fill_witness_on_the_bench_inputs(lib):
+    x = dummy_inputs()
+    rc, pis, t, v, err = fill(lib, x)
+    assert rc == 0, err
+    assert t.tolist() != sorted(t.tolist())                     # siblings and positions interleave per level (fill order)
+    assert sorted(t.tolist()) == list(range(299))               # every logical target exactly once
+    val = dict(zip(t.tolist(), v.tolist()))
+    d = dummy_fields()
+    le4 = lambda h: [int.from_bytes(bytes.fromhex(h)[8 * i:8 * i + 8], "little") % P for i in range(4)]
+    # independent restatement of fill_witness (reference file:line in include/qpgpu_leaf.h)
+    want = {}
+    def put(base, vals):
+        for i, z in enumerate(vals):
+            want[base + i] = z
+    tc = [d["transfer_count"] >> 32, d["transfer_count"] & 0xFFFFFFFF]
+    put(0, le4(d["nullifier"])); put(4, le4(d["secret"])); put(8, tc)
+    unsp = d["unspendable_account"]
+    put(10, le4(unsp)); put(14, le4(d["secret"]))
+    put(18, le4(d["zk_tree_root"])); put(22, [0]); put(23, [0] * 192); put(215, [0] * 16)
+    put(231, le4(unsp)); put(235, tc)
+    put(237, [d["asset_id"], d["input_amount"], d["output_amount_1"], d["output_amount_2"], d["volume_fee_bps"]])
+    put(242, le4(d["exit_account_1"])); put(246, le4(d["exit_account_2"])); put(250, le4(d["block_hash"]))
+    put(254, le4(d["parent_hash"])); put(258, [d["block_number"]]); put(259, le4(d["state_root"])); put(263, le4(d["extrinsics_root"]))
+    put(267, le4(d["zk_tree_root"]))
+    dg = header_digest() + b"\x01" + bytes(1)
+    put(271, [int.from_bytes(dg[4 * i:4 * i + 4], "little") for i in range(28)])
+    assert val == want
+    # the 21 public inputs in registration order (wormhole/inputs/src/lib.rs:68-80)
+    assert pis.tolist() == ([d["asset_id"], d["output_amount_1"], d["output_amount_2"], d["volume_fee_bps"]] + le4(d["nullifier"]) +
+                            le4(d["exit_account_1"]) + le4(d["exit_account_2"]) + le4(d["block_hash"]) + [d["block_number"]])
+    assert lib.qpgpu_leaf_is_not_dummy(ctypes.byref(x)) == 0      # block_hash == 0 and both outputs == 0
+    x.output_amount_1 = 1
+    assert lib.qpgpu_leaf_is_not_dummy(ctypes.byref(x)) == 1
+
+
+def test_fill_witness_with_a_merkle_path_and_validation(lib):
+    rng = np.random.default_rng(3)
+    x = dummy_inputs()
+    x.zk_merkle_depth = 5
+    sib = rng.integers(0, 256, (5, 3, 32), dtype=np.uint8)
+    ctypes.memmove(x.zk_merkle_siblings, sib.tobytes(), sib.size)
+    for l, p in enumerate([0, 3, 1, 2, 0]):
+        x.zk_merkle_positions[l] = p
+    rc, pis, t, v, err = fill(lib, x)
+    assert rc == 0, err
+    val = dict(zip(t.tolist(), v.tolist()))
+    for l in range(16):
+        for s in range(3):
+            want = [int.from_bytes(sib[l, s, 8 * i:8 * i + 8].tobytes(), "little") % P for i in range(4)] if l < 5 else [0] * 4
+            assert [val[23 + (l * 3 + s) * 4 + i] for i in range(4)] == want       # raw sibling bytes may be non-canonical: reduced
+        assert val[215 + l] == ([0, 3, 1, 2, 0][l] if l < 5 else 0)
+    assert val[22] == 5
+    # the order: root, depth, then per level three siblings and the position
+    tl = t.tolist()
+    i0 = tl.index(23)
+    assert tl[i0:i0 + 13] == list(range(23, 35)) + [215] and tl[i0 + 13] == 35
+    # rejections the reference makes (fill_witness / try_from / BytesDigest::try_from)
+    x.zk_merkle_depth = 17
+    rc, *_, err = fill(lib, x)
+    assert rc != 0 and "exceeds maximum supported depth" in err
+    x.zk_merkle_depth = 5; x.zk_merkle_positions[2] = 4
+    rc, *_, err = fill(lib, x)
+    assert rc != 0 and "must be 0-3" in err
+    x.zk_merkle_positions[2] = 1
+    for name in ("nullifier", "exit_account_1", "exit_account_2", "block_hash", "secret", "unspendable_account", "parent_hash", "state_root", "extrinsics_root"):
+        y = dummy_inputs()
+        ctypes.memmove(getattr(y, name), bytes(8) + bytes([0xFF] * 8) + bytes(16), 32)
+        rc, *_, err = fill(lib, y)
+        assert rc != 0 and name in err and "chunk 1" in err, (name, err)
+    # target map: dropped targets are skipped, the others become (cell, value) pairs
+    rc, pis, t, v, err = fill(lib, dummy_inputs())
+    tmap = np.arange(1000, 1299, dtype=np.uint64); tmap[22] = np.uint64(2**64 - 1)
+    cells = np.zeros(299, dtype=np.uint64); vals = np.zeros(299, dtype=np.uint64)
+    n = lib.qpgpu_leaf_map_targets(t.ctypes.data, v.ctypes.data, t.size, tmap.ctypes.data, tmap.size, cells.ctypes.data, vals.ctypes.data)
+    assert n == 298 and 1022 not in cells[:n].tolist() and cells[0] == 1000 + t[0]
+
+
+# ---- the hash-deriving helpers: gated by the reference's known-answer vectors ----
+def candidate_blocks():
+    """Parameter blocks to try, as (name, 146-word array). tools/derivation/p2_search.py enumerates the published families;
+    anything it finds is written to tests/golden/poseidon2_params.json and picked up here."""
+    out = []
+    path = os.path.join(ROOT, "tests", "golden", "poseidon2_params.json")
+    if os.path.exists(path):
+        for name, words in json.load(open(path)).items():
+            out.append((name, np.array([int(w, 16) for w in words], dtype=np.uint64)))
+    return out
+
+
+def kat_score(lib, block):
+    ok = 0
+    out = ctypes.create_string_buffer(32)
+    for k in KATS["address_kats"]:
+        lib.qpgpu_leaf_unspendable_account(block.ctypes.data, block.size, bytes.fromhex(k["secret"]), out)
+        ok += out.raw.hex() == k["address"]
+    for k in KATS["block_header_kats"]:
+        parent = bytes.fromhex(k["parent_hash"]) if "parent_hash" in k else bytes(k["parent_hash_bytes"])
+        lib.qpgpu_leaf_block_hash(block.ctypes.data, block.size, parent, k["block_number"], bytes.fromhex(k["state_root"]),
+                                  bytes.fromhex(k["extrinsics_root"]), bytes.fromhex(k["zk_tree_root"]), header_digest(), out)
+        ok += out.raw == bytes(k["expected_hash_bytes"])
+    return ok
+
+
+def test_hash_helpers_run_and_agree_with_the_oracle_plug(lib, orc):
+    """With ANY parameter block the product's sponge, double hash and block hash equal the oracle's restatement run on the
+    same block: the two sides can only differ in the constants, which neither has."""
+    import test_oracle_poseidon as top
+    rng = np.random.default_rng(5)
+    rc_ext = rng.integers(0, P, (8, 12), dtype=np.uint64); rc_int = rng.integers(0, P, 22, dtype=np.uint64)
+    diag = rng.integers(0, P, 12, dtype=np.uint64); m4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]
+    block = np.concatenate([rc_ext.ravel(), rc_int, diag, np.array(m4, dtype=np.uint64).ravel()])
+    oparams = top._p2_params(orc, rc_ext, rc_int, diag, m4)
+    out = ctypes.create_string_buffer(32)
+    for k in KATS["address_kats"]:
+        assert lib.qpgpu_leaf_unspendable_account(block.ctypes.data, block.size, bytes.fromhex(k["secret"]), out) == 0
+        assert out.raw.hex() == top.p2_address(orc, oparams, k["secret"])
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for n in (0, 1, 7, 8, 9, 45):
+        x = rng.integers(0, P, n, dtype=np.uint64); a = np.zeros(4, dtype=np.uint64); b = np.zeros(4, dtype=np.uint64)
+        assert lib.qpgpu_poseidon2_hash_pad10(block.ctypes.data, block.size, x.ctypes.data, n, a.ctypes.data) == 0
+        orc.lib.orc_p2_hash_pad10(vp(oparams), vp(x), n, vp(b))
+        assert a.tolist() == b.tolist(), n
+    assert lib.qpgpu_poseidon2_hash_pad10(block.ctypes.data, 145, x.ctypes.data, n, a.ctypes.data) != 0    # wrong block size
+    assert kat_score(lib, block) == 0                          # random constants cannot satisfy the reference vectors
+
+
+def test_known_answer_vectors_gate():
+    """All seven reference KATs (5 addresses, 2 block hashes) against every candidate parameter block on record. PINNED iff
+    one block scores 7/7; otherwise the helpers stay parity-unpinned and this test says so (xfail, not a silent pass)."""
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    L = pkg.load_library()
+    L.qpgpu_leaf_unspendable_account.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p]
+    L.qpgpu_leaf_block_hash.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p,
+                                        ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
+    assert len(KATS["address_kats"]) == 5 and len(KATS["block_header_kats"]) == 2
+    scores = {name: kat_score(L, blk) for name, blk in candidate_blocks()}
+    if any(s == 7 for s in scores.values()):
+        return                                                 # pinned
+    pytest.xfail("Poseidon2 PARITY UNPINNED: no parameter block on record reproduces the 7 reference KATs "
+                 f"(candidates tried here: {scores or 'none recorded'}; search log: tools/derivation/p2_search_results.md)")

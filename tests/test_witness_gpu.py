@@ -49,12 +49,19 @@ def test_generation_follows_the_inputs(pkg, gpu):
     circ = pkg.Circuit(gpu, pack)
     try:
         mask = circ.witness_free_mask(*wires.shape)
-        # a free routed cell of an arithmetic row (row 3, multiplicand 0 of operation 0 when it is not a copy)
-        cols = [c for c in (0, 1, 2, 4, 5, 6) if mask[c, 3]]
-        assert cols, "expected at least one free arithmetic input in row 3"
-        partial = wires.copy(); partial[cols[0], 3] = (int(partial[cols[0], 3]) + 12345) % 0xFFFFFFFF00000001
+        # a free routed cell of an arithmetic row (row 12: rows 3.. hold the public-input hash, whose inputs are the public
+        # inputs themselves; an operation input that is not a copy)
+        ROW = 12
+        cols = [c for c in range(0, 40) if c % 4 != 3 and mask[c, ROW]]
+        assert cols, "expected at least one free arithmetic input in row 12"
+        partial = wires.copy(); partial[cols[0], ROW] = (int(partial[cols[0], ROW]) + 12345) % 0xFFFFFFFF00000001
         full = circ.generate_witness(partial, pis)
         assert (full != wires).any() and (full[mask == 1] == partial[mask == 1]).all()
+        # the public-input cells are taken from the public_inputs argument, whatever the matrix holds there
+        pic = pkg.pack_public_input_cells(pack)
+        nw = wires.shape[0]
+        junk = wires.copy(); junk[int(pic[0]) % nw, int(pic[0]) // nw] ^= np.uint64(5)
+        assert (circ.generate_witness(junk, pis) == wires).all()
         circ.set_witness_check(True)
         circ.prove(full, pis)                     # QPGPU_EUNSAT would raise
     finally:
@@ -90,11 +97,13 @@ def test_batched_generation(pkg, gpu):
         rng = np.random.default_rng(9)
         for b in range(B):
             part = np.where(mask == 1, wires, 0).astype(np.uint64)
-            if b:                                      # perturb a free arithmetic input of row 3 and the public inputs
-                col = next(c for c in (0, 1, 2, 4, 5, 6) if mask[c, 3])
-                part[col, 3] = np.uint64(int(rng.integers(1, 2**62)))
+            if b:                                      # perturb a free arithmetic input of row 12 and the public inputs
+                col = next(c for c in range(40) if c % 4 != 3 and mask[c, 12])
+                part[col, 12] = np.uint64(int(rng.integers(1, 2**62)))
             partials.append(part)
             all_pis.append((pis + np.uint64(b)) % np.uint64(0xFFFFFFFF00000001))
+        pic = pkg.pack_public_input_cells(pack)
+        pmask = np.zeros_like(mask); pmask[(pic % np.uint64(wires.shape[0])).astype(int), (pic // np.uint64(wires.shape[0])).astype(int)] = 1
         d = gpu.to_device(np.stack(partials))
         circ.generate_witness_dev(d, np.stack(all_pis), batch=B)
         gpu.sync()
@@ -103,7 +112,10 @@ def test_batched_generation(pkg, gpu):
         assert (got[0] == wires).all()
         circ.set_witness_check(True)
         for b in range(B):
-            assert (got[b][mask == 1] == partials[b][mask == 1]).all()
+            keep = (mask == 1) & (pmask == 0)          # the public-input cells follow the public_inputs argument
+            assert (got[b][keep] == partials[b][keep]).all()
+            nw_ = np.uint64(wires.shape[0])
+            assert (got[b][(pic % nw_).astype(int), (pic // nw_).astype(int)] == all_pis[b]).all()
             if b:
                 assert (got[b] != wires).any()
                 assert (got[b] == circ.generate_witness(partials[b], all_pis[b])).all()    # same as one at a time
@@ -119,9 +131,10 @@ def test_hint_trailer(pkg, gpu, orc):
     plain, _, _ = pkg.synth_circuit(8, **kw)
     pack, wires, pis = pkg.synth_circuit(8, hints=True, **kw)
     n, NW = 1 << 8, 135
-    body = plain.size                                   # same shape without hints: the trailer starts here
-    assert int(pack[body]) == 0x31544E4948 and pack.size == body + 2 + 8 * int(pack[body + 1])
-    hints = pack[body + 2:].reshape(-1, 8)
+    tail = 2 + pis.size                                 # both packs end with the public-input cell trailer
+    body = plain.size - tail                            # same shape without hints: the hint trailer starts here
+    assert int(pack[body]) == 0x31544E4948 and pack.size == body + 2 + 8 * int(pack[body + 1]) + tail
+    hints = pack[body + 2:pack.size - tail].reshape(-1, 8)
     assert set(int(h[0]) for h in hints) == {1, 2, 3, 4, 5, 6, 7}
     circ = pkg.Circuit(gpu, pack)
     try:
