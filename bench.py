@@ -132,12 +132,12 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree-bits", type=int, default=13)
     ap.add_argument("--batch-degree-bits", type=int, default=16, help="rows of the private / public batch circuits of the tree leg")
     ap.add_argument("--streams", type=int, default=2, help="proving workers per GPU (one HIP stream + host transcript thread each)")
-    ap.add_argument("--batch", type=int, default=8, help="proofs a worker proves in lockstep (qpgpu_prove_batch_dev)")
+    ap.add_argument("--batch", type=int, default=32, help="proofs a worker proves in lockstep (qpgpu_prove_batch_dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the per-stage, witness-generation and end-to-end legs (profiling the timed region)")
@@ -345,6 +345,17 @@ def main():
             for _ in range(3):
                 circ.prove(wires, pis)
             extra["host_witness_ms_per_proof"] = round((time.perf_counter() - th) / 3 * 1e3, 3)
+            # what the optional witness check costs (one pass over the trace rows + one sync): single proof, on vs off
+            def _t(n=5):
+                t_ = time.perf_counter()
+                for _ in range(n):
+                    circ.prove_dev(w_t, pis, outs[0])
+                return (time.perf_counter() - t_) / n * 1e3
+            _t(2); off_ms = _t()
+            circ.set_witness_check(True); _t(2); on_ms = _t(); circ.set_witness_check(False)
+            extra["witness_check"] = {"single_proof_ms_off": round(off_ms, 3), "single_proof_ms_on": round(on_ms, 3),
+                                      "note": "qpgpu_circuit_set_witness_check: filtered gate constraints on every trace row + permutation "
+                                              "product closure before the quotient stage; returns QPGPU_EUNSAT naming the row"}
             extra["single_proof_latency_ms"] = round(sum(stages.values()), 4)
             extra["proof_stage_ms"] = stages
             extra["merkle_leaf_hash_avg_ms"] = round(leaf_ms / max(leaf_n, 1), 4)

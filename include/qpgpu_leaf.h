@@ -15,12 +15,14 @@
  * circuit recomputes them). It is therefore pinned by the reference's encoding anchors alone
  * (wormhole/prover/src/lib.rs:262-271, common/src/serialization.rs:92-97) and does not depend on the Poseidon2 constants.
  *
- * The helpers that DERIVE hashes natively (nullifier from its preimage, unspendable account from the secret, block hash,
- * ZK-tree leaf and node hashes) run the fork's Poseidon2 sponge (`input || 1 || 0*` to a multiple of the rate 8,
- * wormhole/circuit/tests/heap_zeroization.rs:133-160) on a caller-supplied parameter block — qp-poseidon-core 3.1.0's
- * constants are not available offline. A parameter block is right iff it reproduces the
- * reference's seven known-answer vectors (tests/golden/poseidon2_kats.json); until one does these helpers are
- * PARITY-UNPINNED and say so in their names' documentation.
+ * The helpers that DERIVE hashes natively (nullifier from its preimage, unspendable account from the secret, block hash)
+ * run the fork's Poseidon2 sponge: `input || 1 || 0*` to a multiple of the rate 8
+ * (wormhole/circuit/tests/heap_zeroization.rs:133-160), every block added into the rate part of the state. qp-poseidon-core
+ * 3.1.0's constants are not in the reference tree; the parameter set the library carries
+ * (qpgpu_poseidon2_qp_params: Plonky3's new_from_rng_128 on ChaCha20Rng::seed_from_u64(0x3141592653589793), MDSMat4,
+ * MATRIX_DIAG_12_GOLDILOCKS) was found by search and is PINNED by all seven of the reference's known-answer vectors
+ * (5 addresses, wormhole/tests/src/circuit/unspendable_account_tests.rs:9-24; 2 block hashes,
+ * wormhole/tests/test-helpers/src/lib.rs:210-219; tests/test_leaf_witness.py). Pass params = NULL, n_words = 0 to use it.
  *
  * Assignments are reported against LOGICAL targets of the leaf circuit (enum below), in the order fill_witness sets
  * them; the circuit-pack exporter (integration/) records which wire cell each logical target became, and
@@ -120,10 +122,12 @@ int qpgpu_leaf_is_not_dummy(const qpgpu_leaf_inputs *in);
 size_t qpgpu_leaf_map_targets(const uint32_t *targets, const uint64_t *values, size_t count, const uint64_t *target_map,
                               size_t map_len, uint64_t *cells_out, uint64_t *cell_values_out);
 
-/* ---- Poseidon2 sponge of the fork on a caller-supplied parameter block (146 words, layout of qpgpu_ctx_set_hasher) ----
- * PARITY-UNPINNED until a block reproduces tests/golden/poseidon2_kats.json. */
+/* ---- Poseidon2 sponge of the fork: params = NULL, n_words = 0 -> qp-poseidon-core's pinned set; otherwise a caller's block
+ * (146 words, layout of qpgpu_ctx_set_hasher) ---- */
+/* the pinned set as 146 words (for qpgpu_ctx_set_hasher, should the fork's proof-system hasher be Poseidon2); returns 146 */
+size_t qpgpu_poseidon2_qp_params(uint64_t *out, size_t cap);
 int qpgpu_poseidon2_permute(const uint64_t *params, size_t n_words, uint64_t state[12]);
-/* Poseidon2Hash::hash_no_pad of the fork: pads `|| 1 || 0*` to a multiple of 8, overwrite-mode absorption, 4 outputs */
+/* Poseidon2Hash::hash_no_pad of the fork: pads `|| 1 || 0*` to a multiple of 8, additive absorption, 4 outputs */
 int qpgpu_poseidon2_hash_pad10(const uint64_t *params, size_t n_words, const uint64_t *in, size_t n, uint64_t out[4]);
 /* hash_no_pad_bytes: the same, output as 32 bytes (digest_to_bytes) */
 int qpgpu_poseidon2_hash_bytes(const uint64_t *params, size_t n_words, const uint64_t *in, size_t n, uint8_t out[32]);

@@ -268,8 +268,9 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
         PowArgs pw{};
         pw.states = w.pow_states; pw.bases = w.pow_bases; pw.results = w.pow_results;
         pw.pos = (uint32_t)chs[0].n_in; pw.pow_bits = p.pow_bits; pw.batch = nb;
-        // expected 2^pow_bits candidates; a batch of 2x that finds it 86% of the time and costs one wave per SIMD
-        const u64 span = std::max<u64>(1ull << 16, 2ull << pw.pow_bits);
+        // expected 2^pow_bits candidates per proof; a span of 4x that finds all of a batch 98 % of the time, and the kernel
+        // drops the candidates above a nonce already found, so the span costs little beyond the expected work
+        const u64 span = std::max<u64>(1ull << 16, 4ull << pw.pow_bits);
         pw.count = span;
         std::vector<u64> bases(nb, 0), res(nb);
         std::vector<char> found(nb, 0);

@@ -3,7 +3,8 @@
 // parameter block. C ABI and reference citations: include/qpgpu_leaf.h.
 //
 // fill_witness (wormhole/prover/src/lib.rs:187-221) is pure re-encoding and does not hash; the derive-a-hash helpers at the
-// end do, and stay parity-unpinned until a Poseidon2 parameter block passes the reference's known-answer vectors.
+// end do, on qp-poseidon-core's parameter set (poseidon2::qp_params, pinned by all seven of the reference's known-answer
+// vectors) or on a caller-supplied block.
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -26,6 +27,7 @@ int fail(char *err, const char *fmt, unsigned long long a = 0, unsigned long lon
 }
 
 bool parse_params(const uint64_t *params, size_t n_words, poseidon2::Params &p) {
+    if (!params && n_words == 0) { p = poseidon2::qp_params(); return true; }     // the pinned qp-poseidon-core set
     if (!params || n_words != (size_t)poseidon2::PARAM_WORDS) return false;
     const uint64_t *w = params;
     for (int i = 0; i < 96; i++) p.rc_ext[i] = gl::canon(*w++);
@@ -35,14 +37,16 @@ bool parse_params(const uint64_t *params, size_t n_words, poseidon2::Params &p) 
     return true;
 }
 
-// Poseidon2Hash::hash_no_pad of the fork: `input || 1 || 0*` to a multiple of the rate, overwrite-mode absorption
+// Poseidon2Hash::hash_no_pad of the fork: `input || 1 || 0*` to a multiple of the rate, each block ADDED into the rate
+// part of the state (the block-header known-answer vectors, 45 elements = 6 blocks, tell additive from overwrite absorption;
+// single-block inputs cannot)
 void hash_pad10(const poseidon2::Params &p, const u64 *in, size_t n, u64 out[4]) {
     u64 st[12] = {0};
     const size_t padded = (n + 1 + 7) / 8 * 8;
     for (size_t i = 0; i < padded; i += 8) {
         for (size_t j = 0; j < 8; j++) {
             const size_t k = i + j;
-            st[j] = k < n ? gl::canon(in[k]) : (k == n ? 1 : 0);
+            st[j] = gl::canon(gl::add(st[j], k < n ? gl::canon(in[k]) : (k == n ? 1 : 0)));
         }
         poseidon2::permute(st, p);
     }
@@ -200,7 +204,18 @@ size_t qpgpu_leaf_map_targets(const uint32_t *targets, const uint64_t *values, s
     return n;
 }
 
-// ---- Poseidon2 of the fork on an injected parameter block: PARITY-UNPINNED until the block passes the KATs ----
+// ---- Poseidon2 of the fork: params == NULL && n_words == 0 selects the pinned qp-poseidon-core set ----
+size_t qpgpu_poseidon2_qp_params(uint64_t *out, size_t cap) {
+    if (out && cap >= (size_t)poseidon2::PARAM_WORDS) {
+        const poseidon2::Params &p = poseidon2::qp_params();
+        uint64_t *w = out;
+        for (int i = 0; i < 96; i++) *w++ = p.rc_ext[i];
+        for (int i = 0; i < 22; i++) *w++ = p.rc_int[i];
+        for (int i = 0; i < 12; i++) *w++ = p.diag_m1[i];
+        for (int i = 0; i < 16; i++) *w++ = p.m4[i];
+    }
+    return poseidon2::PARAM_WORDS;
+}
 int qpgpu_poseidon2_permute(const uint64_t *params, size_t n_words, uint64_t state[12]) {
     poseidon2::Params p;
     if (!state || !parse_params(params, n_words, p)) return -1;

@@ -108,23 +108,35 @@ __global__ void __launch_bounds__(256) node_coop_kernel(const u64 *in, u64 *out,
     if (live && g < 4) out[grp * 4 + g] = s;
 }
 
-// The top of a tree in one launch: workgroup b owns the subtree under cap entry b (m <= 32 digests of the input level),
-// keeps the current level in LDS and walks up to its root, one lane-cooperative permutation deep per level (at most one
-// wave per SIMD, waves without a live node only wait at the barrier); every level is also written to the digest array
-// (Merkle paths read it). Replaces up to five latency-bound launches.
-__global__ void __launch_bounds__(256) tree_top_kernel(u64 *levels, u64 cnt, u32 m, u64 ps) {
-    __shared__ u64 buf[2][32 * 4];
-    const u32 t = threadIdx.x, b = blockIdx.x;
+// The top of a tree in one launch: workgroup b owns the subtree under cap entry b (m <= MAXM digests of the input level),
+// keeps the current level in LDS and walks up to its root; every level is also written to the digest array (Merkle paths read
+// it). A level with more nodes than the workgroup has 16-lane groups runs one node per thread (full work efficiency, one
+// permutation deep); smaller levels run lane-cooperative permutations (16 lanes per node, about a fifth of the latency). Replaces up to ten launches whose
+// levels are too small to fill the chip.
+template <int MAXM>
+__global__ void __launch_bounds__(MAXM >= 512 ? 512 : 256) tree_top_kernel(u64 *levels, u64 cnt, u32 m, u64 ps) {
+    __shared__ u64 buf[2][MAXM * 4];
+    const u32 t = threadIdx.x, b = blockIdx.x, T = blockDim.x;
     levels += (u64)blockIdx.y * ps;
     const int lane = t & 63, g = lane & 15, base = lane & 48;
-    const u32 grp = t >> 4, wave_first = (t >> 6) << 2;
-    for (u32 i = t; i < m * 4; i += blockDim.x) buf[0][i] = levels[(u64)b * m * 4 + i];
+    const u32 grp = t >> 4;
+    for (u32 i = t; i < m * 4; i += T) buf[0][i] = levels[(u64)b * m * 4 + i];
     __syncthreads();
     u64 *out = levels + cnt * 4;          // next level in the digest array
     u64 level_cnt = cnt / 2;
     int cur = 0;
     for (u32 nodes = m / 2; nodes >= 1; nodes >>= 1) {
-        if (wave_first < nodes) {
+        if (nodes > T / 16) {                         // more nodes than 16-lane groups in the workgroup
+            for (u32 i = t; i < nodes; i += T) {      // one node per thread
+                u64 st[12];
+#pragma unroll
+                for (int k = 0; k < 8; k++) st[k] = buf[cur][i * 8 + k];
+                st[8] = st[9] = st[10] = st[11] = 0;
+                poseidon::permute(st, c_poseidon_rc);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { buf[cur ^ 1][i * 4 + k] = st[k]; out[((u64)b * nodes + i) * 4 + k] = st[k]; }
+            }
+        } else if (((t >> 6) << 2) < nodes) {         // waves that hold a live 16-lane group
             const bool live = grp < nodes;
             u64 s = (live && g < 8) ? buf[cur][grp * 8 + g] : 0;
             s = coop_permute(s, g, base);
@@ -236,15 +248,19 @@ __global__ void permute_kernel(u64 *states, u64 n, const poseidon2::Params *p2) 
 }
 
 // s10 fri_proof_of_work: candidate nonce at `pos` of the pre-absorbed duplex state; accept when the last rate
-// element has >= pow_bits leading zeros; result = minimum accepted nonce in [base, base + count). grid.y = proof.
+// element has >= pow_bits leading zeros; result = minimum accepted nonce in [base, base + count). Workgroups are numbered
+// chunk-major over the proofs of the batch (chunk c of every proof before chunk c + 1 of any), and a workgroup whose
+// candidates are all above a nonce already found for its proof leaves at once: the expected work per proof is about
+// 2^pow_bits permutations plus what is in flight, not the whole span.
 template <class Perm>
 __global__ void __launch_bounds__(256) pow_kernel(PowArgs a, const poseidon2::Params *p2) {
-    const u64 idx = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u32 pr = blockIdx.x % a.batch;
+    const u64 idx = (u64)(blockIdx.x / a.batch) * blockDim.x + threadIdx.x;
     if (idx >= a.count) return;
-    const u32 pr = blockIdx.y;
     const u64 base = a.bases[pr];
     if (base == ~0ull) return;                 // this proof already has its nonce
     const u64 nonce = base + idx;
+    if (__hip_atomic_load(&a.results[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) return;
     const u64 *st = a.states + 12 * (u64)pr;
     u64 s[12];
 #pragma unroll
@@ -257,7 +273,9 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a, const poseidon2::Pa
 
 hipError_t pk_pow(const PowArgs &a, const HasherDev &h, hipStream_t st) {
     if (a.count == 0 || a.batch == 0) return hipSuccess;
-    dim3 b(256), g((unsigned)((a.count + 255) / 256), a.batch);
+    const u64 chunks = (a.count + 255) / 256;
+    if (chunks * a.batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 b(256), g((unsigned)(chunks * a.batch));
     if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((pow_kernel<Poseidon2P>), g, b, 0, st, a, h.p2);
     else hipLaunchKernelGGL((pow_kernel<PoseidonV1>), g, b, 0, st, a, h.p2);
     return hipGetLastError();
@@ -326,10 +344,14 @@ hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, u32 batch, u64 
     u64 *lvl = levels;
     while (cnt > cap_n) {
         const u64 m = cnt / cap_n;
-        // latency knob: the fused top saves ~0.1 ms of a single 2^13-row proof and costs ~3 % of the four-in-flight throughput
-        static const bool fuse_top = [] { const char *e = getenv("QPGPU_TREE_TOP"); return e ? atoi(e) != 0 : false; }();
-        if (fuse_top && h.kind != hasher::POSEIDON2 && m <= 32 && cap_n <= 65535 && batch <= 65535 && COOP_MAX >= 64) {
-            hipLaunchKernelGGL(tree_top_kernel, dim3((unsigned)cap_n, batch), dim3(256), 0, st, lvl, cnt, (u32)m, ps);
+        // The levels above this point have too few nodes to fill the chip, one launch each: fuse them. QPGPU_TREE_TOP = the
+        // largest subtree (digests per cap entry) handed to the fused kernel: 0 off, 32 (default: the last five levels, all
+        // lane-cooperative), up to 512 (larger settings measured within noise of 32 with lockstep batches of 16 and 32).
+        static const u32 top_m = [] { const char *e = getenv("QPGPU_TREE_TOP"); const int v = e ? atoi(e) : 32; return (u32)(v < 0 ? 0 : v > 512 ? 512 : v); }();
+        if (top_m >= 2 && h.kind != hasher::POSEIDON2 && m <= top_m && cap_n <= 65535 && batch <= 65535) {
+            if (m <= 32) hipLaunchKernelGGL((tree_top_kernel<32>), dim3((unsigned)cap_n, batch), dim3(256), 0, st, lvl, cnt, (u32)m, ps);
+            else if (m <= 256) hipLaunchKernelGGL((tree_top_kernel<256>), dim3((unsigned)cap_n, batch), dim3(256), 0, st, lvl, cnt, (u32)m, ps);
+            else hipLaunchKernelGGL((tree_top_kernel<512>), dim3((unsigned)cap_n, batch), dim3(512), 0, st, lvl, cnt, (u32)m, ps);
             return hipGetLastError();
         }
         hipError_t e = merkle_reduce_level(lvl, lvl + cnt * 4, cnt / 2, batch, ps, h, st);

@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) {
                 const u32 lo_mask = (1u << a.tw_lo_bits) - 1;
                 const u32 e0 = mm * ka, es = mm << KA;
                 u64 t = gl::mul(a.tw_hi[e0 >> a.tw_lo_bits], a.tw_lo[e0 & lo_mask]);
+                if (a.tw_scale) t = gl::mul(t, a.tw_scale);   // an inverse transform's 1/N rides on the first factor: the last pass multiplies nothing
                 const u64 step = gl::mul(a.tw_hi[es >> a.tw_lo_bits], a.tw_lo[es & lo_mask]);
 #pragma unroll
                 for (int r = 0; r < NB; r++) {
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) {
                     if (e) v = gl::mul(v, gl::mul(a.tw_hi[e >> a.tw_lo_bits], a.tw_lo[e & ((1u << a.tw_lo_bits) - 1)]));
                 }
                 if (a.has_out_scale) v = gl::mul(v, a.out_scale);
-                v = gl::canon(v);
+                if (!a.out_loose) v = gl::canon(v);           // an intermediate pass may hand over any representative
                 const u32 pos = a.out_bitrev ? (u32)(j * NB + jb) : k;
                 if (lane_ok) out[obase + pos * ops] = v;
             }

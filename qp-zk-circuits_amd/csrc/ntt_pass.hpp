@@ -28,6 +28,8 @@ struct NttPassArgs {
     const uint64_t *tw_hi;     // inter-pass twiddle w_rowlen^(mm*k) = tw_hi[e >> bits] * tw_lo[e & mask]
     const uint64_t *tw_lo;     // null: no inter-pass twiddle
     uint32_t tw_lo_bits;
+    uint32_t out_loose;        // 1: the output is an intermediate of the transform and need not be canonical
+    uint64_t tw_scale;         // non-zero: folded into the running twiddle product (the 1/N of an inverse transform)
     uint32_t tw_mode;          // 0: two table reads per element; 1: per-thread running product; 2: skipped (timing experiments only)
     const uint64_t *in_scale_a;  // coset input scale: x[p, mm] *= a[p] * b[mm]; null: none
     const uint64_t *in_scale_b;

@@ -273,6 +273,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
     const u64 R1 = 1ull << L1, M1 = 1ull << L2;
     const u64 in_cs = g.in_col_stride ? g.in_col_stride : n_in, out_cs = g.out_col_stride ? g.out_col_stride : N;
     uint64_t *mid = d_out;
+    bool folded_scale = false;
     u64 mid_cs = out_cs, mid_ps = g.out_ps;
     if (!out_bitrev) {
         int rc = ctx->ensure_scratch((g.scratch_off + (u64)g.nproofs * batch * N) * sizeof(u64));
@@ -301,7 +302,9 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         if (rc) return rc;
         // inter-pass twiddle w_N^(mm*k): e < N, split at lo_bits
         p.tw_lo_bits = (L + 1) / 2;
-        { static const int tw_mode = env_int("QPGPU_NTT_TW", 0); p.tw_mode = (uint32_t)tw_mode; }
+        { static const int tw_mode = env_int("QPGPU_NTT_TW", 1); p.tw_mode = (uint32_t)tw_mode; }
+        p.out_loose = 1;      // the rows pass reduces whatever representative it is handed
+        if (inverse && p.tw_mode == 1) p.tw_scale = out_scale;   // 1/N rides on the running twiddle product: one product per thread
         rc = cached(ctx, "lo" + dir + std::to_string(L), wN, 1ull << p.tw_lo_bits, (uint64_t **)&p.tw_lo);
         if (rc) return rc;
         rc = cached(ctx, "hi" + dir + std::to_string(L), gl::pow(wN, 1ull << p.tw_lo_bits), 1ull << (L - p.tw_lo_bits), (uint64_t **)&p.tw_hi);
@@ -314,6 +317,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
             if (rc) return rc;
         }
         u64 tiles = (M1 + (1ull << p.log_t) - 1) >> p.log_t;
+        folded_scale = p.tw_scale != 0;
         p.in_proof_stride = g.in_ps; p.out_proof_stride = mid_ps;
         ctx->prof_begin("ntt_pass_strided");
         hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream, g.nproofs);
@@ -335,7 +339,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         if (out_bitrev) { p.out_row_stride = M1; p.out_p_stride = 1; p.store_lane_fast = 0; p.out_bitrev = 1; }
         else { p.out_row_stride = g.out_mul; p.out_p_stride = R1 * g.out_mul; p.store_lane_fast = 1; p.out_bitrev = 0; }
         p.out_l_stride = 0;
-        p.has_out_scale = inverse ? 1 : 0; p.out_scale = out_scale;
+        p.has_out_scale = inverse && !folded_scale ? 1 : 0; p.out_scale = out_scale;
         if (s.kb > 0) {
             int rc = cached(ctx, "in" + dir + std::to_string(L2), gl::pow(wN, R1), M1, (uint64_t **)&p.tw_inner);
             if (rc) return rc;

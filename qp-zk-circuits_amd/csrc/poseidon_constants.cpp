@@ -7,8 +7,8 @@
 #include "poseidon.hpp"
 
 namespace poseidon {
-namespace {
 struct ChaCha8 {
+    int double_rounds = 4;     // ChaCha8; 10 = ChaCha20
     uint32_t key[8];
     uint64_t counter = 0;
     uint32_t block[16];
@@ -20,7 +20,7 @@ struct ChaCha8 {
         x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
         x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
     }
-    explicit ChaCha8(uint64_t seed) {
+    explicit ChaCha8(uint64_t seed, int rounds = 8) : double_rounds(rounds / 2) {
         // rand_core::SeedableRng::seed_from_u64: PCG32 stream fills the 32-byte key
         uint64_t st = seed;
         for (int i = 0; i < 8; i++) {
@@ -35,7 +35,7 @@ struct ChaCha8 {
         in[12] = (uint32_t)counter; in[13] = (uint32_t)(counter >> 32); in[14] = 0; in[15] = 0;
         uint32_t x[16];
         std::memcpy(x, in, sizeof x);
-        for (int dr = 0; dr < 4; dr++) {
+        for (int dr = 0; dr < double_rounds; dr++) {
             quarter(x, 0, 4, 8, 12); quarter(x, 1, 5, 9, 13); quarter(x, 2, 6, 10, 14); quarter(x, 3, 7, 11, 15);
             quarter(x, 0, 5, 10, 15); quarter(x, 1, 6, 11, 12); quarter(x, 2, 7, 8, 13); quarter(x, 3, 4, 9, 14);
         }
@@ -52,6 +52,7 @@ struct ChaCha8 {
         }
     }
 };
+namespace {
 u64 g_rc[ROUNDS * WIDTH];
 std::once_flag g_once;
 }  // namespace
@@ -183,6 +184,32 @@ const u64 *host_fast_partial() {
     return g_fp;
 }
 }  // namespace poseidon
+
+// ---- qp-poseidon-core 3.1.0's Poseidon2 parameters (the application hash of the Wormhole circuits) ----
+// Not in the reference tree; established by search against the reference's seven known-answer vectors
+// (tools/derivation/p2_search.py, tests/golden/poseidon2_kats.json): Plonky3's Poseidon2Goldilocks<12>::new_from_rng_128 on
+// rand_chacha's ChaCha20Rng::seed_from_u64(0x3141592653589793): 8 x 12 external round constants first, then the 22 internal
+// ones, every element drawn by rejection (next_u64 below p); external 4x4 block = Plonky3's MDSMat4 circ(2, 3, 1, 1);
+// internal matrix J + diag(MATRIX_DIAG_12_GOLDILOCKS).
+namespace poseidon2 {
+const Params &qp_params() {
+    static Params p;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        poseidon::ChaCha8 rng(0x3141592653589793ULL, 20);
+        auto draw = [&]() { for (;;) { const gl::u64 v = rng.next64(); if (v < gl::P) return v; } };
+        for (int i = 0; i < 96; i++) p.rc_ext[i] = draw();
+        for (int i = 0; i < 22; i++) p.rc_int[i] = draw();
+        static const gl::u64 diag[12] = {0xc3b6c08e23ba9300ULL, 0xd84b5de94a324fb6ULL, 0x0d0c371c5b35b84fULL, 0x7964f570e7188037ULL,
+                                         0x5daf18bbd996604bULL, 0x6743bc47b9595257ULL, 0x5528b9362c59bb70ULL, 0xac45e25b7127b68bULL,
+                                         0xa2077d7dfbb606b5ULL, 0xf3faac6faee378aeULL, 0x0c6388b51545e883ULL, 0xd27dbb6944917b60ULL};
+        for (int i = 0; i < 12; i++) p.diag_m1[i] = diag[i];
+        static const gl::u64 m4[16] = {2, 3, 1, 1, 1, 2, 3, 1, 1, 1, 2, 3, 3, 1, 1, 2};
+        for (int i = 0; i < 16; i++) p.m4[i] = m4[i];
+    });
+    return p;
+}
+}  // namespace poseidon2
 
 // ---- hasher selection (see poseidon.hpp) ----
 namespace hasher {

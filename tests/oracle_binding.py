@@ -78,6 +78,7 @@ class Oracle:
         L.orc_trace_get.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
         L.orc_poseidon_fast_partial.restype = ctypes.c_size_t; L.orc_poseidon_fast_partial.argtypes = [ctypes.c_void_p]
         L.orc_p2_params_size.restype = ctypes.c_size_t
+        L.orc_p2_qp_params.argtypes = [ctypes.c_void_p]
         L.orc_select_hasher_p2.argtypes = [ctypes.c_void_p]
         L.orc_p2_permute.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_p2_hash_pad10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
