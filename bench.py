@@ -84,6 +84,20 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
             roof["traffic_source"] = os.path.relpath(latest, ROOT)
     except Exception:
         pass
+    # VALU issue counters of the same two kernels (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE passes, summarised by
+    # tools/r02_collect.py): lane-level VALU instructions per field element of one forward transform, and the share of the
+    # chip's VALU issue slots (one wave instruction per SIMD per 4 cycles) those instructions occupied
+    roof["valu_insts_per_element"] = None
+    roof["valu_issue_frac"] = None
+    try:
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*ntt_valu_summary.json")))[-1]
+        vs = json.load(open(latest))
+        if vs.get("elements_per_transform") == n * batch:
+            roof["valu_insts_per_element"] = vs["valu_insts_per_element"]
+            roof["valu_issue_frac"] = vs["valu_issue_frac"]
+            roof["valu_source"] = os.path.relpath(latest, ROOT)
+    except Exception:
+        pass
     ok = bool(torch.equal(z, x))
     return gbs, roof, ok, x[0].cpu().numpy().view(np.uint64), y[0].cpu().numpy().view(np.uint64)
 
@@ -251,7 +265,8 @@ def main():
     if args.steps >= 3:
         cuts = [0, args.steps // 3, 2 * args.steps // 3, args.steps]
         marks = [t0] + step_done
-        windows = [round((cuts[i + 1] - cuts[i]) * S / (marks[cuts[i + 1]] - marks[cuts[i]]), 1) for i in range(3)]
+        windows = [round((cuts[i + 1] - cuts[i]) * S * world / (marks[cuts[i + 1]] - marks[cuts[i]]), 1) for i in range(3)]
+    step_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_done[:-1], step_done)][:16]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -283,7 +298,7 @@ def main():
         tpub = None
         if rank == 0:
             tpub = pkg.synth_circuit(args.batch_degree_bits, num_wires=135, num_routed=80, num_public_inputs=NB_PIS * 8 + 8, seed=77, **rec)
-        atree = agg.AggregationTree(pkg, gpus[0], rank, world, tleaf, tpriv, tpub)
+        atree = agg.AggregationTree(pkg, gpus[0], rank, world, tleaf, tpriv, tpub, leaf_batch=32)
         dd = dist if world > 1 else None
         atree.run(dd, coll_dev)
         barrier()
@@ -297,12 +312,12 @@ def main():
             tdt = float(tt.item())
         assert len(t_leaves) == 64 and len(t_batches) == 8
         tree = {"leaves": 64, "private_batches": 8, "public_batches": 1, "seconds": round(tdt, 4),
-                "trees_per_s": round(1.0 / tdt, 3),
+                "trees_per_s": round(1.0 / tdt, 3), "levels_rank0": dict(atree.times),
                 "shape": f"leaf 2^{d} rows (80 routed); private batch 2^{args.batch_degree_bits} rows zero-knowledge, 60 routed wires; "
                          f"public batch 2^{args.batch_degree_bits} rows, 80 routed; 135 wires; batches carry the 14-gate recursive-verifier mix",
                 "note": "shape-equivalent synthetic circuits per level; each level parses the previous level's gathered proof bytes, "
-                        "derives its public inputs from them, generates its witness on the device (stage s1) and proves; the inner "
-                        "proofs are not verified in-circuit; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
+                        "derives its public inputs from them, regenerates its witness on the device (stage s1) and proves — a rank's "
+                        "leaves 32 at a time and its private batches 8 at a time in lockstep; the inner proofs are not verified in-circuit; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
                         "sequential on an M2 Max"}
         if rank == 0:
             # checker, untimed: the oracle verifies the root and one proof per level, and the root's public inputs hold the 8
@@ -529,9 +544,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_proof": round(dt / (args.steps * S) * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "window_proofs_per_s": windows,
+            "window_proofs_per_s": windows, "step_ms_rank0": step_ms,
             "config": {"workload": "BASELINE configs[2]/[3]: full proof (LDE + Poseidon Merkle commit + quotient + FRI) of a "
-                                   "shape-equivalent synthetic leaf circuit, one proof per GPU per step, witness resident in HBM",
+                                   "shape-equivalent synthetic leaf circuit, proofs_per_step_per_gpu different witnesses per GPU per step, resident in HBM",
                        "degree_bits": d, "gates": "PublicInput, Constant, BaseSum<2>(63 limbs), Arithmetic(20 ops), Poseidon(123 constraints), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
                        "num_query_rounds": 28, "proof_of_work_bits": 16, "fri_arity_bits": 4, "proof_bytes": proof_len, "proofs_in_flight_per_gpu": S, "proofs_per_step_per_gpu": S, "workers": WORKERS, "lockstep_batch": LOCKSTEP,
                        "multi_gpu": "independent proofs per rank + RCCL all_gather of proof bytes" if world > 1 else "single GPU"},

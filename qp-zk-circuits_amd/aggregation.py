@@ -65,12 +65,15 @@ class TemplateProver:
         self.values = np.asarray(template_wires, dtype=np.uint64)[col[keep], row[keep]]
         self.mat_bytes = nw * n * 8
         self.d_wires = gpu.alloc(self.mat_bytes * max_batch)
+        self.d_template = None          # the template's PartialWitness expanded on the device (first commit)
         self.pis = None
         self.batch_pis = None
 
     def close(self):
         if self.circ is not None:
             self.d_wires.free()
+            if self.d_template is not None:
+                self.d_template.free()
             self.circ.close()
             self.circ = None
 
@@ -83,13 +86,25 @@ class TemplateProver:
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         if pis.size != self.hdr["num_public_inputs"]:
             raise ValueError("wrong number of public inputs")
-        cells, values = self.cells, self.values
         if len(extra_cells):
-            cells = np.concatenate([cells, np.asarray(extra_cells, dtype=np.uint64)])
-            values = np.concatenate([values, np.asarray(extra_values, dtype=np.uint64)])
-        self.circ.generate_witness_partial_dev(cells, values, pis, self.d_wires)
+            cells = np.concatenate([self.cells, np.asarray(extra_cells, dtype=np.uint64)])
+            values = np.concatenate([self.values, np.asarray(extra_values, dtype=np.uint64)])
+            self.circ.generate_witness_partial_dev(cells, values, pis, self.d_wires)
+        else:
+            self._expand(1, pis)
+            self.circ.generate_witness_dev(self.d_wires, pis)
         self.pis = pis
         return pis
+
+    def _expand(self, nb, pis):
+        """nb copies of the template's expanded PartialWitness in d_wires. The template's free cells are part of the circuit
+        stand-in, not of a proof's input: they go through the PartialWitness entry (upload, conflict check) once per prover;
+        a commit then only rewrites the public inputs and regenerates what depends on them."""
+        if self.d_template is None:
+            self.d_template = self.gpu.alloc(self.mat_bytes)
+            self.circ.generate_witness_partial_dev(self.cells, self.values, pis, self.d_template)
+        for b in range(nb):
+            self.gpu._check(self.gpu.lib.qpgpu_memcpy_d2d(self.gpu.ctx, self.d_wires.ptr + b * self.mat_bytes, self.d_template.ptr, self.mat_bytes))
 
     def commit_many(self, public_inputs_list):
         """Witnesses for up to max_batch public-input vectors at once: the PartialWitness of the first is expanded on the
@@ -99,11 +114,8 @@ class TemplateProver:
         if nb == 0 or nb > self.max_batch:
             raise ValueError("batch size outside 1..max_batch")
         pis = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.uint64) for p in public_inputs_list]))
-        self.circ.generate_witness_partial_dev(self.cells, self.values, pis[0], self.d_wires)
-        if nb > 1:
-            for b in range(1, nb):
-                self.gpu._check(self.gpu.lib.qpgpu_memcpy_d2d(self.gpu.ctx, self.d_wires.ptr + b * self.mat_bytes, self.d_wires.ptr, self.mat_bytes))
-            self.circ.generate_witness_dev(self.d_wires, pis, batch=nb)
+        self._expand(nb, pis[0])
+        self.circ.generate_witness_dev(self.d_wires, pis, batch=nb)
         self.batch_pis = pis
         return pis
 
@@ -115,9 +127,10 @@ class TemplateProver:
         self.batch_pis = None
         return self.circ.prove_batch_dev([self.d_wires.ptr + b * self.mat_bytes for b in range(len(pis))], list(pis))
 
-    def witness(self):
-        """The committed full witness [num_wires, n] (host copy; tests compare it with the oracle's view)."""
-        return self.d_wires.download(count=self.mat_bytes // 8).reshape(self.hdr["num_wires"], 1 << self.hdr["degree_bits"])
+    def witness(self, b=0):
+        """The committed full witness [num_wires, n] of batch slot b (host copy; tests compare it with the oracle's view)."""
+        nw, n = self.hdr["num_wires"], 1 << self.hdr["degree_bits"]
+        return self.d_wires.download(count=(b + 1) * self.mat_bytes // 8)[b * nw * n:].reshape(nw, n)
 
     def prove(self, out=None):
         if self.pis is None:
@@ -133,8 +146,8 @@ class BatchProver(TemplateProver):
     pack / template_wires / template_pis: the level's circuit and one satisfying witness of it (the dummy-proof template the
     reference generates at build time, dummy_proof.rs:104-115)."""
 
-    def __init__(self, gpu, pack, template_wires, template_pis, inner_num_public_inputs, slots):
-        super().__init__(gpu, pack, template_wires)
+    def __init__(self, gpu, pack, template_wires, template_pis, inner_num_public_inputs, slots, max_batch=1):
+        super().__init__(gpu, pack, template_wires, max_batch=max_batch)
         self.inner_npis, self.slots = inner_num_public_inputs, slots
         if self.hdr["num_public_inputs"] != slots * inner_num_public_inputs + BATCH_TRAILER_WORDS:
             self.close()
@@ -146,6 +159,12 @@ class BatchProver(TemplateProver):
         dummy = self.template_pis[:self.inner_npis]
         tr = self.template_pis[-BATCH_TRAILER_WORDS:] if trailer is None else trailer
         return super().commit(batch_public_inputs(inner_proofs, self.inner_npis, self.slots, dummy, tr))
+
+    def commit_many(self, inner_proofs_list, trailer=None):
+        """Several batches of this level at once (one witness-generation pass, proven in lockstep by prove_many)."""
+        dummy = self.template_pis[:self.inner_npis]
+        tr = self.template_pis[-BATCH_TRAILER_WORDS:] if trailer is None else trailer
+        return super().commit_many([batch_public_inputs(ps, self.inner_npis, self.slots, dummy, tr) for ps in inner_proofs_list])
 
 
 def leaf_public_inputs(index, count=LEAF_PUBLIC_INPUTS):
@@ -161,8 +180,9 @@ class AggregationTree:
     gathered (sharding.gather_proof_bytes: RCCL on GPUs, gloo in rehearsals) and consumed by the next level.
     Reference call stack SURVEY.md 3.4; partitioning SURVEY.md 8e."""
 
-    def __init__(self, pkg, gpu, rank, world, leaf, private, public, num_leaves=64, slots=8, leaf_batch=8):
-        """leaf / private / public: (pack, template_wires, template_pis) of the level's circuit (public only on the root)."""
+    def __init__(self, pkg, gpu, rank, world, leaf, private, public, num_leaves=64, slots=8, leaf_batch=8, private_batch=8):
+        """leaf / private / public: (pack, template_wires, template_pis) of the level's circuit (public only on the root).
+        leaf_batch / private_batch: how many proofs of a level this rank proves in lockstep."""
         from . import sharding
         self.sharding, self.rank, self.world, self.slots = sharding, rank, world, slots
         self.plan = sharding.aggregation_schedule(num_leaves, slots, world)
@@ -170,7 +190,9 @@ class AggregationTree:
         self.num_batches = num_leaves // slots
         self.leaf_batch = max(1, min(leaf_batch, len(self.mine["leaves"]))) if self.mine["leaves"] else 1
         self.leaf = TemplateProver(gpu, leaf[0], leaf[1], max_batch=self.leaf_batch)
-        self.private = BatchProver(gpu, private[0], private[1], private[2], LEAF_PUBLIC_INPUTS, slots)
+        self.private_batch = max(1, min(private_batch, len(self.mine["private_batches"])))
+        self.private = BatchProver(gpu, private[0], private[1], private[2], LEAF_PUBLIC_INPUTS, slots, max_batch=self.private_batch)
+        self.times = {}
         self.public = None
         if rank == self.plan["root"]:
             self.public = BatchProver(gpu, public[0], public[1], public[2], LEAF_PUBLIC_INPUTS * slots + BATCH_TRAILER_WORDS, self.num_batches)
@@ -184,7 +206,9 @@ class AggregationTree:
         """One pass over the tree. Returns (all leaf proofs, all private-batch proofs, root proof or None).
         blinding_seed: makes the zero-knowledge level reproducible (tests); keep: a dict that receives, per level, this
         rank's (index, public inputs, full witness) triples for an external checker (costs a device download each)."""
+        import time
         d = dist if self.world > 1 else None
+        t0 = time.perf_counter()
         mine_leaf = []
         ids = list(self.mine["leaves"])
         for k in range(0, len(ids), self.leaf_batch):   # this rank's leaves, leaf_batch at a time in lockstep
@@ -196,19 +220,32 @@ class AggregationTree:
                     keep.setdefault("leaf", []).append((i, pis[j].copy(), all_w[j].copy()))
             mine_leaf += self.leaf.prove_many()
         leaves = [p for r in self.sharding.gather_proof_bytes(mine_leaf, d, device) for p in r]
+        t1 = time.perf_counter()
         mine_priv = []
-        for b in self.mine["private_batches"]:
-            pis = self.private.commit(leaves[b * self.slots:(b + 1) * self.slots])
+        # this rank's private batches in lockstep, in runs of consecutive batch numbers (proof j of a run is blinded with
+        # seed + first + j, the same salts the one-at-a-time order would draw)
+        pb = list(self.mine["private_batches"])
+        k = 0
+        while k < len(pb):
+            run = [pb[k]]
+            while k + len(run) < len(pb) and len(run) < self.private_batch and pb[k + len(run)] == run[-1] + 1:
+                run.append(pb[k + len(run)])
+            pis = self.private.commit_many([leaves[b * self.slots:(b + 1) * self.slots] for b in run])
             if blinding_seed is not None:
-                self.private.circ.set_blinding_seed(blinding_seed + b)
+                self.private.circ.set_blinding_seed(blinding_seed + run[0])
             if keep is not None:
-                keep.setdefault("private", []).append((b, pis.copy(), self.private.witness()))
-            mine_priv.append(self.private.prove())
+                for j, b in enumerate(run):
+                    keep.setdefault("private", []).append((b, pis[j].copy(), self.private.witness(j)))
+            mine_priv += self.private.prove_many()
+            k += len(run)
         batches = [p for r in self.sharding.gather_proof_bytes(mine_priv, d, device) for p in r]
+        t2 = time.perf_counter()
         root = None
         if self.public is not None:
             pis = self.public.commit(batches)
             if keep is not None:
                 keep.setdefault("public", []).append((0, pis.copy(), self.public.witness()))
             root = self.public.prove()
+        t3 = time.perf_counter()
+        self.times = {"leaf_level_s": round(t1 - t0, 4), "private_level_s": round(t2 - t1, 4), "public_level_s": round(t3 - t2, 4)}
         return leaves, batches, root

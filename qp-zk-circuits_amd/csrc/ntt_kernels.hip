@@ -1,5 +1,6 @@
 // ntt_kernels.hip — dispatcher for the NTT pass kernels (template in ntt_kernel_impl.hpp, instances in ntt_inst_*.hip).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "ntt_pass.hpp"
 
 hipError_t ntt_launch_1_0(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
@@ -51,14 +52,20 @@ hipError_t ntt_pass_init() {
     return hipSuccess;
 }
 
-hipError_t ntt_pass_launch(const NttPassArgs &a, uint64_t n_tiles, uint64_t n_cols, hipStream_t st, uint32_t n_proofs) {
+hipError_t ntt_pass_launch(const NttPassArgs &a_in, uint64_t n_tiles, uint64_t n_cols, hipStream_t st, uint32_t n_proofs) {
+    // QPGPU_NTT_SPLIT: 0 whole-word LDS exchange everywhere; 1 (default) split exchange for the 2^9- and 2^10-point passes
+    // with workgroups of at most 256 threads
+    static const int split = [] { const char *e = getenv("QPGPU_NTT_SPLIT"); return e && *e ? atoi(e) : 1; }();
+    NttPassArgs a = a_in;
     const int ka = a.ka, kb = a.kb;
+    a.split_lds = (split && kb > 0 && ka + kb >= 9 && ka + (int)a.log_t <= 8) ? 1 : 0;
     if (n_cols > 65535 || n_proofs > 65535 || n_proofs == 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)n_tiles, (unsigned)n_cols, n_proofs);
     dim3 block((unsigned)(1u << (ka + a.log_t)), 1, 1);
     if (kb == 0) block.x = 1u << a.log_t;
     if (block.x < 64) block.x = 64;
     size_t lds = ntt_pass_lds_bytes(ka, kb, a.log_t);
+    if (a.split_lds) lds /= 2;
     if (ka == 1 && kb == 0) return ntt_launch_1_0(a, grid, block, lds, st);
     if (ka == 2 && kb == 0) return ntt_launch_2_0(a, grid, block, lds, st);
     if (ka == 3 && kb == 0) return ntt_launch_3_0(a, grid, block, lds, st);
