@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassArgs a) { nt
 // Split-exchange variant for the 2^9- and 2^10-point passes: half the LDS per workgroup lets four 256-thread workgroups share
 // a CU, so the register budget is pinned to four wavefronts per SIMD (128 VGPRs) to match.
 template <int KA, int KB, bool INV, bool ROWS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_pass_split_kernel(const NttPassArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_pass_split_kernel(const NttPassArgs a) {
     ntt_pass_body<KA, KB, INV, true>(a);
 }
 
@@ -284,7 +284,6 @@ hipError_t launch_dir(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, h
     const bool rows = KB > 0 && a.log_m == 0 && a.load_lane_fast == 0 && a.in_p_stride == 1 && a.in_row_stride > 1 && a.in_col_stride != 0;
     if constexpr (has_split_variant<KA, KB>()) {
         if (a.split_lds) {
-            if (block.x > 256) return hipErrorInvalidValue;
             if (rows) {
                 if (a.inverse) hipLaunchKernelGGL((ntt_pass_split_kernel<KA, KB, true, true>), grid, block, lds, st, a);
                 else hipLaunchKernelGGL((ntt_pass_split_kernel<KA, KB, false, true>), grid, block, lds, st, a);

@@ -32,10 +32,16 @@ hipError_t ntt_attr_5_4();
 hipError_t ntt_launch_5_5(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t ntt_attr_5_5();
 
+// QPGPU_NTT_SPLIT: 0 whole-word LDS exchange everywhere; 1 (default) split exchange for the 2^9- and 2^10-point passes
+bool ntt_pass_uses_split(int ka, int kb) {
+    static const int split = [] { const char *e = getenv("QPGPU_NTT_SPLIT"); return e && *e ? atoi(e) : 1; }();
+    return split && kb > 0 && ka + kb >= 9;
+}
+
 size_t ntt_pass_lds_bytes(int ka, int kb, int log_t) {
     if (kb == 0) return 0;
     size_t rp = ((size_t)1 << (ka + kb)) + ((size_t)1 << ka) + 1;
-    return (rp << log_t) * sizeof(uint64_t);
+    return (rp << log_t) * (ntt_pass_uses_split(ka, kb) ? sizeof(uint32_t) : sizeof(uint64_t));
 }
 
 hipError_t ntt_pass_init() {
@@ -53,19 +59,15 @@ hipError_t ntt_pass_init() {
 }
 
 hipError_t ntt_pass_launch(const NttPassArgs &a_in, uint64_t n_tiles, uint64_t n_cols, hipStream_t st, uint32_t n_proofs) {
-    // QPGPU_NTT_SPLIT: 0 whole-word LDS exchange everywhere; 1 (default) split exchange for the 2^9- and 2^10-point passes
-    // with workgroups of at most 256 threads
-    static const int split = [] { const char *e = getenv("QPGPU_NTT_SPLIT"); return e && *e ? atoi(e) : 1; }();
     NttPassArgs a = a_in;
     const int ka = a.ka, kb = a.kb;
-    a.split_lds = (split && kb > 0 && ka + kb >= 9 && ka + (int)a.log_t <= 8) ? 1 : 0;
+    a.split_lds = ntt_pass_uses_split(ka, kb) ? 1 : 0;
     if (n_cols > 65535 || n_proofs > 65535 || n_proofs == 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)n_tiles, (unsigned)n_cols, n_proofs);
     dim3 block((unsigned)(1u << (ka + a.log_t)), 1, 1);
     if (kb == 0) block.x = 1u << a.log_t;
     if (block.x < 64) block.x = 64;
     size_t lds = ntt_pass_lds_bytes(ka, kb, a.log_t);
-    if (a.split_lds) lds /= 2;
     if (ka == 1 && kb == 0) return ntt_launch_1_0(a, grid, block, lds, st);
     if (ka == 2 && kb == 0) return ntt_launch_2_0(a, grid, block, lds, st);
     if (ka == 3 && kb == 0) return ntt_launch_3_0(a, grid, block, lds, st);

@@ -36,6 +36,7 @@ struct NttPassArgs {
     const uint64_t *in_scale_b;
 };
 
+bool ntt_pass_uses_split(int ka, int kb);   // split 32-bit LDS exchange (half the LDS per workgroup) for this pass shape
 size_t ntt_pass_lds_bytes(int ka, int kb, int log_t);
 hipError_t ntt_pass_init();
 hipError_t ntt_pass_launch(const NttPassArgs &a, uint64_t n_tiles, uint64_t n_cols, hipStream_t st, uint32_t n_proofs = 1);

@@ -95,6 +95,9 @@ int pick_log_t(int ka, int kb, u64 lanes_total) {
     if (force >= 0 && ka + kb == 10 && lanes_total >= (1ull << force)) return force;
     int log_t = 8 - ka;  // 256 threads per workgroup
     if (log_t < 3) log_t = 3;
+    // 2^10-point passes with the split exchange: 16 lanes (full 128-byte segments on the strided pass), 512 threads, two
+    // workgroups per CU = four wavefronts per SIMD (measured 1.48 -> 1.42 ms per 2^20 x 128 transform against 8 lanes)
+    if (ka + kb == 10 && ntt_pass_uses_split(ka, kb) && lanes_total >= 16) log_t = 4;
     // keep LDS under ~72 KB so two workgroups share a CU
     while (log_t > 0 && ntt_pass_lds_bytes(ka, kb, log_t) > 72 * 1024) log_t--;
     (void)lanes_total;
