@@ -50,6 +50,8 @@ struct qpgpu_ctx {
     // stream sync — a pageable destination makes the runtime stage the copy itself, tens of microseconds per read
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
+    uint64_t *d_stage = nullptr;     // dense staging block of read_back_2d
+    size_t d_stage_bytes = 0;
     int read_back(void *host_dst, const void *dev_src, size_t bytes);
     // `rows` pieces of `width` bytes, `src_pitch` bytes apart on the device, packed back to back on the host
     int read_back_2d(void *host_dst, const void *dev_src, size_t src_pitch, size_t width, size_t rows);

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <string>
 #include "ctx.hpp"
+#include "prover_kernels.hpp"
 #include "gl64.hpp"
 #include "ntt_pass.hpp"
 
@@ -42,17 +43,18 @@ int qpgpu_ctx::read_back(void *host_dst, const void *dev_src, size_t bytes) {
 
 int qpgpu_ctx::read_back_2d(void *host_dst, const void *dev_src, size_t src_pitch, size_t width, size_t rows) {
     if (rows <= 1 || src_pitch == width) return read_back(host_dst, dev_src, width * rows);
+    // the runtime splits a 2D device-to-host copy into one small copy per row (32 of them per stage for a lockstep batch of
+    // 32): pack the rows on the device and bring them over in one piece
     const size_t bytes = width * rows;
-    if (bytes > h_pin_bytes) {
-        if (h_pin) { QP_HIP(this, hipStreamSynchronize(stream)); (void)hipHostFree(h_pin); h_pin = nullptr; h_pin_bytes = 0; }
+    if ((width | src_pitch) & 7) return fail(QPGPU_EINVAL, "read_back_2d: row width and pitch must be multiples of 8 bytes");
+    if (bytes > d_stage_bytes) {
+        if (d_stage) { QP_HIP(this, hipStreamSynchronize(stream)); (void)hipFree(d_stage); d_stage = nullptr; d_stage_bytes = 0; }
         const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-        QP_HIP(this, hipHostMalloc(&h_pin, want, hipHostMallocDefault));
-        h_pin_bytes = want;
+        QP_HIP(this, hipMalloc((void **)&d_stage, want));
+        d_stage_bytes = want;
     }
-    QP_HIP(this, hipMemcpy2DAsync(h_pin, width, dev_src, src_pitch, width, rows, hipMemcpyDeviceToHost, stream));
-    QP_HIP(this, hipStreamSynchronize(stream));
-    memcpy(host_dst, h_pin, bytes);
-    return QPGPU_OK;
+    QP_HIP(this, pk_pack_rows((const uint64_t *)dev_src, src_pitch / 8, width / 8, rows, d_stage, stream));
+    return read_back(host_dst, d_stage, bytes);
 }
 
 int qpgpu_ctx::upload(const std::vector<uint64_t> &host, uint64_t **dptr) {

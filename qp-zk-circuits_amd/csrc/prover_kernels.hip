@@ -644,6 +644,15 @@ __global__ void __launch_bounds__(256) coset_tables_kernel(u64 lde_n, u32 log_ld
 
 }  // namespace
 
+// rows of `width` words, `pitch` words apart -> one dense block (a lockstep batch's per-proof results, so that one
+// contiguous copy brings them to the host; a 2D copy is issued by the runtime as one small copy per row)
+__global__ void __launch_bounds__(256) pack_rows_kernel(const u64 *src, u64 pitch, u64 width, u64 total, u64 *dst) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u64 r = i / width, c = i - r * width;
+    dst[i] = src[r * pitch + c];
+}
+
 #define LAUNCH_1D(kern, count, threads, st, ...) \
     do { if ((count) > 0) { dim3 b(threads), g((unsigned)(((count) + (threads)-1) / (threads))); hipLaunchKernelGGL(kern, g, b, 0, st, __VA_ARGS__); } } while (0)
 // the same over a lockstep batch: grid.z = proof
@@ -719,6 +728,10 @@ hipError_t pk_quotient(const QuotientArgs &a, const GateDev *host_gates, hipStre
         case 4: return quotient_launch<4>(a, host_gates, st);
         default: return hipErrorInvalidValue;
     }
+}
+hipError_t pk_pack_rows(const u64 *src, u64 pitch_words, u64 width_words, u64 rows, u64 *dst, hipStream_t st) {
+    LAUNCH_1D(pack_rows_kernel, width_words * rows, 256, st, src, pitch_words, width_words, width_words * rows, dst);
+    return hipGetLastError();
 }
 hipError_t pk_scale_powers(u64 *data, u64 n, u64 ncols, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits, hipStream_t st) {
     LAUNCH_1D(scale_powers_kernel, n, 256, st, data, n, ncols, pw_lo, pw_hi, lo_bits);
