@@ -1,6 +1,9 @@
 """HBM traffic of the 2^20 x 128 NTT launches from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs, as
 MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled for the fully coalesced rows pass (gfx950 tallies 128-byte
-requests at 64 B); the strided pass reads 128-byte lane segments and is taken as reported.
+requests at 64 B). The strided pass is calibrated on its known byte count, as the guide asks for access patterns it does not
+list: a pass reads every input element exactly once (2^20 x 128 x 8 B = 1 GiB), so a reported value well below that can only
+be the same half-tally (16-lane tiles read whole 128-byte segments) and is doubled; a value at or above it (8-lane tiles,
+64-byte segments, round 1) is taken as reported.
 usage: python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json>"""
 import csv, glob, json, os, sys
 
@@ -8,7 +11,7 @@ def load(d, counter):
     out = []
     for path in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(path)):
-            if r.get("Counter_Name") != counter or "ntt_pass_kernel<5, 5" not in r.get("Kernel_Name", ""):
+            if r.get("Counter_Name") != counter or "_kernel<5, 5" not in r.get("Kernel_Name", ""):
                 continue
             out.append((int(r.get("Dispatch_Id", 0)), r["Kernel_Name"].split("(anonymous namespace)::")[-1], float(r["Counter_Value"])))
     return sorted(out)
@@ -19,7 +22,8 @@ launches, total = [], 0.0
 for (_, name, f), (_, name2, w) in zip(fetch, write):
     assert name == name2
     rows = ", true>(" in name.replace("true, true", "x, true").replace("false, true", "x, true")
-    corr = 2.0 if rows else 1.0
+    must_read = 8.0 * (1 << 20) * 128          # bytes every pass has to read at least
+    corr = 2.0 if rows or f * 1024 < 0.75 * must_read else 1.0
     hbm = (f * corr + w) * 1024
     launches.append({"kind": "rows" if rows else "strided", "kernel": name[:48], "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                      "fetch_correction": corr, "hbm_bytes": int(hbm)})

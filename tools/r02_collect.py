@@ -54,7 +54,7 @@ for db_path in sorted(glob.glob(os.path.join(SRC, "pmc_sq*", "**", "*results.db"
     db = sqlite3.connect(db_path)
     for kname, cname, val, dur, vgpr, lds in db.execute(
             "select kernel_name, counter_name, value, duration, vgpr_count, lds_block_size from counters_collection"):
-        if "ntt_pass_kernel<5, 5" not in kname:
+        if "_kernel<5, 5" not in kname:
             continue
         key = kname.split("(anonymous namespace)::")[-1].split("(")[0]
         per[key][cname].append(val)
