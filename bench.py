@@ -297,7 +297,7 @@ def main():
         tpriv[0][14] = 1
         tpub = None
         if rank == 0:
-            tpub = pkg.synth_circuit(args.batch_degree_bits, num_wires=135, num_routed=80, num_public_inputs=NB_PIS * 8 + 8, seed=77, **rec)
+            tpub = pkg.synth_circuit(args.batch_degree_bits, num_wires=135, num_routed=80, num_public_inputs=agg.public_batch_pi_len(8, 8), seed=77, **rec)
         atree = agg.AggregationTree(pkg, gpus[0], rank, world, tleaf, tpriv, tpub, leaf_batch=32)
         dd = dist if world > 1 else None
         atree.run(dd, coll_dev)
@@ -316,7 +316,7 @@ def main():
                 "shape": f"leaf 2^{d} rows (80 routed); private batch 2^{args.batch_degree_bits} rows zero-knowledge, 60 routed wires; "
                          f"public batch 2^{args.batch_degree_bits} rows, 80 routed; 135 wires; batches carry the 14-gate recursive-verifier mix",
                 "note": "shape-equivalent synthetic circuits per level; each level parses the previous level's gathered proof bytes, "
-                        "derives its public inputs from them, regenerates its witness on the device (stage s1) and proves — a rank's "
+                        "runs the reference's admission checks, pads / shuffles, derives the public inputs the wrapper circuit would emit, regenerates its witness on the device (stage s1) and proves — a rank's "
                         "leaves 32 at a time and its private batches 8 at a time in lockstep; the inner proofs are not verified in-circuit; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
                         "sequential on an M2 Max"}
         if rank == 0:
@@ -329,13 +329,23 @@ def main():
                 oc_t = ob.OracleCircuit(orc_t, pk)
                 ok_t = ok_t and oc_t.verify(pf) == 0
                 oc_t.close()
-            rp = agg.proof_public_inputs(t_root, NB_PIS * 8 + 8)
+            # the root's public inputs (12 + 14*8*8 felts, public_batch/circuit/constants.rs) forward every batch proof's exit
+            # slots and nullifiers in rank order; a batch's exit slots carry its 8 leaves' amounts merged per account
+            rp = agg.proof_public_inputs(t_root, agg.public_batch_pi_len(8, 8))
+            ok_t = ok_t and int(rp[11]) == 128 and tuple(rp[6:10].tolist()) == agg.TEST_BLOCK_HASH
             for b in range(8):
                 bp = agg.proof_public_inputs(t_batches[b], NB_PIS)
-                ok_t = ok_t and bool(np.array_equal(rp[b * NB_PIS:(b + 1) * NB_PIS], bp))
+                ok_t = ok_t and bool(np.array_equal(rp[12 + 80 * b:12 + 80 * (b + 1)], bp[8:88]))
+                ok_t = ok_t and bool(np.array_equal(rp[12 + 640 + 32 * b:12 + 640 + 32 * (b + 1)], bp[88:120]))
+                want = {}
                 for j in range(8):
-                    ok_t = ok_t and bool(np.array_equal(bp[21 * j:21 * j + 21], agg.proof_public_inputs(t_leaves[8 * b + j], 21)))
-            tree["checked"] = "oracle verifier accepts leaf 63, private batch 7 and the root; root public inputs = the 8 batch proofs' in rank order" if ok_t else "FAILED"
+                    lp = agg.proof_public_inputs(t_leaves[8 * b + j], 21)
+                    for acct, amt in ((tuple(lp[8:12].tolist()), int(lp[1])), (tuple(lp[12:16].tolist()), int(lp[2]))):
+                        want[acct] = want.get(acct, 0) + amt
+                got = {tuple(bp[9 + 5 * k:13 + 5 * k].tolist()): int(bp[8 + 5 * k]) for k in range(16) if int(bp[8 + 5 * k])}
+                ok_t = ok_t and got == {a: v for a, v in want.items() if v}
+            tree["checked"] = ("oracle verifier accepts leaf 63, private batch 7 and the root; the root forwards the 8 batch proofs' exit slots and "
+                               "nullifiers in rank order and every batch's exit slots are its leaves' amounts merged per account") if ok_t else "FAILED"
             tree_check = ok_t
         atree.close()
     if rank == 0:

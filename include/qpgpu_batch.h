@@ -1,0 +1,121 @@
+/*
+ * qpgpu_batch.h — the host side of the two aggregation levels, on either side of `prove()` (host only, no GPU):
+ * SURVEY.md section 8 rows a3 / a4 and the public-input formats of row f4.
+ *
+ *   public-input layouts and parsers                    wormhole/inputs/src/lib.rs:25-33,68-80,187-290,365-700
+ *     leaf (21 felts), private batch (21 N + 8), public batch (12 + 14 M N)
+ *   admission checks of PrivateBatchProver::commit      wormhole/aggregator/src/private_batch/prover/lib.rs:244-343,372-460
+ *   dummy leaf template sentinel                        wormhole/aggregator/src/private_batch/prover/lib.rs:478-530
+ *   padding, uniform shuffle, dummy-nullifier preimages wormhole/aggregator/src/private_batch/prover/lib.rs:296-316,537-541,
+ *                                                       wormhole/aggregator/src/dummy_proof.rs:178-187
+ *   admission checks of PublicBatchProver::commit       wormhole/aggregator/src/public_batch/prover/lib.rs:268-300,321-445
+ *   dummy private-batch template sentinel               wormhole/aggregator/src/public_batch/prover/lib.rs:454-510
+ *   what the two wrapper circuits output, natively      wormhole/aggregator/src/private_batch/circuit/circuit_logic.rs:170-523,
+ *                                                       wormhole/aggregator/src/public_batch/circuit/circuit_logic.rs:167-330
+ *     (first non-dummy slot as block / fee reference, dummy exits masked to zero, exit accounts grouped with the first
+ *     occurrence carrying the sum and later ones zeroed, real nullifiers pairwise distinct, dummy nullifiers replaced by
+ *     H(H(preimage)) under Poseidon2, the nullifier region sorted, zero padding to 21 N + 8)
+ *
+ * Cryptographic verification of the inner proofs — the other half of the reference's admission checks — needs a verifier
+ * and is not part of this header: callers run theirs between `*_preflight` and proving.
+ *
+ * Every function returns 0, or -1 with one line in err (QPGPU_BATCH_ERR_CAP bytes, the reference's message where it has
+ * one), or -4 (QPGPU_EUNSAT) from the `*_outputs` functions when the inputs violate a constraint of the wrapper circuit
+ * (the proof could not be generated).
+ */
+#ifndef QPGPU_BATCH_H
+#define QPGPU_BATCH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPGPU_LEAF_PI_LEN 21
+#define QPGPU_BATCH_HEADER_LEN 8
+#define QPGPU_PUBLIC_BATCH_HEADER_LEN 12
+#define QPGPU_EXIT_SLOT_LEN 5
+#define QPGPU_BATCH_MAX_PROOFS 64
+#define QPGPU_BATCH_ERR_CAP 400
+
+/* leaf public inputs: asset_id, output_amount_1, output_amount_2, volume_fee_bps, nullifier(4), exit_account_1(4),
+ * exit_account_2(4), block_hash(4), block_number */
+typedef struct {
+    uint32_t asset_id, output_amount_1, output_amount_2, volume_fee_bps;
+    uint8_t nullifier[32], exit_account_1[32], exit_account_2[32], block_hash[32];
+    uint32_t block_number;
+} qpgpu_leaf_public_inputs;
+
+typedef struct {
+    uint32_t summed_output_amount;
+    uint8_t exit_account[32];
+} qpgpu_exit_slot;
+
+/* header of a private-batch proof's public inputs; account_data has 2 * n_leaf entries, nullifiers n_leaf */
+typedef struct {
+    uint32_t num_exit_slots, asset_id, volume_fee_bps;
+    uint8_t block_hash[32];
+    uint32_t block_number;
+    uint32_t n_leaf;
+} qpgpu_private_batch_public_inputs;
+
+/* header of a public-batch proof's public inputs; account_data has total_exit_slots entries, nullifiers M * N */
+typedef struct {
+    uint8_t aggregator_address[32];
+    uint32_t asset_id, volume_fee_bps;
+    uint8_t block_hash[32];
+    uint32_t block_number;
+    uint32_t total_exit_slots;
+} qpgpu_public_batch_public_inputs;
+
+/* validate_proof_count: 1..=64 */
+int qpgpu_validate_proof_count(uint64_t count, const char *label, char *err);
+size_t qpgpu_private_batch_pi_len(size_t n_leaf);                              /* 21 N + 8 */
+/* 12 + M * 2N * 5 + M * N * 4; 0 when a count is outside 1..=64 */
+size_t qpgpu_public_batch_pi_len(size_t num_private_batch_proofs, size_t num_leaf_proofs);
+
+/* PublicCircuitInputs::try_from_u64_slice */
+int qpgpu_leaf_public_inputs_parse(const uint64_t *pis, size_t n, qpgpu_leaf_public_inputs *out, char *err);
+/* PrivateBatchPublicInputs::try_from_u64_slice; slots: 2 * n_leaf entries (cap 128), nullifiers: n_leaf * 32 bytes (cap 64) */
+int qpgpu_private_batch_public_inputs_parse(const uint64_t *pis, size_t n, qpgpu_private_batch_public_inputs *out,
+                                            qpgpu_exit_slot *slots, uint8_t *nullifiers, char *err);
+/* PublicBatchPublicInputs::try_from_u64_slice; slots: M * 2N entries, nullifiers: M * N * 32 bytes */
+int qpgpu_public_batch_public_inputs_parse(const uint64_t *pis, size_t n, uint64_t num_private_batch_proofs, uint64_t num_leaf_proofs,
+                                           qpgpu_public_batch_public_inputs *out, qpgpu_exit_slot *slots, uint8_t *nullifiers,
+                                           char *err);
+
+/* ---- private batch (client side) ---- */
+/* PrivateBatchProver::commit's checks on the supplied leaves (count rows of 21 canonical felts), before padding:
+ * non-empty, at most num_leaf_proofs, asset_id 0 when padding will be needed, one asset everywhere, one block hash and
+ * fee rate among the non-dummy ones, pairwise distinct nullifiers among them, at least one non-dummy. */
+int qpgpu_private_batch_preflight(const uint64_t *leaf_pis, size_t count, size_t num_leaf_proofs, char *err);
+/* verify_dummy_leaf_template's sentinel part: zero block hash, zero amounts, asset 0, zero exit accounts */
+int qpgpu_dummy_leaf_template_check(const uint64_t *pis, size_t n, char *err);
+/* Pads `count` supplied proofs to num_leaf_proofs slots with the dummy template, shuffles uniformly and draws one dummy
+ * nullifier preimage per slot. slot_source[s] = index of the supplied proof in slot s, or UINT32_MAX for the dummy
+ * template; preimages: num_leaf_proofs * 4 canonical felts. seed32: NULL = operating-system entropy (getrandom); a
+ * 32-byte seed makes the arrangement reproducible (tests). */
+int qpgpu_private_batch_arrange(size_t count, size_t num_leaf_proofs, const uint8_t *seed32, uint32_t *slot_source,
+                                uint64_t *preimages, char *err);
+/* The public inputs the private-batch circuit emits for these slots (n_leaf rows of 21 felts in slot order, n_leaf
+ * preimages of 4 felts): out has 21 n_leaf + 8 words. -4 when a constraint of the circuit is violated. */
+int qpgpu_private_batch_outputs(const uint64_t *leaf_pis, size_t n_leaf, const uint64_t *dummy_preimages, uint64_t *out, char *err);
+
+/* ---- public batch (miner side) ---- */
+/* preflight_private_batch_proofs without the cryptographic part: count rows of pi_len felts; non-empty, at most
+ * num_private_batch_proofs, pi_len == 21 N + 8 for an N in 1..=64, one (block hash, asset, fee) among the non-dummy
+ * proofs, at least one non-dummy. */
+int qpgpu_public_batch_preflight(const uint64_t *inner_pis, size_t count, size_t pi_len, size_t num_private_batch_proofs, char *err);
+/* verify_dummy_private_batch_template's sentinel part */
+int qpgpu_dummy_private_batch_template_check(const uint64_t *pis, size_t n, char *err);
+/* The public inputs the public-batch circuit emits: m rows of 21 n_leaf + 8 felts in order (no shuffle: forwarding is
+ * order-preserving), the aggregator address as 32 bytes (4 felts, 8 bytes each, canonical); out has
+ * qpgpu_public_batch_pi_len(m, n_leaf) words. -4 when a constraint of the circuit is violated. */
+int qpgpu_public_batch_outputs(const uint64_t *inner_pis, size_t m, size_t n_leaf, const uint8_t aggregator_address[32],
+                               uint64_t *out, char *err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

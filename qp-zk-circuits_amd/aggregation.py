@@ -10,10 +10,13 @@ from them; the proof bytes of level k are the input of level k+1.
 
 The recursive wrapper circuits themselves need the Rust CircuitBuilder (circuit-pack exporter), so the
 circuit proven here is the synthetic stand-in of the level's size and gate mix ("shape-equivalent"). What is
-real: inner proofs are parsed from their bytes, the batch's public inputs are the inner public inputs in slot order
-(padded with the dummy template's, as the reference pads a short batch, private_batch/prover/lib.rs:283-300) followed by
-the level's 8 trailing words, the witness is generated on the device from a PartialWitness (stage s1, with plonky2's
-"set twice with different values" check), and the proof is produced by the same qpgpu_prove path as every other proof.
+real: inner proofs are parsed from their bytes; the reference's admission checks run on them (include/qpgpu_batch.h:
+counts, asset / block / fee consistency, duplicate nullifiers, all-dummy, the padding templates' sentinels; the
+cryptographic half through the caller's verifier); short batches are padded with the dummy template, private batches
+shuffled uniformly and given one dummy-nullifier preimage per slot; the batch's public inputs are exactly what the
+wrapper circuit would emit (layout 21 N + 8 / 12 + 14 M N: references from the first non-dummy slot, exit accounts
+merged, dummy nullifiers hashed, the nullifier region sorted); the witness is generated on the device from a
+PartialWitness (stage s1); and the proof is produced by the same qpgpu_prove path as every other proof.
 What is not: the inner proofs are not verified in-circuit (no recursive verifier gates are wired to them).
 """
 import numpy as np
@@ -32,15 +35,65 @@ def proof_public_inputs(proof, num_public_inputs):
     return np.frombuffer(proof, dtype="<u8", offset=len(proof) - 8 * num_public_inputs, count=num_public_inputs).copy()
 
 
-def batch_public_inputs(inner_proofs, inner_num_public_inputs, slots, dummy_public_inputs, trailer):
-    """Public inputs of a batch over `slots` inner proofs: slot i carries inner proof i's public inputs, missing slots the
-    dummy template's; then the level's trailer words."""
-    if len(inner_proofs) > slots:
-        raise ValueError("more inner proofs than slots")
-    rows = [proof_public_inputs(p, inner_num_public_inputs) for p in inner_proofs]
-    rows += [np.asarray(dummy_public_inputs, dtype=np.uint64)] * (slots - len(rows))
-    out = np.concatenate(rows + [np.asarray(trailer, dtype=np.uint64)])
-    return out.astype(np.uint64)
+# ---- include/qpgpu_batch.h: public-input layouts, commit preflights, padding / shuffle, wrapper-circuit outputs ----
+_ERR_CAP = 400
+_batch_lib = None
+
+
+def _lib():
+    global _batch_lib
+    if _batch_lib is None:
+        import ctypes
+        from .binding import load_library
+        L = load_library()
+        vp, sz, cp = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p
+        for name, argt in {"qpgpu_private_batch_preflight": [vp, sz, sz, cp], "qpgpu_dummy_leaf_template_check": [vp, sz, cp],
+                           "qpgpu_private_batch_arrange": [sz, sz, cp, vp, vp, cp], "qpgpu_private_batch_outputs": [vp, sz, vp, vp, cp],
+                           "qpgpu_public_batch_preflight": [vp, sz, sz, sz, cp], "qpgpu_dummy_private_batch_template_check": [vp, sz, cp],
+                           "qpgpu_public_batch_outputs": [vp, sz, sz, cp, vp, cp]}.items():
+            getattr(L, name).argtypes = argt
+            getattr(L, name).restype = ctypes.c_int
+        L.qpgpu_private_batch_pi_len.argtypes = [sz]; L.qpgpu_private_batch_pi_len.restype = sz
+        L.qpgpu_public_batch_pi_len.argtypes = [sz, sz]; L.qpgpu_public_batch_pi_len.restype = sz
+        _batch_lib = L
+    return _batch_lib
+
+
+def _call(fn, *args):
+    """Reference behaviour: an admission failure is an error with the reference's text (anyhow -> ValueError); inputs
+    the wrapper circuit cannot satisfy are QpGpuError(-4)."""
+    import ctypes
+    from .binding import QpGpuError
+    err = ctypes.create_string_buffer(_ERR_CAP)
+    rc = fn(*args, err)
+    if rc == -4:
+        raise QpGpuError(rc, err.value.decode())
+    if rc != 0:
+        raise ValueError(err.value.decode())
+
+
+def private_batch_pi_len(num_leaf_proofs):
+    return int(_lib().qpgpu_private_batch_pi_len(num_leaf_proofs))
+
+
+def public_batch_pi_len(num_private_batch_proofs, num_leaf_proofs):
+    return int(_lib().qpgpu_public_batch_pi_len(num_private_batch_proofs, num_leaf_proofs))
+
+
+def private_batch_outputs(leaf_rows, preimages):
+    """What the private-batch circuit writes into its public inputs for these slots (circuit_logic.rs:170-523)."""
+    rows = np.ascontiguousarray(leaf_rows, dtype=np.uint64).reshape(-1, LEAF_PUBLIC_INPUTS)
+    pre = np.ascontiguousarray(preimages, dtype=np.uint64).reshape(rows.shape[0], 4)
+    out = np.zeros(private_batch_pi_len(rows.shape[0]), dtype=np.uint64)
+    _call(_lib().qpgpu_private_batch_outputs, rows.ctypes.data, rows.shape[0], pre.ctypes.data, out.ctypes.data)
+    return out
+
+
+def public_batch_outputs(inner_rows, num_leaf_proofs, aggregator_address):
+    rows = np.ascontiguousarray(inner_rows, dtype=np.uint64).reshape(-1, private_batch_pi_len(num_leaf_proofs))
+    out = np.zeros(public_batch_pi_len(rows.shape[0], num_leaf_proofs), dtype=np.uint64)
+    _call(_lib().qpgpu_public_batch_outputs, rows.ctypes.data, rows.shape[0], num_leaf_proofs, bytes(aggregator_address), out.ctypes.data)
+    return out
 
 
 class TemplateProver:
@@ -140,38 +193,136 @@ class TemplateProver:
         return proof
 
 
-class BatchProver(TemplateProver):
-    """commit(inner proofs) -> prove(): one batch level on one GPU.
+class PrivateBatchProver(TemplateProver):
+    """PrivateBatchProver::{commit, prove, aggregate} (private_batch/prover/lib.rs:244-343) on one GPU.
 
-    pack / template_wires / template_pis: the level's circuit and one satisfying witness of it (the dummy-proof template the
-    reference generates at build time, dummy_proof.rs:104-115)."""
+    commit: the reference's admission checks on the supplied leaf proofs (qpgpu_private_batch_preflight, then the caller's
+    cryptographic `verify_leaf(proof) -> bool` if one is given), padding with the dummy leaf template, a uniform shuffle,
+    one dummy-nullifier preimage per slot; the batch's public inputs are what the private-batch circuit would emit for
+    those slots (qpgpu_private_batch_outputs) and the witness is regenerated from them on the device."""
 
-    def __init__(self, gpu, pack, template_wires, template_pis, inner_num_public_inputs, slots, max_batch=1):
+    def __init__(self, gpu, pack, template_wires, dummy_leaf_proof, num_leaf_proofs, verify_leaf=None, max_batch=1):
         super().__init__(gpu, pack, template_wires, max_batch=max_batch)
-        self.inner_npis, self.slots = inner_num_public_inputs, slots
-        if self.hdr["num_public_inputs"] != slots * inner_num_public_inputs + BATCH_TRAILER_WORDS:
+        self.num_leaf_proofs, self.verify_leaf = num_leaf_proofs, verify_leaf
+        try:
+            if self.hdr["num_public_inputs"] != private_batch_pi_len(num_leaf_proofs):
+                raise ValueError("private-batch circuit public-input count is not 21 * N + 8")
+            # verify_dummy_leaf_template: the sentinel, then the cryptographic check
+            self.dummy_pis = proof_public_inputs(dummy_leaf_proof, LEAF_PUBLIC_INPUTS)
+            _call(_lib().qpgpu_dummy_leaf_template_check, self.dummy_pis.ctypes.data, self.dummy_pis.size)
+            if verify_leaf is not None and not verify_leaf(dummy_leaf_proof):
+                raise ValueError("dummy leaf proof template failed verification")
+        except Exception:
             self.close()
-            raise ValueError("batch circuit public-input count does not match slots * inner + 8")
-        self.template_pis = np.asarray(template_pis, dtype=np.uint64)
+            raise
+        self.dummy_leaf_proof = dummy_leaf_proof
+        self.arrangement = None       # of the last commit: (slot_source, preimages) per batch
 
-    def commit(self, inner_proofs, trailer=None):
-        """Parse the inner proofs, derive the batch's public inputs, generate the witness on the device."""
-        dummy = self.template_pis[:self.inner_npis]
-        tr = self.template_pis[-BATCH_TRAILER_WORDS:] if trailer is None else trailer
-        return super().commit(batch_public_inputs(inner_proofs, self.inner_npis, self.slots, dummy, tr))
+    def _slots(self, leaf_proofs, seed):
+        """-> (rows of 21 felts in slot order, preimages) after the admission checks, padding and shuffle."""
+        N = self.num_leaf_proofs
+        rows = np.stack([proof_public_inputs(p, LEAF_PUBLIC_INPUTS) for p in leaf_proofs]) if len(leaf_proofs) else np.zeros((0, LEAF_PUBLIC_INPUTS), dtype=np.uint64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        _call(_lib().qpgpu_private_batch_preflight, rows.ctypes.data if rows.size else None, rows.shape[0], N)
+        if self.verify_leaf is not None:
+            for i, p in enumerate(leaf_proofs):
+                if not self.verify_leaf(p):
+                    raise ValueError("leaf proof %d failed verification against the pinned leaf verifier" % i)
+        src = np.zeros(N, dtype=np.uint32)
+        pre = np.zeros(4 * N, dtype=np.uint64)
+        _call(_lib().qpgpu_private_batch_arrange, rows.shape[0], N, seed, src.ctypes.data, pre.ctypes.data)
+        slot_rows = np.stack([self.dummy_pis if k == 0xFFFFFFFF else rows[k] for k in src.tolist()])
+        return slot_rows, pre.reshape(N, 4), src
 
-    def commit_many(self, inner_proofs_list, trailer=None):
-        """Several batches of this level at once (one witness-generation pass, proven in lockstep by prove_many)."""
-        dummy = self.template_pis[:self.inner_npis]
-        tr = self.template_pis[-BATCH_TRAILER_WORDS:] if trailer is None else trailer
-        return super().commit_many([batch_public_inputs(ps, self.inner_npis, self.slots, dummy, tr) for ps in inner_proofs_list])
+    def batch_public_inputs(self, leaf_proofs, seed=None):
+        slot_rows, pre, src = self._slots(leaf_proofs, seed)
+        return private_batch_outputs(slot_rows, pre), (src, pre)
+
+    def commit(self, leaf_proofs, seed=None):
+        pis, arr = self.batch_public_inputs(leaf_proofs, seed)
+        self.arrangement = [arr]
+        return super().commit(pis)
+
+    def commit_many(self, leaf_proofs_list, seed=None):
+        """Several private batches at once (one witness-generation pass, proven in lockstep by prove_many); with a seed,
+        batch k is arranged from seed with its last byte increased by k."""
+        out, arrs = [], []
+        for k, ps in enumerate(leaf_proofs_list):
+            sk = None if seed is None else bytes(seed[:31]) + bytes([(seed[31] + k) & 0xFF])
+            pis, arr = self.batch_public_inputs(ps, sk)
+            out.append(pis); arrs.append(arr)
+        self.arrangement = arrs
+        return super().commit_many(out)
+
+    def prove_dummy_template(self, blinding_seed=None):
+        """generate_dummy_private_batch_proof (private_batch/circuit/build.rs:165-193): the all-dummy private-batch proof the
+        public level pads with; built from explicit dummy leaves, never through commit (which refuses an all-dummy batch)."""
+        N = self.num_leaf_proofs
+        pre = np.zeros(4 * N, dtype=np.uint64); src = np.zeros(N, dtype=np.uint32)
+        _call(_lib().qpgpu_private_batch_arrange, 1, N, None, src.ctypes.data, pre.ctypes.data)     # only the preimages are used
+        pis = private_batch_outputs(np.stack([self.dummy_pis] * N), pre.reshape(N, 4))
+        TemplateProver.commit(self, pis)
+        if blinding_seed is not None:
+            self.circ.set_blinding_seed(blinding_seed)
+        return self.prove()
+
+
+class PublicBatchProver(TemplateProver):
+    """PublicBatchProver::{commit, prove} (public_batch/prover/lib.rs:268-305): admission checks on the supplied private-batch
+    proofs, order-preserving padding with the dummy private-batch template (no shuffle), public inputs as the public-batch
+    circuit emits them."""
+
+    def __init__(self, gpu, pack, template_wires, dummy_private_batch_proof, num_private_batch_proofs, num_leaf_proofs, verify_inner=None):
+        super().__init__(gpu, pack, template_wires)
+        self.M, self.N, self.verify_inner = num_private_batch_proofs, num_leaf_proofs, verify_inner
+        self.inner_len = private_batch_pi_len(num_leaf_proofs)
+        try:
+            if self.hdr["num_public_inputs"] != public_batch_pi_len(self.M, self.N):
+                raise ValueError("public-batch circuit public-input count is not 12 + 14 * M * N")
+            self.dummy_pis = proof_public_inputs(dummy_private_batch_proof, self.inner_len)
+            _call(_lib().qpgpu_dummy_private_batch_template_check, self.dummy_pis.ctypes.data, self.dummy_pis.size)
+            if verify_inner is not None and not verify_inner(dummy_private_batch_proof):
+                raise ValueError("dummy private-batch proof template failed verification")
+        except Exception:
+            self.close()
+            raise
+
+    def batch_public_inputs(self, inner_proofs, aggregator_address=bytes(32)):
+        rows = np.stack([proof_public_inputs(p, self.inner_len) for p in inner_proofs]) if len(inner_proofs) else np.zeros((0, self.inner_len), dtype=np.uint64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        _call(_lib().qpgpu_public_batch_preflight, rows.ctypes.data if rows.size else None, rows.shape[0], self.inner_len, self.M)
+        if self.verify_inner is not None:
+            for i, p in enumerate(inner_proofs):
+                if not self.verify_inner(p):
+                    raise ValueError("private-batch proof %d failed verification against the pinned private-batch verifier" % i)
+        padded = np.concatenate([rows] + [self.dummy_pis[None, :]] * (self.M - rows.shape[0]))
+        return public_batch_outputs(padded, self.N, aggregator_address)
+
+    def commit(self, inner_proofs, aggregator_address=bytes(32)):
+        return super().commit(self.batch_public_inputs(inner_proofs, aggregator_address))
+
+
+TEST_BLOCK_HASH = (0x0B10C0DE, 0x2222, 0x3333, 0x4444)
 
 
 def leaf_public_inputs(index, count=LEAF_PUBLIC_INPUTS):
-    """Deterministic stand-in public inputs for synthetic leaf `index` (canonical field elements)."""
+    """Deterministic stand-in public inputs for synthetic leaf `index`. With the leaf layout (21 felts,
+    wormhole/inputs/src/lib.rs:25-33) they are well-formed leaf public inputs of one block: native asset, two outputs to
+    accounts drawn from a small set (so that batches have exit accounts to merge), fee 10 bps, a distinct nullifier."""
     x = (np.arange(count, dtype=np.uint64) + np.uint64(1 + index * 1000003)) * np.uint64(0x9E3779B97F4A7C15)
     x ^= x >> np.uint64(31)
-    return (x % np.uint64(0xFFFFFFFF00000001)).astype(np.uint64)
+    x = (x % np.uint64(0xFFFFFFFF00000001)).astype(np.uint64)
+    if count != LEAF_PUBLIC_INPUTS:
+        return x
+    p = np.zeros(LEAF_PUBLIC_INPUTS, dtype=np.uint64)
+    p[1], p[2], p[3] = 1000 + index, index % 7, 10
+    p[4:8] = x[4:8]
+    a1, a2 = index % 5, (index + 1) % 5
+    p[8:12] = [0xACC0 + a1, 1, 2, 3]
+    p[12:16] = [0xACC0 + a2, 1, 2, 3]
+    p[16:20] = TEST_BLOCK_HASH
+    p[20] = 42
+    return p
 
 
 class AggregationTree:
@@ -180,31 +331,39 @@ class AggregationTree:
     gathered (sharding.gather_proof_bytes: RCCL on GPUs, gloo in rehearsals) and consumed by the next level.
     Reference call stack SURVEY.md 3.4; partitioning SURVEY.md 8e."""
 
-    def __init__(self, pkg, gpu, rank, world, leaf, private, public, num_leaves=64, slots=8, leaf_batch=8, private_batch=8):
-        """leaf / private / public: (pack, template_wires, template_pis) of the level's circuit (public only on the root).
-        leaf_batch / private_batch: how many proofs of a level this rank proves in lockstep."""
+    def __init__(self, pkg, gpu, rank, world, leaf, private, public, num_leaves=64, slots=8, leaf_batch=8, private_batch=8, verify=None):
+        """leaf / private / public: (pack, template_wires, ...) of the level's circuit (public only on the root).
+        leaf_batch / private_batch: how many proofs of a level this rank proves in lockstep.
+        verify: optional {"leaf": fn(proof) -> bool, "private": fn(proof) -> bool}, the cryptographic half of the admission
+        checks. Construction proves the two padding templates, as the reference's artifact build does (dummy_proof.rs:104-115,
+        private_batch/circuit/build.rs:165-193)."""
         from . import sharding
+        verify = verify or {}
         self.sharding, self.rank, self.world, self.slots = sharding, rank, world, slots
         self.plan = sharding.aggregation_schedule(num_leaves, slots, world)
         self.mine = self.plan["ranks"][rank]
         self.num_batches = num_leaves // slots
         self.leaf_batch = max(1, min(leaf_batch, len(self.mine["leaves"]))) if self.mine["leaves"] else 1
         self.leaf = TemplateProver(gpu, leaf[0], leaf[1], max_batch=self.leaf_batch)
+        self.leaf.commit(np.zeros(LEAF_PUBLIC_INPUTS, dtype=np.uint64))
+        self.dummy_leaf_proof = self.leaf.prove()
         self.private_batch = max(1, min(private_batch, len(self.mine["private_batches"])))
-        self.private = BatchProver(gpu, private[0], private[1], private[2], LEAF_PUBLIC_INPUTS, slots, max_batch=self.private_batch)
+        self.private = PrivateBatchProver(gpu, private[0], private[1], self.dummy_leaf_proof, slots, verify.get("leaf"), max_batch=self.private_batch)
         self.times = {}
         self.public = None
         if rank == self.plan["root"]:
-            self.public = BatchProver(gpu, public[0], public[1], public[2], LEAF_PUBLIC_INPUTS * slots + BATCH_TRAILER_WORDS, self.num_batches)
+            self.dummy_private_batch_proof = self.private.prove_dummy_template()
+            self.public = PublicBatchProver(gpu, public[0], public[1], self.dummy_private_batch_proof, self.num_batches, slots, verify.get("private"))
 
     def close(self):
         for p in (self.leaf, self.private, self.public):
             if p is not None:
                 p.close()
 
-    def run(self, dist=None, device=None, blinding_seed=None, keep=None):
+    def run(self, dist=None, device=None, blinding_seed=None, keep=None, shuffle_seed=None, aggregator_address=bytes(32)):
         """One pass over the tree. Returns (all leaf proofs, all private-batch proofs, root proof or None).
-        blinding_seed: makes the zero-knowledge level reproducible (tests); keep: a dict that receives, per level, this
+        blinding_seed / shuffle_seed (32 bytes): make the zero-knowledge salts / the private batches' slot order and dummy
+        preimages reproducible (tests; default: operating-system entropy); keep: a dict that receives, per level, this
         rank's (index, public inputs, full witness) triples for an external checker (costs a device download each)."""
         import time
         d = dist if self.world > 1 else None
@@ -230,7 +389,8 @@ class AggregationTree:
             run = [pb[k]]
             while k + len(run) < len(pb) and len(run) < self.private_batch and pb[k + len(run)] == run[-1] + 1:
                 run.append(pb[k + len(run)])
-            pis = self.private.commit_many([leaves[b * self.slots:(b + 1) * self.slots] for b in run])
+            sk = None if shuffle_seed is None else bytes(shuffle_seed[:30]) + bytes([run[0] & 0xFF, 0])
+            pis = self.private.commit_many([leaves[b * self.slots:(b + 1) * self.slots] for b in run], seed=sk)
             if blinding_seed is not None:
                 self.private.circ.set_blinding_seed(blinding_seed + run[0])
             if keep is not None:
@@ -242,7 +402,7 @@ class AggregationTree:
         t2 = time.perf_counter()
         root = None
         if self.public is not None:
-            pis = self.public.commit(batches)
+            pis = self.public.commit(batches, aggregator_address)
             if keep is not None:
                 keep.setdefault("public", []).append((0, pis.copy(), self.public.witness()))
             root = self.public.prove()

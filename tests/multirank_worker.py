@@ -73,11 +73,12 @@ def main():
         leaf = pkg.synth_circuit(dl, num_wires=135, num_routed=80, num_public_inputs=21, seed=11, poseidon=True, base_sum=True)
         priv = pkg.synth_circuit(db, num_wires=135, num_routed=60, num_public_inputs=21 * 8 + 8, seed=12, **rec)
         priv[0][14] = 1                                          # standard_recursion_zk_config: salted leaves
-        pub = pkg.synth_circuit(db, num_wires=135, num_routed=80, num_public_inputs=(21 * 8 + 8) * 8 + 8, seed=13, **rec)
+        pub = pkg.synth_circuit(db, num_wires=135, num_routed=80, num_public_inputs=agg.public_batch_pi_len(8, 8), seed=13, **rec)
         tree = agg.AggregationTree(pkg, gpu, rank, world, leaf, priv, pub)
         keep = {}
         SEED = 7000
-        leaves, batches, root = tree.run(dist, None, blinding_seed=SEED, keep=keep)
+        ADDRESS = b"".join(v.to_bytes(8, "little") for v in (0xA661, 2, 3, 4))
+        leaves, batches, root = tree.run(dist, None, blinding_seed=SEED, keep=keep, shuffle_seed=bytes(range(32)), aggregator_address=ADDRESS)
         ok = len(leaves) == 64 and len(batches) == 8
         # every proof this rank produced, against the oracle
         for (i, pis, w) in keep["leaf"]:
@@ -87,15 +88,27 @@ def main():
         if rank == tree.plan["root"]:
             (_, pis, w), = keep["public"]
             ok = ok and oracle_equal(pub[0], w, pis, root)
-            # the root holds exactly the 8 batch proofs in rank order, and they the 64 leaves
+            # the root's public inputs are the public-batch circuit's: aggregator address, the common block, and every batch
+            # proof's exit slots and nullifiers forwarded in rank order; a batch's are its 8 leaves' (any slot order):
+            # amounts merged per exit account, nullifiers sorted
             rp = agg.proof_public_inputs(root, pis.size)
             nb = 21 * 8 + 8
+            ok = ok and rp[:4].tolist() == [0xA661, 2, 3, 4] and tuple(rp[6:10].tolist()) == agg.TEST_BLOCK_HASH and int(rp[10]) == 42 and int(rp[11]) == 128
             for b in range(8):
                 bp = agg.proof_public_inputs(batches[b], nb)
-                ok = ok and np.array_equal(rp[b * nb:(b + 1) * nb], bp)
+                ok = ok and int(bp[0]) == 16 and tuple(bp[3:7].tolist()) == agg.TEST_BLOCK_HASH
+                ok = ok and np.array_equal(rp[12 + 80 * b:12 + 80 * (b + 1)], bp[8:88])
+                ok = ok and np.array_equal(rp[12 + 640 + 32 * b:12 + 640 + 32 * (b + 1)], bp[88:120])
+                want, nulls = {}, []
                 for j in range(8):
-                    ok = ok and np.array_equal(bp[21 * j:21 * j + 21], agg.leaf_public_inputs(8 * b + j))
-                    ok = ok and np.array_equal(agg.proof_public_inputs(leaves[8 * b + j], 21), agg.leaf_public_inputs(8 * b + j))
+                    lp = agg.leaf_public_inputs(8 * b + j)
+                    ok = ok and np.array_equal(agg.proof_public_inputs(leaves[8 * b + j], 21), lp)
+                    nulls.append(tuple(lp[4:8].tolist()))
+                    for acct, amt in ((tuple(lp[8:12].tolist()), int(lp[1])), (tuple(lp[12:16].tolist()), int(lp[2]))):
+                        want[acct] = want.get(acct, 0) + amt
+                got = {tuple(bp[9 + 5 * k:13 + 5 * k].tolist()): int(bp[8 + 5 * k]) for k in range(16) if int(bp[8 + 5 * k])}
+                ok = ok and got == {a: v for a, v in want.items() if v}
+                ok = ok and [tuple(bp[88 + 4 * k:92 + 4 * k].tolist()) for k in range(8)] == sorted(nulls)
         else:
             ok = ok and root is None
         tree.close()
