@@ -510,6 +510,19 @@ def main():
         orc = oracle_binding.Oracle()
         oc = oracle_binding.OracleCircuit(orc, pack)
         ok = ok and oc.verify(proof) == 0
+        # the library's own host verifier (include/qpgpu_verify.h) on the same proof, and its throughput over one step's proofs
+        pv = pkg.Verifier(pack, circuit=circ)
+        tv = time.perf_counter()
+        ok = ok and pv.verify(proof)
+        one_ms = (time.perf_counter() - tv) * 1e3
+        flipped = bytearray(proof); flipped[len(proof) // 2] ^= 1
+        ok = ok and not pv.verify(bytes(flipped))
+        tv = time.perf_counter()
+        ok = ok and all(pv.verify_many([proof] * 64))
+        extra["host_verifier"] = {"single_ms": round(one_ms, 3), "proofs_per_s_all_cores": round(64 / (time.perf_counter() - tv), 1),
+                                  "note": "qpgpu_verifier_verify: transcript replay, vanishing polynomial at zeta, proof of work, 28 query rounds; verifier data = "
+                                          "the circuit handle's constants/sigmas cap; also run by the aggregation tree at every commit and on the root"}
+        pv.close()
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             threads = oracle_binding.usable_cpus(16)

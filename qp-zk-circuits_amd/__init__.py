@@ -9,6 +9,6 @@ imported through `__graft_entry__.load_package()` under the module name `qp_zk_c
 """
 from .binding import poseidon_constants, synth_circuit, Circuit, QpGpu, QpGpuError, lib_path, load_library, P, MULT_GEN  # noqa: F401
 from .binding import PolyOracle, Challenger, fri_prove, set_hasher_poseidon, set_hasher_poseidon2, ProvingPool  # noqa: F401
-from .binding import pack_header, pack_public_input_cells  # noqa: F401
+from .binding import pack_header, pack_public_input_cells, Verifier  # noqa: F401
 from . import sharding  # noqa: F401,E402
 from . import aggregation  # noqa: F401,E402

@@ -196,8 +196,8 @@ class TemplateProver:
 class PrivateBatchProver(TemplateProver):
     """PrivateBatchProver::{commit, prove, aggregate} (private_batch/prover/lib.rs:244-343) on one GPU.
 
-    commit: the reference's admission checks on the supplied leaf proofs (qpgpu_private_batch_preflight, then the caller's
-    cryptographic `verify_leaf(proof) -> bool` if one is given), padding with the dummy leaf template, a uniform shuffle,
+    commit: the reference's admission checks on the supplied leaf proofs (qpgpu_private_batch_preflight, then the
+    cryptographic `verify_leaf(list of proofs) -> list of bool`, e.g. binding.Verifier.verify_many, if one is given), padding with the dummy leaf template, a uniform shuffle,
     one dummy-nullifier preimage per slot; the batch's public inputs are what the private-batch circuit would emit for
     those slots (qpgpu_private_batch_outputs) and the witness is regenerated from them on the device."""
 
@@ -210,7 +210,7 @@ class PrivateBatchProver(TemplateProver):
             # verify_dummy_leaf_template: the sentinel, then the cryptographic check
             self.dummy_pis = proof_public_inputs(dummy_leaf_proof, LEAF_PUBLIC_INPUTS)
             _call(_lib().qpgpu_dummy_leaf_template_check, self.dummy_pis.ctypes.data, self.dummy_pis.size)
-            if verify_leaf is not None and not verify_leaf(dummy_leaf_proof):
+            if verify_leaf is not None and not verify_leaf([dummy_leaf_proof])[0]:
                 raise ValueError("dummy leaf proof template failed verification")
         except Exception:
             self.close()
@@ -225,8 +225,8 @@ class PrivateBatchProver(TemplateProver):
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         _call(_lib().qpgpu_private_batch_preflight, rows.ctypes.data if rows.size else None, rows.shape[0], N)
         if self.verify_leaf is not None:
-            for i, p in enumerate(leaf_proofs):
-                if not self.verify_leaf(p):
+            for i, ok in enumerate(self.verify_leaf(list(leaf_proofs))):
+                if not ok:
                     raise ValueError("leaf proof %d failed verification against the pinned leaf verifier" % i)
         src = np.zeros(N, dtype=np.uint32)
         pre = np.zeros(4 * N, dtype=np.uint64)
@@ -281,7 +281,7 @@ class PublicBatchProver(TemplateProver):
                 raise ValueError("public-batch circuit public-input count is not 12 + 14 * M * N")
             self.dummy_pis = proof_public_inputs(dummy_private_batch_proof, self.inner_len)
             _call(_lib().qpgpu_dummy_private_batch_template_check, self.dummy_pis.ctypes.data, self.dummy_pis.size)
-            if verify_inner is not None and not verify_inner(dummy_private_batch_proof):
+            if verify_inner is not None and not verify_inner([dummy_private_batch_proof])[0]:
                 raise ValueError("dummy private-batch proof template failed verification")
         except Exception:
             self.close()
@@ -292,8 +292,8 @@ class PublicBatchProver(TemplateProver):
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         _call(_lib().qpgpu_public_batch_preflight, rows.ctypes.data if rows.size else None, rows.shape[0], self.inner_len, self.M)
         if self.verify_inner is not None:
-            for i, p in enumerate(inner_proofs):
-                if not self.verify_inner(p):
+            for i, ok in enumerate(self.verify_inner(list(inner_proofs))):
+                if not ok:
                     raise ValueError("private-batch proof %d failed verification against the pinned private-batch verifier" % i)
         padded = np.concatenate([rows] + [self.dummy_pis[None, :]] * (self.M - rows.shape[0]))
         return public_batch_outputs(padded, self.N, aggregator_address)
@@ -331,34 +331,54 @@ class AggregationTree:
     gathered (sharding.gather_proof_bytes: RCCL on GPUs, gloo in rehearsals) and consumed by the next level.
     Reference call stack SURVEY.md 3.4; partitioning SURVEY.md 8e."""
 
-    def __init__(self, pkg, gpu, rank, world, leaf, private, public, num_leaves=64, slots=8, leaf_batch=8, private_batch=8, verify=None):
+    def __init__(self, pkg, gpu, rank, world, leaf, private, public, num_leaves=64, slots=8, leaf_batch=8, private_batch=8, verify="product"):
         """leaf / private / public: (pack, template_wires, ...) of the level's circuit (public only on the root).
         leaf_batch / private_batch: how many proofs of a level this rank proves in lockstep.
-        verify: optional {"leaf": fn(proof) -> bool, "private": fn(proof) -> bool}, the cryptographic half of the admission
-        checks. Construction proves the two padding templates, as the reference's artifact build does (dummy_proof.rs:104-115,
-        private_batch/circuit/build.rs:165-193)."""
+        verify: the cryptographic half of the admission checks and the root's self-verification. "product" (default): the
+        library's host verifier (binding.Verifier, verifier data = the GPU circuit handles' constants/sigmas caps), inner
+        proofs verified on all host cores; None: skipped; or {"leaf": fn, "private": fn, "public": fn} with
+        fn(list of proofs) -> list of bool. Construction proves the two padding templates, as the reference's artifact
+        build does (dummy_proof.rs:104-115, private_batch/circuit/build.rs:165-193)."""
         from . import sharding
-        verify = verify or {}
+        from .binding import Verifier
         self.sharding, self.rank, self.world, self.slots = sharding, rank, world, slots
         self.plan = sharding.aggregation_schedule(num_leaves, slots, world)
         self.mine = self.plan["ranks"][rank]
         self.num_batches = num_leaves // slots
+        self.verifiers = {}
+        product = verify == "product"
+        fns = {} if product or verify is None else dict(verify)
+        hk = gpu.lib.qpgpu_ctx_get_hasher(gpu.ctx) if product else 0
         self.leaf_batch = max(1, min(leaf_batch, len(self.mine["leaves"]))) if self.mine["leaves"] else 1
         self.leaf = TemplateProver(gpu, leaf[0], leaf[1], max_batch=self.leaf_batch)
+        if product:
+            self.verifiers["leaf"] = Verifier(leaf[0], circuit=self.leaf.circ, hasher=hk)
+            fns["leaf"] = self.verifiers["leaf"].verify_many
         self.leaf.commit(np.zeros(LEAF_PUBLIC_INPUTS, dtype=np.uint64))
         self.dummy_leaf_proof = self.leaf.prove()
         self.private_batch = max(1, min(private_batch, len(self.mine["private_batches"])))
-        self.private = PrivateBatchProver(gpu, private[0], private[1], self.dummy_leaf_proof, slots, verify.get("leaf"), max_batch=self.private_batch)
+        self.private = PrivateBatchProver(gpu, private[0], private[1], self.dummy_leaf_proof, slots, fns.get("leaf"), max_batch=self.private_batch)
         self.times = {}
         self.public = None
+        self.verify_root = None
         if rank == self.plan["root"]:
+            if product:
+                self.verifiers["private"] = Verifier(private[0], circuit=self.private.circ, hasher=hk)
+                fns["private"] = self.verifiers["private"].verify_many
             self.dummy_private_batch_proof = self.private.prove_dummy_template()
-            self.public = PublicBatchProver(gpu, public[0], public[1], self.dummy_private_batch_proof, self.num_batches, slots, verify.get("private"))
+            self.public = PublicBatchProver(gpu, public[0], public[1], self.dummy_private_batch_proof, self.num_batches, slots, fns.get("private"))
+            if product:
+                self.verifiers["public"] = Verifier(public[0], circuit=self.public.circ, hasher=hk)
+                fns["public"] = self.verifiers["public"].verify_many
+            self.verify_root = fns.get("public")
 
     def close(self):
         for p in (self.leaf, self.private, self.public):
             if p is not None:
                 p.close()
+        for v in self.verifiers.values():
+            v.close()
+        self.verifiers = {}
 
     def run(self, dist=None, device=None, blinding_seed=None, keep=None, shuffle_seed=None, aggregator_address=bytes(32)):
         """One pass over the tree. Returns (all leaf proofs, all private-batch proofs, root proof or None).
@@ -406,6 +426,9 @@ class AggregationTree:
             if keep is not None:
                 keep.setdefault("public", []).append((0, pis.copy(), self.public.witness()))
             root = self.public.prove()
+            # ProvingContext::prove_batch verifies what it has just proven before handing it on (aggregator.rs:224-225)
+            if self.verify_root is not None and not self.verify_root([root])[0]:
+                raise ValueError("public-batch proof failed self-verification")
         t3 = time.perf_counter()
         self.times = {"leaf_level_s": round(t1 - t0, 4), "private_level_s": round(t2 - t1, 4), "public_level_s": round(t3 - t2, 4)}
         return leaves, batches, root

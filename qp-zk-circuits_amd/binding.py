@@ -40,6 +40,12 @@ def load_library():
     vp, u64p = c.c_void_p, c.c_void_p
     sigs = {
         "qpgpu_version": (c.c_char_p, []),
+        "qpgpu_verifier_create": (c.c_int, [vp, c.c_size_t, vp, c.c_size_t, c.c_int, vp, c.c_size_t, c.POINTER(vp), c.c_char_p]),
+        "qpgpu_verifier_free": (None, [vp]),
+        "qpgpu_verifier_proof_size": (c.c_size_t, [vp]),
+        "qpgpu_verifier_constants_sigmas_cap": (c.c_int, [vp, vp, c.c_size_t]),
+        "qpgpu_verifier_verify": (c.c_int, [vp, c.c_char_p, c.c_size_t, c.c_char_p]),
+        "qpgpu_verifier_verify_many": (c.c_int, [vp, vp, vp, c.c_size_t, c.c_uint, vp, c.c_char_p]),
         "qpgpu_ctx_create": (c.c_int, [c.c_int, c.POINTER(vp)]),
         "qpgpu_ctx_destroy": (None, [vp]),
         "qpgpu_last_error": (c.c_char_p, [vp]),
@@ -333,6 +339,57 @@ class Circuit:
 
 
 ORACLE_VALUES, ORACLE_COEFFS, ORACLE_BLINDING, ORACLE_DEVICE_INPUT = 0, 1, 2, 4
+
+
+class Verifier:
+    """Host-side verifier of one circuit (include/qpgpu_verify.h): plonky2's VerifierCircuitData::verify over the circuit pack.
+    circuit: a loaded Circuit whose constants/sigmas cap becomes the verifier data (without one the cap is rebuilt from the
+    pack on the host). hasher: 0 Poseidon, 1 Poseidon2 (params None = the built-in qp-poseidon-core set)."""
+
+    def __init__(self, pack_words, circuit=None, cap=None, hasher=0, params=None):
+        lib = load_library()
+        self.lib = lib
+        pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
+        if cap is None and circuit is not None:
+            cap = circuit.constants_sigmas_cap(int(pw[11]))
+        cw = None if cap is None else np.ascontiguousarray(cap, dtype=np.uint64).reshape(-1)
+        pr = None if params is None else np.ascontiguousarray(params, dtype=np.uint64)
+        h = ctypes.c_void_p(); err = ctypes.create_string_buffer(200)
+        rc = lib.qpgpu_verifier_create(pw.ctypes.data, pw.size, None if cw is None else cw.ctypes.data, 0 if cw is None else cw.size, hasher,
+                                       None if pr is None else pr.ctypes.data, 0 if pr is None else pr.size, ctypes.byref(h), err)
+        if rc:
+            raise QpGpuError(rc, err.value.decode())
+        self.h = h
+        self.reason = ""
+
+    def close(self):
+        if self.h:
+            self.lib.qpgpu_verifier_free(self.h); self.h = None
+
+    def proof_size(self):
+        return int(self.lib.qpgpu_verifier_proof_size(self.h))
+
+    def verify(self, proof):
+        """True when accepted; otherwise False and .reason says which check failed."""
+        err = ctypes.create_string_buffer(200)
+        b = bytes(proof)
+        rc = self.lib.qpgpu_verifier_verify(self.h, b, len(b), err)
+        self.reason = err.value.decode()
+        return rc == 0
+
+    def verify_many(self, proofs, threads=0):
+        """[accepted?] per proof, verified on up to `threads` host threads (0 = all cores); .reason names the first rejection."""
+        n = len(proofs)
+        if n == 0:
+            return []
+        bufs = [bytes(p) for p in proofs]
+        ptrs = (ctypes.c_char_p * n)(*bufs)
+        lens = (ctypes.c_size_t * n)(*[len(b) for b in bufs])
+        res = (ctypes.c_int * n)()
+        err = ctypes.create_string_buffer(200)
+        self.lib.qpgpu_verifier_verify_many(self.h, ptrs, lens, n, threads, res, err)
+        self.reason = err.value.decode()
+        return [r == 0 for r in res]
 
 
 class ChallengerState(ctypes.Structure):

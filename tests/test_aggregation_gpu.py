@@ -36,7 +36,7 @@ def levels(pkg, gpu, orc):
 @pytest.mark.gpu
 def test_private_batch_commit_pads_shuffles_and_proves(pkg, gpu, levels):
     agg, ocs = levels["agg"], levels["ocs"]
-    verify_leaf = lambda p: ocs["leaf"].verify(p) == 0
+    verify_leaf = lambda ps: [ocs["leaf"].verify(p) == 0 for p in ps]
     pp = agg.PrivateBatchProver(gpu, levels["priv"][0], levels["priv"][1], levels["dummy_leaf"], N_LEAF, verify_leaf)
     try:
         pis = pp.commit(levels["leaves"][:3], seed=bytes(range(32)))
@@ -93,7 +93,7 @@ def test_public_batch_commit_pads_in_order_and_proves(pkg, gpu, levels):
         inner = pp.prove()
     finally:
         pp.close()
-    verify_inner = lambda p: ocs["priv"].verify(p) == 0
+    verify_inner = lambda ps: [ocs["priv"].verify(p) == 0 for p in ps]
     address = b"".join(v.to_bytes(8, "little") for v in (5, 6, 7, 8))
     pub = agg.PublicBatchProver(gpu, levels["pub"][0], levels["pub"][1], dummy_batch, N_INNER, N_LEAF, verify_inner)
     try:
