@@ -1,7 +1,8 @@
 /*
  * prove_example.c — the C ABI used from plain C, the way a Rust `extern "C"` block would use it
  * (INTEGRATION.md): build a synthetic leaf-shaped circuit, load it, prove twice, check determinism; then regenerate the
- * witness on the device from its free cells and push eight proofs through a four-worker proving pool.
+ * witness on the device from its free cells, push eight proofs through a four-worker proving pool, prove four in one
+ * lockstep batch, and check a proof with the library's host verifier (verifier data = the circuit handle's cap).
  *
  *   gcc -O2 -I include examples/prove_example.c -L qp-zk-circuits_amd -lqpgpu -Wl,-rpath,$PWD/qp-zk-circuits_amd -o /tmp/prove_example
  */
@@ -9,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "qpgpu.h"
+#include "qpgpu_verify.h"
 
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, ctx ? qpgpu_last_error(ctx) : "?"); return 1; } } while (0)
 
@@ -60,6 +62,32 @@ int main(int argc, char **argv) {
         }
         qpgpu_pool_destroy(pool);
         CHECK(qpgpu_free(ctx, d_wires));
+        free(outs);
+    }
+    {   /* four proofs of one circuit in lockstep (every stage launched once for the batch), then host verification */
+        qpgpu_circuit *batch = NULL;
+        void *d_w = NULL;
+        size_t bytes = (size_t)num_wires * ((size_t)1 << degree_bits) * 8;
+        CHECK(qpgpu_circuit_load_batch(ctx, pack, got, 4, &batch));
+        CHECK(qpgpu_malloc(ctx, bytes, &d_w));
+        CHECK(qpgpu_memcpy_h2d(ctx, d_w, wires, bytes));
+        const uint64_t *ws[4] = {d_w, d_w, d_w, d_w}, *ps[4] = {pis, pis, pis, pis};
+        uint8_t *outs = malloc(4 * cap), *op[4];
+        size_t lens[4];
+        for (int i = 0; i < 4; i++) op[i] = outs + (size_t)i * cap;
+        CHECK(qpgpu_prove_batch_dev(batch, ws, 4, ps, op, cap, lens));
+        for (int i = 0; i < 4; i++) if (lens[i] != cap || memcmp(op[i], p1, cap)) { fprintf(stderr, "batch proof %d differs\n", i); return 8; }
+        uint64_t cs_cap[4 << 4];
+        char why[QPGPU_VERIFY_ERR_CAP];
+        qpgpu_verifier *v = NULL;
+        CHECK(qpgpu_circuit_constants_sigmas_cap(batch, cs_cap, 4 << 4));
+        if (qpgpu_verifier_create(pack, got, cs_cap, 4 << 4, 0, NULL, 0, &v, why)) { fprintf(stderr, "verifier: %s\n", why); return 9; }
+        if (qpgpu_verifier_verify(v, p1, cap, why)) { fprintf(stderr, "own proof rejected: %s\n", why); return 9; }
+        p2[cap / 3] ^= 1;
+        if (qpgpu_verifier_verify(v, p2, cap, why) != QPGPU_EVERIFY) { fprintf(stderr, "tampered proof accepted\n"); return 9; }
+        qpgpu_verifier_free(v);
+        CHECK(qpgpu_free(ctx, d_w));
+        qpgpu_circuit_free(batch);
         free(outs);
     }
     uint64_t h = 1469598103934665603ull;

@@ -55,6 +55,9 @@ int qpgpu_profile_read(qpgpu_ctx *ctx, const char *kernel, double *total_ms, uin
 /* ---- device memory plumbing ---- */
 int qpgpu_malloc(qpgpu_ctx *ctx, size_t bytes, void **dptr);
 int qpgpu_free(qpgpu_ctx *ctx, void *dptr);
+/* for buffers that held a witness: overwritten with zeros on the ctx stream, then released (the reference's zeroization
+ * policy, wormhole/circuit/src/sensitive.rs:36-44) */
+int qpgpu_free_scrubbed(qpgpu_ctx *ctx, void *dptr, size_t bytes);
 int qpgpu_memcpy_h2d(qpgpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int qpgpu_memcpy_d2h(qpgpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int qpgpu_memcpy_d2d(qpgpu_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);   /* asynchronous on the ctx stream */

@@ -51,8 +51,11 @@ extern "C" {
     pub fn qpgpu_ctx_set_hasher(ctx: *mut QpgpuCtx, kind: i32, params: *const u64, n_words: usize) -> i32;
     pub fn qpgpu_malloc(ctx: *mut QpgpuCtx, bytes: usize, dptr: *mut *mut c_void) -> i32;
     pub fn qpgpu_free(ctx: *mut QpgpuCtx, dptr: *mut c_void) -> i32;
+    pub fn qpgpu_free_scrubbed(ctx: *mut QpgpuCtx, dptr: *mut c_void, bytes: usize) -> i32;
+    pub fn qpgpu_memcpy_h2d(ctx: *mut QpgpuCtx, dst: *mut c_void, src: *const c_void, bytes: usize) -> i32;
     pub fn qpgpu_circuit_load_batch(ctx: *mut QpgpuCtx, pack: *const u64, n_words: usize, max_batch: u32, out: *mut *mut QpgpuCircuit) -> i32;
     pub fn qpgpu_circuit_free(c: *mut QpgpuCircuit);
+    pub fn qpgpu_circuit_scrub(c: *mut QpgpuCircuit) -> i32;
     pub fn qpgpu_circuit_set_witness_check(c: *mut QpgpuCircuit, on: i32) -> i32;
     pub fn qpgpu_proof_size(c: *const QpgpuCircuit) -> usize;
     pub fn qpgpu_prove(c: *mut QpgpuCircuit, wires: *const u64, public_inputs: *const u64, out: *mut u8, out_cap: usize, out_len: *mut usize) -> i32;
@@ -62,7 +65,15 @@ extern "C" {
     pub fn qpgpu_prove_batch_dev(c: *mut QpgpuCircuit, d_wires: *const *const u64, batch: u32, public_inputs: *const *const u64,
                                  outs: *const *mut u8, out_cap: usize, out_lens: *mut usize) -> i32;
     pub fn qpgpu_pack_validate(pack: *const u64, n_words: usize, err: *mut c_char) -> i32;
+    pub fn qpgpu_circuit_constants_sigmas_cap(c: *const QpgpuCircuit, out: *mut u64, out_words: usize) -> i32;
+    // include/qpgpu_verify.h — host-side verification of the bytes the GPU produced (debug self-check; production keeps
+    // plonky2's own `VerifierCircuitData::verify`, which is what consumers of the proof run anyway)
+    pub fn qpgpu_verifier_create(pack: *const u64, n_words: usize, cs_cap: *const u64, cap_words: usize, hasher_kind: i32,
+                                 hasher_params: *const u64, n_params: usize, out: *mut *mut QpgpuVerifier, err: *mut c_char) -> i32;
+    pub fn qpgpu_verifier_free(v: *mut QpgpuVerifier);
+    pub fn qpgpu_verifier_verify(v: *const QpgpuVerifier, proof: *const u8, len: usize, err: *mut c_char) -> i32;
 }
+#[repr(C)] pub struct QpgpuVerifier { _private: [u8; 0] }
 
 fn last_error(ctx: *const QpgpuCtx) -> String {
     unsafe { std::ffi::CStr::from_ptr(qpgpu_last_error(ctx)).to_string_lossy().into_owned() }
@@ -258,6 +269,39 @@ impl GpuCircuit {
         if rc != QPGPU_OK { bail!("{}", last_error(self.ctx)) }      // callers wrap: "Failed to prove: {e}" (prover/src/lib.rs:174)
         bytes.truncate(len);
         ProofWithPublicInputs::from_bytes(bytes, &data.common)
+    }
+
+    /// Many witnesses of this circuit at once (the aggregator's leaves): `GpuCircuit::from_circuit_data(.., max_batch)` sized
+    /// the workspace; every stage is launched once for the batch. Proof i is byte-identical to `prove` of witness i alone.
+    pub fn prove_batch<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+        &self, data: &CircuitData<F, C, D>, witnesses: Vec<PartialWitness<F>>,
+    ) -> Result<Vec<ProofWithPublicInputs<F, C, D>>> {
+        let n = data.common.degree();
+        let size = unsafe { qpgpu_proof_size(self.circuit) };
+        let (mut d_wires, mut pis_all): (Vec<*mut c_void>, Vec<Vec<u64>>) = (Vec::new(), Vec::new());
+        for pw in witnesses {
+            let partition = plonky2::iop::generator::generate_partial_witness(pw, &data.prover_only, &data.common)?;
+            pis_all.push(partition.get_targets(&data.prover_only.public_inputs).iter().map(|f| f.to_canonical_u64()).collect());
+            let full = partition.full_witness();
+            let mut wires: Vec<u64> = Vec::with_capacity(full.wire_values.len() * n);
+            for col in &full.wire_values { wires.extend(col.iter().map(|f| f.to_canonical_u64())); }
+            let mut d: *mut c_void = core::ptr::null_mut();
+            if unsafe { qpgpu_malloc(self.ctx, wires.len() * 8, &mut d) } != QPGPU_OK { bail!("{}", last_error(self.ctx)) }
+            if unsafe { qpgpu_memcpy_h2d(self.ctx, d, wires.as_ptr() as *const c_void, wires.len() * 8) } != QPGPU_OK { bail!("{}", last_error(self.ctx)) }
+            for w in wires.iter_mut() { unsafe { core::ptr::write_volatile(w, 0) } }
+            d_wires.push(d);
+        }
+        let mut bufs: Vec<Vec<u8>> = (0..d_wires.len()).map(|_| vec![0u8; size]).collect();
+        let outs: Vec<*mut u8> = bufs.iter_mut().map(|b| b.as_mut_ptr()).collect();
+        let wire_ptrs: Vec<*const u64> = d_wires.iter().map(|d| *d as *const u64).collect();
+        let pi_ptrs: Vec<*const u64> = pis_all.iter().map(|p| p.as_ptr()).collect();
+        let mut lens = vec![0usize; d_wires.len()];
+        let rc = unsafe { qpgpu_prove_batch_dev(self.circuit, wire_ptrs.as_ptr(), d_wires.len() as u32, pi_ptrs.as_ptr(), outs.as_ptr(), size, lens.as_mut_ptr()) };
+        unsafe { qpgpu_circuit_scrub(self.circuit); }                 // device copies of everything derived from the witnesses
+        let bytes = data.common.config.num_wires * n * 8;
+        for d in d_wires { unsafe { qpgpu_free_scrubbed(self.ctx, d, bytes); } }   // witness copies zeroed before release
+        if rc != QPGPU_OK { bail!("{}", last_error(self.ctx)) }
+        bufs.into_iter().zip(lens).map(|(mut b, l)| { b.truncate(l); ProofWithPublicInputs::from_bytes(b, &data.common) }).collect()
     }
 }
 

@@ -124,9 +124,9 @@ class TemplateProver:
 
     def close(self):
         if self.circ is not None:
-            self.d_wires.free()
+            self.d_wires.free(scrub=True)          # witnesses: zeroed before release
             if self.d_template is not None:
-                self.d_template.free()
+                self.d_template.free(scrub=True)
             self.circ.close()
             self.circ = None
 

@@ -55,6 +55,7 @@ def load_library():
         "qpgpu_profile_read": (c.c_int, [vp, c.c_char_p, c.POINTER(c.c_double), c.POINTER(c.c_uint64)]),
         "qpgpu_malloc": (c.c_int, [vp, c.c_size_t, c.POINTER(vp)]),
         "qpgpu_free": (c.c_int, [vp, vp]),
+        "qpgpu_free_scrubbed": (c.c_int, [vp, vp, c.c_size_t]),
         "qpgpu_memcpy_h2d": (c.c_int, [vp, vp, vp, c.c_size_t]),
         "qpgpu_memcpy_d2h": (c.c_int, [vp, vp, vp, c.c_size_t]),
         "qpgpu_memcpy_d2d": (c.c_int, [vp, vp, vp, c.c_size_t]),
@@ -230,9 +231,13 @@ class DeviceBuffer:
         self.gpu._check(self.gpu.lib.qpgpu_memcpy_d2h(self.gpu.ctx, out.ctypes.data, self.ptr, out.nbytes))
         return out
 
-    def free(self):
+    def free(self, scrub=False):
+        """scrub=True for buffers that held a witness: zeroed on the device before release."""
         if self.ptr:
-            self.gpu.lib.qpgpu_free(self.gpu.ctx, self.ptr)
+            if scrub:
+                self.gpu.lib.qpgpu_free_scrubbed(self.gpu.ctx, self.ptr, self.nbytes)
+            else:
+                self.gpu.lib.qpgpu_free(self.gpu.ctx, self.ptr)
             self.ptr = None
 
 

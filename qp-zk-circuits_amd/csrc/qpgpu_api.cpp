@@ -108,6 +108,14 @@ int qpgpu_malloc(qpgpu_ctx *ctx, size_t bytes, void **dptr) {
     if (e != hipSuccess) return ctx->hip_fail(e, "hipMalloc");
     return QPGPU_OK;
 }
+int qpgpu_free_scrubbed(qpgpu_ctx *ctx, void *dptr, size_t bytes) {
+    if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
+    if (dptr && bytes) QP_HIP(ctx, hipMemsetAsync(dptr, 0, bytes, ctx->stream));
+    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    QP_HIP(ctx, hipFree(dptr));
+    return QPGPU_OK;
+}
 int qpgpu_free(qpgpu_ctx *ctx, void *dptr) {
     if (!ctx) return QPGPU_EINVAL;
     QP_DEV(ctx);
