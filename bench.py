@@ -313,11 +313,13 @@ def main():
         assert len(t_leaves) == 64 and len(t_batches) == 8
         tree = {"leaves": 64, "private_batches": 8, "public_batches": 1, "seconds": round(tdt, 4),
                 "trees_per_s": round(1.0 / tdt, 3), "levels_rank0": dict(atree.times),
+                "witness_dependency_levels": {k: int(p_.circ.witness_info()[1]) for k, p_ in (("leaf", atree.leaf), ("private", atree.private), ("public", atree.public)) if p_ is not None},
                 "shape": f"leaf 2^{d} rows (80 routed); private batch 2^{args.batch_degree_bits} rows zero-knowledge, 60 routed wires; "
                          f"public batch 2^{args.batch_degree_bits} rows, 80 routed; 135 wires; batches carry the 14-gate recursive-verifier mix",
                 "note": "shape-equivalent synthetic circuits per level; each level parses the previous level's gathered proof bytes, "
                         "runs the reference's admission checks, pads / shuffles, derives the public inputs the wrapper circuit would emit, regenerates its witness on the device (stage s1) and proves — a rank's "
-                        "leaves 32 at a time and its private batches 8 at a time in lockstep; the inner proofs are not verified in-circuit; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
+                        "leaves 32 at a time and its private batches 8 at a time in lockstep; the inner proofs are not verified in-circuit; stage s1 of the 2^16-row stand-ins is bound by their dependency depth (witness_dependency_levels x ~26 us per "
+                        "PoseidonGate level, one pass for all proofs of a lockstep batch) and is most of the private and public levels' time; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
                         "sequential on an M2 Max"}
         if rank == 0:
             # checker, untimed: the oracle verifies the root and one proof per level, and the root's public inputs hold the 8
