@@ -118,6 +118,61 @@ def test_zero_knowledge_proof_matches_oracle_under_seed(pkg, gpu, orc):
     circ.close(); oc.close()
 
 
+def _opened_salts(pkg, pack, proof):
+    """The salt elements a zero-knowledge proof publishes: the last four entries of every opened row of the three blinded
+    oracles, 28 query rounds each (proof layout of stage s12)."""
+    h = pkg.pack_header(pack)
+    d, rb, ch, nch = h["degree_bits"], h["rate_bits"], h["cap_height"], h["num_challenges"]
+    ncs = h["num_selectors"] + h["num_constants"] + h["num_routed_wires"]
+    npp = h["num_partial_products"]
+    widths = [ncs, h["num_wires"] + 4, nch * (1 + npp) + 4, nch * h["quotient_degree_factor"] + 4]
+    cap = (1 << ch) * 32
+    arity = [int(x) for x in pack[18:18 + h["num_arity_rounds"]]]
+    pos = 3 * cap + (ncs + h["num_wires"] + 2 * nch + nch * npp + nch * h["quotient_degree_factor"]) * 16 + len(arity) * cap
+    L = d + rb
+    out = []
+    for _ in range(h["num_query_rounds"]):
+        for o, w in enumerate(widths):
+            row = np.frombuffer(proof, dtype="<u8", count=w, offset=pos)
+            if o:
+                out.extend(int(v) for v in row[-4:])
+            pos += 8 * w
+            plen = proof[pos]; pos += 1 + 32 * plen
+        lvl = L
+        for ab in arity:
+            lvl -= ab
+            pos += (1 << ab) * 16
+            plen = proof[pos]; pos += 1 + 32 * plen
+    fin = d - sum(arity)
+    assert pos + (1 << fin) * 16 + 8 + 8 * h["num_public_inputs"] == len(proof)      # the walk ended where the final polynomial starts
+    return out
+
+
+def test_salts_are_fresh_per_proof_and_look_uniform(pkg, gpu, orc):
+    """Zero-knowledge salts come from ChaCha20 keyed with operating-system entropy per proof: what one proof opens (28 x 3 x 4
+    values with known positions) must not recur in, or line up with, another proof of the same witness."""
+    pack, wires, pis = pkg.synth_circuit(9, num_wires=135, num_routed=80, num_public_inputs=21, seed=9)
+    zk = pack.copy(); zk[14] = 1
+    circ = pkg.Circuit(gpu, zk); oc = OracleCircuit(orc, zk)
+    try:
+        proofs = [circ.prove(wires, pis) for _ in range(3)]
+        salts = [_opened_salts(pkg, zk, p) for p in proofs]
+        for p, s in zip(proofs, salts):
+            assert oc.verify(p) == 0 and len(s) == 28 * 3 * 4 and all(v < pkg.P for v in s)
+        # a query may hit the same leaf twice; apart from that the values neither repeat inside a proof nor across proofs
+        assert all(len(set(s)) > 0.9 * len(s) for s in salts)
+        assert not (set(salts[0]) & set(salts[1])) and not (set(salts[0]) & set(salts[2])) and not (set(salts[1]) & set(salts[2]))
+        allv = np.array([v for s in salts for v in s], dtype=np.uint64)
+        for bit in (63, 40, 17, 0):
+            frac = float(((allv >> np.uint64(bit)) & np.uint64(1)).mean())
+            assert 0.4 < frac < 0.6, (bit, frac)
+        # a linear or counter-based generator shows up as few distinct consecutive differences; here all differ
+        diffs = {(int(b) - int(a)) % pkg.P for a, b in zip(salts[0][:-1], salts[0][1:])}
+        assert len(diffs) > 0.9 * (len(salts[0]) - 1)
+    finally:
+        circ.close(); oc.close()
+
+
 def test_private_batch_sized_trace_verifies(pkg, gpu, orc):
     """2^15 rows (the N=7 private-batch degree, reference common/src/circuit.rs:393-395): too slow for a byte
     comparison against the CPU prover inside the suite, so the size-independent property is used: the restated
