@@ -1,5 +1,6 @@
 """Randomised differential run: circuit shapes, gate mixes, FRI knobs, zero knowledge and witness hints drawn at random;
-GPU proof bytes against the CPU restatement, the restated verifier, and device witness generation against the full witness.
+GPU proof bytes against the CPU restatement, the restated verifier and the library's own host verifier, a lockstep batch of
+three against the single-proof bytes, and device witness generation against the full witness.
 usage: fuzz_shapes.py [cases] [seed] [max degree_bits]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -40,6 +41,20 @@ for i in range(cases):
     want = oc.prove(wires, pis, seed=7 + i)
     assert got == want, "BYTES DIFFER " + desc
     assert oc.verify(got) == 0, "REJECTED " + desc
+    ver = pkg.Verifier(pack, circuit=circ)
+    assert ver.verify(got), "LIBRARY VERIFIER REJECTED " + desc + " " + ver.reason
+    bad = bytearray(got); bad[int(rng.integers(0, len(got)))] ^= 1 << int(rng.integers(0, 8))
+    assert not ver.verify(bytes(bad)) and oc.verify(bytes(bad)) != 0, "TAMPERING ACCEPTED " + desc
+    ver.close()
+    if d <= 9 or i % 4 == 0:      # the lockstep path over the same shape: proof b of the batch is blinded with seed + b
+        cb = pkg.Circuit(gpu, pack, max_batch=3)
+        cb.set_blinding_seed(7 + i)
+        dense = gpu.to_device(np.stack([wires] * 3))
+        outs = cb.prove_batch_dev([dense.ptr + b * wires.nbytes for b in range(3)], [pis] * 3)
+        assert outs[0] == got, "BATCH PROOF 0 DIFFERS " + desc
+        for b in (1, 2):
+            assert outs[b] == (oc.prove(wires, pis, seed=7 + i + b) if zk else got), f"BATCH PROOF {b} DIFFERS " + desc
+        dense.free(); cb.close()
     mask = circ.witness_free_mask(*wires.shape)
     full = circ.generate_witness(np.where(mask == 1, wires, 0).astype(np.uint64), pis)
     assert (full == wires).all(), "WITNESS DIFFERS " + desc
