@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 --kernel-trace --stats output directory: copies the kernel stats table and extracts the
 per-launch durations of the 2^20 x 128 NTT launches (Grid_Size_Y == 128) the bench's roofline object refers to.
-usage: python tools/profile_summary.py <rocprof_dir> <out_prefix>"""
+usage: python tools/profile_summary.py <rocprof_dir> <out_prefix> [profiled command]"""
 import csv, glob, json, os, shutil, sys
 
 src, prefix = sys.argv[1], sys.argv[2]
@@ -19,8 +19,15 @@ for path in trace:
         if gy // max(wy, 1) != 128 and gy != 128:
             continue
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-        launches.setdefault(name.split("(anonymous namespace)::")[-1], []).append(dur)
-out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py (default command), MI355X; 2^20 x 128 launches selected by grid Y == 128",
+        gx = int(r.get("Grid_Size_X", r.get("Grid_Size_x", "0")) or 0)
+        launches.setdefault(name.split("(anonymous namespace)::")[-1], []).append((gx, dur))
+# other legs launch the same kernels on 128 columns of shorter polynomials (a 2^19-point LDE): keep the 2^20-point launches,
+# the ones with the widest grid
+for k, v in launches.items():
+    top = max(g for g, _ in v)
+    launches[k] = [d for g, d in v if g == top]
+cmd = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py (default command)"
+out = {"source": f"rocprofv3 --kernel-trace --stats -- {cmd}, MI355X; 2^20 x 128 launches selected by grid Y == 128",
        "launches": [{"kernel": k, "calls": len(v), "avg_ms": round(sum(v) / len(v), 4), "min_ms": round(min(v), 4)} for k, v in sorted(launches.items())]}
 json.dump(out, open(prefix + "_ntt_2p20_launches.json", "w"), indent=1)
 print(json.dumps(out["launches"]))

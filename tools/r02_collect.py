@@ -2,8 +2,9 @@
 """Turns the output of tools/r02_final.sh (gpurun_out/r02_final) into the tracked files under profiles/:
   r02_final_bench.json                  the default `python bench.py` line
   r02_final_bench_2rank_gloo.json       `bench.py --gpus 2` self-launched (two ranks on the box's one GPU, gloo rehearsal)
-  r02_final_bench_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the headline leg
-  r02_final_ntt_kernel_stats.csv / r02_final_ntt_2p20_launches.json   the same for tools/ntt_only.py (2^20 x 128 NTT)
+  r02_final_bench_kernel_stats.csv / r02_final_bench_ntt_2p20_launches.json    rocprofv3 --kernel-trace --stats of the default
+                                        command and the 2^20 x 128 NTT launches inside it
+  r02_final_ntt_only_kernel_stats.csv / r02_final_ntt_only_ntt_2p20_launches.json   the same for tools/ntt_only.py
   r02_final_ntt_pmc_summary.json        HBM bytes per transform (FETCH_SIZE / WRITE_SIZE passes)
   r02_final_ntt_valu_summary.json       VALU instructions per element and issue-slot share (SQ passes)
   r02_final_ntt_isa_hist.json           static instruction mix of the compiled NTT kernels (tools/isa_hist.py)
@@ -33,15 +34,15 @@ for name, out in (("bench.json", "r02_final_bench.json"), ("bench_2rank_gloo.jso
         json.dump(last_json_line(p), open(os.path.join(DST, out), "w"), indent=1)
         print("wrote", out)
 
-for d, prefix in (("prof_bench", "r02_final_bench"), ("prof_ntt", "r02_final_ntt")):
+# prof_bench: rocprofv3 --kernel-trace --stats of the default command (`python3 bench.py`) -> kernel stats of the whole run and
+# the 2^20 x 128 NTT launches inside it (what roofline.avg_ms must agree with); prof_ntt: the same for tools/ntt_only.py
+for d, prefix, cmd in (("prof_bench", "r02_final_bench", "python3 bench.py (default command)"),
+                       ("prof_ntt", "r02_final_ntt_only", "python3 tools/ntt_only.py 40")):
     if os.path.isdir(os.path.join(SRC, d)):
-        subprocess.check_call([PY, os.path.join(ROOT, "tools", "profile_summary.py"), os.path.join(SRC, d), os.path.join(DST, prefix)])
-bad = os.path.join(DST, "r02_final_ntt_ntt_2p20_launches.json")
-if os.path.exists(bad):
-    os.replace(bad, os.path.join(DST, "r02_final_ntt_2p20_launches.json"))
-empty = os.path.join(DST, "r02_final_bench_ntt_2p20_launches.json")     # the headline-only leg runs no 2^20 transform
-if os.path.exists(empty):
-    os.remove(empty)
+        subprocess.check_call([PY, os.path.join(ROOT, "tools", "profile_summary.py"), os.path.join(SRC, d), os.path.join(DST, prefix), cmd])
+for stale in ("r02_final_ntt_kernel_stats.csv", "r02_final_ntt_2p20_launches.json", "r02_final_ntt_ntt_2p20_launches.json"):
+    if os.path.exists(os.path.join(DST, stale)):
+        os.remove(os.path.join(DST, stale))
 
 if os.path.isdir(os.path.join(SRC, "pmc_fetch")) and os.path.isdir(os.path.join(SRC, "pmc_write")):
     subprocess.check_call([PY, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(SRC, "pmc_fetch"), os.path.join(SRC, "pmc_write"),

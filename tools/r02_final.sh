@@ -12,7 +12,7 @@ python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/
 QPGPU_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 2 --no-ntt --no-cpu-baseline --headline-only --batch-degree-bits 13 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; echo "2rank rc=$?" | tee -a $O/summary.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bench -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-tree --no-ntt --no-cpu-baseline --headline-only > $R/$O/prof_bench.log 2>&1; echo "prof rc=$?" | tee -a $R/$O/summary.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bench -o bench -- python3 $R/bench.py > $R/$O/prof_bench.log 2>&1; echo "prof rc=$?" | tee -a $R/$O/summary.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_ntt -o ntt -- python3 $R/tools/ntt_only.py 40 > $R/$O/prof_ntt.log 2>&1; echo "prof_ntt rc=$?" | tee -a $R/$O/summary.txt
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $R/$O/pmc_sq1 -o ntt -- python3 $R/tools/ntt_only.py 3 > $R/$O/pmc_sq1.log 2>&1; echo "pmc_sq1 rc=$?" | tee -a $R/$O/summary.txt
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE -d $R/$O/pmc_sq2 -o ntt -- python3 $R/tools/ntt_only.py 3 > $R/$O/pmc_sq2.log 2>&1; echo "pmc_sq2 rc=$?" | tee -a $R/$O/summary.txt
