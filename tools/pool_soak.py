@@ -1,5 +1,7 @@
 """Soak: thousands of proofs through the proving pool, every one compared with the first (same witness -> same bytes),
-plus a second witness interleaved. Catches rare races between workers / streams. usage: pool_soak.py [seconds]"""
+plus a second witness interleaved, through the batched pool (workers take up to max_batch queued jobs per lockstep pass, so
+batches mix the two witnesses in every composition). Catches rare races between workers / streams / batch slots.
+usage: pool_soak.py [seconds] [workers] [max_batch]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -17,13 +19,16 @@ w2 = circ.generate_witness(part2, pis)
 want = [circ.prove(wires, pis), circ.prove(w2, pis)]
 circ.close()
 d = [gpu.to_device(wires), gpu.to_device(w2)]
-pool = pkg.ProvingPool(pack, workers=6)
+workers = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+max_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+pool = pkg.ProvingPool(pack, workers=workers, max_batch=max_batch)
+rng = np.random.default_rng(1)
 t0 = time.time(); n = 0; bad = 0
 while time.time() - t0 < secs:
-    ts = [(pool.submit(d[i & 1], pis), i & 1) for i in range(64)]
+    ts = [(pool.submit(d[k], pis), k) for k in rng.integers(0, 2, 96).tolist()]
     for t, k in ts:
         bad += pool.wait(t) != want[k]
         n += 1
-print(f"{n} proofs in {time.time()-t0:.1f} s ({n/(time.time()-t0):.0f}/s), mismatches: {bad}")
+print(f"{n} proofs in {time.time()-t0:.1f} s ({n/(time.time()-t0):.0f}/s) through {workers} workers x {max_batch} lockstep slots, mismatches: {bad}")
 pool.close()
 assert bad == 0

@@ -12,11 +12,14 @@ pack, wires, pis = pkg.synth_circuit(10, num_routed=60, seed=8, poseidon=True, b
 pack[14] = 1
 gpu = pkg.QpGpu(0)
 d = gpu.to_device(wires)
-pool = pkg.ProvingPool(pack, workers=4)
+pool = pkg.ProvingPool(pack, workers=2, max_batch=16)
+circ = pkg.Circuit(gpu, pack)
+ver = pkg.Verifier(pack, circuit=circ)
 oc = oracle_binding.OracleCircuit(orc, pack)
 tickets = [pool.submit(d, pis) for _ in range(count)]
 proofs = [pool.wait(t) for t in tickets]
-bad = sum(oc.verify(p) != 0 for p in proofs)
-print(f"{count} zero-knowledge proofs: {bad} rejected, {len(set(proofs))} distinct")
+bad = sum(not ok for ok in ver.verify_many(proofs)) + sum(oc.verify(p) != 0 for p in proofs[::10])
+print(f"{count} zero-knowledge proofs through the batched pool: {bad} rejected (library verifier on all, oracle on every tenth), {len(set(proofs))} distinct")
+ver.close(); circ.close()
 pool.close()
 assert bad == 0 and len(set(proofs)) == count
