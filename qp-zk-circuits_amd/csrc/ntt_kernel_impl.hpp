@@ -79,6 +79,39 @@ __device__ __forceinline__ void dif_level(u64 (&x)[1 << K]) {
 template <int K, bool INV>
 __device__ __forceinline__ void dif_regs(u64 (&x)[1 << K]) { dif_level<K, INV, (1 << K)>(x); }
 
+// The same transform when only the first V = 2^LV of the 2^K inputs are non-zero (the first pass of a zero-padded LDE: a
+// coefficient vector of length n in a transform of length 8 n). With k = k1 + (2^K / V) k2: X[k] = DFT_V(x[v] w^(k1 v))[k2], so
+// the first K - LV butterfly levels collapse into one shift-multiply per element and only LV levels of butterflies remain.
+template <int K, bool INV, int LV>
+__device__ __forceinline__ void dif_sparse(u64 (&x)[1 << K]) {
+    constexpr int N = 1 << K, V = 1 << LV, G = N / V, UNIT = 192 / N;
+    u64 in[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) in[v] = x[v];
+#pragma unroll
+    for (int jh = 0; jh < G; jh++) {
+        const int k1 = brev(jh, K - LV);
+        if constexpr (LV == 1) {
+            int e = (UNIT * k1) % 192;
+            if (INV) e = (192 - e) % 192;
+            const u64 t = mul_pow2_dyn(in[1], e >= 96 ? e - 96 : e);       // a factor 2^96 = -1 swaps the two outputs
+            x[2 * jh] = e >= 96 ? gl::sub(in[0], t) : gl::add(in[0], t);
+            x[2 * jh + 1] = e >= 96 ? gl::add(in[0], t) : gl::sub(in[0], t);
+        } else {
+            u64 t[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                int e = (UNIT * k1 * v) % 192;
+                if (INV) e = (192 - e) % 192;
+                t[v] = e >= 96 ? gl::neg(mul_pow2_dyn(in[v], e - 96)) : mul_pow2_dyn(in[v], e);
+            }
+            dif_regs<LV, INV>(t);
+#pragma unroll
+            for (int v = 0; v < V; v++) x[jh * V + v] = t[v];
+        }
+    }
+}
+
 // Tile geometry shared by the two rounds of a pass.
 struct PassGeom {
     int T, tid, RP;
@@ -90,7 +123,7 @@ struct PassGeom {
 // Round A of a pass: loads 2^KA points per thread, coset scale, register transform, inner twiddles. With KB == 0 it also
 // finishes the pass. On return x holds the values to exchange and wr_base the LDS word of x[0] (x[q] goes NB + 1 words
 // further per q); TO_LDS stores them as whole 8-byte words right away. Returns whether this thread took part.
-template <int KA, int KB, bool INV, bool TO_LDS>
+template <int KA, int KB, bool INV, bool TO_LDS, int SPARSE>
 __device__ __forceinline__ bool ntt_round_a(const NttPassArgs &a, const PassGeom &g, u64 *lds, u64 (&x)[1 << KA], int &wr_base) {
     constexpr int NA = 1 << KA, NB = 1 << KB;
     const int T = g.T, tid = g.tid;
@@ -124,7 +157,9 @@ __device__ __forceinline__ bool ntt_round_a(const NttPassArgs &a, const PassGeom
             if (p < a.p_valid) x[i] = gl::mul(x[i], gl::mul(a.in_scale_a[p], sb));
         }
     }
-    dif_regs<KA, INV>(x);
+    // SPARSE > 0 (the LDE kernels): inputs i >= 2^SPARSE are zero for every thread of the pass (p_valid <= 2^SPARSE * NB)
+    if constexpr (SPARSE > 0) dif_sparse<KA, INV, SPARSE>(x);
+    else dif_regs<KA, INV>(x);
     if constexpr (KB > 0) {
 #pragma unroll
         for (int j = 0; j < NA; j++) {
@@ -197,7 +232,7 @@ __device__ __forceinline__ void ntt_round_b(const NttPassArgs &a, const PassGeom
 // One pass of one tile. Element s = j * NB + m of lane l crosses the rounds through LDS word l * RP + s + (s >> KB).
 // Whole-word mode: one 8-byte exchange, one barrier. SPLIT: the low and the high 32-bit halves go through the same 4-byte
 // slots one after the other — half the LDS per workgroup, so twice as many wavefronts share a CU, for two more barriers.
-template <int KA, int KB, bool INV, bool SPLIT>
+template <int KA, int KB, bool INV, bool SPLIT, int SPARSE = 0>
 __device__ __forceinline__ void ntt_pass_body(const NttPassArgs &a) {
     constexpr int NA = 1 << KA, NB = 1 << KB, R = 1 << (KA + KB);
     extern __shared__ __align__(16) u64 lds[];
@@ -214,7 +249,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs &a) {
         {
             u64 x[NA];
             int wr_base;
-            ntt_round_a<KA, KB, INV, true>(a, g, lds, x, wr_base);
+            ntt_round_a<KA, KB, INV, true, SPARSE>(a, g, lds, x, wr_base);
         }
         if constexpr (KB == 0) return;
         __syncthreads();
@@ -234,7 +269,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs &a) {
         u32 *lds32 = reinterpret_cast<u32 *>(lds);
         u64 x[NA];
         int wr_base;
-        const bool active_a = ntt_round_a<KA, KB, INV, false>(a, g, lds, x, wr_base);
+        const bool active_a = ntt_round_a<KA, KB, INV, false, SPARSE>(a, g, lds, x, wr_base);
         int j, l;   // round B thread mapping
         if (a.store_lane_fast) { l = g.tid & (g.T - 1); j = g.tid >> a.log_t; }
         else { j = g.tid & (NA - 1); l = g.tid >> KA; }
@@ -279,9 +314,31 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 template <int KA, int KB>
 constexpr bool has_split_variant() { return KB > 0 && KA + KB >= 9; }
 
+// First pass of a zero-padded LDE (forward, strided): only the first 2 (KA = 4: a 2^13-coefficient column in a 2^16-point
+// transform) or 4 (KA = 5) inputs of every round-A thread are non-zero, so round A is dif_sparse.
+template <int KA, int KB>
+constexpr int lde_sparse_lv() { return (KB > 0 && KA == 4) ? 1 : (KB > 0 && KA == 5) ? 2 : 0; }
+template <int KA, int KB>
+__global__ void __launch_bounds__(512) ntt_pass_lde_kernel(const NttPassArgs a) {
+    ntt_pass_body<KA, KB, false, false, lde_sparse_lv<KA, KB>()>(a);
+}
+template <int KA, int KB>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_pass_lde_split_kernel(const NttPassArgs a) {
+    ntt_pass_body<KA, KB, false, true, lde_sparse_lv<KA, KB>()>(a);
+}
+
 template <int KA, int KB>
 hipError_t launch_dir(const NttPassArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
     const bool rows = KB > 0 && a.log_m == 0 && a.load_lane_fast == 0 && a.in_p_stride == 1 && a.in_row_stride > 1 && a.in_col_stride != 0;
+    if constexpr (lde_sparse_lv<KA, KB>() > 0) {
+        if (a.sparse_lv == lde_sparse_lv<KA, KB>() && !a.inverse) {
+            if constexpr (has_split_variant<KA, KB>()) {
+                if (a.split_lds) { hipLaunchKernelGGL((ntt_pass_lde_split_kernel<KA, KB>), grid, block, lds, st, a); return hipGetLastError(); }
+            }
+            hipLaunchKernelGGL((ntt_pass_lde_kernel<KA, KB>), grid, block, lds, st, a);
+            return hipGetLastError();
+        }
+    }
     if constexpr (has_split_variant<KA, KB>()) {
         if (a.split_lds) {
             if (rows) {
@@ -313,6 +370,14 @@ hipError_t set_lds_attr() {
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+    }
+    if constexpr (lde_sparse_lv<KA, KB>() > 0) {
+        hipError_t e = hipFuncSetAttribute((const void *)ntt_pass_lde_kernel<KA, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if constexpr (has_split_variant<KA, KB>()) {
+            e = hipFuncSetAttribute((const void *)ntt_pass_lde_split_kernel<KA, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
     }
     if constexpr (has_split_variant<KA, KB>()) {
         const void *sp[4] = {(const void *)ntt_pass_split_kernel<KA, KB, false, false>, (const void *)ntt_pass_split_kernel<KA, KB, true, false>,

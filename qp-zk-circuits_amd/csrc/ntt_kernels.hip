@@ -62,6 +62,14 @@ hipError_t ntt_pass_launch(const NttPassArgs &a_in, uint64_t n_tiles, uint64_t n
     NttPassArgs a = a_in;
     const int ka = a.ka, kb = a.kb;
     a.split_lds = ntt_pass_uses_split(ka, kb) ? 1 : 0;
+    // zero-padded input (first pass of an LDE): thread inputs i * 2^kb + m are zero from p_valid on. QPGPU_NTT_SPARSE=0 disables.
+    static const int sparse = [] { const char *e = getenv("QPGPU_NTT_SPARSE"); return e && *e ? atoi(e) : 1; }();
+    a.sparse_lv = -1;
+    if (sparse && kb > 0 && !a.inverse) {       // the LDE kernels exist for ka = 4 (two live inputs) and ka = 5 (four)
+        const uint64_t nb = 1ull << kb;
+        if (ka == 4 && a.p_valid <= 2 * nb) a.sparse_lv = 1;
+        else if (ka == 5 && a.p_valid <= 4 * nb) a.sparse_lv = 2;
+    }
     if (n_cols > 65535 || n_proofs > 65535 || n_proofs == 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)n_tiles, (unsigned)n_cols, n_proofs);
     dim3 block((unsigned)(1u << (ka + a.log_t)), 1, 1);

@@ -31,6 +31,7 @@ struct NttPassArgs {
     uint32_t out_loose;        // 1: the output is an intermediate of the transform and need not be canonical
     uint64_t tw_scale;         // non-zero: folded into the running twiddle product (the 1/N of an inverse transform)
     uint32_t tw_mode;          // 0: two table reads per element; 1: per-thread running product; 2: skipped (timing experiments only)
+    int32_t sparse_lv;         // set by ntt_pass_launch: >= 0 when only the first 2^sparse_lv inputs of every round-A thread can be non-zero
     uint32_t split_lds;        // set by ntt_pass_launch: exchange the 32-bit halves one after the other (half the LDS per workgroup)
     const uint64_t *in_scale_a;  // coset input scale: x[p, mm] *= a[p] * b[mm]; null: none
     const uint64_t *in_scale_b;
