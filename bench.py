@@ -69,7 +69,7 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
     roof = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "ntt_pass_kernel<5,5,*> (one strided launch + one rows launch = one 2^20 transform; each launch is credited half of the transform's 16*N*B algorithmic bytes)",
+        "kernel": "ntt_pass_split_kernel<5,5,*> (one strided launch + one rows launch = one 2^20 transform; each launch is credited half of the transform's 16*N*B algorithmic bytes)",
         "avg_ms": {"ntt_pass_strided": round(ms_s / max(n_s, 1), 4), "ntt_pass_rows": round(ms_r / max(n_r, 1), 4)},
         "algorithmic_bytes_per_transform": 16 * n * batch, "workload": f"2^{log_n} points x {batch} columns",
     }
