@@ -25,6 +25,7 @@ extern "C" {
 #define QPGPU_MAX_PROOF_COUNT 64
 #define QPGPU_MAX_ARTIFACT_FILE_BYTES (64ull * 1024 * 1024)
 #define QPGPU_WIRE_ERR_CAP 200
+#define QPGPU_CONFIG_ERR_CAP 400     /* err buffers of the CircuitConfig policy functions (the reference's messages are long) */
 
 /* ---- proof hex (the CLI hand-off format) ---- */
 /* hex::encode: lowercase, no prefix; returns 2 * len, or 0 when out_cap < 2 * len + 1 (the output is NUL-terminated) */
@@ -59,6 +60,25 @@ const char *qpgpu_artifact_name(int level, int kind);
  * outside every wire coset, or two cells mapping to one), k_is not distinct cosets, FRI reduction schedule inconsistent
  * with degree_bits / cap_height, public-input cells outside the routed trace, hint cells outside the routed trace. */
 int qpgpu_pack_validate(const uint64_t *pack_words, size_t n_words, char *err);
+
+/* ---- CircuitConfig policy (common/src/circuit.rs:378-571) ----
+ * plonky2's CircuitConfig as plain data, the three canonical Wormhole configs, the structural validation every Wormhole
+ * circuit constructor applies before building (validate_circuit_config, with its messages), and the canonicality check of
+ * the artifact loaders (ensure_config_is_canonical, aggregator/src/common/utils.rs:248-262) applied to a circuit pack's
+ * header — what the exporter runs before handing a pack to the prover. */
+typedef struct {
+    uint64_t num_wires, num_routed_wires, num_constants, security_bits, num_challenges, max_quotient_degree_factor;
+    int use_base_arithmetic_gate, zero_knowledge;
+    uint64_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds;     /* fri_config */
+    uint64_t reduction_arity_bits, reduction_final_poly_bits;                  /* FriReductionStrategy::ConstantArityBits(4, 5) */
+} qpgpu_circuit_config;
+/* level: QPGPU_LEVEL_LEAF / _PUBLIC_BATCH = standard_recursion_config; _PRIVATE_BATCH = standard_recursion_zk_config with
+ * 135 wires, 60 routed. Returns -1 for an unknown level. */
+int qpgpu_wormhole_circuit_config(int level, qpgpu_circuit_config *out);
+int qpgpu_validate_circuit_config(const qpgpu_circuit_config *cfg, char *err);     /* err: QPGPU_CONFIG_ERR_CAP bytes */
+/* The config fields a pack header carries (wires, routed wires, challenges, quotient degree factor, rate, cap height, proof
+ * of work, query rounds, zero knowledge) against the level's canonical config. */
+int qpgpu_pack_config_is_canonical(const uint64_t *pack_words, size_t n_words, int level, char *err);   /* err: QPGPU_CONFIG_ERR_CAP bytes */
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // wire.cpp — proof hex, config.json, artifact names and the circuit-pack validator (host only). C ABI and reference
 // citations: include/qpgpu_wire.h.
 #include <cctype>
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -238,6 +239,73 @@ int qpgpu_pack_validate(const uint64_t *pack_words, size_t n_words, char *err) {
             if (h) return fail(err, "sigma is not a permutation: two cells map to (row " + std::to_string(ri->second) + ", wire " + std::to_string(ci->second) + ")");
             h = 1;
         }
+    return 0;
+}
+
+
+// ---- CircuitConfig policy ----
+int qpgpu_wormhole_circuit_config(int level, qpgpu_circuit_config *out) {
+    if (!out || level < QPGPU_LEVEL_LEAF || level > QPGPU_LEVEL_PUBLIC_BATCH) return -1;
+    // CircuitConfig::standard_recursion_config (SURVEY.md section 8 "Parameters common to all rows")
+    qpgpu_circuit_config c{};
+    c.num_wires = 135; c.num_routed_wires = 80; c.num_constants = 2; c.use_base_arithmetic_gate = 1; c.security_bits = 100;
+    c.num_challenges = 2; c.zero_knowledge = 0; c.max_quotient_degree_factor = 8;
+    c.rate_bits = 3; c.cap_height = 4; c.proof_of_work_bits = 16; c.num_query_rounds = 28;
+    c.reduction_arity_bits = 4; c.reduction_final_poly_bits = 5;
+    if (level == QPGPU_LEVEL_PRIVATE_BATCH) { c.zero_knowledge = 1; c.num_routed_wires = 60; }   // wormhole_private_batch_circuit_config
+    *out = c;
+    return 0;
+}
+
+static int cfg_fail(char *err, const char *fmt, ...) {
+    if (err) { va_list ap; va_start(ap, fmt); vsnprintf(err, QPGPU_CONFIG_ERR_CAP, fmt, ap); va_end(ap); }
+    return -1;
+}
+
+int qpgpu_validate_circuit_config(const qpgpu_circuit_config *c, char *err) {
+    if (!c) return cfg_fail(err, "null argument");
+    const struct { const char *name; uint64_t v; } zero[3] = {{"num_challenges", c->num_challenges}, {"security_bits", c->security_bits},
+                                                              {"fri_config.num_query_rounds", c->num_query_rounds}};
+    for (const auto &z : zero) if (z.v == 0) return cfg_fail(err, "circuit config %s must be greater than 0", z.name);
+    if (c->num_wires < 135) return cfg_fail(err, "circuit config num_wires (%llu) must be >= 135 (Poseidon gate floor)", (unsigned long long)c->num_wires);
+    if (c->num_routed_wires < 37)
+        return cfg_fail(err, "circuit config num_routed_wires (%llu) must be >= 37 (recursion gate floor: the FRI coset-interpolation gate routes 37 wires, "
+                             "and narrower widths leave slot-packed gates with zero operation slots)", (unsigned long long)c->num_routed_wires);
+    if (c->num_routed_wires > c->num_wires)
+        return cfg_fail(err, "circuit config num_routed_wires (%llu) must be <= num_wires (%llu); routed wires are a prefix of the wire columns",
+                        (unsigned long long)c->num_routed_wires, (unsigned long long)c->num_wires);
+    if (c->max_quotient_degree_factor < 7)
+        return cfg_fail(err, "circuit config max_quotient_degree_factor (%llu) must be >= 7 (Poseidon constraint degree)", (unsigned long long)c->max_quotient_degree_factor);
+    if (c->rate_bits > 8)
+        return cfg_fail(err, "circuit config fri_config.rate_bits (%llu) must be <= 8 (LDE memory doubles per bit: lde_size = 2^(degree_bits + rate_bits) per "
+                             "committed polynomial)", (unsigned long long)c->rate_bits);
+    if (c->cap_height > 8)
+        return cfg_fail(err, "circuit config fri_config.cap_height (%llu) must be <= 8 (Merkle caps and recursive verifier-data allocations scale as "
+                             "2^cap_height)", (unsigned long long)c->cap_height);
+    uint64_t bits = 0;
+    while ((1ull << bits) < c->max_quotient_degree_factor && bits < 63) bits++;
+    if (c->rate_bits < bits)
+        return cfg_fail(err, "circuit config fri_config.rate_bits (%llu) must be >= ceil(log2(max_quotient_degree_factor = %llu)) = %llu; plonky2's prover cannot "
+                             "compute quotient chunks of degree higher than the FRI rate and asserts this only at proving time, after the full circuit build",
+                        (unsigned long long)c->rate_bits, (unsigned long long)c->max_quotient_degree_factor, (unsigned long long)bits);
+    return 0;
+}
+
+int qpgpu_pack_config_is_canonical(const uint64_t *w, size_t n, int level, char *err) {
+    static const char *labels[3] = {"leaf", "private-batch", "public-batch"};
+    qpgpu_circuit_config c;
+    if (!w || qpgpu_wormhole_circuit_config(level, &c)) return cfg_fail(err, "bad argument");
+    if (n < 18 || w[0] != 0x0000003150435051ull) return cfg_fail(err, "not a circuit pack");
+    // header words (csrc/circuit.hpp): 2 num_wires, 3 routed, 6 challenges, 7 quotient degree factor, 10 rate, 11 cap, 12 pow, 13 queries, 14 zk
+    const struct { const char *name; uint64_t got, want; } f[9] = {
+        {"num_wires", w[2], c.num_wires}, {"num_routed_wires", w[3], c.num_routed_wires}, {"num_challenges", w[6], c.num_challenges},
+        {"quotient_degree_factor", w[7], c.max_quotient_degree_factor}, {"fri_config.rate_bits", w[10], c.rate_bits},
+        {"fri_config.cap_height", w[11], c.cap_height}, {"fri_config.proof_of_work_bits", w[12], c.proof_of_work_bits},
+        {"fri_config.num_query_rounds", w[13], c.num_query_rounds}, {"zero_knowledge", w[14], (uint64_t)c.zero_knowledge}};
+    for (const auto &x : f)
+        if (x.got != x.want)
+            return cfg_fail(err, "loaded %s circuit config does not match the canonical Wormhole config (%s loaded=%llu, expected=%llu)", labels[level], x.name,
+                            (unsigned long long)x.got, (unsigned long long)x.want);
     return 0;
 }
 

@@ -153,3 +153,22 @@ def test_poseidon2_as_the_proof_system_hasher(pkg, orc):
         oc.close()
     finally:
         orc.select_poseidon(); pkg.set_hasher_poseidon()
+
+
+def test_every_public_input_bit_flip_fails(pkg, orc):
+    """wormhole/tests/src/prover/verifier_tests.rs:110-128: a proof verifies only against the public inputs it was made for."""
+    pack, wires, pis = pkg.synth_circuit(7, num_wires=135, num_routed=80, num_public_inputs=21, seed=12, poseidon=True, base_sum=True)
+    oc = OracleCircuit(orc, pack); v = Verifier(pack)
+    try:
+        proof = oc.prove(wires, pis)
+        assert v.verify(proof)[0] == 0
+        base = len(proof) - 8 * len(pis)
+        rng = np.random.default_rng(2)
+        for i in range(len(pis)):
+            for bit in (0, int(rng.integers(1, 63)), 63):
+                b = bytearray(proof)
+                b[base + 8 * i + bit // 8] ^= 1 << (bit % 8)
+                rc, msg = v.verify(bytes(b))
+                assert rc == EVERIFY, (i, bit)
+    finally:
+        v.close(); oc.close()

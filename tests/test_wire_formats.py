@@ -125,3 +125,85 @@ def test_pack_validator_explains_refusals(lib, pkg):
         b = p2.copy(); b[11] = 7
         rc, err = check(b)
         assert rc != 0 and ("cap height" in err or "cap_height" in err), err
+
+
+# ---- CircuitConfig policy (common/src/circuit.rs:378-571, tests :589-675) ----
+
+class CircuitConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("num_wires", "num_routed_wires", "num_constants", "security_bits", "num_challenges", "max_quotient_degree_factor")] + \
+               [("use_base_arithmetic_gate", ctypes.c_int), ("zero_knowledge", ctypes.c_int)] + \
+               [(n, ctypes.c_uint64) for n in ("rate_bits", "cap_height", "proof_of_work_bits", "num_query_rounds", "reduction_arity_bits", "reduction_final_poly_bits")]
+
+
+def _lib():
+    import __graft_entry__ as ge
+    return ge.load_package().load_library()
+
+
+def _config(level):
+    lib = _lib()
+    c = CircuitConfig()
+    assert lib.qpgpu_wormhole_circuit_config(level, ctypes.byref(c)) == 0
+    return c
+
+
+def _validate(c):
+    err = ctypes.create_string_buffer(400)
+    rc = _lib().qpgpu_validate_circuit_config(ctypes.byref(c), err)
+    return rc, err.value.decode()
+
+
+def test_canonical_wormhole_configs_pass():
+    for level in (0, 1, 2):
+        assert _validate(_config(level))[0] == 0
+    leaf, priv, pub = _config(0), _config(1), _config(2)
+    assert (leaf.num_wires, leaf.num_routed_wires, leaf.zero_knowledge, leaf.rate_bits, leaf.cap_height, leaf.num_query_rounds) == (135, 80, 0, 3, 4, 28)
+    assert (priv.num_wires, priv.num_routed_wires, priv.zero_knowledge) == (135, 60, 1)
+    assert (pub.num_routed_wires, pub.zero_knowledge) == (80, 0)
+
+
+def test_structural_floors_are_enforced():
+    for field, value, needle in (("num_wires", 134, "num_wires"), ("num_routed_wires", 36, "num_routed_wires"), ("num_routed_wires", 136, "prefix"),
+                                 ("max_quotient_degree_factor", 6, "max_quotient_degree_factor")):
+        c = _config(1); setattr(c, field, value)
+        rc, msg = _validate(c)
+        assert rc != 0 and needle in msg, msg
+
+
+def test_fri_exponent_ceilings_are_enforced():
+    for bits in (9, 20, 63, (1 << 64) - 1):
+        c = _config(1); c.rate_bits = bits
+        assert "rate_bits" in _validate(c)[1]
+        c = _config(1); c.cap_height = bits
+        assert "cap_height" in _validate(c)[1]
+    c = _config(1); c.rate_bits = 8; c.cap_height = 8
+    assert _validate(c)[0] == 0
+
+
+def test_rate_bits_below_quotient_degree_are_rejected():
+    for bits in (1, 2):
+        c = _config(1); c.rate_bits = bits
+        rc, msg = _validate(c)
+        assert rc != 0 and "proving time" in msg
+
+
+def test_zero_knobs_are_rejected():
+    for field, needle in (("num_challenges", "num_challenges"), ("num_query_rounds", "num_query_rounds"), ("security_bits", "security_bits")):
+        c = _config(1); setattr(c, field, 0)
+        rc, msg = _validate(c)
+        assert rc != 0 and needle in msg
+
+
+def test_pack_config_is_canonical(pkg):
+    lib = _lib()
+    lib.qpgpu_pack_config_is_canonical.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p]
+    err = ctypes.create_string_buffer(400)
+    leaf, _, _ = pkg.synth_circuit(6, num_wires=135, num_routed=80, num_public_inputs=21, seed=1, poseidon=True)
+    assert lib.qpgpu_pack_config_is_canonical(leaf.ctypes.data, leaf.size, 0, err) == 0, err.value
+    assert lib.qpgpu_pack_config_is_canonical(leaf.ctypes.data, leaf.size, 2, err) == 0
+    assert lib.qpgpu_pack_config_is_canonical(leaf.ctypes.data, leaf.size, 1, err) != 0 and b"private-batch circuit config does not match" in err.value
+    priv, _, _ = pkg.synth_circuit(6, num_wires=135, num_routed=60, num_public_inputs=21, seed=1, poseidon=True)
+    priv[14] = 1
+    assert lib.qpgpu_pack_config_is_canonical(priv.ctypes.data, priv.size, 1, err) == 0, err.value
+    priv[13] = 20
+    assert lib.qpgpu_pack_config_is_canonical(priv.ctypes.data, priv.size, 1, err) != 0 and b"num_query_rounds loaded=20, expected=28" in err.value
