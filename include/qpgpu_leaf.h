@@ -140,6 +140,40 @@ int qpgpu_leaf_block_hash(const uint64_t *params, size_t n_words, const uint8_t 
                           const uint8_t state_root[32], const uint8_t extrinsics_root[32], const uint8_t zk_tree_root[32],
                           const uint8_t digest[QPGPU_LEAF_DIGEST_LOGS_SIZE], uint8_t out[32]);
 
+/* ---- the chain's 4-ary ZK Merkle tree, natively (common/src/zk_merkle.rs) ----
+ * Leaves: Poseidon2 of (to_account x4 at 8 bytes per element, transfer_count as two 32-bit limbs, asset_id, input_amount)
+ * (wormhole/circuit/src/zk_merkle_proof.rs:103-112,222-262,503-504). Internal nodes: Poseidon2 over the four children's 16
+ * limbs (8 bytes per element), children in sorted byte order; a proof carries the three siblings of every level in sorted
+ * order plus the position (0..3) where the running hash is inserted, so that neither the verifier nor the circuit sorts.
+ * Hash bytes must be canonical (every 8-byte limb below p): a non-canonical alias would hash like the genuine child. */
+#define QPGPU_ZK_ARITY 4
+int qpgpu_zk_leaf_hash(const uint8_t to_account[32], uint64_t transfer_count, uint32_t asset_id, uint32_t input_amount, uint8_t out[32]);
+/* hash_node_presorted: children = 4 x 32 bytes as given; -1 for a non-canonical child */
+int qpgpu_zk_hash_node_presorted(const uint8_t *children, uint8_t out[32]);
+/* hash_node: sorts the children first (order independent) */
+int qpgpu_zk_hash_node(const uint8_t *children, uint8_t out[32]);
+/* insert_at_position: out = 4 x 32 bytes; -1 when position > 3 */
+int qpgpu_zk_insert_at_position(const uint8_t current[32], const uint8_t *sorted_siblings, unsigned position, uint8_t *out);
+/* ZkMerkleProof::verify (= verify_with_positions): siblings = depth x 3 x 32 bytes, positions = depth bytes. Returns 1 when
+ * the proof leads to root, 0 otherwise (depth above 16, a position above 3, a non-canonical hash, a different root). */
+int qpgpu_zk_proof_verify(const uint8_t leaf_hash[32], const uint8_t *siblings, const uint8_t *positions, size_t depth, const uint8_t root[32]);
+/* ZkMerkleProof::from_unsorted: sorts every level's siblings, computes the position hints and the root the path leads to.
+ * sorted_out: depth x 3 x 32 bytes, positions_out: depth bytes. -1 with the reference's message for a depth above 16 or
+ * non-canonical hash bytes. */
+int qpgpu_zk_proof_from_unsorted(const uint8_t leaf_hash[32], const uint8_t *unsorted_siblings, size_t depth, uint8_t *sorted_out,
+                                 uint8_t *positions_out, uint8_t root_out[32], char *err);
+
+/* ---- the leaf circuit's constraints, natively ----
+ * What WormholeCircuit constrains about a CircuitInputs (wormhole/circuit/src/circuit.rs:233-323 and the fragments it wires:
+ * unspendable_account.rs:215-237, nullifier.rs:285-325, block_header/mod.rs:93-108, zk_merkle_proof.rs:480-626), evaluated on
+ * the host before any proving: the unspendable account is H(H("wormhole" || secret)); the fee relation
+ * (out_1 + out_2) * 10000 <= input * (10000 - fee_bps) with fee_bps <= 10000; depth <= 16 and positions <= 3; and, unless the
+ * inputs are a dummy (zero block hash and zero outputs): the nullifier is H(H("~nullif~" || secret || transfer_count)), the
+ * block hash is the Poseidon2 hash of the header, and the Merkle path from the leaf hash leads to the header's ZK tree
+ * root. Returns 0 when a proof can be generated, -4 naming the first constraint that cannot hold (what the reference's
+ * negative tests observe as a failed prove), -1 for malformed inputs (as qpgpu_leaf_fill_witness). */
+int qpgpu_leaf_check_constraints(const qpgpu_leaf_inputs *in, char *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,8 @@
 // end do, on qp-poseidon-core's parameter set (poseidon2::qp_params, pinned by all seven of the reference's known-answer
 // vectors) or on a caller-supplied block.
 #include <cstdio>
+#include <algorithm>
+#include <array>
 #include <cstring>
 #include <vector>
 #include "../../include/qpgpu_leaf.h"
@@ -283,6 +285,126 @@ int qpgpu_leaf_block_hash(const uint64_t *params, size_t n_words, const uint8_t 
     if (qpgpu_bytes_to_felts(digest, QPGPU_LEAF_DIGEST_LOGS_SIZE, pre + 17, 28) != 28) return -1;
     hash_pad10(p, pre, 45, h);
     qpgpu_digest_to_bytes(h, out);
+    return 0;
+}
+
+
+// ---- common/src/zk_merkle.rs ----
+static bool canonical32(const uint8_t *h) { return qpgpu_bytes_digest_is_canonical(h) == 1; }
+
+int qpgpu_zk_leaf_hash(const uint8_t to_account[32], uint64_t transfer_count, uint32_t asset_id, uint32_t input_amount, uint8_t out[32]) {
+    if (!to_account || !out) return -1;
+    u64 pre[8];
+    qpgpu_bytes_to_digest(to_account, pre);
+    qpgpu_u64_to_felts(transfer_count, pre + 4);
+    pre[6] = asset_id; pre[7] = input_amount;
+    const int rc = qpgpu_poseidon2_hash_bytes(nullptr, 0, pre, 8, out);
+    std::memset(pre, 0, sizeof pre);       // the deposit's account and amount
+    return rc;
+}
+
+int qpgpu_zk_hash_node_presorted(const uint8_t *children, uint8_t out[32]) {
+    if (!children || !out) return -1;
+    u64 limbs[16];
+    for (int c = 0; c < 4; c++) {
+        if (!canonical32(children + 32 * c)) return -1;         // hash_bytes_compact rejects a limb >= p
+        qpgpu_bytes_to_digest(children + 32 * c, limbs + 4 * c);
+    }
+    return qpgpu_poseidon2_hash_bytes(nullptr, 0, limbs, 16, out);
+}
+
+int qpgpu_zk_hash_node(const uint8_t *children, uint8_t out[32]) {
+    if (!children || !out) return -1;
+    std::array<std::array<uint8_t, 32>, 4> sorted;      // [u8; 32]'s Ord: byte-lexicographic
+    std::memcpy(sorted.data(), children, 128);
+    std::sort(sorted.begin(), sorted.end());
+    return qpgpu_zk_hash_node_presorted(sorted[0].data(), out);
+}
+
+int qpgpu_zk_insert_at_position(const uint8_t current[32], const uint8_t *sibs, unsigned position, uint8_t *out) {
+    if (!current || !sibs || !out || position > 3) return -1;
+    for (unsigned slot = 0, k = 0; slot < 4; slot++) {
+        if (slot == position) std::memcpy(out + 32 * slot, current, 32);
+        else std::memcpy(out + 32 * slot, sibs + 32 * k++, 32);
+    }
+    return 0;
+}
+
+int qpgpu_zk_proof_verify(const uint8_t leaf_hash[32], const uint8_t *siblings, const uint8_t *positions, size_t depth, const uint8_t root[32]) {
+    if (!leaf_hash || !root || depth > QPGPU_LEAF_MAX_DEPTH || (depth && (!siblings || !positions))) return 0;
+    if (!canonical32(leaf_hash)) return 0;
+    for (size_t i = 0; i < depth * 3; i++) if (!canonical32(siblings + 32 * i)) return 0;
+    uint8_t cur[32], four[128];
+    std::memcpy(cur, leaf_hash, 32);
+    for (size_t l = 0; l < depth; l++) {
+        if (qpgpu_zk_insert_at_position(cur, siblings + 96 * l, positions[l], four)) return 0;
+        if (qpgpu_zk_hash_node_presorted(four, cur)) return 0;
+    }
+    return std::memcmp(cur, root, 32) == 0;
+}
+
+int qpgpu_zk_proof_from_unsorted(const uint8_t leaf_hash[32], const uint8_t *unsorted, size_t depth, uint8_t *sorted_out, uint8_t *positions_out,
+                                 uint8_t root_out[32], char *err) {
+    auto fail = [&](const char *m) { if (err) std::snprintf(err, QPGPU_LEAF_ERR_CAP, "%s", m); return -1; };
+    if (!leaf_hash || !root_out || (depth && (!unsorted || !sorted_out || !positions_out))) return fail("null argument");
+    if (depth > QPGPU_LEAF_MAX_DEPTH) return fail("from_unsorted: proof depth exceeds MAX_DEPTH");
+    if (!canonical32(leaf_hash)) return fail("from_unsorted: leaf hash bytes are noncanonical");
+    for (size_t i = 0; i < depth * 3; i++) if (!canonical32(unsorted + 32 * i)) return fail("from_unsorted: sibling hash bytes are noncanonical");
+    uint8_t cur[32];
+    std::memcpy(cur, leaf_hash, 32);
+    for (size_t l = 0; l < depth; l++) {
+        std::array<std::array<uint8_t, 32>, 4> four;
+        std::memcpy(four[0].data(), cur, 32);
+        std::memcpy(four[1].data(), unsorted + 96 * l, 96);
+        std::sort(four.begin(), four.end());
+        unsigned pos = 0;
+        while (std::memcmp(four[pos].data(), cur, 32)) pos++;   // the first slot holding the running hash
+        positions_out[l] = (uint8_t)pos;
+        for (unsigned slot = 0, k = 0; slot < 4; slot++) if (slot != pos) std::memcpy(sorted_out + 96 * l + 32 * k++, four[slot].data(), 32);
+        if (qpgpu_zk_hash_node_presorted(four[0].data(), cur)) return fail("from_unsorted: node hash failed");
+    }
+    std::memcpy(root_out, cur, 32);
+    return 0;
+}
+
+// ---- the leaf circuit's constraints on CircuitInputs ----
+int qpgpu_leaf_check_constraints(const qpgpu_leaf_inputs *in, char *err) {
+    auto fail = [&](int code, const char *m) { if (err) std::snprintf(err, QPGPU_LEAF_ERR_CAP, "%s", m); return code; };
+    if (!in) return fail(-1, "null argument");
+    {   // the same input validation as fill_witness (depth, positions, canonical digests)
+        uint64_t pis[QPGPU_LEAF_PUBLIC_INPUTS];
+        std::vector<uint32_t> t(QPGPU_LT_COUNT);
+        std::vector<uint64_t> v(QPGPU_LT_COUNT);
+        size_t cnt = 0;
+        const int rc = qpgpu_leaf_fill_witness(in, pis, t.data(), v.data(), QPGPU_LT_COUNT, &cnt, err);
+        for (auto &x : v) x = 0;
+        if (rc) return -1;
+    }
+    uint8_t h[32];
+    // UnspendableAccount::circuit: account_id == H(H(salt || secret)), unconditional
+    if (qpgpu_leaf_unspendable_account(nullptr, 0, in->secret, h)) return fail(-1, "hashing failed");
+    if (std::memcmp(h, in->unspendable_account, 32)) return fail(-4, "unspendable_account is not H(H(\"wormhole\" || secret))");
+    // ZkMerkleProofData::circuit: fee relation with its range checks (all amounts are 32-bit by type)
+    if (in->volume_fee_bps > 10000) return fail(-4, "volume_fee_bps exceeds 10000 (range check of 10000 - fee_bps)");
+    const uint64_t lhs = ((uint64_t)in->output_amount_1 + in->output_amount_2) * 10000ull;
+    const uint64_t rhs = (uint64_t)in->input_amount * (10000ull - in->volume_fee_bps);
+    if (lhs > rhs) return fail(-4, "fee constraint violated: (output_1 + output_2) * 10000 > input * (10000 - fee_bps)");
+    static const uint8_t zero32[32] = {0};
+    const bool dummy = !std::memcmp(in->block_hash, zero32, 32) && in->output_amount_1 == 0 && in->output_amount_2 == 0;
+    if (dummy) return 0;                    // the remaining bindings are multiplied by is_not_dummy
+    if (qpgpu_leaf_nullifier(nullptr, 0, in->secret, in->transfer_count, h)) return fail(-1, "hashing failed");
+    if (std::memcmp(h, in->nullifier, 32)) return fail(-4, "nullifier is not H(H(\"~nullif~\" || secret || transfer_count))");
+    if (qpgpu_leaf_block_hash(nullptr, 0, in->parent_hash, in->block_number, in->state_root, in->extrinsics_root, in->zk_tree_root, in->digest, h))
+        return fail(-1, "hashing failed");
+    if (std::memcmp(h, in->block_hash, 32)) return fail(-4, "block_hash is not the hash of the header contents");
+    // the Merkle path from the leaf (to_account = unspendable account) to the header's ZK tree root
+    if (qpgpu_zk_leaf_hash(in->unspendable_account, in->transfer_count, in->asset_id, in->input_amount, h)) return fail(-1, "hashing failed");
+    uint8_t four[128];
+    for (uint32_t l = 0; l < in->zk_merkle_depth; l++) {
+        if (qpgpu_zk_insert_at_position(h, &in->zk_merkle_siblings[l][0][0], in->zk_merkle_positions[l], four) || qpgpu_zk_hash_node_presorted(four, h))
+            return fail(-1, "malformed Merkle level");
+    }
+    if (std::memcmp(h, in->zk_tree_root, 32)) return fail(-4, "ZK Merkle path does not lead to the header's zk_tree_root");
     return 0;
 }
 

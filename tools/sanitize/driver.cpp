@@ -116,6 +116,27 @@ int main(int argc, char **argv) {
         std::vector<uint64_t> felts(bytes.size() / 4 + 2);
         (void)qpgpu_bytes_to_felts(bytes.data(), bytes.size(), felts.data(), felts.size());
     }
+    // ---- native ZK Merkle tree and leaf constraint check on random bytes ----
+    for (int i = 0; i < iters; i++) {
+        const size_t depth = rng() % 20;
+        std::vector<uint8_t> sib(96 * depth + 128), pos(depth + 1), sorted(96 * depth + 128), posout(depth + 1);
+        uint8_t leaf[32], root[32], out[128];
+        for (auto &b : sib) b = (uint8_t)rng();
+        for (auto &b : pos) b = (uint8_t)(rng() % 6);
+        for (auto &b : leaf) b = (uint8_t)rng();
+        if (i % 2) for (size_t k = 7; k < sib.size(); k += 8) sib[k] &= 0x7F;      // canonical limbs half of the time
+        if (i % 2) for (size_t k = 7; k < 32; k += 8) leaf[k] &= 0x7F;
+        (void)qpgpu_zk_proof_verify(leaf, sib.data(), pos.data(), depth, root);
+        if (qpgpu_zk_proof_from_unsorted(leaf, sib.data(), depth, sorted.data(), posout.data(), root, err) == 0 &&
+            qpgpu_zk_proof_verify(leaf, sorted.data(), posout.data(), depth, root) != 1) { fprintf(stderr, "from_unsorted proof does not verify\n"); return 1; }
+        (void)qpgpu_zk_hash_node(sib.data(), out);
+        (void)qpgpu_zk_insert_at_position(leaf, sib.data(), (unsigned)(rng() % 6), out);
+        qpgpu_leaf_inputs in;
+        uint8_t *raw = reinterpret_cast<uint8_t *>(&in);
+        for (size_t k = 0; k < sizeof in; k++) raw[k] = (uint8_t)rng();
+        if (i % 2) in.zk_merkle_depth %= 17;
+        (void)qpgpu_leaf_check_constraints(&in, err);
+    }
     printf("ok: %ld accepted, %ld rejected, %ld mutated packs refused\n", accepted, rejected, refused_packs);
     return 0;
 }
