@@ -219,3 +219,14 @@ def test_dummy_inputs_skip_the_conditional_bindings(L):
     y = consistent_inputs(L, outs=(5, 0))
     y.block_hash[:] = bytes(32)
     assert check(L, y)[0] == -4
+
+
+def test_the_reference_dummy_inputs_satisfy_the_circuit(L):
+    """build_dummy_circuit_inputs (wormhole/aggregator/src/dummy_proof.rs:58-84,125-170) — the reference's bench input and the
+    padding template's witness — is a dummy whose unspendable account is the first address known-answer vector: the one binding
+    that applies to it holds, with values the reference itself supplies."""
+    from test_leaf_witness import dummy_inputs
+    x = dummy_inputs()
+    assert check(L, x) == (0, "")
+    x.unspendable_account[0] ^= 1
+    assert check(L, x)[0] == -4
