@@ -398,6 +398,13 @@ int qpgpu_verifier_create(const uint64_t *pack_words, size_t n_words, const uint
     const CircuitPack &p = v->pack;
     if (p.num_challenges > 4 || p.arity_bits.size() > 16) { delete v; return fail(err, QPGPU_EINVAL, "circuit outside the supported range"); }
     for (u64 ab : p.arity_bits) if (ab == 0 || ab > 5) { delete v; return fail(err, QPGPU_EINVAL, "FRI arity outside 2..32"); }
+    {   // every FRI round's tree must still be at least as tall as the cap (the proof layout subtracts the two)
+        u64 lvl = p.degree_bits + p.rate_bits;
+        for (u64 ab : p.arity_bits) {
+            if (ab > lvl || lvl - ab < p.cap_height) { delete v; return fail(err, QPGPU_EINVAL, "FRI reduction schedule is inconsistent with degree_bits / cap_height"); }
+            lvl -= ab;
+        }
+    }
     const size_t want = ((size_t)1 << p.cap_height) * 4;
     if (cs_cap) {
         if (cap_words != want) { delete v; return fail(err, QPGPU_EINVAL, "constants/sigmas cap has %zu words, the circuit's cap height needs %zu", cap_words, want); }
@@ -621,7 +628,9 @@ int qpgpu_verifier_verify_many(const qpgpu_verifier *v, const uint8_t *const *pr
         }
     };
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+    try {
+        for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+    } catch (...) {}                 // no more threads to be had: the ones that started (and this one) drain the queue
     work();
     for (auto &t : pool) t.join();
     for (size_t i = 0; i < count; i++)
