@@ -12,7 +12,7 @@ launches = {}
 for path in trace:
     for r in csv.DictReader(open(path)):
         name = r.get("Kernel_Name", "")
-        if "_kernel<5, 5" not in name:
+        if "_kernel<5, 5" not in name or "_lde_" in name:      # the LDE variants belong to the proof legs, not to the 2^20 transform
             continue
         gy = int(r.get("Grid_Size_Y", r.get("Grid_Size_y", "0")) or 0)
         wy = int(r.get("Workgroup_Size_Y", "1") or 1)
