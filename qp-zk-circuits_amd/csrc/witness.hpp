@@ -27,6 +27,7 @@ struct WitnessArgs {
 };
 
 hipError_t wk_run_level(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st);
+hipError_t wk_run_combined(const WitnessArgs &a, uint32_t first, uint32_t n_generic, uint32_t n_poseidon, uint32_t batch, hipStream_t st);
 hipError_t wk_run_poseidon(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st);   // PoseidonGate instances, 16 lanes each
 hipError_t wk_fill_copies(const WitnessArgs &a, uint32_t batch, hipStream_t st);
 // wires[b * batch_stride + idx[i]] = vals[b * val_stride + i] (flat cell index = column * n + row); out[i] = wires[idx[i]]

@@ -18,8 +18,7 @@ using gl::u64;
 
 namespace {
 
-__global__ void __launch_bounds__(128) witness_level_kernel(WitnessArgs a, u32 first, u32 count) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void witness_level_body(WitnessArgs a, u32 first, u32 count, const u32 t) {
     if (t >= count) return;
     const WitnessInst in = a.insts[first + t];
     const u64 n = a.n;
@@ -182,9 +181,9 @@ __global__ void __launch_bounds__(128) witness_level_kernel(WitnessArgs a, u32 f
 // parallel, MDS gathered with wave shuffles. A single thread needs ~100 us for the 30 rounds, and a dependency level ends
 // when its slowest generator does. The S-box inputs recorded for the partial rounds are those of the textbook schedule:
 // the fast-basis formulation the gate's constraints use feeds the same values to the S-box.
-__global__ void __launch_bounds__(256) witness_poseidon_kernel(WitnessArgs a, u32 first, u32 count) {
+__device__ __forceinline__ void witness_poseidon_body(WitnessArgs a, u32 first, u32 count, const u32 tid) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x, slot = tid >> 4;
+    const u32 slot = tid >> 4;
     const int g = threadIdx.x & 15, lane_base = (threadIdx.x & 63) & ~15;
     const bool live = slot < count;
     const WitnessInst in = a.insts[first + (live ? slot : count - 1)];   // idle groups shadow the last instance, without stores
@@ -231,6 +230,20 @@ __global__ void __launch_bounds__(256) witness_poseidon_kernel(WitnessArgs a, u3
     if (g < 12) WR(12 + g, s);
 }
 
+__global__ void __launch_bounds__(128) witness_level_kernel(WitnessArgs a, u32 first, u32 count) {
+    witness_level_body(a, first, count, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) witness_poseidon_kernel(WitnessArgs a, u32 first, u32 count) {
+    witness_poseidon_body(a, first, count, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// One dependency level in one launch: the first `generic_blocks` workgroups run the level's ordinary generator instances (a
+// thread each), the rest its PoseidonGate rows (16 lanes each). Both halves are latency-bound (a level ends when its slowest
+// generator does), so running them side by side instead of back to back takes the longer of the two, not the sum.
+__global__ void __launch_bounds__(256) witness_combined_kernel(WitnessArgs a, u32 first, u32 n_generic, u32 n_poseidon, u32 generic_blocks) {
+    if (blockIdx.x < generic_blocks) witness_level_body(a, first, n_generic, blockIdx.x * blockDim.x + threadIdx.x);
+    else witness_poseidon_body(a, first + n_generic, n_poseidon, (blockIdx.x - generic_blocks) * blockDim.x + threadIdx.x);
+}
+
 // every routed cell takes the value of its copy class's source cell
 __global__ void __launch_bounds__(256) witness_fill_kernel(WitnessArgs a) {
     const u64 cell = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -272,6 +285,14 @@ hipError_t wk_run_level(const WitnessArgs &a, uint32_t first, uint32_t count, ui
 hipError_t wk_run_poseidon(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st) {
     if (count == 0 || batch == 0) return hipSuccess;
     hipLaunchKernelGGL(witness_poseidon_kernel, dim3((count + 15) / 16, batch), dim3(256), 0, st, a, first, count);
+    return hipGetLastError();
+}
+hipError_t wk_run_combined(const WitnessArgs &a, uint32_t first, uint32_t n_generic, uint32_t n_poseidon, uint32_t batch, hipStream_t st) {
+    if (batch == 0 || (n_generic == 0 && n_poseidon == 0)) return hipSuccess;
+    if (n_poseidon == 0) return wk_run_level(a, first, n_generic, batch, st);
+    if (n_generic == 0) return wk_run_poseidon(a, first, n_poseidon, batch, st);
+    const uint32_t gb = (n_generic + 255) / 256, pb = (n_poseidon + 15) / 16;
+    hipLaunchKernelGGL(witness_combined_kernel, dim3(gb + pb, batch), dim3(256), 0, st, a, first, n_generic, n_poseidon, gb);
     return hipGetLastError();
 }
 hipError_t wk_fill_copies(const WitnessArgs &a, uint32_t batch, hipStream_t st) {

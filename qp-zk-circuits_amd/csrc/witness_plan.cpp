@@ -368,11 +368,16 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
     a.hints = plan.d_hints; a.num_wires = (uint32_t)c->pack.num_wires;
     a.n = c->pack.n(); a.batch_stride = c->pack.num_wires * c->pack.n();
     a.num_routed = (uint32_t)c->pack.num_routed_wires; a.num_selectors = (uint32_t)c->pack.num_selectors;
+    // one launch per dependency level (ordinary instances and PoseidonGate rows side by side); QPGPU_WITNESS_COMBINED=0: two
+    static const bool combined = [] { const char *e = getenv("QPGPU_WITNESS_COMBINED"); return !(e && *e == '0'); }();
     ctx->prof_begin("witness_generate");
     for (size_t l = 0; l + 1 < plan.level_start.size(); l++) {
         const uint32_t lo = plan.level_start[l], mid = plan.level_poseidon[l], hi = plan.level_start[l + 1];
-        QP_HIP(ctx, wk_run_level(a, lo, mid - lo, batch, ctx->stream));
-        QP_HIP(ctx, wk_run_poseidon(a, mid, hi - mid, batch, ctx->stream));
+        if (combined) QP_HIP(ctx, wk_run_combined(a, lo, mid - lo, hi - mid, batch, ctx->stream));
+        else {
+            QP_HIP(ctx, wk_run_level(a, lo, mid - lo, batch, ctx->stream));
+            QP_HIP(ctx, wk_run_poseidon(a, mid, hi - mid, batch, ctx->stream));
+        }
     }
     QP_HIP(ctx, wk_fill_copies(a, batch, ctx->stream));
     ctx->prof_end();
