@@ -190,7 +190,22 @@ GL_HD u64 pow(u64 b, u64 e) {
     while (e) { if (e & 1) r = mul(r, b); b = sqr(b); e >>= 1; }
     return canon(r);
 }
-GL_HD u64 inv(u64 a) { return pow(a, P - 2); }
+GL_HD u64 sqr_n(u64 v, int n) { for (int i = 0; i < n; i++) v = sqr(v); return v; }
+// a^(p-2) by an addition chain: p - 2 = (2^31 - 1) * 2^33 + (2^32 - 1); e_k = a^(2^k - 1). 64 squarings + 10 products
+// (the binary method needs 63 + 63: the exponent has 63 one bits) — inversions sit on the critical path of the witness
+// generators (EqualityGenerator, NonzeroTestGenerator, QuotientGeneratorExtension) and of the partial-product rows.
+GL_HD u64 inv(u64 a) {
+    const u64 e2 = mul(sqr(a), a);
+    const u64 e4 = mul(sqr_n(e2, 2), e2);
+    const u64 e8 = mul(sqr_n(e4, 4), e4);
+    const u64 e16 = mul(sqr_n(e8, 8), e8);
+    const u64 e24 = mul(sqr_n(e16, 8), e8);
+    const u64 e28 = mul(sqr_n(e24, 4), e4);
+    const u64 e30 = mul(sqr_n(e28, 2), e2);
+    const u64 e31 = mul(sqr(e30), a);
+    const u64 e32 = mul(sqr(e31), a);
+    return canon(mul(sqr_n(e31, 33), e32));
+}
 GL_HD u64 root_of_unity(unsigned log_n) {
     u64 r = ROOT_2_32;
     for (unsigned i = log_n; i < 32; i++) r = sqr(r);
