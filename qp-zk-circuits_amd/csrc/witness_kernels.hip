@@ -110,10 +110,20 @@ __device__ __forceinline__ void witness_level_body(WitnessArgs a, u32 first, u32
         const u32 nc = g.param0, start_accs = 6 + (ext ? 2 * nc : nc);
         const e2 alpha = RD2(2);
         e2 acc = RD2(4);
-        for (u32 i = 0; i < nc; i++) {
-            const e2 cf = ext ? RD2(6 + 2 * i) : gl::e2_from(RD(6 + i));
-            acc = gl::e2_canon(gl::e2_add(gl::e2_mul(acc, alpha), cf));
-            WR2(i == nc - 1 ? 0 : start_accs + 2 * i, acc);
+        // the coefficients are fetched eight at a time before the chain that consumes them: a load issued inside the chain
+        // waits behind the previous step's store (same array), and its latency would be paid once per coefficient
+        for (u32 i0 = 0; i0 < nc; i0 += 8) {
+            e2 cf[8];
+#pragma unroll
+            for (u32 k = 0; k < 8; k++) cf[k] = i0 + k < nc ? (ext ? RD2(6 + 2 * (i0 + k)) : gl::e2_from(RD(6 + i0 + k))) : gl::e2_from(0);
+#pragma unroll
+            for (u32 k = 0; k < 8; k++) {
+                const u32 i = i0 + k;
+                if (i < nc) {
+                    acc = gl::e2_canon(gl::e2_add(gl::e2_mul(acc, alpha), cf[k]));
+                    WR2(i == nc - 1 ? 0 : start_accs + 2 * i, acc);
+                }
+            }
         }
         break;
     }
@@ -129,9 +139,17 @@ __device__ __forceinline__ void witness_level_body(WitnessArgs a, u32 first, u32
     case 11: {                                                                          // ExponentiationGate
         const u32 nb = g.param0;
         const u64 base = RD(0);
+        // all power bits first (independent loads, up to 128 of them), then the square-and-multiply chain without a load in it
+        u64 bits_lo = 0, bits_hi = 0;
+#pragma unroll 8
+        for (u32 i = 0; i < nb; i++) {
+            const u64 b = gl::canon(RD(1 + i)) & 1;
+            if (i < 64) bits_lo |= b << i; else bits_hi |= b << (i - 64);
+        }
         u64 cur = 1;
         for (u32 i = 0; i < nb; i++) {
-            const u64 prev = i == 0 ? 1 : gl::mul(cur, cur), bit = gl::canon(RD(1 + (nb - 1 - i)));
+            const u32 src = nb - 1 - i;
+            const u64 prev = i == 0 ? 1 : gl::mul(cur, cur), bit = src < 64 ? (bits_lo >> src) & 1 : (bits_hi >> (src - 64)) & 1;
             cur = gl::canon(bit ? gl::mul(prev, base) : prev);
             WR(2 + nb + i, cur);
         }
@@ -158,13 +176,20 @@ __device__ __forceinline__ void witness_level_body(WitnessArgs a, u32 first, u32
         u64 x = 1;
         u32 lo = 0, hi = deg;
         for (u32 c = 0; c <= ni; c++) {
-            for (u32 q = lo; q < hi; q++) {
+            e2 vals[8];                          // the chunk's values up front (a chunk has `deg` points, then deg - 1; longer chunks read the rest in place)
+            const u32 cnt = hi - lo;
+#pragma unroll
+            for (u32 k = 0; k < 8; k++) vals[k] = k < cnt ? RD2(1 + 2 * (lo + k)) : gl::e2_from(0);
+            auto step = [&](e2 v) {
                 e2 term = sp; term.a = gl::sub(term.a, x);
-                const e2 tv = gl::e2_scale(gl::e2_mul(RD2(1 + 2 * q), pr), gl::mul(x, inv_n));
+                const e2 tv = gl::e2_scale(gl::e2_mul(v, pr), gl::mul(x, inv_n));
                 ev = gl::e2_add(gl::e2_mul(ev, term), tv);
                 pr = gl::e2_mul(pr, term);
                 x = gl::mul(x, omega);
-            }
+            };
+#pragma unroll
+            for (u32 k = 0; k < 8; k++) if (k < cnt) step(vals[k]);
+            for (u32 q = lo + 8; q < hi; q++) step(RD2(1 + 2 * q));
             ev = gl::e2_canon(ev); pr = gl::e2_canon(pr);
             if (c == ni) break;
             WR2(s_int + 2 * c, ev); WR2(s_int + 2 * (ni + c), pr);
