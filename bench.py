@@ -4,11 +4,12 @@
 BASELINE.json metric: "Wormhole proofs/sec + ms/proof at 1/2/4/8 GPUs; NTT HBM GB/s vs peak".
 
 Headline workload (BASELINE configs[2], "Full Wormhole proof (LDE + Poseidon Merkle commit + FRI) on 1
-MI355X"): one proof per step per GPU of a shape-equivalent synthetic leaf circuit (the real circuit pack needs
-a Rust exporter): 2^13 rows, 135 wires, 80 routed, standard_recursion_config FRI (rate
-1/8, cap height 4, 28 queries, 16 PoW bits, arity 16). The witness is resident in HBM when the timed region
-starts; a proof ends when its bytes are in host memory. A step = one proof on each of the S streams of every GPU
-(S = --streams, 4 by default: independent pipelines, one HIP stream + workspace + host thread each).
+MI355X"): proofs of a shape-equivalent synthetic leaf circuit (the real circuit pack needs the Rust exporter under
+integration/): 2^13 rows, 135 wires, 80 routed, standard_recursion_config FRI (rate 1/8, cap
+height 4, 28 queries, 16 PoW bits, arity 16). The witnesses are resident in HBM when the timed region starts; a proof
+ends when its bytes are in host memory. A step = S proofs per GPU, S = --streams x --batch (6 workers x 32 proofs in
+lockstep by default: every worker has its HIP stream, batched workspace and host transcript thread inside the
+library's proving pool, and launches every stage once for its 32 proofs).
 value = proofs/s over all ranks.
 
 N ranks (BASELINE configs[3]): independent proofs per rank; every step's proof bytes are gathered over RCCL
@@ -150,7 +151,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree-bits", type=int, default=13)
     ap.add_argument("--batch-degree-bits", type=int, default=16, help="rows of the private / public batch circuits of the tree leg")
-    ap.add_argument("--streams", type=int, default=2, help="proving workers per GPU (one HIP stream + host transcript thread each)")
+    ap.add_argument("--streams", type=int, default=6, help="proving workers per GPU (one HIP stream + host transcript thread each)")
     ap.add_argument("--batch", type=int, default=32, help="proofs a worker proves in lockstep (qpgpu_prove_batch_dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
@@ -239,14 +240,20 @@ def main():
         """k steps = k*S proofs through the library's proving pool. All jobs are queued at once and the workers free-run;
         the main thread closes step j when its S proofs are written and, with several ranks, gathers that step's proof
         bytes over RCCL while the workers are already proving step j+1."""
-        bufs = [np.empty(proof_len, dtype=np.uint8) for _ in range(k * S)]
-        tickets = [prover_pool.submit(w_all.ptr + (i % S) * mat_bytes, pis_all[i % S], bufs[i]) for i in range(k * S)]
+        AHEAD = max(1, min(8, 3000 // S))   # steps queued ahead of the one being collected (the pool keeps at most 4096 unwaited jobs)
+        bufs = [np.empty(proof_len, dtype=np.uint8) for _ in range(min(k, AHEAD + 1) * S)]     # a ring: step j reuses step j - AHEAD - 1's
+
+        def submit_step(j):
+            return [prover_pool.submit(w_all.ptr + i * mat_bytes, pis_all[i], bufs[(j % (AHEAD + 1)) * S + i]) for i in range(S)]
+        tickets = {j: submit_step(j) for j in range(min(k, AHEAD))}
         last = None
         nonlocal gathered
         layout = step_layout          # proofs of one circuit have one size: metadata collectives run once
         step_done.clear()
         for j in range(k):
-            proofs = [prover_pool.wait(t) for t in tickets[j * S:(j + 1) * S]]
+            if j + AHEAD < k:
+                tickets[j + AHEAD] = submit_step(j + AHEAD)
+            proofs = [prover_pool.wait(t) for t in tickets.pop(j)]
             if world > 1:
                 gathered = pkg.sharding.gather_proof_bytes(proofs, dist, coll_dev, layout)
             last = proofs[0]

@@ -532,11 +532,22 @@ class ProvingPool:
             raise QpGpuError(rc, "qpgpu_pool_create failed")
         self.h = h
         self._keep = {}
+        # the workers write into the callers' output buffers: the pool must have drained before the interpreter frees them,
+        # also when an exception unwinds past the owner or the process exits without close()
+        import atexit
+        atexit.register(self.close)
 
     def close(self):
         if self.h:
-            self.lib.qpgpu_pool_destroy(self.h)
+            self.lib.qpgpu_pool_destroy(self.h)      # drains the queue first
             self.h = None
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def proof_size(self):
         return self.lib.qpgpu_pool_proof_size(self.h)

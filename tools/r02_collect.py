@@ -34,15 +34,15 @@ for name, out in (("bench.json", "r02_final_bench.json"), ("bench_2rank_gloo.jso
         json.dump(last_json_line(p), open(os.path.join(DST, out), "w"), indent=1)
         print("wrote", out)
 
-# prof_bench: rocprofv3 --kernel-trace --stats of the default command (`python3 bench.py`) -> kernel stats of the whole run and
-# the 2^20 x 128 NTT launches inside it (what roofline.avg_ms must agree with); prof_ntt: the same for tools/ntt_only.py
-for d, prefix, cmd in (("prof_bench", "r02_final_bench", "python3 bench.py (default command)"),
-                       ("prof_ntt", "r02_final_ntt_only", "python3 tools/ntt_only.py 40")):
-    if os.path.isdir(os.path.join(SRC, d)):
-        subprocess.check_call([PY, os.path.join(ROOT, "tools", "profile_summary.py"), os.path.join(SRC, d), os.path.join(DST, prefix), cmd])
-for stale in ("r02_final_ntt_kernel_stats.csv", "r02_final_ntt_2p20_launches.json", "r02_final_ntt_ntt_2p20_launches.json"):
-    if os.path.exists(os.path.join(DST, stale)):
-        os.remove(os.path.join(DST, stale))
+# the box summarised its kernel traces (tools/r02_final.sh -> tools/profile_summary.py): sum_bench = `python3 bench.py` (the default
+# command: kernel stats of the whole run and the 2^20 x 128 NTT launches inside it, what roofline.avg_ms must agree with),
+# sum_ntt_only = tools/ntt_only.py, sum_headline = the headline leg alone (kernel shares of a proof)
+for prefix, out in (("sum_bench", "r02_final_bench"), ("sum_ntt_only", "r02_final_ntt_only"), ("sum_headline", "r02_final_headline")):
+    for suffix in ("_kernel_stats.csv", "_ntt_2p20_launches.json"):
+        src = os.path.join(SRC, prefix + suffix)
+        if os.path.exists(src) and os.path.getsize(src) > 2 and not (prefix == "sum_headline" and suffix.endswith(".json")):
+            shutil.copy(src, os.path.join(DST, out + suffix))
+            print("copied", out + suffix)
 
 if os.path.isdir(os.path.join(SRC, "pmc_fetch")) and os.path.isdir(os.path.join(SRC, "pmc_write")):
     subprocess.check_call([PY, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(SRC, "pmc_fetch"), os.path.join(SRC, "pmc_write"),
