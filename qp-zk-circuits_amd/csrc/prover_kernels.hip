@@ -476,19 +476,20 @@ __global__ void __launch_bounds__(256) poly_eval_kernel(const u64 *coeffs, u64 n
 
 // ---------------------------------------------------------------- s8
 // comp[i] = sum_p alpha^p f_p[i] over the listed polynomials (several source batches)
-__global__ void __launch_bounds__(256) reduce_polys_kernel(ReduceArgs a) {
+__global__ void __launch_bounds__(256) reduce_polys_kernel(const ReduceArgs a) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const u64 pr = blockIdx.z;
-    a.alpha_pows += pr * a.ps_alpha; a.comp_a += pr * a.ps_comp; a.comp_b += pr * a.ps_comp;
+    // the argument block stays read-only: its arrays are indexed by the loop variable, and a modified copy would live in scratch
+    const e2 *alpha_pows = a.alpha_pows + pr * a.ps_alpha;
     e2 acc = gl::e2_from(0);
     u32 p = 0;
     for (u32 s = 0; s < a.nsrc; s++) {
         const u64 *base = a.src[s] + pr * a.ps_src[s];
-        for (u32 c = 0; c < a.ncols[s]; c++, p++) acc = gl::e2_add(acc, gl::e2_scale(a.alpha_pows[p], base[(u64)c * a.n + i]));
+        for (u32 c = 0; c < a.ncols[s]; c++, p++) acc = gl::e2_add(acc, gl::e2_scale(alpha_pows[p], base[(u64)c * a.n + i]));
     }
-    a.comp_a[i] = gl::canon(acc.a);
-    a.comp_b[i] = gl::canon(acc.b);
+    a.comp_a[pr * a.ps_comp + i] = gl::canon(acc.a);
+    a.comp_b[pr * a.ps_comp + i] = gl::canon(acc.b);
 }
 
 // q = comp / (X - z) by synthetic division: b_{i-1} = b_i z + comp_i (from the top), quotient coefficient
