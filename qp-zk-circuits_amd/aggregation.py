@@ -193,6 +193,24 @@ class TemplateProver:
         return proof
 
 
+class MemoVerifier:
+    """verify(list of proofs) -> list of bool over a verifier's verify_many, remembering verdicts: a level that admits its
+    inner proofs batch by batch can have all of them verified in one call (all host cores busy once) beforehand."""
+
+    def __init__(self, verify_many):
+        self.verify_many, self.seen = verify_many, {}
+
+    def __call__(self, proofs):
+        todo = [p for p in proofs if p not in self.seen]
+        if todo:
+            for p, ok in zip(todo, self.verify_many(todo)):
+                self.seen[p] = ok
+        return [self.seen[p] for p in proofs]
+
+    def forget(self):
+        self.seen.clear()
+
+
 class PrivateBatchProver(TemplateProver):
     """PrivateBatchProver::{commit, prove, aggregate} (private_batch/prover/lib.rs:244-343) on one GPU.
 
@@ -353,7 +371,7 @@ class AggregationTree:
         self.leaf = TemplateProver(gpu, leaf[0], leaf[1], max_batch=self.leaf_batch)
         if product:
             self.verifiers["leaf"] = Verifier(leaf[0], circuit=self.leaf.circ, hasher=hk)
-            fns["leaf"] = self.verifiers["leaf"].verify_many
+            fns["leaf"] = MemoVerifier(self.verifiers["leaf"].verify_many)
         self.leaf.commit(np.zeros(LEAF_PUBLIC_INPUTS, dtype=np.uint64))
         self.dummy_leaf_proof = self.leaf.prove()
         self.private_batch = max(1, min(private_batch, len(self.mine["private_batches"])))
@@ -404,6 +422,9 @@ class AggregationTree:
         # this rank's private batches in lockstep, in runs of consecutive batch numbers (proof j of a run is blinded with
         # seed + first + j, the same salts the one-at-a-time order would draw)
         pb = list(self.mine["private_batches"])
+        if isinstance(self.private.verify_leaf, MemoVerifier):     # all of this rank's leaves in one pass over the host cores
+            self.private.verify_leaf.forget()
+            self.private.verify_leaf([p for b in pb for p in leaves[b * self.slots:(b + 1) * self.slots]])
         k = 0
         while k < len(pb):
             run = [pb[k]]
