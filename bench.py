@@ -305,7 +305,7 @@ def main():
         tpub = None
         if rank == 0:
             tpub = pkg.synth_circuit(args.batch_degree_bits, num_wires=135, num_routed=80, num_public_inputs=agg.public_batch_pi_len(8, 8), seed=77, **rec)
-        atree = agg.AggregationTree(pkg, gpus[0], rank, world, tleaf, tpriv, tpub, leaf_batch=32)
+        atree = agg.AggregationTree(pkg, gpus[0], rank, world, tleaf, tpriv, tpub, leaf_batch=64)
         dd = dist if world > 1 else None
         atree.run(dd, coll_dev)
         barrier()
@@ -325,8 +325,8 @@ def main():
                          f"public batch 2^{args.batch_degree_bits} rows, 80 routed; 135 wires; batches carry the 14-gate recursive-verifier mix",
                 "note": "shape-equivalent synthetic circuits per level; each level parses the previous level's gathered proof bytes, "
                         "runs the reference's admission checks, pads / shuffles, derives the public inputs the wrapper circuit would emit, regenerates its witness on the device (stage s1) and proves — a rank's "
-                        "leaves 32 at a time and its private batches 8 at a time in lockstep; the inner proofs are not verified in-circuit; stage s1 of the 2^16-row stand-ins is bound by their dependency depth (witness_dependency_levels x ~26 us per "
-                        "PoseidonGate level, one pass for all proofs of a lockstep batch) and is most of the private and public levels' time; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
+                        "leaves (up to 64) and its private batches (up to 8) each as one lockstep batch; the inner proofs are not verified in-circuit; stage s1 of the 2^16-row stand-ins is bound by their dependency depth (witness_dependency_levels x ~40 us per "
+                        "level: its slowest generator, e.g. a lane-cooperative PoseidonGate row; one pass for all proofs of a lockstep batch) and is most of the private and public levels' time; reference (paper/main.tex:449-492): 64*0.020 + 8*5.39 + 3.84 = 48 s "
                         "sequential on an M2 Max"}
         if rank == 0:
             # checker, untimed: the oracle verifies the root and one proof per level, and the root's public inputs hold the 8

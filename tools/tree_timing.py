@@ -13,7 +13,7 @@ d, db = 13, 16
 tleaf = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000, poseidon=True, base_sum=True)
 tpriv = pkg.synth_circuit(db, num_wires=135, num_routed=60, num_public_inputs=176, seed=78, **rec); tpriv[0][14] = 1
 tpub = pkg.synth_circuit(db, num_wires=135, num_routed=80, num_public_inputs=agg.public_batch_pi_len(8, 8), seed=77, **rec)
-t = agg.AggregationTree(pkg, gpu, 0, 1, tleaf, tpriv, tpub, leaf_batch=32)
+t = agg.AggregationTree(pkg, gpu, 0, 1, tleaf, tpriv, tpub, leaf_batch=64)
 t.run(); t.run()
 print("levels", t.times)
 def clock(label, fn, reps=3):
