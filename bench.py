@@ -222,12 +222,16 @@ def main():
     # WORKERS lockstep batches of LOCKSTEP proofs in flight: streams, circuit workspaces and transcript threads live inside
     # the library (qpgpu_pool_create_batched)
     prover_pool = pkg.ProvingPool(pack, workers=WORKERS, device=local_rank, max_batch=LOCKSTEP)
-    # S different witnesses of the circuit resident in HBM (setup, untimed): witness 0 is the generator's own, the others
+    # S different witnesses of the circuit resident in HBM (setup, untimed): witness 0 carries the reference bench input's public inputs, the others
     # come from its free cells with other public inputs, completed by stage s1 on the device
     agg = pkg.aggregation
     mat_bytes = wires.size * 8
     w_all = gpu.alloc(S * mat_bytes)
-    pis_all = [pis] + [agg.leaf_public_inputs(1000 * rank + i) for i in range(1, S)]
+    # witness 0 carries the 21 public inputs of the reference bench's own input (build_dummy_circuit_inputs,
+    # wormhole/aggregator/src/dummy_proof.rs:125-170 as used by wormhole/prover/benches/prover.rs:31-42): asset 0, outputs 0/0,
+    # fee 10 bps, every digest zero (tests/test_leaf_witness.py derives the same vector through qpgpu_leaf_fill_witness)
+    pis0 = np.array([0, 0, 0, 10] + [0] * 17, dtype=np.uint64)
+    pis_all = [pis0] + [agg.leaf_public_inputs(1000 * rank + i) for i in range(1, S)]
     tp_ = agg.TemplateProver(gpu, pack, wires, max_batch=min(S, 16))
     for k0 in range(0, S, tp_.max_batch):
         chunk = pis_all[k0:k0 + tp_.max_batch]
@@ -235,6 +239,8 @@ def main():
         gpu._check(gpu.lib.qpgpu_memcpy_d2d(gpu.ctx, w_all.ptr + k0 * mat_bytes, tp_.d_wires.ptr, len(chunk) * mat_bytes))
     gpu.sync()
     tp_.close()
+    wires0 = np.empty(wires.shape, dtype=np.uint64)              # witness 0 as proved, for the oracle's byte-parity check below
+    gpu._check(gpu.lib.qpgpu_memcpy_d2h(gpu.ctx, wires0.ctypes.data, w_all.ptr, mat_bytes))
 
     def run_steps(k):
         """k steps = k*S proofs through the library's proving pool. All jobs are queued at once and the workers free-run;
@@ -439,7 +445,7 @@ def main():
             e2e = None
             WB16, s1_batch16 = WB, s1_batch
             WB = S
-            pB = np.tile(pis, (WB, 1))
+            pB = np.tile(pis0, (WB, 1))
             try:
                 ggen = pkg.QpGpu(local_rank)
                 cgen = pkg.Circuit(ggen, pack)
@@ -453,7 +459,7 @@ def main():
                 e2e_outs = [[np.empty(proof_len, dtype=np.uint8) for _ in range(WB)] for _ in range(2)]
 
                 def submit_batch(k):
-                    return [prover_pool.submit(bufs[k % 2].ptr + j * mat_bytes, pis, e2e_outs[k % 2][j]) for j in range(WB)]
+                    return [prover_pool.submit(bufs[k % 2].ptr + j * mat_bytes, pis0, e2e_outs[k % 2][j]) for j in range(WB)]
                 gen(bufs[0])
                 NB = 8
                 te = time.perf_counter()
@@ -542,7 +548,7 @@ def main():
             reps = 0
             t1 = time.perf_counter()
             while True:
-                cpu_proof = oc.prove(wires, pis)
+                cpu_proof = oc.prove(wires0, pis0)
                 reps += 1
                 if time.perf_counter() - t1 > 12.0 or reps >= 30:
                     break
