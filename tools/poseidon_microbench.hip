@@ -1,7 +1,8 @@
 // poseidon_microbench.hip — what bounds the Poseidon permutation on gfx950 (evidence for DESIGN.md section 4: "at the floor").
 //   * the MDS layer alone, in registers: the library's form (two 32-bit halves in signed 64-bit arithmetic, v_lshl_add_u64)
 //     against a three-limb form (22/21/21 bits) whose whole convolution fits 32-bit adds — fewer "expensive" instructions
-//     on paper, measured slower;
+//     on paper, measured slower; and the 64-bit form with its first butterfly stage on the 32-bit halves (carry pairs
+//     instead of zero-extended register pairs: 331 instead of 364 VALU instructions, 68 instead of 86 VGPRs, not faster);
 //   * the permutation in registers, with the round constants behind a kernel argument, the __constant__ symbol, and two
 //     laundered pointers (batched vs one-at-a-time scalar loads: no difference);
 //   * a leaf-hash-shaped kernel (135 columns, 17 permutations per leaf), plain and with the next chunk's loads issued early.
@@ -58,6 +59,53 @@ template <class RC> GL_HD void permute_as(u64 (&s)[WIDTH], RC rc) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
 }
+
+// first butterfly stage on the 32-bit halves themselves (33-bit results built from the carry / borrow), so no
+// zero-extended register pairs have to be materialised for the inputs
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ i64 add33(u32 a, u32 b) {
+    u32 lo, hi;
+    asm("v_add_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b) : "vcc");
+    return (i64)(((u64)hi << 32) | lo);
+}
+#else
+inline i64 add33(u32 a, u32 b) { return (i64)((u64)a + b); }
+#endif
+GL_HD i64 sub33(u32 a, u32 b) { return (i64)a - (i64)b; }
+GL_HD void mds_circulant_half_v2(const u32 (&x)[WIDTH], i64 (&o)[WIDTH]) {
+    i64 U1[3], Um[3], F[3], H[3];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const i64 e = add33(x[b], x[b + 6]), f = sub33(x[b], x[b + 6]), g = add33(x[b + 3], x[b + 9]), h = sub33(x[b + 3], x[b + 9]);
+        U1[b] = e + g; Um[b] = e - g; F[b] = f; H[b] = h;
+    }
+    const i64 T = U1[0] + U1[1] + U1[2];
+    const i64 A[3] = {T + U1[2], T + U1[0], T + U1[1]};
+    const i64 B[3] = {shl(Um[2], 3) - Um[0] - shl(Um[1], 1), -(shl(Um[0], 3) + Um[1] + shl(Um[2], 1)), shl(Um[0], 1) - shl(Um[1], 3) - Um[2]};
+    const i64 f0 = F[0], f1 = F[1], f2 = F[2], h0 = H[0], h1 = H[1], h2 = H[2];
+    const i64 R[3] = {shl(f0, 1) - h0 + f1 - shl(h1, 4) + f2 + shl(h2, 2), -shl(f0, 2) + h0 + shl(f1, 1) - h1 + f2 - shl(h2, 4), shl(f0, 4) + h0 - shl(f1, 2) + h1 + shl(f2, 1) - h2};
+    const i64 I[3] = {f0 + shl(h0, 1) + shl(f1, 4) + h1 - shl(f2, 2) + h2, -f0 - shl(h0, 2) + f1 + shl(h1, 1) + shl(f2, 4) + h2, -f0 + shl(h0, 4) - f1 - shl(h1, 2) + f2 + shl(h2, 1)};
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const i64 a16 = shl(A[b], 4), p = a16 + B[b], q = a16 - B[b];
+        o[b] = p + R[b]; o[b + 3] = q + I[b]; o[b + 6] = p - R[b]; o[b + 9] = q - I[b];
+    }
+}
+GL_HD void mds_layer_v2(u64 (&s)[WIDTH]) {
+    u32 lo[WIDTH], hi[WIDTH]; i64 ol[WIDTH], oh[WIDTH];
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    mds_circulant_half_v2(lo, ol);
+    mds_circulant_half_v2(hi, oh);
+    ol[0] += (i64)((u64)lo[0] << 3); oh[0] += (i64)((u64)hi[0] << 3);
+#pragma unroll
+    for (int r = 0; r < WIDTH; r++) {
+        const u64 al = (u64)ol[r], ah = (u64)oh[r];
+        const u64 low = al + (ah << 32);
+        const u32 top = (u32)(ah >> 32) + (low < al ? 1u : 0u);
+        s[r] = gl::reduce96(low, top);
+    }
+}
 GL_HD void mds_layer3(u64 (&s)[WIDTH]) {
     u32 l0[WIDTH], l1[WIDTH], l2[WIDTH], o0[WIDTH], o1[WIDTH], o2[WIDTH];
 #pragma unroll
@@ -76,7 +124,7 @@ GL_HD void mds_layer3(u64 (&s)[WIDTH]) {
 }
 }
 using gl::u64;
-template <int V> __device__ __forceinline__ void mds(u64 (&s)[12]) { if (V == 0) poseidon::mds_layer(s); else poseidon::mds_layer3(s); }
+template <int V> __device__ __forceinline__ void mds(u64 (&s)[12]) { if (V == 0) poseidon::mds_layer(s); else if (V == 1) poseidon::mds_layer3(s); else poseidon::mds_layer_v2(s); }
 template <int V> __device__ void perm(u64 (&s)[12], const u64 *rc) {
     using namespace poseidon;
     int r = 0;
@@ -202,7 +250,8 @@ int main() {
     u64 h[360]; for (int i = 0; i < 360; i++) h[i] = (0x123456789ABCDEFull * (i + 1)) % 0xFFFFFFFF00000001ull;
     u64 *rc; hipMalloc(&rc, sizeof h); hipMemcpy(rc, h, sizeof h, hipMemcpyHostToDevice);
     run<0, 0>("mds i64", 2000, rc); run<1, 0>("mds 3x u32", 2000, rc);
-    run<0, 1>("permute i64", 64, rc); run<1, 1>("permute 3x u32", 64, rc);
+    run<2, 0>("mds i64, 33-bit stage 1", 2000, rc);
+    run<0, 1>("permute i64", 64, rc); run<2, 1>("permute, 33-bit stage 1", 64, rc); run<1, 1>("permute 3x u32", 64, rc);
     hipMemcpyToSymbol(HIP_SYMBOL(c_rc), h, sizeof h);
     runc<1>("permute, __constant__", 64, rc); runc<2>("permute, laundered flat", 64, rc); runc<3>("permute, laundered as4", 64, rc);
     run_leaf<135, 0>("leaf W=135", 1ull << 21, rc); run_leaf<135, 1>("leaf W=135 prefetch", 1ull << 21, rc);
