@@ -28,6 +28,10 @@ struct WitnessArgs {
 
 hipError_t wk_run_level(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st);
 hipError_t wk_run_combined(const WitnessArgs &a, uint32_t first, uint32_t n_generic, uint32_t n_poseidon, uint32_t batch, hipStream_t st);
+// A run of consecutive narrow levels [l0, l1) in one launch: one workgroup per witness walks the levels with a workgroup barrier
+// between them (level l = insts[level_start[l] .. level_start[l+1]), its PoseidonGate rows from level_poseidon[l] on).
+constexpr uint32_t WITNESS_RUN_GENERIC_CAP = 1024, WITNESS_RUN_POSEIDON_CAP = 32;   // widest level a run takes
+hipError_t wk_run_levels(const WitnessArgs &a, const uint32_t *d_level_start, const uint32_t *d_level_poseidon, uint32_t l0, uint32_t l1, uint32_t batch, hipStream_t st);
 hipError_t wk_run_poseidon(const WitnessArgs &a, uint32_t first, uint32_t count, uint32_t batch, hipStream_t st);   // PoseidonGate instances, 16 lanes each
 hipError_t wk_fill_copies(const WitnessArgs &a, uint32_t batch, hipStream_t st);
 // wires[b * batch_stride + idx[i]] = vals[b * val_stride + i] (flat cell index = column * n + row); out[i] = wires[idx[i]]

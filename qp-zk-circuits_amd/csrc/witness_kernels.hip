@@ -206,7 +206,13 @@ __device__ __forceinline__ void witness_level_body(WitnessArgs a, u32 first, u32
 // parallel, MDS gathered with wave shuffles. A single thread needs ~100 us for the 30 rounds, and a dependency level ends
 // when its slowest generator does. The S-box inputs recorded for the partial rounds are those of the textbook schedule:
 // the fast-basis formulation the gate's constraints use feeds the same values to the S-box.
-__device__ __forceinline__ void witness_poseidon_body(WitnessArgs a, u32 first, u32 count, const u32 tid) {
+// rc: the 360 round constants staged in LDS by the calling kernel (stage_round_constants): the round loop is one dependent
+// chain per row, and a global load per round would put an L2 round trip on it thirty times.
+__device__ __forceinline__ void stage_round_constants(const WitnessArgs &a, u64 *rc_lds) {
+    for (u32 i = threadIdx.x; i < poseidon::ROUNDS * 12; i += blockDim.x) rc_lds[i] = a.poseidon_rc[i];
+    __syncthreads();
+}
+__device__ __forceinline__ void witness_poseidon_body(WitnessArgs a, u32 first, u32 count, const u32 tid, const u64 *rc) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     const u32 slot = tid >> 4;
     const int g = threadIdx.x & 15, lane_base = (threadIdx.x & 63) & ~15;
@@ -230,7 +236,7 @@ __device__ __forceinline__ void witness_poseidon_body(WitnessArgs a, u32 first, 
     }
 #pragma unroll 1
     for (int r = 0; r < poseidon::ROUNDS; r++) {
-        s = gl::canon(gl::add(s, g < 12 ? a.poseidon_rc[r * 12 + g] : 0));
+        s = gl::canon(gl::add(s, g < 12 ? rc[r * 12 + g] : 0));
         const bool full = r < poseidon::HALF_FULL || r >= poseidon::HALF_FULL + poseidon::PARTIAL;
         if (g < 12) {
             if (full && r >= 1 && r < poseidon::HALF_FULL) WR(29 + 12 * (r - 1) + g, s);
@@ -259,14 +265,39 @@ __global__ void __launch_bounds__(128) witness_level_kernel(WitnessArgs a, u32 f
     witness_level_body(a, first, count, blockIdx.x * blockDim.x + threadIdx.x);
 }
 __global__ void __launch_bounds__(256) witness_poseidon_kernel(WitnessArgs a, u32 first, u32 count) {
-    witness_poseidon_body(a, first, count, blockIdx.x * blockDim.x + threadIdx.x);
+    __shared__ u64 rc_lds[poseidon::ROUNDS * 12];
+    stage_round_constants(a, rc_lds);
+    witness_poseidon_body(a, first, count, blockIdx.x * blockDim.x + threadIdx.x, rc_lds);
 }
 // One dependency level in one launch: the first `generic_blocks` workgroups run the level's ordinary generator instances (a
 // thread each), the rest its PoseidonGate rows (16 lanes each). Both halves are latency-bound (a level ends when its slowest
 // generator does), so running them side by side instead of back to back takes the longer of the two, not the sum.
 __global__ void __launch_bounds__(256) witness_combined_kernel(WitnessArgs a, u32 first, u32 n_generic, u32 n_poseidon, u32 generic_blocks) {
-    if (blockIdx.x < generic_blocks) witness_level_body(a, first, n_generic, blockIdx.x * blockDim.x + threadIdx.x);
-    else witness_poseidon_body(a, first + n_generic, n_poseidon, (blockIdx.x - generic_blocks) * blockDim.x + threadIdx.x);
+    __shared__ u64 rc_lds[poseidon::ROUNDS * 12];
+    if (blockIdx.x < generic_blocks) { witness_level_body(a, first, n_generic, blockIdx.x * blockDim.x + threadIdx.x); return; }
+    stage_round_constants(a, rc_lds);
+    witness_poseidon_body(a, first + n_generic, n_poseidon, (blockIdx.x - generic_blocks) * blockDim.x + threadIdx.x, rc_lds);
+}
+
+// A run of narrow dependency levels in one launch. A level of a deep circuit is a handful of generator instances (a serial
+// chain of reducing / arithmetic operations, a Merkle path's hashes), and one launch per level costs 20-40 us of launch and
+// drain latency against a few us of work. Here one workgroup per witness walks levels [l0, l1): waves 0-7 take the level's
+// ordinary instances (a thread each, strided), waves 8-15 its PoseidonGate rows (16 lanes each), then a workgroup barrier —
+// all waves of a workgroup share one L1, so the barrier's memory fence makes the level's stores visible to the next level.
+__global__ void __launch_bounds__(1024) witness_run_kernel(WitnessArgs a, const u32 *level_start, const u32 *level_poseidon, u32 l0, u32 l1) {
+    __shared__ u64 rc_lds[poseidon::ROUNDS * 12];
+    stage_round_constants(a, rc_lds);
+    const u32 t = threadIdx.x;
+    for (u32 l = l0; l < l1; l++) {
+        const u32 lo = level_start[l], mid = level_poseidon[l], hi = level_start[l + 1];
+        if (t < 512) {
+            for (u32 i = t; i < mid - lo; i += 512) witness_level_body(a, lo, mid - lo, i);
+        } else if (hi > mid) {
+            for (u32 base = 0; base < (hi - mid) * 16; base += 512) witness_poseidon_body(a, mid, hi - mid, base + (t - 512), rc_lds);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // every routed cell takes the value of its copy class's source cell
@@ -318,6 +349,11 @@ hipError_t wk_run_combined(const WitnessArgs &a, uint32_t first, uint32_t n_gene
     if (n_generic == 0) return wk_run_poseidon(a, first, n_poseidon, batch, st);
     const uint32_t gb = (n_generic + 255) / 256, pb = (n_poseidon + 15) / 16;
     hipLaunchKernelGGL(witness_combined_kernel, dim3(gb + pb, batch), dim3(256), 0, st, a, first, n_generic, n_poseidon, gb);
+    return hipGetLastError();
+}
+hipError_t wk_run_levels(const WitnessArgs &a, const uint32_t *d_level_start, const uint32_t *d_level_poseidon, uint32_t l0, uint32_t l1, uint32_t batch, hipStream_t st) {
+    if (batch == 0 || l1 <= l0) return hipSuccess;
+    hipLaunchKernelGGL(witness_run_kernel, dim3(1, batch), dim3(1024), 0, st, a, d_level_start, d_level_poseidon, l0, l1);
     return hipGetLastError();
 }
 hipError_t wk_fill_copies(const WitnessArgs &a, uint32_t batch, hipStream_t st) {

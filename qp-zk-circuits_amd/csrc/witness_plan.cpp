@@ -11,6 +11,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <map>
 #include <unordered_map>
 #include <vector>
 #include "circuit_state.hpp"
@@ -22,6 +23,8 @@ struct WitnessPlan {
     std::vector<WitnessInst> insts;          // sorted by level
     std::vector<uint32_t> level_start;       // level l = insts[level_start[l] .. level_start[l+1])
     std::vector<uint32_t> level_poseidon;    // first PoseidonGate instance of level l (they come last in their level)
+    std::vector<std::pair<uint32_t, uint32_t>> segments;   // launches: [l0, l1) — one wide level, or a run of narrow ones
+    uint32_t *d_level_start = nullptr, *d_level_poseidon = nullptr;
     std::vector<uint8_t> free_mask;          // [num_wires][n]: 1 = supplied by the caller
     uint64_t num_free = 0;
     uint32_t *d_src_of = nullptr;
@@ -42,6 +45,8 @@ void witness_plan_free(WitnessPlan *p) {
     if (!p) return;
     if (p->d_src_of) (void)hipFree(p->d_src_of);
     if (p->d_insts) (void)hipFree(p->d_insts);
+    if (p->d_level_start) (void)hipFree(p->d_level_start);
+    if (p->d_level_poseidon) (void)hipFree(p->d_level_poseidon);
     if (p->d_pi_hash) (void)hipFree(p->d_pi_hash);
     if (p->d_hints) (void)hipFree(p->d_hints);
     if (p->d_pi_idx) (void)hipFree(p->d_pi_idx);
@@ -286,6 +291,38 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     };
     if (!up(src_of.data(), src_of.size() * 4, (void **)&plan.d_src_of)) return "witness plan: device allocation failed";
     if (!up(plan.insts.data(), plan.insts.size() * sizeof(WitnessInst), (void **)&plan.d_insts)) return "witness plan: device allocation failed";
+    if (!up(plan.level_start.data(), plan.level_start.size() * 4, (void **)&plan.d_level_start)) return "witness plan: device allocation failed";
+    if (!up(plan.level_poseidon.data(), plan.level_poseidon.size() * 4, (void **)&plan.d_level_poseidon)) return "witness plan: device allocation failed";
+    // launches: consecutive levels narrow enough for one workgroup go out as one run. Measured both ways (tools/witness_time.py):
+    // a run keeps a witness on one CU, which saves the launch gap and the cross-XCD L2 misses of a launch per level (2^16 rows,
+    // 2 562 levels: 108 -> 95 ms) but funnels every level's scattered loads through one CU's address unit (2^13 rows, 294 wider
+    // levels: 5.7 -> 6.7 ms). Default: runs for deep plans only. QPGPU_WITNESS_FUSE=0 never, =1 always.
+    {
+        const char *e = getenv("QPGPU_WITNESS_FUSE");
+        const bool fuse = e && (*e == '0' || *e == '1') ? *e == '1' : max_level >= 1024;
+        const uint32_t L = (uint32_t)max_level;
+        auto narrow = [&](uint32_t l) { return fuse && plan.level_poseidon[l] - plan.level_start[l] <= WITNESS_RUN_GENERIC_CAP &&
+                                               plan.level_start[l + 1] - plan.level_poseidon[l] <= WITNESS_RUN_POSEIDON_CAP; };
+        for (uint32_t l = 0; l < L;) {
+            uint32_t e1 = l + 1;
+            if (narrow(l)) while (e1 < L && narrow(e1)) e1++;
+            plan.segments.push_back({l, e1});
+            l = e1;
+        }
+    }
+    if (getenv("QPGPU_WITNESS_DUMP")) {
+        for (uint32_t l = 0; l < (uint32_t)max_level; l++) {
+            std::map<int, int> hist;
+            for (uint32_t k = plan.level_start[l]; k < plan.level_start[l + 1]; k++) {
+                const WitnessInst &in = plan.insts[k];
+                hist[in.gate == WITNESS_HINT ? 1000 + (int)in.op : (int)p.gates[in.gate].type]++;
+            }
+            fprintf(stderr, "LEVEL %u n=%u pos=%u :", l, plan.level_start[l + 1] - plan.level_start[l], plan.level_start[l + 1] - plan.level_poseidon[l]);
+            for (auto &kv : hist) fprintf(stderr, " t%d=%d", kv.first, kv.second);
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "SEGMENTS %zu\n", plan.segments.size());
+    }
     if (!p.hints.empty() && !up(p.hints.data(), p.hints.size() * sizeof(HintOp), (void **)&plan.d_hints)) return "witness plan: device allocation failed";
     if (!p.pi_cells.empty()) {
         std::vector<uint32_t> flat(p.pi_cells.size());
@@ -371,7 +408,9 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
     // one launch per dependency level (ordinary instances and PoseidonGate rows side by side); QPGPU_WITNESS_COMBINED=0: two
     static const bool combined = [] { const char *e = getenv("QPGPU_WITNESS_COMBINED"); return !(e && *e == '0'); }();
     ctx->prof_begin("witness_generate");
-    for (size_t l = 0; l + 1 < plan.level_start.size(); l++) {
+    for (const auto &seg : plan.segments) {
+        if (seg.second - seg.first > 1) { QP_HIP(ctx, wk_run_levels(a, plan.d_level_start, plan.d_level_poseidon, seg.first, seg.second, batch, ctx->stream)); continue; }
+        const size_t l = seg.first;
         const uint32_t lo = plan.level_start[l], mid = plan.level_poseidon[l], hi = plan.level_start[l + 1];
         if (combined) QP_HIP(ctx, wk_run_combined(a, lo, mid - lo, hi - mid, batch, ctx->stream));
         else {

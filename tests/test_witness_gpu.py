@@ -18,8 +18,16 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=["per_level", "runs"])
+def launch_mode(request, monkeypatch):
+    """Both launch schedules of the generation plan: one launch per dependency level, and runs of narrow levels walked by one
+    workgroup per witness (witness_run_kernel; the default only for plans of 1024 levels and more)."""
+    monkeypatch.setenv("QPGPU_WITNESS_FUSE", "1" if request.param == "runs" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("kw", CASES)
-def test_generated_witness_equals_the_full_witness(pkg, gpu, orc, kw):
+def test_generated_witness_equals_the_full_witness(pkg, gpu, orc, kw, launch_mode):
     kw = dict(kw)
     d = kw.pop("degree_bits")
     pack, wires, pis = pkg.synth_circuit(d, **kw)
@@ -86,7 +94,7 @@ def test_device_resident_generation_then_prove(pkg, gpu, orc):
         circ.close()
 
 
-def test_batched_generation(pkg, gpu):
+def test_batched_generation(pkg, gpu, launch_mode):
     """Several witnesses of one circuit in one pass: different free cells and public inputs per witness."""
     pack, wires, pis = pkg.synth_circuit(8, seed=77, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
     circ = pkg.Circuit(gpu, pack)
