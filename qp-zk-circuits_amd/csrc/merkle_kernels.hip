@@ -254,8 +254,11 @@ __global__ void permute_kernel(u64 *states, u64 n, const poseidon2::Params *p2) 
 // 2^pow_bits permutations plus what is in flight, not the whole span.
 template <class Perm>
 __global__ void __launch_bounds__(256) pow_kernel(PowArgs a, const poseidon2::Params *p2) {
-    const u32 pr = blockIdx.x % a.batch;
-    const u64 idx = (u64)(blockIdx.x / a.batch) * blockDim.x + threadIdx.x;
+    // chunk-major over the proofs, and the proof a workgroup serves rotates with the chunk: workgroups go to the 8 XCDs round
+    // robin, so with a fixed assignment (batch a multiple of 8) each proof's candidates would all run on one XCD, and the XCD whose
+    // proofs find their nonce last would finish the launch alone
+    const u32 chunk = blockIdx.x / a.batch, pr = (blockIdx.x % a.batch + chunk) % a.batch;
+    const u64 idx = (u64)chunk * blockDim.x + threadIdx.x;
     if (idx >= a.count) return;
     const u64 base = a.bases[pr];
     if (base == ~0ull) return;                 // this proof already has its nonce
