@@ -46,13 +46,16 @@ struct qpgpu_ctx {
         return QPGPU_EDEVICE;
     }
     int ensure_scratch(size_t bytes);
-    // small device-to-host reads on the proving path (caps, openings, query data): through a pinned bounce buffer, then a
-    // stream sync — a pageable destination makes the runtime stage the copy itself, tens of microseconds per read
+    // small device-to-host reads on the proving path (caps, openings, query data): a kernel writes them into a pinned host
+    // buffer in place (read_back_2d packs the per-proof rows on the way), then one stream sync. The runtime's own small-copy
+    // path is not used on the proving path: with several proving threads it faulted inside hipMemcpyAsync now and then under
+    // rocprofv3 (a host memcpy to or from device memory through the BAR mapping), and a launch costs no more than a copy command.
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
-    uint64_t *d_stage = nullptr;     // dense staging block of read_back_2d
-    size_t d_stage_bytes = 0;
     int read_back(void *host_dst, const void *dev_src, size_t bytes);
+    // size the pinned buffer up front (circuit load: every read-back of a batch is a piece of its proofs), so that proving
+    // neither allocates nor frees
+    int reserve_read_back(size_t bytes);
     // `rows` pieces of `width` bytes, `src_pitch` bytes apart on the device, packed back to back on the host
     int read_back_2d(void *host_dst, const void *dev_src, size_t src_pitch, size_t width, size_t rows);
     int upload(const std::vector<uint64_t> &host, uint64_t **dptr);

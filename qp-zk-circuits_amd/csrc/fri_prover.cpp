@@ -26,7 +26,7 @@ int Stager::put(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     u64 *slot = h + pos;
     pos += w;
     std::memcpy(slot, src, bytes);
-    QP_HIP(ctx, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QP_HIP(ctx, pk_copy(dst, slot, bytes, ctx->stream));   // the device reads the pinned slot in place (see ctx.hpp: read_back)
     return QPGPU_OK;
 }
 

@@ -27,15 +27,21 @@ int qpgpu_ctx::ensure_scratch(size_t bytes) {
     return QPGPU_OK;
 }
 
+int qpgpu_ctx::reserve_read_back(size_t bytes) {
+    if (bytes < (1u << 20)) bytes = 1u << 20;
+    if (bytes > h_pin_bytes) {
+        QP_HIP(this, hipStreamSynchronize(stream));
+        if (h_pin) { (void)hipHostFree(h_pin); h_pin = nullptr; h_pin_bytes = 0; }
+        QP_HIP(this, hipHostMalloc(&h_pin, bytes, hipHostMallocDefault));
+        h_pin_bytes = bytes;
+    }
+    return QPGPU_OK;
+}
+
 int qpgpu_ctx::read_back(void *host_dst, const void *dev_src, size_t bytes) {
     if (bytes == 0) return QPGPU_OK;
-    if (bytes > h_pin_bytes) {
-        if (h_pin) { QP_HIP(this, hipStreamSynchronize(stream)); (void)hipHostFree(h_pin); h_pin = nullptr; h_pin_bytes = 0; }
-        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-        QP_HIP(this, hipHostMalloc(&h_pin, want, hipHostMallocDefault));
-        h_pin_bytes = want;
-    }
-    QP_HIP(this, hipMemcpyAsync(h_pin, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+    QP_TRY(reserve_read_back(bytes));
+    QP_HIP(this, pk_copy(h_pin, dev_src, bytes, stream));
     QP_HIP(this, hipStreamSynchronize(stream));
     memcpy(host_dst, h_pin, bytes);
     return QPGPU_OK;
@@ -44,17 +50,14 @@ int qpgpu_ctx::read_back(void *host_dst, const void *dev_src, size_t bytes) {
 int qpgpu_ctx::read_back_2d(void *host_dst, const void *dev_src, size_t src_pitch, size_t width, size_t rows) {
     if (rows <= 1 || src_pitch == width) return read_back(host_dst, dev_src, width * rows);
     // the runtime splits a 2D device-to-host copy into one small copy per row (32 of them per stage for a lockstep batch of
-    // 32): pack the rows on the device and bring them over in one piece
+    // 32): one kernel packs the rows straight into the pinned buffer
     const size_t bytes = width * rows;
     if ((width | src_pitch) & 7) return fail(QPGPU_EINVAL, "read_back_2d: row width and pitch must be multiples of 8 bytes");
-    if (bytes > d_stage_bytes) {
-        if (d_stage) { QP_HIP(this, hipStreamSynchronize(stream)); (void)hipFree(d_stage); d_stage = nullptr; d_stage_bytes = 0; }
-        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-        QP_HIP(this, hipMalloc((void **)&d_stage, want));
-        d_stage_bytes = want;
-    }
-    QP_HIP(this, pk_pack_rows((const uint64_t *)dev_src, src_pitch / 8, width / 8, rows, d_stage, stream));
-    return read_back(host_dst, d_stage, bytes);
+    QP_TRY(reserve_read_back(bytes));
+    QP_HIP(this, pk_pack_rows((const uint64_t *)dev_src, src_pitch / 8, width / 8, rows, (uint64_t *)h_pin, stream));
+    QP_HIP(this, hipStreamSynchronize(stream));
+    memcpy(host_dst, h_pin, bytes);
+    return QPGPU_OK;
 }
 
 int qpgpu_ctx::upload(const std::vector<uint64_t> &host, uint64_t **dptr) {

@@ -220,6 +220,8 @@ int qpgpu_circuit_load_batch(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t 
         if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipHostMalloc(stage)"));
         c->stage.h = (u64 *)hp;
     }
+    // everything a batch reads back ends up in its proofs: their total size bounds any single read
+    if ((rc = ctx->reserve_read_back((size_t)B * qpgpu_proof_size(c) + (1u << 16))) != QPGPU_OK) return fail(rc);
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #undef CK
     *out = c;

@@ -654,6 +654,18 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const u64 *src, u64 pitc
     dst[i] = src[r * pitch + c];
 }
 
+// dst[0..bytes) = src[0..bytes): the small transfers of the proving path between pinned host memory and device memory (either
+// side may be the pinned one: the device reads and writes it in place). 8-byte words when both ends are aligned, bytes otherwise.
+__global__ void __launch_bounds__(256) copy_words_kernel(u64 *dst, const u64 *src, u64 words, u64 tail_bytes) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) dst[i] = src[i];
+    if (i == 0) for (u64 k = 0; k < tail_bytes; k++) ((unsigned char *)(dst + words))[k] = ((const unsigned char *)(src + words))[k];
+}
+__global__ void __launch_bounds__(256) copy_bytes_kernel(unsigned char *dst, const unsigned char *src, u64 bytes) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bytes) dst[i] = src[i];
+}
+
 #define LAUNCH_1D(kern, count, threads, st, ...) \
     do { if ((count) > 0) { dim3 b(threads), g((unsigned)(((count) + (threads)-1) / (threads))); hipLaunchKernelGGL(kern, g, b, 0, st, __VA_ARGS__); } } while (0)
 // the same over a lockstep batch: grid.z = proof
@@ -729,6 +741,16 @@ hipError_t pk_quotient(const QuotientArgs &a, const GateDev *host_gates, hipStre
         case 4: return quotient_launch<4>(a, host_gates, st);
         default: return hipErrorInvalidValue;
     }
+}
+hipError_t pk_copy(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 7) == 0) {
+        const u64 words = bytes / 8, tail = bytes % 8;
+        LAUNCH_1D(copy_words_kernel, words ? words : 1, 256, st, (u64 *)dst, (const u64 *)src, words, tail);
+    } else {
+        LAUNCH_1D(copy_bytes_kernel, bytes, 256, st, (unsigned char *)dst, (const unsigned char *)src, (u64)bytes);
+    }
+    return hipGetLastError();
 }
 hipError_t pk_pack_rows(const u64 *src, u64 pitch_words, u64 width_words, u64 rows, u64 *dst, hipStream_t st) {
     LAUNCH_1D(pack_rows_kernel, width_words * rows, 256, st, src, pitch_words, width_words, width_words * rows, dst);

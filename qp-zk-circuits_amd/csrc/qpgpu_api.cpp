@@ -76,7 +76,6 @@ void qpgpu_ctx_destroy(qpgpu_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_p2) (void)hipFree(ctx->d_p2);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

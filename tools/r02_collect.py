@@ -5,6 +5,8 @@
   r02_final_bench_kernel_stats.csv / r02_final_bench_ntt_2p20_launches.json    rocprofv3 --kernel-trace --stats of the default
                                         command and the 2^20 x 128 NTT launches inside it
   r02_final_ntt_only_kernel_stats.csv / r02_final_ntt_only_ntt_2p20_launches.json   the same for tools/ntt_only.py
+  r02_final_headline_kernel_stats.csv / r02_final_single_worker_kernel_stats.csv   the headline leg alone with six workers
+                                        overlapping, and with one worker (every kernel alone on the GPU: isolated stage costs)
   r02_final_ntt_pmc_summary.json        HBM bytes per transform (FETCH_SIZE / WRITE_SIZE passes)
   r02_final_ntt_valu_summary.json       VALU instructions per element and issue-slot share (SQ passes)
   r02_final_ntt_isa_hist.json           static instruction mix of the compiled NTT kernels (tools/isa_hist.py)
@@ -37,10 +39,10 @@ for name, out in (("bench.json", "r02_final_bench.json"), ("bench_2rank_gloo.jso
 # the box summarised its kernel traces (tools/r02_final.sh -> tools/profile_summary.py): sum_bench = `python3 bench.py` (the default
 # command: kernel stats of the whole run and the 2^20 x 128 NTT launches inside it, what roofline.avg_ms must agree with),
 # sum_ntt_only = tools/ntt_only.py, sum_headline = the headline leg alone (kernel shares of a proof)
-for prefix, out in (("sum_bench", "r02_final_bench"), ("sum_ntt_only", "r02_final_ntt_only"), ("sum_headline", "r02_final_headline")):
+for prefix, out in (("sum_bench", "r02_final_bench"), ("sum_ntt_only", "r02_final_ntt_only"), ("sum_headline", "r02_final_headline"), ("sum_single_worker", "r02_final_single_worker")):
     for suffix in ("_kernel_stats.csv", "_ntt_2p20_launches.json"):
         src = os.path.join(SRC, prefix + suffix)
-        if os.path.exists(src) and os.path.getsize(src) > 2 and not (prefix == "sum_headline" and suffix.endswith(".json")):
+        if os.path.exists(src) and os.path.getsize(src) > 2 and not (prefix in ("sum_headline", "sum_single_worker") and suffix.endswith(".json")):
             shutil.copy(src, os.path.join(DST, out + suffix))
             print("copied", out + suffix)
 

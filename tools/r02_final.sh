@@ -19,10 +19,13 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU S
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -o ntt -- python3 $R/tools/ntt_only.py 3 > $R/$O/pmc_fetch.log 2>&1; echo "pmc_fetch rc=$?" | tee -a $R/$O/summary.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -o ntt -- python3 $R/tools/ntt_only.py 3 > $R/$O/pmc_write.log 2>&1; echo "pmc_write rc=$?" | tee -a $R/$O/summary.txt
 bash $R/tools/r02_z.sh
+# one worker, one lockstep batch at a time: every kernel alone on the GPU, i.e. the isolated cost of each stage of a batch of 32
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_single_worker -o sw -- python3 $R/bench.py --streams 1 --batch 32 --steps 8 --warmup 2 --no-tree --no-ntt --no-cpu-baseline --headline-only > $R/$O/prof_single_worker.log 2>&1; echo "prof_single_worker rc=$?" | tee -a $R/$O/summary.txt
 # summarise the kernel traces here and drop them: gpurun brings back at most 64 MiB
 cd $R
 python tools/profile_summary.py $O/prof_bench $O/sum_bench "python3 bench.py (default command)" >> $O/summary.txt 2>&1
 python tools/profile_summary.py $O/prof_ntt $O/sum_ntt_only "python3 tools/ntt_only.py 40" >> $O/summary.txt 2>&1
+python tools/profile_summary.py $O/prof_single_worker $O/sum_single_worker "python3 bench.py --streams 1 --batch 32 --steps 8 --warmup 2 --no-tree --no-ntt --no-cpu-baseline --headline-only" >> $O/summary.txt 2>&1
 python tools/profile_summary.py $O/prof_headline $O/sum_headline "python3 bench.py --steps 120 --warmup 5 --no-tree --no-ntt --no-cpu-baseline --headline-only" >> $O/summary.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete
 du -sh $O | tee -a $O/summary.txt
