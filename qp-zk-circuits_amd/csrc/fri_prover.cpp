@@ -18,9 +18,11 @@ using gl::u64;
 
 int Stager::put(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     const size_t w = (bytes + 7) / 8;
-    if (!h || pos + w > words) {   // not sized for this table: fall back to a synchronous upload
-        QP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!h || pos + w > words) {   // not sized for this table: through the context's pinned bounce buffer, synchronously
+        QP_TRY(ctx->reserve_read_back(bytes));
+        std::memcpy(ctx->h_pin, src, bytes);
+        QP_HIP(ctx, pk_copy(dst, ctx->h_pin, bytes, ctx->stream));
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the bounce buffer is shared with read_back
         return QPGPU_OK;
     }
     u64 *slot = h + pos;
@@ -268,15 +270,18 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
         PowArgs pw{};
         pw.states = w.pow_states; pw.bases = w.pow_bases; pw.results = w.pow_results;
         pw.pos = (uint32_t)chs[0].n_in; pw.pow_bits = p.pow_bits; pw.batch = nb;
-        // expected 2^pow_bits candidates per proof; a span of 4x that finds all of a batch 98 % of the time, and the kernel
-        // drops the candidates above a nonce already found, so the span costs little beyond the expected work
+        // expected 2^pow_bits candidates per proof; a span of 4x that finds a proof's nonce 98 % of the time (all 32 of a batch
+        // in a little over half of the batches; the rest take a second, nearly empty launch), and the kernel drops the candidates
+        // above a nonce already found, so the span costs little beyond the expected work
         const u64 span = std::max<u64>(1ull << 16, 4ull << pw.pow_bits);
         pw.count = span;
         std::vector<u64> bases(nb, 0), res(nb);
         std::vector<char> found(nb, 0);
         uint32_t n_found = 0;
         QP_HIP(ctx, hipMemsetAsync(w.pow_results, 0xFF, 8 * (size_t)nb, st));
+        const size_t stage_pos = stage.pos;
         for (u64 round = 0; n_found < nb; round++) {
+            stage.pos = stage_pos;   // the previous round's upload has completed (read_back below syncs): its slot is free again
             for (uint32_t b = 0; b < nb; b++) bases[b] = found[b] ? ~0ull : round * span;
             QP_TRY(stage.put(ctx, w.pow_bases, bases.data(), 8 * (size_t)nb));
             QP_HIP(ctx, pk_pow(pw, hd, st));

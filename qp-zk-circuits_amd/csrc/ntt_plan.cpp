@@ -40,7 +40,7 @@ int qpgpu_ctx::reserve_read_back(size_t bytes) {
 
 int qpgpu_ctx::read_back(void *host_dst, const void *dev_src, size_t bytes) {
     if (bytes == 0) return QPGPU_OK;
-    QP_TRY(reserve_read_back(bytes));
+    QP_TRY_NTT(reserve_read_back(bytes));
     QP_HIP(this, pk_copy(h_pin, dev_src, bytes, stream));
     QP_HIP(this, hipStreamSynchronize(stream));
     memcpy(host_dst, h_pin, bytes);
@@ -53,7 +53,7 @@ int qpgpu_ctx::read_back_2d(void *host_dst, const void *dev_src, size_t src_pitc
     // 32): one kernel packs the rows straight into the pinned buffer
     const size_t bytes = width * rows;
     if ((width | src_pitch) & 7) return fail(QPGPU_EINVAL, "read_back_2d: row width and pitch must be multiples of 8 bytes");
-    QP_TRY(reserve_read_back(bytes));
+    QP_TRY_NTT(reserve_read_back(bytes));
     QP_HIP(this, pk_pack_rows((const uint64_t *)dev_src, src_pitch / 8, width / 8, rows, (uint64_t *)h_pin, stream));
     QP_HIP(this, hipStreamSynchronize(stream));
     memcpy(host_dst, h_pin, bytes);
