@@ -20,6 +20,7 @@ int Stager::put(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     const size_t w = (bytes + 7) / 8;
     if (!h || pos + w > words) {   // not sized for this table: through the context's pinned bounce buffer, synchronously
         QP_TRY(ctx->reserve_read_back(bytes));
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // nothing queued earlier still reads the bounce buffer
         std::memcpy(ctx->h_pin, src, bytes);
         QP_HIP(ctx, pk_copy(dst, ctx->h_pin, bytes, ctx->stream));
         QP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the bounce buffer is shared with read_back

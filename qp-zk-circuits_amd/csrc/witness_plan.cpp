@@ -16,6 +16,7 @@
 #include <vector>
 #include "circuit_state.hpp"
 #include "witness.hpp"
+#include "prover_kernels.hpp"
 
 using gl::u64;
 
@@ -391,14 +392,19 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
         QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_vals, std::max<size_t>((size_t)batch * npis * 8, 8)));
         plan.pi_cap = batch;
     }
-    if (plan.d_pi_idx && npis) {   // PartialWitness::set_target for every public-input target
-        QP_HIP(ctx, hipMemcpyAsync(plan.d_pi_vals, public_inputs, (size_t)batch * npis * 8, hipMemcpyHostToDevice, ctx->stream));
+    // the public inputs and their hash go up through the context's pinned bounce buffer and a copy kernel (ctx.hpp: read_back)
+    const size_t pi_bytes = plan.d_pi_idx ? (size_t)batch * npis * 8 : 0, hash_bytes = (size_t)batch * 32;
+    QP_TRY(ctx->reserve_read_back(pi_bytes + hash_bytes));
+    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));       // nothing of an earlier call still reads the bounce buffer
+    u64 *bounce = (u64 *)ctx->h_pin;
+    if (pi_bytes) {   // PartialWitness::set_target for every public-input target
+        std::memcpy(bounce, public_inputs, pi_bytes);
+        QP_HIP(ctx, pk_copy(plan.d_pi_vals, bounce, pi_bytes, ctx->stream));
         QP_HIP(ctx, wk_scatter(d_wires, plan.d_pi_idx, plan.d_pi_vals, (uint32_t)npis, batch, c->pack.num_wires * c->pack.n(), (uint32_t)npis, ctx->stream));
     }
-    std::vector<u64> pih((size_t)batch * 4);
-    for (uint32_t b = 0; b < batch; b++) host_pi_hash(ctx->hasher, public_inputs + (size_t)b * c->pack.num_public_inputs, c->pack.num_public_inputs, pih.data() + 4 * b);
-    QP_HIP(ctx, hipMemcpyAsync(plan.d_pi_hash, pih.data(), pih.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));       // pih goes out of scope
+    u64 *pih = bounce + pi_bytes / 8;
+    for (uint32_t b = 0; b < batch; b++) host_pi_hash(ctx->hasher, public_inputs + (size_t)b * c->pack.num_public_inputs, c->pack.num_public_inputs, pih + 4 * b);
+    QP_HIP(ctx, pk_copy(plan.d_pi_hash, pih, hash_bytes, ctx->stream));
     WitnessArgs a{};
     a.wires = d_wires; a.src_of = plan.d_src_of; a.insts = plan.d_insts; a.gates = c->d_gates; a.cs = c->d_cs_values;
     a.poseidon_rc = c->d_poseidon_rc; a.poseidon_fast = c->d_poseidon_fast; a.pi_hash = plan.d_pi_hash;
