@@ -215,6 +215,8 @@ int qpgpu_circuit_load_batch(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t 
     }
     {
         c->stage.words = (size_t)B * (c->small_words + 8 + 4 + 8) + FriWork::stage_words(c->fri, n_open, B) + 64;
+        // test hook: a staging ring too small for anything sends every table through the synchronous bounce path of Stager::put
+        if (const char *e = getenv("QPGPU_STAGE_FALLBACK")) if (*e == '1') c->stage.words = 1;
         void *hp = nullptr;
         hipError_t e = hipHostMalloc(&hp, c->stage.words * 8, hipHostMallocDefault);
         if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipHostMalloc(stage)"));

@@ -170,3 +170,27 @@ def test_set_twice_with_different_values(pkg, gpu):
         assert np.array_equal(tp.witness(), wires)
     finally:
         tp.close()
+
+
+@pytest.mark.gpu
+def test_staging_fallback_path_gives_the_same_bytes(pkg, gpu, orc, monkeypatch):
+    """Stager::put's synchronous route (tables that do not fit the staging ring go through the context's pinned bounce buffer):
+    forced for every table by the QPGPU_STAGE_FALLBACK hook, it must produce the proofs of the ring route."""
+    pack, wires, _ = pkg.synth_circuit(8, num_wires=135, num_routed=80, num_public_inputs=21, seed=340, poseidon=True, base_sum=True,
+                                       ext_arith=True, recursion=True)
+    pis, ws = _witnesses(pkg, gpu, pack, wires, 3)
+    ring = pkg.Circuit(gpu, pack, max_batch=3)
+    monkeypatch.setenv("QPGPU_STAGE_FALLBACK", "1")
+    bounce = pkg.Circuit(gpu, pack, max_batch=3)          # the hook is read when the handle is created
+    monkeypatch.delenv("QPGPU_STAGE_FALLBACK")
+    oc = OracleCircuit(orc, pack)
+    try:
+        bufs = [gpu.to_device(w) for w in ws]
+        a = ring.prove_batch_dev(bufs, pis)
+        b = bounce.prove_batch_dev(bufs, pis)
+        assert a == b and all(b[k] == oc.prove(ws[k], pis[k]) for k in range(3))
+        assert bounce.prove_dev(bufs[1], pis[1]) == a[1]
+        for x in bufs:
+            x.free()
+    finally:
+        ring.close(); bounce.close(); oc.close()
