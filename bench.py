@@ -209,7 +209,7 @@ def main():
     pool = ThreadPoolExecutor(max_workers=1)
     pool_gen = ThreadPoolExecutor(max_workers=1)
     gathered = None
-    step_layout = {}
+    step_gather = None
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -247,26 +247,35 @@ def main():
         the main thread closes step j when its S proofs are written and, with several ranks, gathers that step's proof
         bytes over RCCL while the workers are already proving step j+1."""
         AHEAD = max(1, min(8, 3000 // S))   # steps queued ahead of the one being collected (the pool keeps at most 4096 unwaited jobs)
-        bufs = [np.empty(proof_len, dtype=np.uint8) for _ in range(min(k, AHEAD + 1) * S)]     # a ring: step j reuses step j - AHEAD - 1's
+        ring = min(k, AHEAD + 1)            # step j writes block j % ring, i.e. reuses step j - AHEAD - 1's
+        # the workers write each step's proofs straight into one pinned block per ring slot; with several ranks that block is
+        # what the step's collective sends (sharding.ProofBlockGather: no per-proof copies on the host)
+        nonlocal gathered, step_gather
+        if step_gather is None or len(step_gather.send) < ring:
+            step_gather = pkg.sharding.ProofBlockGather(S, proof_len, dist if world > 1 else None, coll_dev, blocks=AHEAD + 1)
+        sg = step_gather
 
         def submit_step(j):
-            return [prover_pool.submit(w_all.ptr + i * mat_bytes, pis_all[i], bufs[(j % (AHEAD + 1)) * S + i]) for i in range(S)]
+            return [prover_pool.submit(w_all.ptr + i * mat_bytes, pis_all[i], sg.slot(j % ring, i)) for i in range(S)]
         tickets = {j: submit_step(j) for j in range(min(k, AHEAD))}
         last = None
-        nonlocal gathered
-        layout = step_layout          # proofs of one circuit have one size: metadata collectives run once
         step_done.clear()
         for j in range(k):
             if j + AHEAD < k:
                 tickets[j + AHEAD] = submit_step(j + AHEAD)
-            proofs = [prover_pool.wait(t) for t in tickets.pop(j)]
+            for t in tickets.pop(j):
+                if prover_pool.wait(t, copy=False) != proof_len:
+                    raise SystemExit("bench.py: a proof of unexpected length")
             if world > 1:
-                gathered = pkg.sharding.gather_proof_bytes(proofs, dist, coll_dev, layout)
-            last = proofs[0]
+                _tg = time.perf_counter()
+                gathered = sg.gather(j % ring)        # [world][S][proof_len] on the host
+                gather_ms.append((time.perf_counter() - _tg) * 1e3)
+            last = sg.slot(j % ring, 0).tobytes()
             step_done.append(time.perf_counter())
         return last
 
     step_done = []
+    gather_ms = []
     proof = run_steps(max(args.warmup, 1))
     barrier()
     t0 = time.perf_counter()
@@ -285,7 +294,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         if rank == 0:   # every rank's S proofs arrived; rank 0's own are unchanged
-            assert len(gathered) == world and all(len(g_) == S for g_ in gathered) and gathered[0][0] == proof
+            assert tuple(gathered.shape) == (world, S, proof_len) and gathered[0, 0].numpy().tobytes() == proof
     value = args.steps * S * world / dt
 
     extra = {}
@@ -593,7 +602,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_proof": round(dt / (args.steps * S) * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "window_proofs_per_s": windows, "step_ms_rank0": step_ms,
+            "window_proofs_per_s": windows, "step_ms_rank0": step_ms, "gather_ms_rank0": [round(x, 2) for x in gather_ms[-16:]],
             "config": {"workload": "BASELINE configs[2]/[3]: full proof (LDE + Poseidon Merkle commit + quotient + FRI) of a "
                                    "shape-equivalent synthetic leaf circuit, proofs_per_step_per_gpu different witnesses per GPU per step, resident in HBM",
                        "degree_bits": d, "gates": "PublicInput, Constant, BaseSum<2>(63 limbs), Arithmetic(20 ops), Poseidon(123 constraints), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,

@@ -564,13 +564,14 @@ class ProvingPool:
         self._keep[t.value] = (p, out, d_wires)
         return t.value
 
-    def wait(self, ticket):
+    def wait(self, ticket, copy=True):
+        """The proof of a ticket (bytes); copy=False: only its length — the bytes are in the `out` buffer given to submit()."""
         ln = ctypes.c_size_t()
         rc = self.lib.qpgpu_pool_wait(self.h, ticket, ctypes.byref(ln))
         p, out, _ = self._keep.pop(ticket, (None, None, None))
         if rc != 0:
             raise QpGpuError(rc, self.lib.qpgpu_pool_last_error(self.h).decode())
-        return out[:ln.value].tobytes()
+        return out[:ln.value].tobytes() if copy else ln.value
 
 
 class _Stage3:

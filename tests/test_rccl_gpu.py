@@ -29,6 +29,13 @@ def test_gather_proof_bytes_over_rccl_single_rank():
         for _ in range(2):                     # second call: cached layout, flag all_reduce + payload all_gather only
             got = pkg.sharding.gather_proof_bytes(proofs, dist, dev, layout)
             assert got == [proofs], "round trip over RCCL differs"
+        # the bench's per-step exchange: pinned block -> device -> all_gather -> pinned host tensor
+        blk = pkg.sharding.ProofBlockGather(3, 4096, dist, dev, blocks=2)
+        for step in range(3):
+            for i in range(3):
+                blk.slot(step %% 2, i)[:] = (17 * step + i) %% 251
+            got = blk.gather(step %% 2)
+            assert tuple(got.shape) == (1, 3, 4096) and all(int(got[0, i, 0]) == (17 * step + i) %% 251 and int(got[0, i, -1]) == (17 * step + i) %% 251 for i in range(3))
         t = torch.ones(4, device=dev); dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize(dev)
         dist.destroy_process_group()
         print("rccl ok")

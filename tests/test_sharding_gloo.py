@@ -41,6 +41,17 @@ def _worker(rank, world, port, ret):
     except ValueError:
         pass
     ok = ok and [p for r in sh.gather_proof_bytes(mine, dist, None, layout) for p in r] == all_proofs   # still usable
+    # the bench's per-step exchange: fixed-size proofs written into the sender's block in place, one collective, no decoding
+    count, plen = 4, 777
+    blk = sh.ProofBlockGather(count, plen, dist, torch.device("cpu"), blocks=3)
+    want = [[np.random.default_rng(50 * r + i).integers(0, 256, plen, dtype=np.uint8) for i in range(count)] for r in range(world)]
+    for step in range(5):                                   # ring of 3 blocks reused
+        b = step % 3
+        for i in range(count):
+            blk.slot(b, i)[:] = want[rank][i] ^ np.uint8(step)
+        got = blk.gather(b)
+        ok = ok and tuple(got.shape) == (world, count, plen)
+        ok = ok and all(np.array_equal(got[r, i].numpy(), want[r][i] ^ np.uint8(step)) for r in range(world) for i in range(count))
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
@@ -67,6 +78,9 @@ def test_schedule_and_shards(pkg):
     assert [len(plan2["ranks"][r]["private_batches"]) for r in range(2)] == [4, 4]
     # single process: gather is the identity
     assert sh.gather_proof_bytes([b"ab", b"c"]) == [[b"ab", b"c"]]
+    one = sh.ProofBlockGather(2, 5, None, torch.device("cpu"))
+    one.slot(0, 0)[:] = 7; one.slot(0, 1)[:] = 9
+    assert one.gather(0).tolist() == [[[7] * 5, [9] * 5]]
 
 
 def _tree_worker(rank, world, port, ret):
