@@ -432,6 +432,14 @@ def main():
                                          "wires_leaf_hash_algorithmic_GBps": round(8.0 * 135 * lde_leaves / 1e9 / (17 * lde_leaves / perm_rate), 1),
                                          "note": "leaf hashing reads 8*W bytes per leaf and runs ceil(W/8) permutations: at the permutation "
                                                  "rate above the wires oracle streams this many GB/s, far below HBM"}
+            try:   # hardware counters of the same kernel, committed (tools/gpurun_scripts/r02_leaf_pmc.sh)
+                with open(os.path.join(ROOT, "profiles", "r02_final_leaf_hash_valu_summary.json")) as f:
+                    lk = json.load(f)["kernels"]["leaf_hash_kernel<PoseidonV1>"]
+                extra["poseidon_hashing"].update(valu_insts_per_permutation=lk["valu_insts_per_permutation"],
+                                                 cycles_per_valu_inst_per_simd=lk["cycles_per_valu_inst_per_simd"],
+                                                 valu_source="profiles/r02_final_leaf_hash_valu_summary.json")
+            except (OSError, KeyError, ValueError):
+                pass
 
             # stage s1 on the device (separate leg, not part of the headline: the metric is quoted with the witness resident):
             # regenerate the witness from its free cells alone, one at a time and 16 per pass
