@@ -615,7 +615,7 @@ def main():
                                    "shape-equivalent synthetic leaf circuit, proofs_per_step_per_gpu different witnesses per GPU per step, resident in HBM",
                        "degree_bits": d, "gates": "PublicInput, Constant, BaseSum<2>(63 limbs), Arithmetic(20 ops), Poseidon(123 constraints), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
                        "num_query_rounds": 28, "proof_of_work_bits": 16, "fri_arity_bits": 4, "proof_bytes": proof_len, "proofs_in_flight_per_gpu": S, "proofs_per_step_per_gpu": S, "workers": WORKERS, "lockstep_batch": LOCKSTEP,
-                       "multi_gpu": "independent proofs per rank + RCCL all_gather of proof bytes" if world > 1 else "single GPU"},
+                       "multi_gpu": ("independent proofs per rank + one all_gather of each step's proof bytes (%s)" % ("RCCL" if backend == "nccl" else backend + " rehearsal, ranks share the visible GPUs")) if world > 1 else "single GPU"},
         }
         line.update(extra)
         if "roofline" not in line:
