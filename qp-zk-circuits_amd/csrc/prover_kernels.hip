@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
 
 // (3) PoseidonGate (plonky2::gates::poseidon) at one point: wires 0..11 input, 12..23 output, 24 swap, 25..28 delta,
 // 29..64 / 65..86 / 87..134 S-box inputs of the full / partial / full rounds; 123 constraints, each weighted by
-// alpha_c^(t0+q) on the fly. Partial rounds in upstream's fast-partial basis (tables derived at start-up).
+// alpha_c^(t0+q) on the fly.
 template <int NCH>
 __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, u32 gi, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -397,14 +397,17 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
         for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
         poseidon::mds_layer(st);
     }
-    poseidon::fast_partial_enter(st, a.poseidon_fast);
-    for (int r = 0; r < 22; r++) {
+    // partial rounds in the textbook schedule: the value fed to the S-box is the same in upstream's fast-partial basis (that
+    // change of basis leaves lane 0 alone), and the multiplication-free MDS layer is cheaper here than the fast basis's 23 full
+    // products per round plus its 11x11 entry matrix
+    for (int r = 0; r < 22; r++, rc++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);
         const u64 in = W(65 + r);
         emit(gl::sub(st[0], in));
         st[0] = poseidon::sbox7(in);
-        poseidon::fast_partial_linear(st, a.poseidon_fast, r);
+        poseidon::mds_layer(st);
     }
-    rc += 22;
     for (int r = 0; r < 4; r++, rc++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);
