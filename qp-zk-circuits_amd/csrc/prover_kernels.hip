@@ -463,11 +463,22 @@ __global__ void __launch_bounds__(256) poly_eval_kernel(const u64 *coeffs, u64 n
     const u64 p = blockIdx.x;
     const e2 z = points[blockIdx.y];
     const u64 *f = coeffs + p * n;
-    const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = lo + per < n ? lo + per : n;
+    // thread t takes the coefficients t, t + T, t + 2T, ... (unit stride across the wave): Horner in w = z^T, then times z^t.
+    // z^(2^b) on the way to w serve as the factors of z^t.
+    e2 zp[8];                                   // T = 256 = 2^8
+    zp[0] = z;
+#pragma unroll
+    for (int b = 1; b < 8; b++) zp[b] = gl::e2_mul(zp[b - 1], zp[b - 1]);
+    const e2 w = gl::e2_mul(zp[7], zp[7]);
     e2 acc = gl::e2_from(0);
-    for (u64 i = hi; i-- > lo;) acc = gl::e2_add(gl::e2_mul(acc, z), gl::e2_from(f[i]));   // Horner on the slice
-    // slice value * z^lo
-    if (lo < n) acc = gl::e2_mul(acc, gl::e2_pow(z, lo)); else acc = gl::e2_from(0);
+    if (t < n) {
+        const u64 terms = (n - t + T - 1) / T;
+        for (u64 k = terms; k-- > 0;) acc = gl::e2_add(gl::e2_mul(acc, w), gl::e2_from(f[t + k * T]));
+        e2 zt = gl::e2_from(1);
+#pragma unroll
+        for (int b = 0; b < 8; b++) if ((t >> b) & 1) zt = gl::e2_mul(zt, zp[b]);
+        acc = gl::e2_mul(acc, zt);
+    }
     part[t] = acc;
     __syncthreads();
     for (u32 off = T >> 1; off > 0; off >>= 1) {
