@@ -49,7 +49,8 @@ struct qpgpu_ctx {
     // small device-to-host reads on the proving path (caps, openings, query data): a kernel writes them into a pinned host
     // buffer in place (read_back_2d packs the per-proof rows on the way), then one stream sync. The runtime's own small-copy
     // path is not used on the proving path: with several proving threads it faulted inside hipMemcpyAsync now and then under
-    // rocprofv3 (a host memcpy to or from device memory through the BAR mapping), and a launch costs no more than a copy command.
+    // rocprofv3 (a host memcpy to or from device memory through the BAR mapping; the same fault has since been seen once inside a
+    // plain kernel launch, so this lowers the exposure, it does not remove it), and a launch costs no more than a copy command.
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     int read_back(void *host_dst, const void *dev_src, size_t bytes);
