@@ -46,6 +46,10 @@ const char *qpgpu_last_error(const qpgpu_ctx *ctx);
 int qpgpu_ctx_set_stream(qpgpu_ctx *ctx, void *hip_stream);
 int qpgpu_sync(qpgpu_ctx *ctx);
 const char *qpgpu_version(void);
+/* Post-mortem evidence (csrc/crash_trace.cpp): with QPGPU_CRASH_TRACE=1 (stderr) or =<file> in the environment when the
+ * library is loaded, a fatal signal writes its address, the mapping that holds it and the native backtrace of the faulting
+ * thread before the previous handler (e.g. python -X faulthandler) or the default action runs. 1 = armed. */
+int qpgpu_crash_trace_armed(void);
 
 /* ---- measurement: per-kernel HIP-event timing on the ctx stream (off by default) ---- */
 int qpgpu_profile_enable(qpgpu_ctx *ctx, int on);   /* on: clears the counters */
@@ -110,6 +114,15 @@ int qpgpu_lde_batch_dev(qpgpu_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_ou
 /* ---- stage s3: plonky2::hash::{poseidon, merkle_tree} ---- */
 /* Poseidon permutation (width 12) on n states of 12 elements each, in place. */
 int qpgpu_poseidon_permute_dev(qpgpu_ctx *ctx, uint64_t *d_states, size_t n);
+/* The APPLICATION hash of the Wormhole circuits on the device: Poseidon2Hash::hash_no_pad of the qp fork (reference call
+ * sites wormhole/circuit/src/unspendable_account.rs:87-88, nullifier.rs:119-120, block_header/header.rs:140,
+ * common/src/zk_merkle.rs:53-58) for `count` preimages of `len` elements each, row-major at d_in: padded `|| 1 || 0*` to a
+ * multiple of the rate 8 (wormhole/circuit/tests/heap_zeroization.rs:133-160), blocks added into the rate part, 4 outputs
+ * per preimage at d_out. params = NULL, n_words = 0: qp-poseidon-core's parameter set, pinned by the reference's seven
+ * known-answer vectors (include/qpgpu_leaf.h); otherwise a 146-word block as for qpgpu_ctx_set_hasher. Independent of the
+ * context's proof-system hasher. Asynchronous on the ctx stream with the built-in set. */
+int qpgpu_poseidon2_hash_pad10_dev(qpgpu_ctx *ctx, const uint64_t *params, size_t n_words, const uint64_t *d_in, size_t len,
+                                   size_t count, uint64_t *d_out);
 /* Digests stored by a tree: level 0 (2^log_leaves leaf digests), then each parent level down to the
  * cap level (2^cap_height digests), concatenated; 4 elements per digest. */
 size_t qpgpu_merkle_digest_count(unsigned log_leaves, unsigned cap_height);
@@ -138,6 +151,7 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
  * 260 MB per proof at 2^13 rows x 135 wires. The constants/sigmas commitment is shared by the batch. */
 int qpgpu_circuit_load_batch(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_words, unsigned max_batch, qpgpu_circuit **out);
 unsigned qpgpu_circuit_max_batch(const qpgpu_circuit *c);
+size_t qpgpu_circuit_num_public_inputs(const qpgpu_circuit *c);
 /* Releases the handle; every device region that held witness-derived data is overwritten first. */
 void qpgpu_circuit_free(qpgpu_circuit *c);
 /* Overwrites the witness-derived workspace now (witness copy, Z / quotient values, coefficients, LDEs, salts, FRI
@@ -278,7 +292,12 @@ int qpgpu_pool_create(int device, const uint64_t *pack_words, size_t n_words, un
 /* Workers that prove in lockstep: each takes up to max_batch queued proofs at once (qpgpu_prove_batch_dev). Two workers of
  * eight keep the GPU busy while one of them is in a host-side stage. The workers' contexts use the process-default hasher. */
 int qpgpu_pool_create_batched(int device, const uint64_t *pack_words, size_t n_words, unsigned workers, unsigned max_batch, qpgpu_pool **out);
+/* A job's arguments are checked at submit (null pointers: QPGPU_EINVAL; out_cap below qpgpu_pool_proof_size:
+ * QPGPU_EBUFSIZE). Jobs of different callers share a lockstep batch: when a batch fails, its jobs are proven again one at
+ * a time, so only the failing job's wait() returns the error (with that job's own message). */
 void qpgpu_pool_destroy(qpgpu_pool *p);          /* drains the queue first */
+/* qpgpu_circuit_set_witness_check on every worker's circuit; only while no ticket is outstanding (QPGPU_EINVAL otherwise) */
+int qpgpu_pool_set_witness_check(qpgpu_pool *p, int on);
 size_t qpgpu_pool_proof_size(const qpgpu_pool *p);
 unsigned qpgpu_pool_workers(const qpgpu_pool *p);
 const char *qpgpu_pool_last_error(const qpgpu_pool *p);

@@ -63,6 +63,11 @@ def load_library():
         "qpgpu_ntt_batch_dev": (c.c_int, [vp, u64p, u64p, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
         "qpgpu_lde_batch_dev": (c.c_int, [vp, u64p, u64p, c.c_uint, c.c_uint, c.c_size_t, c.c_int, c.c_uint64]),
         "qpgpu_poseidon_permute_dev": (c.c_int, [vp, u64p, c.c_size_t]),
+        "qpgpu_poseidon2_hash_pad10_dev": (c.c_int, [vp, u64p, c.c_size_t, u64p, c.c_size_t, c.c_size_t, u64p]),
+        "qpgpu_poseidon2_qp_params": (c.c_size_t, [u64p, c.c_size_t]),
+        "qpgpu_poseidon2_hash_pad10": (c.c_int, [u64p, c.c_size_t, u64p, c.c_size_t, u64p]),
+        "qpgpu_crash_trace_armed": (c.c_int, []),
+        "qpgpu_circuit_num_public_inputs": (c.c_size_t, [vp]),
         "qpgpu_merkle_digest_count": (c.c_size_t, [c.c_uint, c.c_uint]),
         "qpgpu_merkle_build_dev": (c.c_int, [vp, u64p, c.c_uint64, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
         "qpgpu_merkle_build_rows_dev": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, u64p, u64p]),
@@ -91,6 +96,7 @@ def load_library():
         "qpgpu_pool_last_error": (c.c_char_p, [vp]),
         "qpgpu_pool_submit": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
         "qpgpu_pool_wait": (c.c_int, [vp, c.c_uint64, c.POINTER(c.c_size_t)]),
+        "qpgpu_pool_set_witness_check": (c.c_int, [vp, c.c_int]),
         "qpgpu_set_hasher": (c.c_int, [c.c_int, u64p, c.c_size_t]),
         "qpgpu_get_hasher": (c.c_int, []),
         "qpgpu_witness_info": (c.c_int, [vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)]),
@@ -154,6 +160,15 @@ def set_hasher_poseidon2(rc_ext, rc_int, diag_m1, m4):
     rc = load_library().qpgpu_set_hasher(1, flat.ctypes.data, flat.size)
     if rc != 0:
         raise QpGpuError(rc, "qpgpu_set_hasher: bad Poseidon2 parameter block")
+
+
+def poseidon2_qp_params():
+    """qp-poseidon-core 3.1.0's Poseidon2 parameter set as the library carries it (pinned by the reference's seven known-answer
+    vectors): (rc_ext[8,12], rc_int[22], diag_m1[12], m4[4,4]) — the arguments of set_hasher_poseidon2 / QpGpu(hasher=...)."""
+    flat = np.empty(146, dtype=np.uint64)
+    n = load_library().qpgpu_poseidon2_qp_params(flat.ctypes.data, flat.size)
+    assert n == 146
+    return flat[:96].reshape(8, 12).copy(), flat[96:118].copy(), flat[118:130].copy(), flat[130:146].reshape(4, 4).copy()
 
 
 def poseidon_constants():
@@ -552,6 +567,11 @@ class ProvingPool:
     def proof_size(self):
         return self.lib.qpgpu_pool_proof_size(self.h)
 
+    def set_witness_check(self, on=True):
+        rc = self.lib.qpgpu_pool_set_witness_check(self.h, 1 if on else 0)
+        if rc != 0:
+            raise QpGpuError(rc, self.lib.qpgpu_pool_last_error(self.h).decode())
+
     def submit(self, d_wires, public_inputs, out=None):
         """Queue one proof of a device-resident witness; returns a ticket for wait()."""
         p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
@@ -584,6 +604,25 @@ class _Stage3:
         out = d.download().reshape(-1, 12)
         d.free()
         return out
+
+    def poseidon2_hash_pad10(self, preimages, params=None):
+        """The fork's application hash on the device (qpgpu_poseidon2_hash_pad10_dev): preimages [count, len] -> [count, 4].
+        params None = qp-poseidon-core's pinned set; otherwise the 146-word block."""
+        pre = np.ascontiguousarray(preimages, dtype=np.uint64)
+        pre = pre.reshape(1, -1) if pre.ndim == 1 else pre
+        count, ln = pre.shape
+        d_in = self.to_device(pre) if pre.size else self.alloc(8)
+        d_out = self.alloc(max(count, 1) * 32)
+        try:
+            if params is None:
+                self._check(self.lib.qpgpu_poseidon2_hash_pad10_dev(self.ctx, None, 0, d_in.ptr, ln, count, d_out.ptr))
+            else:
+                blk = np.ascontiguousarray(params, dtype=np.uint64)
+                self._check(self.lib.qpgpu_poseidon2_hash_pad10_dev(self.ctx, blk.ctypes.data, blk.size, d_in.ptr, ln, count, d_out.ptr))
+            self.sync()
+            return d_out.download()[:count * 4].reshape(count, 4).copy()
+        finally:
+            d_in.free(); d_out.free()
 
     def merkle_digest_count(self, log_leaves, cap_height):
         return self.lib.qpgpu_merkle_digest_count(log_leaves, cap_height)

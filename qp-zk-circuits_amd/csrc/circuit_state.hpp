@@ -15,7 +15,10 @@ struct qpgpu_circuit {
     qpgpu_ctx *ctx = nullptr;
     CircuitPack pack;
     std::vector<void *> allocs;
-    std::vector<std::pair<void *, size_t>> secret_allocs;   // witness-derived regions, scrubbed after every proof and before release
+    // witness-derived regions: overwritten by qpgpu_circuit_scrub, by qpgpu_circuit_free, and after every proof of the
+    // host-buffer entry qpgpu_prove. The _dev / batch / pool entries leave them resident between proofs (the next proof
+    // overwrites them); include/qpgpu.h says so at qpgpu_circuit_scrub.
+    std::vector<std::pair<void *, size_t>> secret_allocs;
     uint32_t max_batch = 1;          // proofs the per-proof workspace below has room for (lockstep batch)
     // setup-time residents
     gl::u64 *d_cs_values = nullptr;

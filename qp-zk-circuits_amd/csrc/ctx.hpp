@@ -22,11 +22,19 @@ struct qpgpu_ctx {
     size_t scratch_bytes = 0;
     std::map<std::string, std::shared_ptr<NttTables>> ntt_tables;
     std::vector<void *> owned;  // table allocations freed at destroy
+    // plan_only: ntt_run goes through its planning (twiddle / coset tables uploaded and cached, scratch sized) without
+    // launching anything. A circuit load replays the transforms a proof will issue this way, so that the proving threads
+    // never allocate, free or upload.
+    bool plan_only = false;
     // the proof-system hasher of everything created on this context (copied from the process default at creation,
     // changed by qpgpu_ctx_set_hasher until the first circuit or oracle is created here)
     hasher::Config hasher;
     poseidon2::Params *d_p2 = nullptr;       // device copy of hasher.p2 (Poseidon2 only)
     bool hasher_in_use = false;
+    // the APPLICATION hash of the Wormhole circuits (Poseidon2 with qp-poseidon-core's parameters: the Poseidon2 gate's
+    // constants and the pad-10 sponge), independent of which permutation is the proof-system hasher above
+    poseidon2::Params *d_p2_app = nullptr;
+    int ensure_p2_app();
     HasherDev hasher_dev() const { HasherDev h; h.kind = hasher.kind; h.p2 = d_p2; return h; }
 
     // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)

@@ -30,3 +30,5 @@ hipError_t merkle_leaf_hash_rows(const uint64_t *rows, uint64_t n_leaves, uint32
 // all levels above `levels` (cnt digests per tree, the following levels stored behind them) down to the cap
 hipError_t merkle_reduce_to_cap(uint64_t *levels, uint64_t cnt, uint64_t cap_n, uint32_t batch, uint64_t ps_digests, const HasherDev &h, hipStream_t st);
 hipError_t poseidon_permute_batch(uint64_t *states, uint64_t n, const HasherDev &h, hipStream_t st);
+// `count` preimages of `len` elements (row-major) through the qp fork's Poseidon2 sponge (pad `|| 1 || 0*`, additive absorption)
+hipError_t poseidon2_hash_pad10_batch(const uint64_t *in, uint64_t len, uint64_t count, uint64_t *out, const poseidon2::Params *p2, hipStream_t st);

@@ -22,8 +22,21 @@ int merkle_ensure_constants(qpgpu_ctx *ctx) {
         void *v = nullptr;
         QP_HIP(ctx, hipMalloc(&v, sizeof(poseidon2::Params)));
         ctx->d_p2 = (poseidon2::Params *)v;
-        QP_HIP(ctx, hipMemcpy(ctx->d_p2, &ctx->hasher.p2, sizeof(poseidon2::Params), hipMemcpyHostToDevice));
+        QP_HIP(ctx, hipMemcpyAsync(ctx->d_p2, &ctx->hasher.p2, sizeof(poseidon2::Params), hipMemcpyHostToDevice, ctx->stream));
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return QPGPU_OK;
+}
+
+int qpgpu_ctx::ensure_p2_app() {
+    if (d_p2_app) return QPGPU_OK;
+    void *v = nullptr;
+    QP_HIP(this, hipMalloc(&v, sizeof(poseidon2::Params)));
+    // pageable source with static lifetime (qp_params() is a function-local static); the copy is ordered on the ctx stream
+    hipError_t e = hipMemcpyAsync(v, &poseidon2::qp_params(), sizeof(poseidon2::Params), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { (void)hipFree(v); return hip_fail(e, "upload of the Poseidon2 application parameters"); }
+    d_p2_app = (poseidon2::Params *)v;
     return QPGPU_OK;
 }
 
@@ -57,7 +70,10 @@ extern "C" int qpgpu_ctx_set_hasher(qpgpu_ctx *ctx, int kind, const uint64_t *pa
     poseidon2::Params p;
     if (parse_p2(params, n_words, p) != QPGPU_OK) return ctx->fail(QPGPU_EINVAL, "ctx_set_hasher: bad Poseidon2 parameter block");
     ctx->hasher.kind = hasher::POSEIDON2; ctx->hasher.p2 = p;
-    if (ctx->d_p2) QP_HIP(ctx, hipMemcpy(ctx->d_p2, &ctx->hasher.p2, sizeof(poseidon2::Params), hipMemcpyHostToDevice));
+    if (ctx->d_p2) {
+        QP_HIP(ctx, hipMemcpyAsync(ctx->d_p2, &ctx->hasher.p2, sizeof(poseidon2::Params), hipMemcpyHostToDevice, ctx->stream));
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return QPGPU_OK;
 }
 extern "C" int qpgpu_ctx_get_hasher(const qpgpu_ctx *ctx) { return ctx ? ctx->hasher.kind : QPGPU_EINVAL; }
@@ -127,6 +143,30 @@ int qpgpu_merkle_build_rows_dev(qpgpu_ctx *ctx, const uint64_t *d_rows, uint32_t
         QP_HIP(ctx, hipMemcpyAsync(h_cap_out, lvl, cap_n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return QPGPU_OK;
+}
+
+int qpgpu_poseidon2_hash_pad10_dev(qpgpu_ctx *ctx, const uint64_t *params, size_t n_words, const uint64_t *d_in, size_t len, size_t count, uint64_t *d_out) {
+    if (!ctx) return QPGPU_EINVAL;
+    QP_DEV(ctx);
+    if ((!d_in && len && count) || (!d_out && count)) return ctx->fail(QPGPU_EINVAL, "poseidon2_hash_pad10: null buffer");
+    if (len > (1u << 20)) return ctx->fail(QPGPU_EINVAL, "poseidon2_hash_pad10: preimage longer than 2^20 elements");
+    if (!params && n_words == 0) {
+        int rc = ctx->ensure_p2_app();
+        if (rc) return rc;
+        QP_HIP(ctx, poseidon2_hash_pad10_batch(d_in, len, count, d_out, ctx->d_p2_app, ctx->stream));
+        return QPGPU_OK;
+    }
+    poseidon2::Params p;
+    if (parse_p2(params, n_words, p) != QPGPU_OK) return ctx->fail(QPGPU_EINVAL, "poseidon2_hash_pad10: bad Poseidon2 parameter block");
+    void *v = nullptr;   // a caller-supplied block: uploaded for this call only
+    QP_HIP(ctx, hipMalloc(&v, sizeof p));
+    hipError_t e = hipMemcpyAsync(v, &p, sizeof p, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = poseidon2_hash_pad10_batch(d_in, len, count, d_out, (const poseidon2::Params *)v, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);   // `p` and the block outlive the kernel
+    (void)hipFree(v);
+    if (e != hipSuccess) return ctx->hip_fail(e, "poseidon2_hash_pad10");
+    if (e2 != hipSuccess) return ctx->hip_fail(e2, "poseidon2_hash_pad10");
     return QPGPU_OK;
 }
 

@@ -235,6 +235,30 @@ __global__ void __launch_bounds__(256) node_kernel(const u64 *in, u64 *out, u64 
     o[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// Poseidon2Hash::hash_no_pad of the qp fork (the application hash inside the Wormhole circuits; reference call sites
+// wormhole/circuit/src/unspendable_account.rs:87-88, nullifier.rs:119-120, block_header/header.rs:140): preimage i = `len`
+// elements at in + i * len, padded `|| 1 || 0*` to a multiple of the rate 8 (wormhole/circuit/tests/heap_zeroization.rs:133-160),
+// every block ADDED into the rate part of the state, 4 outputs. One thread per preimage.
+__global__ void __launch_bounds__(256) p2_pad10_sponge_kernel(const u64 *in, u64 len, u64 count, u64 *out, const poseidon2::Params *p2) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64 *src = in + i * len;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    for (u64 c = 0; c <= len; c += 8) {          // the block that holds the terminator is the last one
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u64 idx = c + k;
+            const u64 v = idx < len ? gl::canon(src[idx]) : (idx == len ? 1 : 0);
+            s[k] = gl::add_canonical(s[k], v);
+        }
+        poseidon2::permute(s, *p2);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[i * 4 + k] = s[k];
+}
+
 template <class Perm>
 __global__ void permute_kernel(u64 *states, u64 n, const poseidon2::Params *p2) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -362,6 +386,11 @@ hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, u32 batch, u64 
         lvl += cnt * 4; cnt >>= 1;
     }
     return hipSuccess;
+}
+hipError_t poseidon2_hash_pad10_batch(const u64 *in, u64 len, u64 count, u64 *out, const poseidon2::Params *p2, hipStream_t st) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(p2_pad10_sponge_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, in, len, count, out, p2);
+    return hipGetLastError();
 }
 hipError_t poseidon_permute_batch(u64 *states, u64 n, const HasherDev &h, hipStream_t st) {
     if (n == 0) return hipSuccess;

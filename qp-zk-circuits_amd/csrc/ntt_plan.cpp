@@ -64,8 +64,10 @@ int qpgpu_ctx::upload(const std::vector<uint64_t> &host, uint64_t **dptr) {
     void *p = nullptr;
     QP_HIP(this, hipMalloc(&p, host.size() * sizeof(uint64_t)));
     owned.push_back(p);
-    // tables are tiny; a synchronous copy from pageable memory keeps lifetime simple
-    QP_HIP(this, hipMemcpy(p, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    // tables are tiny; the copy is ordered on the context's own stream (never the legacy null stream, which every proving
+    // thread of a process shares) and waited for, so the pageable source may go out of scope
+    QP_HIP(this, hipMemcpyAsync(p, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    QP_HIP(this, hipStreamSynchronize(stream));
     *dptr = (uint64_t *)p;
     return QPGPU_OK;
 }
@@ -196,7 +198,7 @@ int ntt_run(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_
         }
         const u64 tiles = (M0 + (1ull << p.log_t) - 1) >> p.log_t;
         ctx->prof_begin("ntt_pass_outer");
-        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream);
+        hipError_t le = ctx->plan_only ? hipSuccess : ntt_pass_launch(p, tiles, batch, ctx->stream);
         ctx->prof_end();
         QP_HIP(ctx, le);
     }
@@ -220,7 +222,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
     const u64 N = 1ull << L, n_in = 1ull << log_n_in;
     const bool coset = coset_shift > 1;
     if (L == 0) {
-        if (d_in != d_out) QP_HIP(ctx, hipMemcpyAsync(d_out, d_in, batch * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_in != d_out && !ctx->plan_only) QP_HIP(ctx, hipMemcpyAsync(d_out, d_in, batch * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         return QPGPU_OK;
     }
     {   // one-time kernel attribute setup, safe when several proving threads start together
@@ -271,7 +273,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         u64 tiles = (batch + (1ull << a.log_t) - 1) >> a.log_t;
         a.in_proof_stride = g.in_ps; a.out_proof_stride = g.out_ps;
         ctx->prof_begin("ntt_pass_single");
-        hipError_t le = ntt_pass_launch(a, tiles, 1, ctx->stream, g.nproofs);
+        hipError_t le = ctx->plan_only ? hipSuccess : ntt_pass_launch(a, tiles, 1, ctx->stream, g.nproofs);
         ctx->prof_end();
         QP_HIP(ctx, le);
         return QPGPU_OK;
@@ -328,7 +330,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         folded_scale = p.tw_scale != 0;
         p.in_proof_stride = g.in_ps; p.out_proof_stride = mid_ps;
         ctx->prof_begin("ntt_pass_strided");
-        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream, g.nproofs);
+        hipError_t le = ctx->plan_only ? hipSuccess : ntt_pass_launch(p, tiles, batch, ctx->stream, g.nproofs);
         ctx->prof_end();
         QP_HIP(ctx, le);
     }
@@ -355,7 +357,7 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         u64 tiles = (R1 + (1ull << p.log_t) - 1) >> p.log_t;
         p.in_proof_stride = mid_ps; p.out_proof_stride = g.out_ps;
         ctx->prof_begin("ntt_pass_rows");
-        hipError_t le = ntt_pass_launch(p, tiles, batch, ctx->stream, g.nproofs);
+        hipError_t le = ctx->plan_only ? hipSuccess : ntt_pass_launch(p, tiles, batch, ctx->stream, g.nproofs);
         ctx->prof_end();
         QP_HIP(ctx, le);
     }

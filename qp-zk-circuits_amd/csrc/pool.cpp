@@ -16,6 +16,8 @@
 #include "ctx.hpp"
 
 struct qpgpu_circuit;
+extern "C" size_t qpgpu_circuit_num_public_inputs(const qpgpu_circuit *c);
+extern "C" int qpgpu_circuit_set_witness_check(qpgpu_circuit *c, int on);
 
 namespace {
 struct Job {
@@ -61,13 +63,26 @@ void worker(qpgpu_pool *p, size_t w) {
         std::vector<size_t> lens(nb, 0);
         size_t cap = ~(size_t)0;
         for (uint32_t i = 0; i < nb; i++) { wires[i] = js[i].d_wires; pis[i] = js[i].public_inputs; outs[i] = js[i].out; cap = std::min(cap, js[i].out_cap); }
+        std::vector<int> rcs(nb, QPGPU_OK);
+        std::vector<std::string> errs(nb);
         const int rc = qpgpu_prove_batch_dev(p->circuits[w], wires.data(), nb, pis.data(), outs.data(), cap, lens.data());
+        if (rc != QPGPU_OK && nb > 1) {
+            // the jobs of a lockstep batch are unrelated callers' proofs, and in the reference a failing prove concerns its
+            // caller only: prove them again one at a time, so that the offender alone gets the error (and its own text)
+            for (uint32_t i = 0; i < nb; i++) {
+                lens[i] = 0;
+                rcs[i] = qpgpu_prove_batch_dev(p->circuits[w], &wires[i], 1, &pis[i], &outs[i], js[i].out_cap, &lens[i]);
+                if (rcs[i] != QPGPU_OK) errs[i] = qpgpu_last_error(p->ctxs[w]);
+            }
+        } else if (rc != QPGPU_OK) {
+            rcs[0] = rc; errs[0] = qpgpu_last_error(p->ctxs[w]);
+        }
         {
             std::lock_guard<std::mutex> lk(p->mu);
             for (uint32_t i = 0; i < nb; i++) {
                 Done &d = p->done[js[i].ticket % p->done.size()];
-                d.rc = rc; d.len = lens[i];
-                if (rc != QPGPU_OK) d.err = qpgpu_last_error(p->ctxs[w]);
+                d.len = lens[i]; d.err = errs[i];
+                d.rc = rcs[i];          // last: wait() watches rc
             }
         }
         p->cv_done.notify_all();
@@ -117,8 +132,26 @@ size_t qpgpu_pool_proof_size(const qpgpu_pool *p) { return p && !p->circuits.emp
 unsigned qpgpu_pool_workers(const qpgpu_pool *p) { return p ? (unsigned)p->circuits.size() : 0; }
 const char *qpgpu_pool_last_error(const qpgpu_pool *p) { return p ? p->err.c_str() : "null pool"; }
 
+// qpgpu_circuit_set_witness_check for every worker; call while no job is queued or running
+int qpgpu_pool_set_witness_check(qpgpu_pool *p, int on) {
+    if (!p) return QPGPU_EINVAL;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->queue.empty() || p->next_ticket != p->oldest_live) { p->err = "pool_set_witness_check: jobs in flight"; return QPGPU_EINVAL; }
+    for (auto *c : p->circuits) qpgpu_circuit_set_witness_check(c, on);
+    return QPGPU_OK;
+}
+
 int qpgpu_pool_submit(qpgpu_pool *p, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, uint64_t *ticket) {
-    if (!p || !d_wires || !out || !ticket) return QPGPU_EINVAL;
+    if (!p || !ticket) return QPGPU_EINVAL;
+    // a job is checked on its own here, so that a bad one cannot reach a lockstep batch of other callers' proofs
+    const size_t need = qpgpu_pool_proof_size(p);
+    const bool has_pis = !p->circuits.empty() && qpgpu_circuit_num_public_inputs(p->circuits[0]) > 0;
+    if (!d_wires || !out || (has_pis && !public_inputs) || out_cap < need) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->err = out_cap < need && d_wires && out ? "pool_submit: output buffer smaller than the proof (" + std::to_string(out_cap) + " < " + std::to_string(need) + " bytes)"
+                                                  : "pool_submit: null argument";
+        return out_cap < need && d_wires && out ? QPGPU_EBUFSIZE : QPGPU_EINVAL;
+    }
     {
         std::lock_guard<std::mutex> lk(p->mu);
         if (p->next_ticket - p->oldest_live >= p->done.size()) { p->err = "pool_submit: too many unwaited jobs"; return QPGPU_EBUFSIZE; }

@@ -73,6 +73,42 @@ int h2d(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
 void scrub(qpgpu_circuit *c) {
     for (auto &r : c->secret_allocs) (void)hipMemsetAsync(r.first, 0, r.second, c->ctx->stream);
     (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->stage.h) std::memset(c->stage.h, 0, c->stage.words * 8);   // the staging ring held challenges and salt keys
+}
+
+// Replays, in planning mode, every transform a lockstep batch of max_batch proofs will issue (prove_batch_impl, fri_prove):
+// the context caches their twiddle and coset tables and sizes its scratch here, on the loading thread, so that a proving
+// thread never calls hipMalloc / hipFree / an upload (with six of them starting together, each used to create its tables and
+// grow its scratch inside its first batch, next to the other threads' launches).
+int plan_transforms(qpgpu_circuit *c) {
+    qpgpu_ctx *ctx = c->ctx;
+    const CircuitPack &p = c->pack;
+    const unsigned d = (unsigned)p.degree_bits, L = (unsigned)(p.degree_bits + p.rate_bits);
+    unsigned qbits = 0; while ((1ull << qbits) < p.quotient_degree_factor) qbits++;
+    const uint32_t B = c->max_batch, nch = (uint32_t)p.num_challenges;
+    struct Restore { qpgpu_ctx *c; ~Restore() { c->plan_only = false; } } restore{ctx};
+    ctx->plan_only = true;
+    const PolyOracle *os[3] = {&c->wires, &c->zs, &c->quot};
+    for (const PolyOracle *o : os) {
+        if (o != &c->quot) QP_TRY(ntt_run(ctx, o->lde, o->coeffs, d, d, (size_t)B * o->ncols, true, false, 0));   // from_values
+        QP_TRY(ntt_run(ctx, o->coeffs, o->lde, d, L, (size_t)B * o->ncols, false, true, gl::MULT_GEN));            // from_coeffs
+    }
+    QP_TRY(ntt_run(ctx, c->quot.coeffs, c->quot.coeffs, d + qbits, d + qbits, (size_t)nch * B, true, false, 0));   // quotient values -> coefficients
+    // FRI commit phase: the batched opening polynomial and every folded polynomial, as two component columns per proof
+    NttProofs np; np.nproofs = B; np.in_ps = c->fri_work.ws; np.out_ps = c->fri_work.ws;
+    u64 shift = gl::MULT_GEN, valid = p.n();
+    unsigned log_len = L;
+    QP_TRY(ntt_run(ctx, c->fri_work.fin, c->fri_work.vals, d, L, 2, false, true, shift, np));
+    for (size_t r = 0; r < p.arity_bits.size(); r++) {
+        const unsigned ab = (unsigned)p.arity_bits[r];
+        valid >>= ab; log_len -= ab;
+        shift = gl::pow(shift, 1ull << ab);
+        if (r + 1 < p.arity_bits.size()) {
+            unsigned lv = 0; while ((1ull << lv) < valid) lv++;
+            QP_TRY(ntt_run(ctx, c->fri_work.coeffs[0], c->fri_work.vals, lv, log_len, 2, false, true, shift, np));
+        }
+    }
+    return QPGPU_OK;
 }
 
 }  // namespace
@@ -99,7 +135,7 @@ void qpgpu_circuit_free(qpgpu_circuit *c) {
     (void)hipStreamSynchronize(c->ctx->stream);
     // the workspace held witness-derived data (reference wormhole/circuit/src/sensitive.rs:36-44): clear it before the
     // allocator can hand the memory to someone else
-    scrub(c);
+    scrub(c);                                    // includes the pinned staging ring
     if (c->stage.h) (void)hipHostFree(c->stage.h);
     for (void *p : c->allocs) (void)hipFree(p);
     witness_plan_free(c->wplan);
@@ -224,7 +260,11 @@ int qpgpu_circuit_load_batch(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t 
     }
     // everything a batch reads back ends up in its proofs: their total size bounds any single read
     if ((rc = ctx->reserve_read_back((size_t)B * qpgpu_proof_size(c) + (1u << 16))) != QPGPU_OK) return fail(rc);
-    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CK(plan_transforms(c));
+    {   // asynchronous faults of the setup kernels surface here: release everything on the way out
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx->hip_fail(e, "circuit_load: hipStreamSynchronize"));
+    }
 #undef CK
     *out = c;
     return QPGPU_OK;
@@ -235,6 +275,7 @@ int qpgpu_circuit_load(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t n_word
 }
 
 unsigned qpgpu_circuit_max_batch(const qpgpu_circuit *c) { return c ? c->max_batch : 0; }
+size_t qpgpu_circuit_num_public_inputs(const qpgpu_circuit *c) { return c ? (size_t)c->pack.num_public_inputs : 0; }
 
 int qpgpu_circuit_set_witness_check(qpgpu_circuit *c, int on) {
     if (!c) return QPGPU_EINVAL;
@@ -276,6 +317,7 @@ static int prove_batch_impl(qpgpu_circuit *c, uint32_t nb, const u64 *d_wires, c
     const size_t SW = c->small_words;
 
     c->stage.pos = 0;
+    u64 *ring_keys = nullptr; size_t ring_key_words = 0;
     c->wires.set_batch(nb); c->zs.set_batch(nb); c->quot.set_batch(nb);
     c->quot.ps_coeffs = (u64)nch * q_n;    // = num_quotient_cols * n: the same dense array seen as nq chunk polynomials
     std::vector<std::array<u64, 4>> pih(nb);
@@ -288,14 +330,26 @@ static int prove_batch_impl(qpgpu_circuit *c, uint32_t nb, const u64 *d_wires, c
             if (c->seed_set) salt_key_from_seed(c->blinding_seed + b, keys.data() + 8 * (size_t)b);
             else if (salt_key_random(keys.data() + 8 * (size_t)b) != QPGPU_OK) return ctx->fail(QPGPU_EDEVICE, "prove: the OS entropy source failed");
         }
-        QP_TRY(c->stage.put(ctx, c->d_salt_keys, keys.data(), keys.size() * 4));
+        const size_t ring_at = c->stage.pos;
+        const int put_rc = c->stage.put(ctx, c->d_salt_keys, keys.data(), keys.size() * 4);
+        // the keys are secrets: the host vector goes now, the ring slot as soon as the device has read it (ring_keys below)
+        volatile uint32_t *kz = keys.data();
+        for (size_t i = 0; i < keys.size(); i++) kz[i] = 0;
+        QP_TRY(put_rc);
+        if (c->stage.pos > ring_at) { ring_keys = c->stage.h + ring_at; ring_key_words = c->stage.pos - ring_at; }
     }
     c->seed_set = false;
 
     // ---- s2/s3 wires ----
     ctx->prof_begin("prove_commit_wires");
-    QP_TRY(oracle_commit_values(ctx, d_wires, c->wires, c->d_salt_keys));
+    const int wires_rc = oracle_commit_values(ctx, d_wires, c->wires, c->d_salt_keys);
     ctx->prof_end();
+    if (ring_keys) {   // the commit read its cap back (a stream sync), so the copy kernel that pulled the keys in is done; on a failure wait for it
+        if (wires_rc) (void)hipStreamSynchronize(st);
+        volatile u64 *rz = ring_keys;
+        for (size_t i = 0; i < ring_key_words; i++) rz[i] = 0;
+    }
+    QP_TRY(wires_rc);
     std::vector<Challenger> chs(nb, Challenger(ctx->hasher));
     std::vector<std::array<u64, 4>> betas(nb), gammas(nb), alphas(nb);
 

@@ -75,6 +75,7 @@ void qpgpu_ctx_destroy(qpgpu_ctx *ctx) {
     for (void *p : ctx->owned) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_p2) (void)hipFree(ctx->d_p2);
+    if (ctx->d_p2_app) (void)hipFree(ctx->d_p2_app);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -62,3 +62,25 @@ def test_library_challenger_matches_oracle(pkg, orc):
         m = int(rng.integers(0, 11))
         assert a.get_n(m) == b.get_n(m), step
     assert a.state.input_len == 0 or a.state.output_len == 0
+
+
+def test_crash_trace_leaves_a_native_backtrace(pkg, tmp_path):
+    """QPGPU_CRASH_TRACE (csrc/crash_trace.cpp): a fatal signal in a process that has the library loaded leaves the faulting
+    address, its mapping and the native backtrace in the named file, then the previous handler (python's faulthandler) runs and
+    the process still dies of the signal. Off by default."""
+    import subprocess
+    import sys
+    so = pkg.lib_path()
+    log = tmp_path / "crash.txt"
+    code = ("import ctypes, faulthandler, sys; faulthandler.enable(); lib = ctypes.CDLL(%r); "
+            "assert lib.qpgpu_crash_trace_armed() == int(sys.argv[1]); ctypes.string_at(16)" % so)
+    env = dict(os.environ, QPGPU_CRASH_TRACE=str(log))
+    r = subprocess.run([sys.executable, "-c", code, "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == -11, (r.returncode, r.stderr[-400:])
+    text = log.read_text()
+    assert "libqpgpu crash trace: signal 11 (SIGSEGV)" in text and "address 0x0000000000000010" in text
+    assert "not mapped" in text and "native backtrace" in text and "end of libqpgpu crash trace" in text
+    assert "Fatal Python error: Segmentation fault" in r.stderr          # faulthandler still had its turn
+    env.pop("QPGPU_CRASH_TRACE")
+    r = subprocess.run([sys.executable, "-c", code, "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == -11

@@ -2,6 +2,8 @@
 all of them. Each proof must be byte-equal to the CPU oracle's proof of the same witness (and therefore to the single-proof
 entry), for dense and scattered witness layouts, with zero-knowledge salts, through the batched proving pool, and on the
 exact shape bench.py times."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -100,6 +102,48 @@ def test_batched_pool(pkg, gpu, orc):
         want = [oc.prove(ws[i], pis[i]) for i in range(6)]
         for k, t in enumerate(tickets):
             assert res[t] == want[k % 6], k
+        for x in bufs:
+            x.free()
+    finally:
+        pool.close(); oc.close()
+
+
+@pytest.mark.gpu
+def test_pool_failure_concerns_only_the_failing_job(pkg, gpu, orc):
+    """Unrelated callers' jobs share a lockstep batch. In the reference a failing prove affects its caller only
+    (every proof is its own `prove` call, wormhole/prover/src/lib.rs:171-175): one unsatisfied witness among valid ones must
+    fail alone, with its own message, and the others must come out byte-equal to the oracle's proofs. Bad arguments are
+    refused at submit, before they can reach a batch."""
+    pack, wires, _ = pkg.synth_circuit(8, num_wires=135, num_routed=80, num_public_inputs=21, seed=321, poseidon=True, base_sum=True)
+    pis, ws = _witnesses(pkg, gpu, pack, wires, 4)
+    pool = pkg.ProvingPool(pack, workers=1, device=0, max_batch=8)
+    oc = OracleCircuit(orc, pack)
+    try:
+        pool.set_witness_check(True)
+        bad = ws[2].copy()
+        bad[3, 40] = (int(bad[3, 40]) + 1) % pkg.P            # an arithmetic output no longer matches its operands
+        bufs = [gpu.to_device(w) for w in (ws[0], ws[1], bad, ws[3])]
+        # queued together: one worker takes all six as one lockstep batch
+        order = [0, 1, 2, 3, 2, 0]
+        tickets = [pool.submit(bufs[i], pis[i]) for i in order]
+        want = [oc.prove(ws[i], pis[i]) for i in range(4)]
+        for i, t in zip(order, tickets):
+            if i == 2:
+                with pytest.raises(pkg.QpGpuError) as e:
+                    pool.wait(t)
+                assert e.value.code == -4 and "row" in str(e.value) and "of the batch" not in str(e.value)
+            else:
+                assert pool.wait(t) == want[i], i
+        # argument checks happen per job, at submit
+        small = np.empty(pool.proof_size() - 1, dtype=np.uint8)
+        with pytest.raises(pkg.QpGpuError) as e:
+            pool.submit(bufs[0], pis[0], small)
+        assert e.value.code == -5
+        t = ctypes.c_uint64()
+        out = np.empty(pool.proof_size(), dtype=np.uint8)
+        assert pool.lib.qpgpu_pool_submit(pool.h, bufs[0].ptr, None, out.ctypes.data, out.size, ctypes.byref(t)) == -1   # no public inputs
+        # the pool still works afterwards
+        assert pool.wait(pool.submit(bufs[3], pis[3])) == want[3]
         for x in bufs:
             x.free()
     finally:
