@@ -324,7 +324,18 @@ size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned
  * bit 3: every 8th row cycles through ReducingGate, ReducingExtensionGate, RandomAccessGate(4 bits), ExponentiationGate
  * and PoseidonMdsGate, the rest of the gates plonky2's in-circuit verifier uses (needs >= 48 routed wires). bit 4: some
  * operation inputs come from generators that are not attached to a gate (Equality, LowHigh, NonzeroTest, Constant, Copy,
- * WireSplit, extension quotient): the pack gets a hint trailer (circuit.hpp) and qpgpu_synth_pack_words_ex is an upper bound. */
+ * WireSplit, extension quotient): the pack gets a hint trailer (circuit.hpp) and qpgpu_synth_pack_words_ex is an upper bound.
+ * bit 6: the LEAF PROFILE — the Wormhole leaf circuit's application hashes as rows of the qp fork's Poseidon2 gate (gate type 14,
+ * qp-zk-circuits_amd/csrc/circuit.hpp): pad-10 sponge chains over 7, 4, 9, 4, 8, 45 and 16 x 16 elements (the eight
+ * `hash_n_to_hash_no_pad_p2` call sites: wormhole/circuit/src/unspendable_account.rs:229-231, nullifier.rs:298-299,
+ * zk_merkle_proof.rs:482,504,606, block_header/mod.rs:66; 61 permutations), one gate row per permutation and one ArithmeticGate
+ * row of eight additions per further block, as many as the rows hold, plus four free-standing permutation rows; the pack
+ * carries the gate's wire layout ("P2GL1"). bit 7 (with bit 6): a deliberately different wire layout (no swap wires, other block
+ * order) to exercise the layout table. qpgpu_synth_p2_sites lists the hash sites (3 words each: preimage length, gate rows,
+ * first slot; gate row k of a site is row 8 * (slot + k) + 3, the additions for block k + 1 are operations 0..7 of the row after
+ * it, message element i is input wire i of the first gate row or the addend wire 4 (i % 8) + 2 of the add row before block i / 8,
+ * the digest is the first four output wires of the last gate row). */
+size_t qpgpu_synth_p2_sites(unsigned degree_bits, unsigned num_public_inputs, unsigned flags, uint64_t *out, size_t cap_words);
 size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned flags);
 int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                            uint64_t seed, unsigned flags, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words,

@@ -13,7 +13,7 @@
 #include "gl.h"
 
 enum { OG_NOOP = 0, OG_CONSTANT = 1, OG_PUBLIC_INPUT = 2, OG_ARITHMETIC = 3, OG_POSEIDON = 4, OG_BASE_SUM = 5, OG_ARITHMETIC_EXT = 6, OG_MUL_EXT = 7,
-       OG_REDUCING = 8, OG_REDUCING_EXT = 9, OG_RANDOM_ACCESS = 10, OG_EXPONENTIATION = 11, OG_POSEIDON_MDS = 12, OG_COSET_INTERP = 13 };
+       OG_REDUCING = 8, OG_REDUCING_EXT = 9, OG_RANDOM_ACCESS = 10, OG_EXPONENTIATION = 11, OG_POSEIDON_MDS = 12, OG_COSET_INTERP = 13, OG_POSEIDON2 = 14 };
 
 typedef struct { uint64_t type, param0, param1, selector_index, group_start, group_end, num_constraints, reserved; } orc_gate;
 
@@ -33,6 +33,7 @@ typedef struct {
     size_t n_arity; uint64_t arity[16];
     size_t n_gates; orc_gate *gates;
     gl_t *k_is; gl_t digest[4];
+    uint64_t p2_layout[10];      /* wire layout of the Poseidon2 gate: pack trailer "P2GL1", or the default (oracle/poseidon2_gate.c) */
     gl_t *cs_values;             /* [ncs][n] */
     orc_batch cs;                /* constants_sigmas commitment (setup) */
 } orc_circuit;
@@ -51,6 +52,11 @@ size_t orc_proof_size(const orc_circuit *c);
 /* stage trace of the last orc_prove call in this process (not thread-safe; tests only) */
 size_t orc_trace_len(const char *name);              /* number of u64 words, 0 if absent */
 int orc_trace_get(const char *name, uint64_t *out);  /* copies the words */
+
+/* the qp fork's Poseidon2 gate (oracle/poseidon2_gate.c): unfiltered constraints at one point; returns how many */
+size_t orc_p2_gate_num_constraints(const uint64_t lay[10]);
+size_t orc_p2_gate_base(const uint64_t lay[10], const gl_t *w, gl_t *out);
+size_t orc_p2_gate_ext(const uint64_t lay[10], const gl2_t *w, gl2_t *out);
 
 /* hashing primitives from poseidon.c */
 void orc_poseidon_permute(gl_t s[12]);

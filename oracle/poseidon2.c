@@ -18,13 +18,7 @@
 #include <string.h>
 #include <stdlib.h>
 
-typedef struct {
-    gl_t rc_ext[8][12];
-    gl_t rc_int[22];
-    gl_t diag_m1[12];   /* internal matrix = J + diag(diag_m1) */
-    gl_t m4[4][4];
-    int absorb_add;     /* 0: overwrite rate lanes, 1: add into rate lanes */
-} orc_p2_params;
+#include "poseidon2.h"
 
 size_t orc_p2_params_size(void) { return sizeof(orc_p2_params); }
 

@@ -136,6 +136,7 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
     memcpy(c->k_is, w + p, sizeof(gl_t) * c->num_routed); p += c->num_routed;
     memcpy(c->digest, w + p, 32); p += 4;
     size_t n = (size_t)1 << c->degree_bits, ncs = c->num_selectors + c->num_constants + c->num_routed;
+    { static const uint64_t dflt[10] = {0, 12, 24, 25, 29, 65, 87, 0, 0, 135}; memcpy(c->p2_layout, dflt, sizeof dflt); }
     /* optional trailers are of no concern to the prover: witness hints (stage s1; magic "HINT1", 8 words per entry) and
      * the public-input cells (magic "PUBI1", one word per entry); they are only checked for being well formed */
     {
@@ -144,10 +145,21 @@ orc_circuit *orc_circuit_load(const uint64_t *w, size_t nw) {
         while (ok && q != nw) {
             if (q + 2 > nw) { ok = 0; break; }
             const uint64_t magic = w[q], cnt = w[q + 1];
-            const uint64_t per = magic == 0x00000031544E4948ULL ? 8 : magic == 0x0000003149425550ULL ? 1 : 0;
+            const uint64_t per = magic == 0x00000031544E4948ULL ? 8 : (magic == 0x0000003149425550ULL || magic == 0x000000314C473250ULL) ? 1 : 0;
             if (!per || cnt > (nw - q - 2) / per) { ok = 0; break; }
+            if (magic == 0x000000314C473250ULL) {     /* "P2GL1": the Poseidon2 gate's wire layout, ten words */
+                if (cnt != 10) { ok = 0; break; }
+                memcpy(c->p2_layout, w + q + 2, sizeof c->p2_layout);
+            }
             q += 2 + per * cnt;
         }
+        for (size_t i = 0; ok && i < c->n_gates; i++)
+            if (c->gates[i].type == OG_POSEIDON2) {    /* the layout must stay inside the wires (scratch bounds of eval_gates_*) */
+                const uint64_t *l = c->p2_layout, nwir = c->num_wires;
+                const uint64_t f0 = l[7] ? 48 : 36;
+                if (l[0] + 12 > nwir || l[1] + 12 > nwir || (l[2] != 0xFFFFFFFFULL && (l[2] >= nwir || l[3] + 4 > nwir)) || l[4] + f0 > nwir || l[5] + 22 > nwir ||
+                    l[6] + 48 > nwir || l[7] > 1 || l[8] != 0 || c->gates[i].num_constraints != orc_p2_gate_num_constraints(l)) ok = 0;
+            }
         if (!ok) { free(c->gates); free(c->k_is); free(c); return NULL; }
     }
     c->cs_values = (gl_t *)malloc(sizeof(gl_t) * ncs * n);
@@ -413,6 +425,12 @@ static void eval_gates_base(const orc_circuit *c, const gl_t *cs_row, const gl_t
             for (int i = 0; i < 123; i++) acc[i] = gl_add(acc[i], gl_mul(f, cst[i]));
             break;
         }
+        case OG_POSEIDON2: {
+            gl_t cst[128];
+            const size_t nc = orc_p2_gate_base(c->p2_layout, wires, cst);
+            for (size_t i = 0; i < nc; i++) acc[i] = gl_add(acc[i], gl_mul(f, cst[i]));
+            break;
+        }
         case OG_ARITHMETIC_EXT:   /* ArithmeticExtensionGate<2>: out - (c0 m0 m1 + c1 addend) over F[x]/(x^2-7), 8 wires per op */
             for (uint64_t i = 0; i < g->param0; i++) {
                 const gl_t *w = wires + 8 * i;
@@ -476,6 +494,12 @@ void orc_eval_gates_ext(const orc_circuit *c, const gl2_t *cs_row, const gl2_t *
             gl2_t cst[123];
             poseidon_gate_ext(wires, cst);
             for (int i = 0; i < 123; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, cst[i]));
+            break;
+        }
+        case OG_POSEIDON2: {
+            gl2_t cst[128];
+            const size_t nc = orc_p2_gate_ext(c->p2_layout, wires, cst);
+            for (size_t i = 0; i < nc; i++) acc[i] = gl2_add(acc[i], gl2_mul(f, cst[i]));
             break;
         }
         case OG_ARITHMETIC_EXT:   /* wires are extension values: the algebra F2[X]/(X^2-7) with coefficients in F2 */

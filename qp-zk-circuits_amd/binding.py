@@ -120,6 +120,7 @@ def load_library():
                                       c.POINTER(c.c_size_t)]),
         "qpgpu_synth_pack_words": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint]),
         "qpgpu_synth_pack_words_ex": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint, c.c_uint]),
+        "qpgpu_synth_p2_sites": (c.c_size_t, [c.c_uint, c.c_uint, c.c_uint, u64p, c.c_size_t]),
         "qpgpu_synth_circuit_ex": (c.c_int, [c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint, u64p, c.c_size_t,
                                              c.POINTER(c.c_size_t), u64p, u64p]),
         "qpgpu_synth_circuit": (c.c_int, [c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, u64p, c.c_size_t,
@@ -180,14 +181,26 @@ def poseidon_constants():
     return rc, fp
 
 
+def synth_flags(poseidon=False, base_sum=False, ext_arith=False, recursion=False, hints=False, poseidon2=False, p2_alt_layout=False):
+    return ((1 if poseidon else 0) | (2 if base_sum else 0) | (4 if ext_arith else 0) | (8 if recursion else 0) | (16 if hints else 0) |
+            (64 if poseidon2 else 0) | (128 if p2_alt_layout else 0))
+
+
+def synth_p2_sites(degree_bits, num_public_inputs=21, **kw):
+    """Hash sites of a poseidon2=True synthetic circuit: list of (preimage length, gate rows, first slot); see include/qpgpu.h."""
+    out = np.zeros(3 * 64, dtype=np.uint64)
+    n = load_library().qpgpu_synth_p2_sites(degree_bits, num_public_inputs, synth_flags(**kw), out.ctypes.data, out.size)
+    return [tuple(int(x) for x in out[3 * i:3 * i + 3]) for i in range(n)]
+
+
 def synth_circuit(degree_bits, num_wires=135, num_routed=80, num_public_inputs=21, seed=1, poseidon=False, base_sum=False,
-                  ext_arith=False, recursion=False, hints=False):
+                  ext_arith=False, recursion=False, hints=False, poseidon2=False, p2_alt_layout=False):
     """Synthetic satisfied circuit: returns (pack_words, wires[num_wires, n], public_inputs). Host only.
     poseidon=True adds PoseidonGate rows (needs 135 wires), base_sum=True BaseSumGate<2> rows, ext_arith=True
     ArithmeticExtensionGate and MulExtensionGate rows, recursion=True Reducing / ReducingExtension / RandomAccess /
     Exponentiation / PoseidonMds rows, hints=True free-standing witness generators (a hint trailer in the pack)."""
     lib = load_library()
-    flags = (1 if poseidon else 0) | (2 if base_sum else 0) | (4 if ext_arith else 0) | (8 if recursion else 0) | (16 if hints else 0)
+    flags = synth_flags(poseidon, base_sum, ext_arith, recursion, hints, poseidon2, p2_alt_layout)
     # with Poseidon rows the pack also carries the public-input cell trailer (2 + num_public_inputs words, circuit.hpp)
     words = lib.qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, flags) + 2 + num_public_inputs
     pack = np.empty(words, dtype=np.uint64)
@@ -223,6 +236,48 @@ def pack_public_input_cells(pack_words):
         else:
             break
     return None
+
+
+P2_LAYOUT_FIELDS = ("w_input", "w_output", "w_swap", "w_delta", "w_full0", "w_partial", "w_full1", "first_round_wires", "constraint_order", "end_wire")
+P2_NO_SWAP = 0xFFFFFFFF
+
+
+def pack_trailers(pack_words):
+    """(magic, first word index, count) of every optional trailer of a circuit pack, in order."""
+    h = pack_header(pack_words)
+    pos = 18 + h["num_arity_rounds"] + 8 * h["num_gates"] + h["num_routed_wires"] + 4
+    pos += (h["num_selectors"] + h["num_constants"] + h["num_routed_wires"]) << h["degree_bits"]
+    out = []
+    while pos + 2 <= len(pack_words):
+        magic, cnt = int(pack_words[pos]), int(pack_words[pos + 1])
+        per = {0x31544E4948: 8, 0x3149425550: 1, 0x314C473250: 1}.get(magic)
+        if per is None:
+            break
+        out.append((magic, pos + 2, cnt))
+        pos += 2 + per * cnt
+    return out
+
+
+def pack_p2_layout(pack_words):
+    """Wire layout of the Poseidon2 gate from the pack's "P2GL1" trailer as a dict, or None when the pack has none (the
+    library then assumes the default layout, csrc/circuit.hpp)."""
+    for magic, at, cnt in pack_trailers(pack_words):
+        if magic == 0x314C473250 and cnt == len(P2_LAYOUT_FIELDS):
+            return {k: int(v) for k, v in zip(P2_LAYOUT_FIELDS, pack_words[at:at + cnt])}
+    return None
+
+
+def p2_site_cells(pack_words, site):
+    """Cells of one Poseidon2 hash site of a synthetic circuit (synth_p2_sites): (preimage cells, digest cells), each a list of
+    (wire, row), by the placement rule documented at qpgpu_synth_p2_sites in include/qpgpu.h."""
+    lay = pack_p2_layout(pack_words) or dict(zip(P2_LAYOUT_FIELDS, (0, 12, 24, 25, 29, 65, 87, 0, 0, 135)))
+    ln, blocks, slot = site
+    pre = []
+    for i in range(ln):
+        k, j = divmod(i, 8)
+        pre.append((lay["w_input"] + j, 8 * slot + 3) if k == 0 else (4 * j + 2, 8 * (slot + k - 1) + 4))
+    last = 8 * (slot + blocks - 1) + 3
+    return pre, [(lay["w_output"] + i, last) for i in range(4)]
 
 
 class DeviceBuffer:

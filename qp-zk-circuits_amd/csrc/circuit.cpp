@@ -25,6 +25,13 @@ std::vector<uint64_t> CircuitPack::serialize() const {
         w.push_back(QPCP_PUBI_MAGIC); w.push_back(pi_cells.size());
         w.insert(w.end(), pi_cells.begin(), pi_cells.end());
     }
+    if (has_p2_layout) {
+        const P2GateLayout &l = p2_layout;
+        const uint64_t lw[P2GateLayout::WORDS] = {l.w_input, l.w_output, l.w_swap, l.w_delta, l.w_full0, l.w_partial, l.w_full1,
+                                                  l.first_round_wires, l.constraint_order, l.end_wire};
+        w.push_back(QPCP_P2GL_MAGIC); w.push_back(P2GateLayout::WORDS);
+        w.insert(w.end(), lw, lw + P2GateLayout::WORDS);
+    }
     return w;
 }
 
@@ -67,6 +74,7 @@ std::string CircuitPack::parse(const uint64_t *words, size_t n_words) {
     if (!need(cs)) return "truncated constants_sigmas";
     constants_sigmas.assign(words + pos, words + pos + cs); pos += cs;
     hints.clear(); pi_cells.clear();
+    p2_layout = P2GateLayout(); has_p2_layout = false;
     bool seen_hints = false, seen_pubi = false;
     while (pos != n_words) {   // optional trailers, each at most once
         if (!need(2)) return "trailing data";
@@ -81,6 +89,15 @@ std::string CircuitPack::parse(const uint64_t *words, size_t n_words) {
             seen_pubi = true;
             if (cnt != num_public_inputs || !need(cnt)) return "public-input cell list does not match num_public_inputs";
             pi_cells.assign(words + pos, words + pos + cnt); pos += cnt;
+        } else if (magic == QPCP_P2GL_MAGIC && !has_p2_layout) {
+            if (cnt != P2GateLayout::WORDS || !need(cnt)) return "Poseidon2 gate layout trailer has the wrong size";
+            for (int i = 0; i < P2GateLayout::WORDS; i++) if (words[pos + i] > 0xFFFFFFFFull) return "Poseidon2 gate layout field out of range";
+            P2GateLayout &l = p2_layout;
+            l.w_input = (uint32_t)words[pos]; l.w_output = (uint32_t)words[pos + 1]; l.w_swap = (uint32_t)words[pos + 2]; l.w_delta = (uint32_t)words[pos + 3];
+            l.w_full0 = (uint32_t)words[pos + 4]; l.w_partial = (uint32_t)words[pos + 5]; l.w_full1 = (uint32_t)words[pos + 6];
+            l.first_round_wires = (uint32_t)words[pos + 7]; l.constraint_order = (uint32_t)words[pos + 8]; l.end_wire = (uint32_t)words[pos + 9];
+            has_p2_layout = true;
+            pos += cnt;
         } else return "trailing data";
     }
     return validate();
@@ -100,7 +117,12 @@ std::string CircuitPack::validate() const {
     for (auto a : arity_bits) { if (a == 0 || a > 4) return "unsupported FRI arity"; sum += a; }
     if (sum > degree_bits) return "FRI reductions exceed degree";
     for (const auto &g : gates) {
-        if (g.type > GATE_COSET_INTERPOLATION) return "unknown gate type";
+        if (g.type > GATE_POSEIDON2) return "unknown gate type";
+        if (g.type == GATE_POSEIDON2) {
+            const std::string why = p2_layout.validate(num_wires, num_routed_wires);
+            if (!why.empty()) return why;
+            if (g.num_constraints != p2_layout.num_constraints()) return "bad poseidon2 gate: constraint count does not match its wire layout";
+        }
         if (g.selector_index >= num_selectors) return "gate selector index out of range";
         if (g.group_end > gates.size() || g.group_start >= g.group_end) return "gate group out of range";
         if (g.num_constraints > num_gate_constraints) return "gate constraint count exceeds num_gate_constraints";
@@ -141,6 +163,24 @@ std::string CircuitPack::validate() const {
         if (h.w[0] == HINT_WIRE_SPLIT && (h.w[3] > 63 || h.w[4] == 0 || h.w[4] > 63)) return "bad wire-split hint";
         if (h.w[0] == HINT_LOW_HIGH && (h.w[4] == 0 || h.w[4] > 63)) return "bad low-high hint";
     }
+    return "";
+}
+
+// every wire block inside the trace, inputs / outputs / swap routed, no two blocks overlapping
+std::string P2GateLayout::validate(uint64_t num_wires, uint64_t num_routed) const {
+    if (first_round_wires > 1) return "poseidon2 gate layout: first_round_wires must be 0 or 1";
+    if (constraint_order != 0) return "poseidon2 gate layout: unknown constraint order";
+    struct Blk { uint64_t lo, len; bool routed; };
+    std::vector<Blk> b = {{w_input, 12, true}, {w_output, 12, true}, {w_full0, 12ull * full0_rounds(), false}, {w_partial, 22, false}, {w_full1, 48, false}};
+    if (has_swap()) { b.push_back({w_swap, 1, true}); b.push_back({w_delta, 4, false}); }
+    for (const Blk &x : b) {
+        if (x.lo + x.len > num_wires || x.lo + x.len > end_wire) return "poseidon2 gate layout: a wire block lies outside the gate's wires";
+        if (x.routed && x.lo + x.len > num_routed) return "poseidon2 gate layout: inputs, outputs and the swap wire must be routed wires";
+    }
+    if (end_wire > num_wires) return "poseidon2 gate layout: end_wire exceeds num_wires";
+    for (size_t i = 0; i < b.size(); i++)
+        for (size_t j = i + 1; j < b.size(); j++)
+            if (b[i].lo < b[j].lo + b[j].len && b[j].lo < b[i].lo + b[i].len) return "poseidon2 gate layout: wire blocks overlap";
     return "";
 }
 

@@ -15,7 +15,8 @@
 //           (type, param0, param1, param2): 0 Noop; 1 Constant(num_consts); 2 PublicInput; 3 Arithmetic(num_ops); 4 Poseidon;
 //           5 BaseSum(num_limbs, base 2); 6 ArithmeticExtension(num_ops); 7 MulExtension(num_ops); 8 Reducing(num_coeffs);
 //           9 ReducingExtension(num_coeffs); 10 RandomAccess(bits, num_copies, num_extra_constants);
-//           11 Exponentiation(num_power_bits); 12 PoseidonMds; 13 CosetInterpolation(subgroup_bits, degree)
+//           11 Exponentiation(num_power_bits); 12 PoseidonMds; 13 CosetInterpolation(subgroup_bits, degree);
+//           14 Poseidon2 (the qp fork's gate behind `hash_n_to_hash_no_pad_p2`; wire layout in the trailer "P2GL1" below)
 //   k_is[num_routed_wires]; circuit_digest[4]
 //   constants_sigmas values: (num_selectors + num_constants + num_routed_wires) columns x 2^degree_bits,
 //           column-major, natural subgroup order (column order = plonky2's constants_sigmas oracle:
@@ -32,13 +33,25 @@
 //           the trace: magic 0x0000003149425550 ("PUBI1"), count (= num_public_inputs), count cells. Stage s1 writes the
 //           caller's public inputs there (PartialWitness::set_target for each public-input target); in plonky2 those
 //           cells feed the PoseidonGate rows whose output is copy-connected to the PublicInputGate's wires.
+//   optional trailer, anywhere among the others: the wire layout of the Poseidon2 gate (type 14): magic 0x000000314C473250
+//           ("P2GL1"), count (= 10), then: first input wire, first output wire, swap wire (0xFFFFFFFF: the gate has no swap /
+//           delta wires and no constraints for them), first delta wire, first S-box-input wire of the first half's full rounds,
+//           first S-box-input wire of the 22 partial rounds, first S-box-input wire of the second half's four full rounds,
+//           whether round 0 of the first half carries S-box-input wires too (0: its S-box inputs are linear in the gate's
+//           inputs and are not recorded, as in upstream's PoseidonGate; 1: all four rounds are recorded), constraint order (0:
+//           swap boolean, deltas, first-half rounds, partial rounds, second-half rounds, outputs), and one past the last wire
+//           the gate uses. The fork's gate lives in un-vendored qp-plonky2 1.5.5 and its layout cannot be read offline: a pack
+//           WITHOUT the trailer gets the default = upstream PoseidonGate's layout carried over to Poseidon2 (135 wires, 123
+//           constraints of degree 7, consistent with reference common/src/circuit.rs:428-431,447-449); the Rust exporter
+//           (integration/qpgpu_backend.rs) fills the trailer from the fork's gate. LAYOUT UNPINNED until then.
 #pragma once
 #include <stdint.h>
+#include <cstring>
 #include <string>
 #include <vector>
 
 enum GateType : uint64_t { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4, GATE_BASE_SUM = 5, GATE_ARITHMETIC_EXT = 6, GATE_MUL_EXT = 7,
-                           GATE_REDUCING = 8, GATE_REDUCING_EXT = 9, GATE_RANDOM_ACCESS = 10, GATE_EXPONENTIATION = 11, GATE_POSEIDON_MDS = 12, GATE_COSET_INTERPOLATION = 13 };
+                           GATE_REDUCING = 8, GATE_REDUCING_EXT = 9, GATE_RANDOM_ACCESS = 10, GATE_EXPONENTIATION = 11, GATE_POSEIDON_MDS = 12, GATE_COSET_INTERPOLATION = 13, GATE_POSEIDON2 = 14 };
 
 struct GateInfo {
     uint64_t type, param0, param1, selector_index, group_start, group_end, num_constraints, param2;
@@ -49,6 +62,26 @@ enum HintOpcode : uint64_t { HINT_COPY = 1, HINT_EQUALITY = 2, HINT_WIRE_SPLIT =
 struct HintOp { uint64_t w[8]; };
 constexpr uint64_t QPCP_HINT_MAGIC = 0x00000031544E4948ull;
 constexpr uint64_t QPCP_PUBI_MAGIC = 0x0000003149425550ull;   // "PUBI1"
+constexpr uint64_t QPCP_P2GL_MAGIC = 0x000000314C473250ull;   // "P2GL1"
+
+// Wire layout of the Poseidon2 gate (see the format notes above). Plain 32-bit fields: handed to kernels by value.
+struct P2GateLayout {
+    uint32_t w_input = 0, w_output = 12, w_swap = 24, w_delta = 25, w_full0 = 29, w_partial = 65, w_full1 = 87;
+    uint32_t first_round_wires = 0, constraint_order = 0, end_wire = 135;
+    static constexpr uint32_t NO_SWAP = 0xFFFFFFFFu;
+    static constexpr int WORDS = 10;
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    bool has_swap() const { return w_swap != NO_SWAP; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t full0_rounds() const { return first_round_wires ? 4u : 3u; }
+    uint32_t num_constraints() const { return (has_swap() ? 5u : 0u) + 12u * full0_rounds() + 22u + 48u + 12u; }
+    bool is_default() const { P2GateLayout d; return std::memcmp(this, &d, sizeof d) == 0; }
+    std::string validate(uint64_t num_wires, uint64_t num_routed) const;
+};
 
 struct CircuitPack {
     uint64_t degree_bits = 0, num_wires = 0, num_routed_wires = 0, num_constants = 0, num_selectors = 0,
@@ -62,6 +95,8 @@ struct CircuitPack {
     std::vector<uint64_t> constants_sigmas;  // column-major values
     std::vector<HintOp> hints;               // optional: free-standing witness generators (stage s1)
     std::vector<uint64_t> pi_cells;          // optional: the wire cell (row * num_wires + column) of every public input
+    P2GateLayout p2_layout;                  // wire layout of the Poseidon2 gate (default unless the pack carries "P2GL1")
+    bool has_p2_layout = false;              // the trailer was present (serialize() writes it back)
 
     uint64_t n() const { return 1ull << degree_bits; }
     uint64_t num_cs_cols() const { return num_selectors + num_constants + num_routed_wires; }

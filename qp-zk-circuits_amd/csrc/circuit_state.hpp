@@ -27,6 +27,7 @@ struct qpgpu_circuit {
     std::vector<GateDev> h_gates;
     gl::u64 *d_qacc = nullptr;
     gl::u64 *d_poseidon_rc = nullptr, *d_poseidon_fast = nullptr;
+    bool has_p2_gate = false;        // the gate list holds a Poseidon2 gate: its constants are the context's d_p2_app block
     gl::u64 *d_omega = nullptr, *d_x_coset = nullptr, *d_l0_coset = nullptr, *d_zh_inv = nullptr;
     gl::u64 *d_ginv_lo = nullptr, *d_ginv_hi = nullptr; uint32_t ginv_lo_bits = 0;
     // per-proof workspace: every buffer is [max_batch][one proof's size]

@@ -198,6 +198,14 @@ GL_HD void ext_layer(u64 (&s)[12], const Params &p) {
         for (int b = 0; b < 3; b++) s[4 * b + i] = gl::add(t[4 * b + i], sum);
     }
 }
+// internal (partial-round) linear layer: s <- (J + diag(diag_m1)) s
+GL_HD void int_layer(u64 (&s)[12], const Params &p) {
+    u64 sum = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) sum = gl::add(sum, s[i]);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::add(gl::mul(s[i], p.diag_m1[i]), sum);
+}
 GL_HD void permute(u64 (&s)[12], const Params &p) {
     ext_layer(s, p);
     for (int r = 0; r < 4; r++) {
@@ -207,11 +215,7 @@ GL_HD void permute(u64 (&s)[12], const Params &p) {
     }
     for (int r = 0; r < 22; r++) {
         s[0] = poseidon::sbox7(gl::add(s[0], p.rc_int[r]));
-        u64 sum = 0;
-#pragma unroll
-        for (int i = 0; i < 12; i++) sum = gl::add(sum, s[i]);
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl::add(gl::mul(s[i], p.diag_m1[i]), sum);
+        int_layer(s, p);
     }
     for (int r = 4; r < 8; r++) {
 #pragma unroll

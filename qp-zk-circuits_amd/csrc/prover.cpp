@@ -185,6 +185,8 @@ int qpgpu_circuit_load_batch(qpgpu_ctx *ctx, const uint64_t *pack_words, size_t 
                  (uint32_t)g.group_end, (uint32_t)g.num_constraints, (uint32_t)g.param2};
     }
     c->h_gates = gd;
+    for (const GateInfo &g : p.gates) c->has_p2_gate = c->has_p2_gate || g.type == GATE_POSEIDON2;
+    if (c->has_p2_gate) CK(ctx->ensure_p2_app());
     CK(c->alloc(&c->d_gates, gd.size()));
     CK(h2d(ctx, c->d_gates, gd.data(), gd.size() * sizeof(GateDev)));
     CK(c->alloc(&c->d_poseidon_rc, 360));
@@ -400,6 +402,7 @@ static int prove_batch_impl(qpgpu_circuit *c, uint32_t nb, const u64 *d_wires, c
         QuotientArgs ta{};
         ta.wires = d_wires; ta.cs = c->d_cs_values; ta.alpha_pows = d_apow; ta.pi_hash = d_pih; ta.gates = c->d_gates;
         ta.acc = c->d_qacc; ta.out = c->d_qacc; ta.poseidon_rc = c->d_poseidon_rc; ta.poseidon_fast = c->d_poseidon_fast;
+        ta.p2_gate = ctx->d_p2_app; ta.p2_layout = p.p2_layout;
         ta.zh_inv = c->d_zh_inv; ta.lde_n = n; ta.q_n = n; ta.q_shift = 0; ta.log_lde = d; ta.rate = 1; ta.nch = nch; ta.num_routed = (uint32_t)R;
         ta.chunk = (uint32_t)p.quotient_degree_factor; ta.nchunks = nchunks; ta.sig0 = (uint32_t)sig0;
         ta.num_selectors = (uint32_t)p.num_selectors; ta.num_gates = (uint32_t)p.gates.size(); ta.nterms = (uint32_t)nterms;
@@ -422,7 +425,8 @@ static int prove_batch_impl(qpgpu_circuit *c, uint32_t nb, const u64 *d_wires, c
     QuotientArgs qa{};
     qa.wires = c->wires.lde; qa.cs = c->cs.lde; qa.zs_pp = c->zs.lde; qa.x_coset = c->d_x_coset; qa.l0_coset = c->d_l0_coset;
     qa.zh_inv = c->d_zh_inv; qa.alpha_pows = d_apow; qa.beta_k_is = d_bk; qa.betas = d_betas; qa.gammas = d_gammas; qa.pi_hash = d_pih;
-    qa.gates = c->d_gates; qa.acc = c->d_qacc; qa.poseidon_rc = c->d_poseidon_rc; qa.poseidon_fast = c->d_poseidon_fast; qa.out = c->quot.coeffs; qa.lde_n = lde_n; qa.q_n = q_n; qa.q_shift = q_shift; qa.log_lde = L; qa.rate = 1u << p.rate_bits; qa.nch = nch;
+    qa.gates = c->d_gates; qa.acc = c->d_qacc; qa.poseidon_rc = c->d_poseidon_rc; qa.poseidon_fast = c->d_poseidon_fast; qa.out = c->quot.coeffs;
+    qa.p2_gate = ctx->d_p2_app; qa.p2_layout = p.p2_layout; qa.lde_n = lde_n; qa.q_n = q_n; qa.q_shift = q_shift; qa.log_lde = L; qa.rate = 1u << p.rate_bits; qa.nch = nch;
     qa.num_routed = (uint32_t)R; qa.chunk = (uint32_t)p.quotient_degree_factor; qa.nchunks = nchunks; qa.sig0 = (uint32_t)sig0;
     qa.num_selectors = (uint32_t)p.num_selectors; qa.num_gates = (uint32_t)p.gates.size(); qa.nterms = (uint32_t)nterms;
     qa.batch = nb; qa.ps_wires = c->wires.ps_lde; qa.ps_zs = c->zs.ps_lde; qa.ps_small = SW; qa.ps_acc = (u64)nch * lde_n; qa.ps_out = (u64)nch * q_n;

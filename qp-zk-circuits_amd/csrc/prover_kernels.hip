@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
     const u64 *ap = a.alpha_pows + t0;
     for (u32 gi = 0; gi < a.num_gates; gi++) {
         const GateDev g = a.gates[gi];
-        if (g.num_constraints == 0 || g.type == 4) continue;
+        if (g.num_constraints == 0 || g.type == 4 || g.type == 14) continue;   // the hash gates have kernels of their own
         const u64 f = gate_filter(a, gi, a.cs[(u64)g.selector_index * S + j]);
         u64 sum[NCH];
 #pragma unroll
@@ -419,6 +419,92 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) emit(gl::sub(st[i], W(12 + i)));
+    const u64 f = gate_filter(a, gi, a.cs[(u64)a.gates[gi].selector_index * S + j]);
+    if (finalize) {
+        const u64 i = brev32((u32)j, a.log_lde);
+        const u64 zi = a.zh_inv[i & (a.rate - 1)];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a.out[(u64)c * a.q_n + (i >> a.q_shift)] = gl::canon(gl::mul(gl::add(a.acc[(u64)c * S + j], gl::mul(f, sum[c])), zi));
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = gl::add(a.acc[(u64)c * S + j], gl::mul(f, sum[c]));
+    }
+}
+
+// (4) the qp fork's Poseidon2 gate (type 14; the gate behind `hash_n_to_hash_no_pad_p2`, reference call sites
+// wormhole/circuit/src/zk_merkle_proof.rs:482,504,606, nullifier.rs:298-299, unspendable_account.rs:229-231,
+// block_header/mod.rs:66) at one point. The permutation is qp-poseidon-core's Poseidon2 (pinned by the reference's seven
+// known-answer vectors); the wire layout comes from the pack (P2GateLayout, default = upstream PoseidonGate's layout carried
+// over: LAYOUT UNPINNED). Structure: optional swap of the first two 4-element groups (boolean + 4 delta constraints), the
+// initial external layer, then per round `add constants -> S-box input equals its wire -> S-box -> linear layer` with the
+// S-box inputs of full rounds [first_round_wires ? 0 : 1 .. 3], the 22 partial rounds (lane 0) and the last four full rounds on
+// wires, and the 12 outputs: 123 constraints of degree 7 with the default layout.
+template <int NCH>
+__global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a, u32 gi, u32 t0, int finalize) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= a.q_n) return;
+    quotient_select_proof(a);
+    const u64 S = a.lde_n;
+    const u64 *ap = a.alpha_pows + t0;
+    const P2GateLayout &lay = a.p2_layout;
+    const poseidon2::Params &P2 = *a.p2_gate;
+    auto W = [&](u32 i) -> u64 { return a.wires[(u64)i * S + j]; };
+    u64 sum[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) sum[c] = 0;
+    u32 q = 0;
+    auto emit = [&](u64 cst) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) sum[c] = gl::add(sum[c], gl::mul(cst, ap[(u64)c * a.nterms + q]));
+        q++;
+    };
+    u64 st[12];
+    if (lay.has_swap()) {
+        const u64 swap = W(lay.w_swap);
+        emit(gl::mul(swap, gl::sub(swap, 1)));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const u64 lhs = W(lay.w_input + i), rhs = W(lay.w_input + 4 + i), delta = W(lay.w_delta + i);
+            emit(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+            st[i] = gl::add(lhs, delta); st[i + 4] = gl::sub(rhs, delta);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) st[i] = W(lay.w_input + i);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) st[i] = W(lay.w_input + i);
+    poseidon2::ext_layer(st, P2);
+    u32 wf = lay.w_full0;
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2.rc_ext[r * 12 + i]);
+        if (r || lay.first_round_wires) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const u64 in = W(wf + i); emit(gl::sub(st[i], in)); st[i] = in; }
+            wf += 12;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+        poseidon2::ext_layer(st, P2);
+    }
+    for (int r = 0; r < 22; r++) {
+        const u64 in = W(lay.w_partial + r);
+        emit(gl::sub(gl::add(st[0], P2.rc_int[r]), in));
+        st[0] = poseidon::sbox7(in);
+        poseidon2::int_layer(st, P2);
+    }
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2.rc_ext[(4 + r) * 12 + i]);
+#pragma unroll
+        for (int i = 0; i < 12; i++) { const u64 in = W(lay.w_full1 + 12 * r + i); emit(gl::sub(st[i], in)); st[i] = in; }
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+        poseidon2::ext_layer(st, P2);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) emit(gl::sub(st[i], W(lay.w_output + i)));
     const u64 f = gate_filter(a, gi, a.cs[(u64)a.gates[gi].selector_index * S + j]);
     if (finalize) {
         const u64 i = brev32((u32)j, a.log_lde);
@@ -709,16 +795,18 @@ static hipError_t quotient_launch(const QuotientArgs &a, const GateDev *host_gat
     dim3 b(256), g((unsigned)((a.q_n + 255) / 256), 1, a.batch);
     const u32 t0 = a.nch + a.nch * a.nchunks;
     // Poseidon gates (heavy, one launch each) come last; the final launch also applies 1/Z_H and stores
+    auto is_hash_gate = [&](u32 i) { return (host_gates[i].type == 4 || host_gates[i].type == 14) && host_gates[i].num_constraints; };
     int n_pos = 0;
-    for (u32 i = 0; i < a.num_gates; i++) if (host_gates[i].type == 4 && host_gates[i].num_constraints) n_pos++;
+    for (u32 i = 0; i < a.num_gates; i++) if (is_hash_gate(i)) n_pos++;
     hipLaunchKernelGGL((quotient_perm_kernel<NCH>), g, b, 0, st, a);
     if (wide_random_access(a, host_gates)) hipLaunchKernelGGL((quotient_gates_kernel<NCH, true>), g, b, 0, st, a, t0, n_pos == 0 ? 1 : 0);
     else hipLaunchKernelGGL((quotient_gates_kernel<NCH, false>), g, b, 0, st, a, t0, n_pos == 0 ? 1 : 0);
     int seen = 0;
     for (u32 i = 0; i < a.num_gates; i++)
-        if (host_gates[i].type == 4 && host_gates[i].num_constraints) {
+        if (is_hash_gate(i)) {
             seen++;
-            hipLaunchKernelGGL((quotient_poseidon_kernel<NCH>), g, b, 0, st, a, i, t0, seen == n_pos ? 1 : 0);
+            if (host_gates[i].type == 4) hipLaunchKernelGGL((quotient_poseidon_kernel<NCH>), g, b, 0, st, a, i, t0, seen == n_pos ? 1 : 0);
+            else hipLaunchKernelGGL((quotient_poseidon2_kernel<NCH>), g, b, 0, st, a, i, t0, seen == n_pos ? 1 : 0);
         }
     return hipGetLastError();
 }
@@ -729,8 +817,10 @@ static hipError_t gates_only_launch(const QuotientArgs &a, const GateDev *host_g
     const u32 t0 = a.nch + a.nch * a.nchunks;
     if (wide_random_access(a, host_gates)) hipLaunchKernelGGL((quotient_gates_kernel<NCH, true>), g, b, 0, st, a, t0, 0);
     else hipLaunchKernelGGL((quotient_gates_kernel<NCH, false>), g, b, 0, st, a, t0, 0);
-    for (u32 i = 0; i < a.num_gates; i++)
+    for (u32 i = 0; i < a.num_gates; i++) {
         if (host_gates[i].type == 4 && host_gates[i].num_constraints) hipLaunchKernelGGL((quotient_poseidon_kernel<NCH>), g, b, 0, st, a, i, t0, 0);
+        if (host_gates[i].type == 14 && host_gates[i].num_constraints) hipLaunchKernelGGL((quotient_poseidon2_kernel<NCH>), g, b, 0, st, a, i, t0, 0);
+    }
     return hipGetLastError();
 }
 hipError_t pk_gate_sums(const QuotientArgs &a, const GateDev *host_gates, hipStream_t st) {

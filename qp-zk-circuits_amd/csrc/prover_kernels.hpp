@@ -6,7 +6,10 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include "circuit.hpp"
 #include "gl64.hpp"
+
+namespace poseidon2 { struct Params; }
 
 struct GateDev { uint32_t type, param0, param1, selector_index, group_start, group_end, num_constraints, param2; };
 
@@ -33,6 +36,8 @@ struct QuotientArgs {
     const GateDev *gates;
     const uint64_t *poseidon_rc;          // 360 round constants (PoseidonGate)
     const uint64_t *poseidon_fast;        // FAST_PARTIAL_* tables, poseidon::FP_WORDS entries
+    const poseidon2::Params *p2_gate;     // constants of the Poseidon2 gate (qp-poseidon-core's set), device block
+    P2GateLayout p2_layout;               // its wire layout (circuit.hpp)
     uint64_t *acc;                        // [nch][lde_n] slot order: running alpha-weighted sums between the s6 kernels
     uint64_t *out;                        // [nch][lde_n] natural order
     uint64_t lde_n;                       // column stride of the LDE batches (slots)

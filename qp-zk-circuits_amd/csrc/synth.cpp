@@ -37,10 +37,50 @@ void host_hash_no_pad(const u64 *in, size_t n, u64 out[4]) {
 struct GateSpec { uint64_t type, p0, p1, degree, ncons; std::string id; uint64_t p2 = 0; };
 }  // namespace
 
+// Wire layout of the synthetic circuits' Poseidon2 gate: the default (upstream PoseidonGate's layout carried over), or with
+// flag bit 7 a deliberately different one — outputs first, no swap / delta wires, other block order, 118 constraints — which
+// exists to prove that prover, generator and verifiers really read the layout table instead of assuming the default.
+P2GateLayout synth_p2_layout(unsigned flags) {
+    P2GateLayout l;
+    if (flags & 128) {
+        l.w_output = 0; l.w_input = 12; l.w_swap = P2GateLayout::NO_SWAP; l.w_delta = 0;
+        l.w_partial = 24; l.w_full1 = 46; l.w_full0 = 94; l.first_round_wires = 0; l.end_wire = 130;
+    }
+    return l;
+}
+
+// The application hashes of the Wormhole leaf circuit, as preimage lengths: unspendable account
+// H(H(7)) (wormhole/circuit/src/unspendable_account.rs:215-237), nullifier H(H(9)) (nullifier.rs:285-325), the ZK-tree leaf
+// H(8) (zk_merkle_proof.rs:486-504), the block header H(45) (block_header/mod.rs:61-108) and one H(16) per level of the 4-ary
+// Merkle walk, MAX_DEPTH = 16 of them (zk_merkle_proof.rs:515-618): 61 permutations with the pad-10 sponge of rate 8. A
+// synthetic circuit takes as many of them, in this order, as its rows have room for.
+static const unsigned P2_SITE_LENS[] = {7, 4, 9, 4, 8, 45, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
+// Hash site h of a synthetic circuit: `blocks` Poseidon2-gate rows at rows 8 * (slot + k) + 3, k < blocks; between two of them
+// the ArithmeticGate row 8 * (slot + k) + 4 whose operations j < 8 add block k + 1 into the rate part (prev_out[j] * 1 + m).
+// Message element i sits in input wire i of the first gate row (i < 8) or in the addend wire (4 j + 2, j = i % 8) of the add
+// row in front of block i / 8; the digest is the first four output wires of the last gate row.
+struct P2Site { unsigned len, blocks, slot; };
+std::vector<P2Site> synth_p2_sites(unsigned degree_bits, unsigned num_public_inputs, unsigned flags) {
+    std::vector<P2Site> out;
+    if (!(flags & 64)) return out;
+    const u64 n = 1ull << degree_bits, n_noop = std::max<u64>(1, n / 16);
+    const u64 slots = (n - n_noop) / 8 > 1 ? (n - n_noop - 4) / 8 : 0;     // slot s uses rows 8 s + 3 and 8 s + 4
+    // rows 3 .. 3 + ceil(num_public_inputs / 8) belong to the public-input hash: the first slot lies behind them
+    unsigned next = std::max<unsigned>(1, ((num_public_inputs + 7) / 8 + 7) / 8);
+    for (unsigned len : P2_SITE_LENS) {
+        const unsigned blocks = (len + 1 + 7) / 8;
+        if (next + blocks > slots) break;
+        out.push_back({len, blocks, next});
+        next += blocks;
+    }
+    return out;
+}
+
 // Gate list of a synthetic circuit: sorted by (degree, id) and grouped into selector polynomials the way
 // CircuitBuilder::build does (a group holds gates while size + degree < max_degree; one group if everything fits).
 std::string synth_gate_layout(unsigned num_wires, unsigned num_routed, unsigned flags, std::vector<GateInfo> &gates, u64 &num_selectors) {
     const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0, with_rec = (flags & 8) != 0;
+    const bool with_p2 = (flags & 64) != 0;
     if (with_rec && (num_routed < 48 || num_wires < 64)) return "recursion gates need at least 48 routed wires and 64 wires";
     const u64 num_limbs = std::min<u64>(63, num_routed - 1), num_ops = num_routed / 4;
     const u64 ext_ops = num_routed / 8, mul_ops = num_routed / 6;
@@ -52,6 +92,10 @@ std::string synth_gate_layout(unsigned num_wires, unsigned num_routed, unsigned 
     };
     if (with_base_sum) gs.push_back({GATE_BASE_SUM, num_limbs, 2, 2, num_limbs + 1, "BaseSumGate { num_limbs: " + std::to_string(num_limbs) + " } + Base: 2"});
     if (with_poseidon) gs.push_back({GATE_POSEIDON, 0, 0, 7, 123, "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"});
+    if (with_p2) {
+        const P2GateLayout lay = synth_p2_layout(flags);
+        gs.push_back({GATE_POSEIDON2, 0, 0, 7, lay.num_constraints(), "Poseidon2Gate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"});
+    }
     if (with_ext) {
         gs.push_back({GATE_ARITHMETIC_EXT, ext_ops, 0, 3, 2 * ext_ops, "ArithmeticExtensionGate { num_ops: " + std::to_string(ext_ops) + " }"});
         gs.push_back({GATE_MUL_EXT, mul_ops, 0, 3, 2 * mul_ops, "MulExtensionGate { num_ops: " + std::to_string(mul_ops) + " }"});
@@ -104,8 +148,9 @@ void synth_public_inputs_hash(const u64 *pis, size_t n, u64 out[4]) { host_hash_
 std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,
                         u64 seed, unsigned flags, CircuitPack &pack, std::vector<u64> &wires, std::vector<u64> &pis) {
     const bool with_poseidon = (flags & 1) != 0, with_base_sum = (flags & 2) != 0, with_ext = (flags & 4) != 0, with_rec = (flags & 8) != 0;
-    const bool with_hints = (flags & 16) != 0;
+    const bool with_hints = (flags & 16) != 0, with_p2 = (flags & 64) != 0;
     if (degree_bits < 3 || degree_bits > 20) return "degree_bits out of range";
+    if (with_p2 && (num_wires < 135 || num_routed < 40 || degree_bits < 5)) return "poseidon2 gates need 135 wires, 40 routed wires and 32 rows";
     if (num_routed < 8 || num_routed > num_wires || num_routed % 4) return "num_routed_wires must be a multiple of 4, >= 8";
     if (with_poseidon && (num_wires < 135 || num_routed < 28)) return "poseidon gates need 135 wires";
     SplitMix rng{seed ^ 0x5EED5EED5EEDull};
@@ -124,6 +169,8 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     pack.zero_knowledge = 0;
     pack.arity_bits = fri_reduction_arity_bits(degree_bits, 3, 4, 4, 5);
     pack.num_gate_constraints = 0;
+    if (with_p2) { pack.p2_layout = synth_p2_layout(flags); pack.has_p2_layout = true; }
+    const P2GateLayout &P2L = pack.p2_layout;
     uint64_t idx_of[16] = {0}, sel_of[16] = {0};
     const GateInfo *info_of[16] = {nullptr};
     pack.gates = layout;
@@ -151,6 +198,26 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
     if (with_rec) {
         const uint8_t cyc[6] = {GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS, GATE_EXPONENTIATION, GATE_POSEIDON_MDS, GATE_COSET_INTERPOLATION};
         for (u64 r = 7, k = 0; r + n_noop < n; r += 8, k++) row_gate[r] = cyc[k % 6];
+    }
+
+    // Poseidon2-gate rows: the leaf circuit's application hashes as sponge chains (synth_p2_sites), then a few free-standing
+    // permutation rows (random swap bit where the layout has one)
+    struct P2Role { int site, block; };
+    std::map<u64, P2Role> p2_row, p2_add_row;      // gate row -> (site, block); add row -> (site, block it feeds)
+    const std::vector<P2Site> p2_sites = synth_p2_sites(degree_bits, num_public_inputs, flags);
+    if (with_p2) {
+        unsigned next_slot = std::max<unsigned>(1, ((num_public_inputs + 7) / 8 + 7) / 8);
+        for (size_t h = 0; h < p2_sites.size(); h++)
+            for (unsigned k = 0; k < p2_sites[h].blocks; k++) {
+                const u64 r = 8ull * (p2_sites[h].slot + k) + 3;
+                row_gate[r] = GATE_POSEIDON2; p2_row[r] = {(int)h, (int)k};
+                if (k + 1 < p2_sites[h].blocks) p2_add_row[r + 1] = {(int)h, (int)k + 1};
+                next_slot = p2_sites[h].slot + k + 1;
+            }
+        for (unsigned extra = 0; extra < 4; extra++) {
+            const u64 r = 8ull * (next_slot + extra) + 3;
+            if (r + n_noop < n) { row_gate[r] = GATE_POSEIDON2; p2_row[r] = {-1, 0}; }
+        }
     }
 
     // the public-input hash in-circuit (plonky2's CircuitBuilder::build): ceil(npis / 8) chained PoseidonGate rows right
@@ -284,6 +351,48 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
         }
     };
 
+    // fills the delta wires and the recorded S-box inputs of a Poseidon2-gate row (layout P2L); st receives the permutation output
+    auto poseidon2_row = [&](u64 r, const u64 (&in)[12], u64 swap, u64 (&st)[12]) {
+        const poseidon2::Params &P = poseidon2::qp_params();
+        for (int i = 0; i < 12; i++) st[i] = in[i];
+        if (P2L.has_swap()) {
+            W(r, P2L.w_swap) = swap;
+            for (int i = 0; i < 4; i++) {
+                const u64 delta = swap ? gl::canon(gl::sub(in[i + 4], in[i])) : 0;
+                W(r, P2L.w_delta + i) = delta;
+                st[i] = gl::canon(gl::add(in[i], delta)); st[i + 4] = gl::canon(gl::sub(in[i + 4], delta));
+            }
+        }
+        poseidon2::ext_layer(st, P);
+        u64 rec = P2L.w_full0;
+        for (int rr = 0; rr < 4; rr++) {
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], P.rc_ext[rr * 12 + i]));
+            if (rr || P2L.first_round_wires) { for (int i = 0; i < 12; i++) W(r, rec + i) = st[i]; rec += 12; }
+            for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+            poseidon2::ext_layer(st, P);
+        }
+        for (int rr = 0; rr < 22; rr++) {
+            st[0] = gl::canon(gl::add(st[0], P.rc_int[rr]));
+            W(r, P2L.w_partial + rr) = st[0];
+            st[0] = poseidon::sbox7(st[0]);
+            poseidon2::int_layer(st, P);
+        }
+        for (int rr = 0; rr < 4; rr++) {
+            for (int i = 0; i < 12; i++) st[i] = gl::canon(gl::add(st[i], P.rc_ext[(4 + rr) * 12 + i]));
+            for (int i = 0; i < 12; i++) W(r, P2L.w_full1 + 12 * rr + i) = st[i];
+            for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+            poseidon2::ext_layer(st, P);
+        }
+        for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+    };
+    // cell (r, col) := copy of cell (sr, sc): value and copy constraint
+    auto tie = [&](u64 r, u64 col, u64 sr, u64 sc) {
+        W(r, col) = W(sr, sc);
+        const uint32_t a = find(cell(sr, sc)), b = find(cell(r, col));
+        if (a != b) parent[b] = a;
+    };
+    const u64 P2_ZERO_ROW = 2, P2_ZERO_COL = 0, P2_ONE_COL = 1;     // with Poseidon2 rows the second ConstantGate row holds 0 and 1
+
     for (u64 r = 0; r < n; r++) {
         const u64 kind = row_gate[r];
         for (u64 s = 0; s < sel_cols; s++) CS(r, s) = sel_of[kind] == s ? idx_of[kind] : UNUSED;   // selector polynomials
@@ -294,12 +403,30 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
                 u64 c = rng.felt();
                 // builder.zero(): the constant the unused inputs of the public-input hash are wired to (kept out of the copy pool)
                 if (r == 1 && i == 0 && !pi_hash_row.empty()) { CS(r, sel_cols) = 0; W(r, 0) = 0; continue; }
+                // builder.zero() / builder.one() for the Poseidon2 sponges' padding, capacity and additions (kept out of the copy pool)
+                if (with_p2 && r == P2_ZERO_ROW) { CS(r, sel_cols + i) = (u64)i; W(r, i) = (u64)i; continue; }
                 CS(r, sel_cols + i) = c; output(r, i, c);
             }
         } else if (kind == GATE_ARITHMETIC) {
             const u64 c0 = (r & 1) ? rng.felt() : 1, c1 = (r & 2) ? rng.felt() : 1;
             CS(r, sel_cols) = c0; CS(r, sel_cols + 1) = c1;
-            for (u64 op = 0; op < num_ops; op++) {
+            u64 op0 = 0;
+            if (p2_add_row.count(r)) {
+                // additive absorption of block k of a sponge: rate element j of the previous permutation's output plus message
+                // element 8 k + j (builder.add = 1 * prev * one + 1 * m; this row's constants are 1, 1 since r = 4 mod 8)
+                const P2Role role = p2_add_row[r];
+                const P2Site &site = p2_sites[role.site];
+                for (u64 j = 0; j < 8; j++) {
+                    const u64 idx = 8ull * role.block + j;
+                    tie(r, 4 * j, r - 1, P2L.w_output + j);
+                    tie(r, 4 * j + 1, P2_ZERO_ROW, P2_ONE_COL);
+                    if (idx < site.len) input(r, 4 * j + 2);
+                    else tie(r, 4 * j + 2, P2_ZERO_ROW, idx == site.len ? P2_ONE_COL : P2_ZERO_COL);
+                    W(r, 4 * j + 3) = gl::canon(gl::add(gl::mul(gl::mul(W(r, 4 * j), W(r, 4 * j + 1)), c0), gl::mul(W(r, 4 * j + 2), c1)));
+                }
+                op0 = 8;
+            }
+            for (u64 op = op0; op < num_ops; op++) {
                 u64 m0, m1;
                 if (hinted_pair(r, 4 * op)) { m0 = W(r, 4 * op); m1 = W(r, 4 * op + 1); }
                 else { m0 = input(r, 4 * op); m1 = input(r, 4 * op + 1); }
@@ -417,6 +544,37 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
             }
             output(r, 0, v);
             for (u64 i = 0; i < num_limbs; i++) W(r, 1 + i) = (v >> i) & 1;
+        } else if (kind == GATE_POSEIDON2) {
+            u64 in[12], st[12];
+            const P2Role role = p2_row[r];
+            const u64 wi = P2L.w_input, wo = P2L.w_output;
+            if (role.site < 0) {
+                // free-standing permutation row: inputs partly copied, a random swap bit where the gate has one, outputs offered for copying
+                for (int k = 0; k < 12; k++) in[k] = input(r, wi + k);
+                poseidon2_row(r, in, P2L.has_swap() ? rng.below(2) : 0, st);
+                for (int i = 0; i < 12; i++) output(r, wo + i, st[i]);
+            } else {
+                const P2Site &site = p2_sites[role.site];
+                if (role.block == 0) {
+                    // first block: the message elements are this row's own input cells, then the terminator 1 and zeros; capacity zero
+                    for (u64 j = 0; j < 12; j++) {
+                        if (j < 8 && j < site.len) input(r, wi + j);
+                        else tie(r, wi + j, P2_ZERO_ROW, (j < 8 && j == site.len) ? P2_ONE_COL : P2_ZERO_COL);
+                    }
+                } else {
+                    // later blocks: rate part = the add row's sums, capacity = the previous permutation's capacity
+                    for (u64 j = 0; j < 8; j++) tie(r, wi + j, r - 7, 4 * j + 3);
+                    for (u64 j = 8; j < 12; j++) tie(r, wi + j, r - 8, wo + j);
+                }
+                for (int k = 0; k < 12; k++) in[k] = W(r, wi + k);
+                if (P2L.has_swap()) tie(r, P2L.w_swap, P2_ZERO_ROW, P2_ZERO_COL);
+                poseidon2_row(r, in, 0, st);
+                const bool last = role.block + 1 == (int)site.blocks;
+                for (int i = 0; i < 12; i++) {
+                    if (last && i < 4) output(r, wo + i, st[i]);      // the digest: available to the rest of the circuit
+                    else W(r, wo + i) = st[i];                        // sponge state: not offered to the copy pool
+                }
+            }
         } else if (kind == GATE_POSEIDON) {
             u64 in[12], st[12];
             if (pi_hash_row.count(r)) {

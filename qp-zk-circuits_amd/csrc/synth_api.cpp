@@ -8,6 +8,8 @@ std::string synth_build(unsigned degree_bits, unsigned num_wires, unsigned num_r
                         uint64_t seed, unsigned flags, CircuitPack &pack, std::vector<uint64_t> &wires, std::vector<uint64_t> &pis);
 
 std::string synth_gate_layout(unsigned num_wires, unsigned num_routed, unsigned flags, std::vector<GateInfo> &gates, uint64_t &num_selectors);
+struct P2Site { unsigned len, blocks, slot; };
+std::vector<P2Site> synth_p2_sites(unsigned degree_bits, unsigned num_public_inputs, unsigned flags);
 
 extern "C" {
 
@@ -31,10 +33,19 @@ size_t qpgpu_synth_pack_words_ex(unsigned degree_bits, unsigned num_wires, unsig
     // with Poseidon rows (flag bit 0) the pack carries the public-input cell trailer: room for 4094 public inputs here; for
     // more, qpgpu_synth_circuit_ex with pack_out = NULL reports the exact size
     const size_t pubi_cap = (flags & 1) ? 4096 : 0;
-    return 18 + arity + gates.size() * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits) + hint_cap + pubi_cap;
+    const size_t p2_cap = (flags & 64) ? 2 + P2GateLayout::WORDS : 0;
+    return 18 + arity + gates.size() * 8 + num_routed + 4 + ((size_t)p.num_cs_cols() << degree_bits) + hint_cap + pubi_cap + p2_cap;
 }
 size_t qpgpu_synth_pack_words(unsigned degree_bits, unsigned num_wires, unsigned num_routed) {
     return qpgpu_synth_pack_words_ex(degree_bits, num_wires, num_routed, 0);
+}
+
+// the Poseidon2 hash sites of a synthetic circuit built with flag bit 6: 3 words each (preimage length, gate rows, first slot);
+// returns how many there are (writes at most cap / 3 of them)
+size_t qpgpu_synth_p2_sites(unsigned degree_bits, unsigned num_public_inputs, unsigned flags, uint64_t *out, size_t cap_words) {
+    const std::vector<P2Site> sites = synth_p2_sites(degree_bits, num_public_inputs, flags);
+    for (size_t i = 0; i < sites.size() && 3 * i + 3 <= cap_words && out; i++) { out[3 * i] = sites[i].len; out[3 * i + 1] = sites[i].blocks; out[3 * i + 2] = sites[i].slot; }
+    return sites.size();
 }
 
 int qpgpu_synth_circuit_ex(unsigned degree_bits, unsigned num_wires, unsigned num_routed, unsigned num_public_inputs,

@@ -160,8 +160,68 @@ void poseidon_gate(const e2 *w, e2 *out) {
     for (int i = 0; i < 12; i++) out[k++] = st[i] - w[12 + i];
 }
 
+// The qp fork's Poseidon2 gate (type 14) at one extension point, verifier side: wires as the pack's layout table places them
+// (circuit.hpp P2GateLayout; default = upstream PoseidonGate's layout carried over, LAYOUT UNPINNED), permutation =
+// qp-poseidon-core's Poseidon2 (pinned by the reference's known-answer vectors). The linear layers have base-field entries, so
+// they act on an extension element coefficient-wise (scale); only the S-boxes multiply extension elements.
+void p2_external(e2 (&s)[12], const poseidon2::Params &P) {
+    e2 t[12];
+    for (int b = 0; b < 3; b++)
+        for (int i = 0; i < 4; i++) {
+            e2 acc = E(0);
+            for (int j = 0; j < 4; j++) acc = acc + scale(s[4 * b + j], P.m4[4 * i + j]);
+            t[4 * b + i] = acc;
+        }
+    for (int i = 0; i < 4; i++) {
+        const e2 colsum = t[i] + t[4 + i] + t[8 + i];
+        for (int b = 0; b < 3; b++) s[4 * b + i] = t[4 * b + i] + colsum;
+    }
+}
+void p2_internal(e2 (&s)[12], const poseidon2::Params &P) {
+    e2 total = E(0);
+    for (int i = 0; i < 12; i++) total = total + s[i];
+    for (int i = 0; i < 12; i++) s[i] = scale(s[i], P.diag_m1[i]) + total;
+}
+size_t poseidon2_gate(const P2GateLayout &lay, const e2 *w, e2 *out) {
+    const poseidon2::Params &P = poseidon2::qp_params();
+    size_t k = 0;
+    e2 st[12];
+    for (int i = 0; i < 12; i++) st[i] = w[lay.w_input + i];
+    if (lay.has_swap()) {
+        const e2 swap = w[lay.w_swap];
+        out[k++] = swap * (swap - E(1));
+        for (int i = 0; i < 4; i++) {
+            const e2 delta = w[lay.w_delta + i];
+            out[k++] = swap * (st[i + 4] - st[i]) - delta;
+            st[i] = st[i] + delta; st[i + 4] = st[i + 4] - delta;
+        }
+    }
+    p2_external(st, P);
+    uint32_t rec = lay.w_full0;
+    for (int r = 0; r < 8; r++) {
+        if (r == 4) {   // the 22 internal rounds sit between the two halves
+            for (int q = 0; q < 22; q++) {
+                const e2 in = w[lay.w_partial + q];
+                out[k++] = st[0] + E(P.rc_int[q]) - in;
+                st[0] = sbox7(in);
+                p2_internal(st, P);
+            }
+            rec = lay.w_full1;
+        }
+        for (int i = 0; i < 12; i++) st[i] = st[i] + E(P.rc_ext[r * 12 + i]);
+        if (r != 0 || lay.first_round_wires) {
+            for (int i = 0; i < 12; i++) { const e2 in = w[rec + i]; out[k++] = st[i] - in; st[i] = in; }
+            rec += 12;
+        }
+        for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
+        p2_external(st, P);
+    }
+    for (int i = 0; i < 12; i++) out[k++] = st[i] - w[lay.w_output + i];
+    return k;
+}
+
 // the unfiltered constraints of gate g in upstream order; returns how many were written
-size_t gate_constraints(const GateInfo &g, const e2 *consts, const e2 *w, const u64 pih[4], std::vector<e2> &out) {
+size_t gate_constraints(const GateInfo &g, const P2GateLayout &p2_layout, const e2 *consts, const e2 *w, const u64 pih[4], std::vector<e2> &out) {
     size_t k = 0;
     out.assign((size_t)g.num_constraints + 8, E(0));
     switch (g.type) {
@@ -178,6 +238,9 @@ size_t gate_constraints(const GateInfo &g, const e2 *consts, const e2 *w, const 
         case GATE_POSEIDON:
             poseidon_gate(w, out.data());
             k = 123;
+            break;
+        case GATE_POSEIDON2:
+            k = poseidon2_gate(p2_layout, w, out.data());
             break;
         case GATE_BASE_SUM: {           // wire 0 = sum, wires 1..num_limbs = bits (little endian)
             e2 s = E(0);
@@ -518,7 +581,7 @@ int qpgpu_verifier_verify(const qpgpu_verifier *v, const uint8_t *proof, size_t 
             const e2 s = o_cs[g.selector_index];
             for (u64 j = g.group_start; j < g.group_end; j++) if (j != gi) f = f * (E(j) - s);
             if (c.num_selectors > 1) f = f * (E(0xFFFFFFFFull) - s);
-            const size_t cnt = gate_constraints(g, consts, o_w.data(), pih, cst);
+            const size_t cnt = gate_constraints(g, c.p2_layout, consts, o_w.data(), pih, cst);
             if (cnt != g.num_constraints || cnt > gate_terms.size())
                 return fail(err, QPGPU_EVERIFY, "gate %zu: the pack declares %llu constraints, the gate has %zu", gi, (unsigned long long)g.num_constraints, cnt);
             for (size_t i = 0; i < cnt; i++) gate_terms[i] = gate_terms[i] + f * cst[i];

@@ -18,6 +18,8 @@ struct WitnessArgs {
     const GateDev *gates;
     const uint64_t *cs;         // constants_sigmas VALUES [ncs][n] (constants of the row)
     const uint64_t *poseidon_rc, *poseidon_fast;
+    const poseidon2::Params *p2_gate;   // Poseidon2 gate: qp-poseidon-core's constants (device block) and the gate's wire layout
+    P2GateLayout p2_layout;
     const uint64_t *hints;      // [n_hints][8]: the pack's free-standing generators (circuit.hpp)
     uint32_t num_wires;
     const uint64_t *pi_hash;    // [batch][4]: PublicInputGate wires

@@ -210,7 +210,70 @@ __device__ __forceinline__ void witness_level_body(WitnessArgs a, u32 first, u32
 // chain per row, and a global load per round would put an L2 round trip on it thirty times.
 __device__ __forceinline__ void stage_round_constants(const WitnessArgs &a, u64 *rc_lds) {
     for (u32 i = threadIdx.x; i < poseidon::ROUNDS * 12; i += blockDim.x) rc_lds[i] = a.poseidon_rc[i];
+    if (a.p2_gate) {   // the Poseidon2 gate's parameter block behind the Poseidon constants (same reason)
+        const u64 *src = reinterpret_cast<const u64 *>(a.p2_gate);
+        for (u32 i = threadIdx.x; i < poseidon2::PARAM_WORDS; i += blockDim.x) rc_lds[poseidon::ROUNDS * 12 + i] = src[i];
+    }
     __syncthreads();
+}
+constexpr u32 WITNESS_CONST_WORDS = poseidon::ROUNDS * 12 + poseidon2::PARAM_WORDS;
+
+// Poseidon2 gate generator (gate type 14), lane-cooperative like the PoseidonGate one: state element g in lane g of a 16-lane
+// group. External layer: every lane takes its 4x4 block row over its group of four (4 shuffles), then adds the column sum over
+// the three blocks (3 shuffles). Internal layer: the state sum by a 4-step butterfly over the 16 lanes (lanes 12..15 hold 0),
+// then s * diag + sum. The S-box inputs go to the wires the layout names; they are what the gate's constraints pin.
+__device__ __forceinline__ void witness_poseidon2_row(WitnessArgs a, const WitnessInst in, const bool live, const u64 *p2w) {
+    const P2GateLayout &lay = a.p2_layout;
+    const u64 *rc_ext = p2w, *rc_int = p2w + 96, *diag = p2w + 118, *m4 = p2w + 130;
+    const int g = threadIdx.x & 15, lane_base = (threadIdx.x & 63) & ~15;
+    const u64 n = a.n;
+    const u32 R = a.num_routed, row = in.row;
+    a.wires += (u64)blockIdx.y * a.batch_stride;
+    auto RD = [&](u32 col) -> u64 { return col < R ? a.wires[a.src_of[(u64)row * R + col]] : a.wires[(u64)col * n + row]; };
+    auto WR = [&](u32 col, u64 v) { if (live) a.wires[(u64)col * n + row] = gl::canon(v); };
+    auto shfl64 = [&](u64 v, int src) { return ((u64)(u32)__shfl((int)(v >> 32), src, 64) << 32) | (u32)__shfl((int)(u32)v, src, 64); };
+    const bool act = g < 12;
+    u64 s = act ? RD(lay.w_input + g) : 0;
+    if (lay.has_swap()) {
+        const u64 swap = gl::canon(RD(lay.w_swap));
+        const u64 partner = shfl64(s, lane_base + (g < 4 ? g + 4 : (g < 8 ? g - 4 : g)));
+        if (g < 4) { const u64 delta = swap ? gl::canon(gl::sub(partner, s)) : 0; WR(lay.w_delta + g, delta); s = gl::add(s, delta); }
+        else if (g < 8) { const u64 delta = swap ? gl::canon(gl::sub(s, partner)) : 0; s = gl::sub(s, delta); }
+    }
+    const int blk = lane_base + (g & 12), col = g & 3;
+    const u64 m0 = m4[4 * col], m1 = m4[4 * col + 1], m2 = m4[4 * col + 2], m3 = m4[4 * col + 3];
+    auto ext = [&](u64 v) -> u64 {
+        u64 t = gl::mul(m0, shfl64(v, blk));
+        t = gl::add(t, gl::mul(m1, shfl64(v, blk + 1)));
+        t = gl::add(t, gl::mul(m2, shfl64(v, blk + 2)));
+        t = gl::add(t, gl::mul(m3, shfl64(v, blk + 3)));
+        const u64 cs = gl::add(gl::add(shfl64(t, lane_base + col), shfl64(t, lane_base + 4 + col)), shfl64(t, lane_base + 8 + col));
+        return act ? gl::add(t, cs) : 0;
+    };
+    s = ext(s);
+    u32 wf = lay.w_full0;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+        s = gl::canon(gl::add(s, act ? rc_ext[r * 12 + g] : 0));
+        if (r || lay.first_round_wires) { if (act) WR(wf + g, s); wf += 12; }
+        s = ext(poseidon::sbox7(s));
+    }
+    const u64 dg = act ? diag[g] : 0;
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        if (g == 0) { s = gl::canon(gl::add(s, rc_int[r])); WR(lay.w_partial + r, s); s = poseidon::sbox7(s); }
+        u64 sum = s;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) sum = gl::add(sum, shfl64(sum, (threadIdx.x & 63) ^ off));
+        s = act ? gl::add(gl::mul(s, dg), sum) : 0;
+    }
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+        s = gl::canon(gl::add(s, act ? rc_ext[(4 + r) * 12 + g] : 0));
+        if (act) WR(lay.w_full1 + 12 * r + g, s);
+        s = ext(poseidon::sbox7(s));
+    }
+    if (act) WR(lay.w_output + g, s);
 }
 __device__ __forceinline__ void witness_poseidon_body(WitnessArgs a, u32 first, u32 count, const u32 tid, const u64 *rc) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
@@ -218,11 +281,17 @@ __device__ __forceinline__ void witness_poseidon_body(WitnessArgs a, u32 first, 
     const int g = threadIdx.x & 15, lane_base = (threadIdx.x & 63) & ~15;
     const bool live = slot < count;
     const WitnessInst in = a.insts[first + (live ? slot : count - 1)];   // idle groups shadow the last instance, without stores
+    // a wave's four 16-lane groups may hold rows of either hash gate; both bodies use wave shuffles, so the wave runs
+    // them one after the other with all of its lanes (a group whose row is of the other kind computes on it without storing)
+    const bool is_p2 = a.gates[in.gate].type == 14;
+    if (__any(is_p2)) witness_poseidon2_row(a, in, live && is_p2, rc + poseidon::ROUNDS * 12);
+    if (!__any(!is_p2)) return;
+    const bool live1 = live && !is_p2;
     const u64 n = a.n;
     const u32 R = a.num_routed, row = in.row;
     a.wires += (u64)blockIdx.y * a.batch_stride;
     auto RD = [&](u32 col) -> u64 { return col < R ? a.wires[a.src_of[(u64)row * R + col]] : a.wires[(u64)col * n + row]; };
-    auto WR = [&](u32 col, u64 v) { if (live) a.wires[(u64)col * n + row] = gl::canon(v); };
+    auto WR = [&](u32 col, u64 v) { if (live1) a.wires[(u64)col * n + row] = gl::canon(v); };
     auto shfl64 = [&](u64 v, int src) { return ((u64)(u32)__shfl((int)(v >> 32), src, 64) << 32) | (u32)__shfl((int)(u32)v, src, 64); };
     int src[12];
 #pragma unroll
@@ -265,7 +334,7 @@ __global__ void __launch_bounds__(128) witness_level_kernel(WitnessArgs a, u32 f
     witness_level_body(a, first, count, blockIdx.x * blockDim.x + threadIdx.x);
 }
 __global__ void __launch_bounds__(256) witness_poseidon_kernel(WitnessArgs a, u32 first, u32 count) {
-    __shared__ u64 rc_lds[poseidon::ROUNDS * 12];
+    __shared__ u64 rc_lds[WITNESS_CONST_WORDS];
     stage_round_constants(a, rc_lds);
     witness_poseidon_body(a, first, count, blockIdx.x * blockDim.x + threadIdx.x, rc_lds);
 }
@@ -273,7 +342,7 @@ __global__ void __launch_bounds__(256) witness_poseidon_kernel(WitnessArgs a, u3
 // thread each), the rest its PoseidonGate rows (16 lanes each). Both halves are latency-bound (a level ends when its slowest
 // generator does), so running them side by side instead of back to back takes the longer of the two, not the sum.
 __global__ void __launch_bounds__(256) witness_combined_kernel(WitnessArgs a, u32 first, u32 n_generic, u32 n_poseidon, u32 generic_blocks) {
-    __shared__ u64 rc_lds[poseidon::ROUNDS * 12];
+    __shared__ u64 rc_lds[WITNESS_CONST_WORDS];
     if (blockIdx.x < generic_blocks) { witness_level_body(a, first, n_generic, blockIdx.x * blockDim.x + threadIdx.x); return; }
     stage_round_constants(a, rc_lds);
     witness_poseidon_body(a, first + n_generic, n_poseidon, (blockIdx.x - generic_blocks) * blockDim.x + threadIdx.x, rc_lds);
@@ -285,7 +354,7 @@ __global__ void __launch_bounds__(256) witness_combined_kernel(WitnessArgs a, u3
 // ordinary instances (a thread each, strided), waves 8-15 its PoseidonGate rows (16 lanes each), then a workgroup barrier —
 // all waves of a workgroup share one L1, so the barrier's memory fence makes the level's stores visible to the next level.
 __global__ void __launch_bounds__(1024) witness_run_kernel(WitnessArgs a, const u32 *level_start, const u32 *level_poseidon, u32 l0, u32 l1) {
-    __shared__ u64 rc_lds[poseidon::ROUNDS * 12];
+    __shared__ u64 rc_lds[WITNESS_CONST_WORDS];
     stage_round_constants(a, rc_lds);
     const u32 t = threadIdx.x;
     for (u32 l = l0; l < l1; l++) {

@@ -64,7 +64,7 @@ struct Cell { uint32_t row, col; };
 struct CellIO { std::vector<Cell> in, out; };
 
 // the cells (wire columns of its row) a generator instance reads and writes; must match witness_level_kernel
-void describe(const GateInfo &g, uint32_t op, IO &io) {
+void describe(const GateInfo &g, uint32_t op, const P2GateLayout &lay, IO &io) {
     io.in.clear(); io.out.clear();
     auto range = [](std::vector<uint32_t> &v, uint32_t a, uint32_t b) { for (uint32_t i = a; i < b; i++) v.push_back(i); };
     switch (g.type) {
@@ -75,6 +75,12 @@ void describe(const GateInfo &g, uint32_t op, IO &io) {
     case GATE_MUL_EXT: range(io.in, 6 * op, 6 * op + 4); range(io.out, 6 * op + 4, 6 * op + 6); break;
     case GATE_BASE_SUM: io.in = {0}; range(io.out, 1, 1 + (uint32_t)g.param0); break;
     case GATE_POSEIDON: range(io.in, 0, 12); io.in.push_back(24); range(io.out, 12, 24); range(io.out, 25, 135); break;
+    case GATE_POSEIDON2:
+        range(io.in, lay.w_input, lay.w_input + 12); range(io.out, lay.w_output, lay.w_output + 12);
+        if (lay.has_swap()) { io.in.push_back(lay.w_swap); range(io.out, lay.w_delta, lay.w_delta + 4); }
+        range(io.out, lay.w_full0, lay.w_full0 + 12 * lay.full0_rounds()); range(io.out, lay.w_partial, lay.w_partial + 22);
+        range(io.out, lay.w_full1, lay.w_full1 + 48);
+        break;
     case GATE_REDUCING: case GATE_REDUCING_EXT: {
         const uint32_t nc = (uint32_t)g.param0, ncw = g.type == GATE_REDUCING_EXT ? 2 * nc : nc;
         range(io.in, 2, 6 + ncw); range(io.out, 0, 2); range(io.out, 6 + ncw, 6 + ncw + 2 * (nc - 1));
@@ -116,7 +122,7 @@ uint32_t num_instances(const GateInfo &g) {
 void describe_any(const CircuitPack &p, const WitnessInst &w, IO &tmp, CellIO &io) {
     io.in.clear(); io.out.clear();
     if (w.gate != WITNESS_HINT) {
-        describe(p.gates[w.gate], w.op, tmp);
+        describe(p.gates[w.gate], w.op, p.p2_layout, tmp);
         for (uint32_t c : tmp.in) io.in.push_back({w.row, c});
         for (uint32_t c : tmp.out) io.out.push_back({w.row, c});
         return;
@@ -267,7 +273,8 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     for (int32_t l : level) max_level = std::max(max_level, l);
     std::vector<uint32_t> order(insts.size());
     std::iota(order.begin(), order.end(), 0u);
-    auto is_pos = [&](uint32_t i) { return insts[i].gate != WITNESS_HINT && p.gates[insts[i].gate].type == GATE_POSEIDON ? 1 : 0; };
+    auto hash_gate = [&](const WitnessInst &w) { return w.gate != WITNESS_HINT && (p.gates[w.gate].type == GATE_POSEIDON || p.gates[w.gate].type == GATE_POSEIDON2); };
+    auto is_pos = [&](uint32_t i) { return hash_gate(insts[i]) ? 1 : 0; };   // rows of the two hash gates: lane-cooperative generators, last in their level
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return level[a] != level[b] ? level[a] < level[b] : is_pos(a) < is_pos(b); });
     plan.insts.resize(insts.size());
     plan.level_start.assign(max_level + 1, 0);
@@ -280,7 +287,7 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     plan.level_poseidon.assign(max_level, 0);
     for (int32_t l = 0; l < max_level; l++) {
         uint32_t k = plan.level_start[l];
-        while (k < plan.level_start[l + 1] && (plan.insts[k].gate == WITNESS_HINT || p.gates[plan.insts[k].gate].type != GATE_POSEIDON)) k++;
+        while (k < plan.level_start[l + 1] && !hash_gate(plan.insts[k])) k++;
         plan.level_poseidon[l] = k;
     }
 
@@ -408,6 +415,7 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
     WitnessArgs a{};
     a.wires = d_wires; a.src_of = plan.d_src_of; a.insts = plan.d_insts; a.gates = c->d_gates; a.cs = c->d_cs_values;
     a.poseidon_rc = c->d_poseidon_rc; a.poseidon_fast = c->d_poseidon_fast; a.pi_hash = plan.d_pi_hash;
+    a.p2_gate = c->has_p2_gate ? ctx->d_p2_app : nullptr; a.p2_layout = c->pack.p2_layout;
     a.hints = plan.d_hints; a.num_wires = (uint32_t)c->pack.num_wires;
     a.n = c->pack.n(); a.batch_stride = c->pack.num_wires * c->pack.n();
     a.num_routed = (uint32_t)c->pack.num_routed_wires; a.num_selectors = (uint32_t)c->pack.num_selectors;

@@ -329,9 +329,9 @@ def test_proving_pool(pkg, gpu, orc):
         with pytest.raises(pkg.QpGpuError):
             pool.wait(tickets[0][0])                       # a ticket is waited for once
         small = np.empty(16, dtype=np.uint8)
-        t = pool.submit(variants[0][0], variants[0][1], out=small)
-        with pytest.raises(pkg.QpGpuError):
-            pool.wait(t)                                   # output buffer too small: reported on the ticket
+        with pytest.raises(pkg.QpGpuError) as e:           # output buffer too small: refused at submit, before it can join
+            pool.submit(variants[0][0], variants[0][1], out=small)   # a lockstep batch of other callers' proofs
+        assert e.value.code == -5
         assert pool.wait(pool.submit(variants[1][0], variants[1][1])) == variants[1][2]    # the pool keeps working
     finally:
         pool.close()
