@@ -6,7 +6,10 @@ BASELINE.json metric: "Wormhole proofs/sec + ms/proof at 1/2/4/8 GPUs; NTT HBM G
 Headline workload (BASELINE configs[2], "Full Wormhole proof (LDE + Poseidon Merkle commit + FRI) on 1
 MI355X"): proofs of a shape-equivalent synthetic leaf circuit (the real circuit pack needs the Rust exporter under
 integration/): 2^13 rows, 135 wires, 80 routed, standard_recursion_config FRI (rate 1/8, cap
-height 4, 28 queries, 16 PoW bits, arity 16). The witnesses are resident in HBM when the timed region starts; a proof
+height 4, 28 queries, 16 PoW bits, arity 16), carrying the LEAF PROFILE: the leaf circuit's 61 application-hash permutations
+as rows of the qp fork's Poseidon2 gate (sponge chains over 7, 4, 9, 4, 8, 45 and 16 x 16 elements, the eight
+hash_n_to_hash_no_pad_p2 call sites; gate wire layout from the pack's table, LAYOUT UNPINNED) next to PoseidonGate rows
+(public-input hash), BaseSum<2> range checks and arithmetic. The witnesses are resident in HBM when the timed region starts; a proof
 ends when its bytes are in host memory. A step = S proofs per GPU, S = --streams x --batch (6 workers x 32 proofs in
 lockstep by default: every worker has its HIP stream, batched workspace and host transcript thread inside the
 library's proving pool, and launches every stage once for its 32 proofs).
@@ -76,11 +79,20 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
     }
     # HBM traffic from the PMC counters cannot be collected inside this process; it is read from the committed
     # rocprofv3 --pmc summary of the same kernels on the same workload (profiles/*ntt_pmc_summary.json)
+    # A summary counts only while it was measured on THIS library's NTT kernels: tools/r03_collect.py stores the hash of the
+    # kernel sources (tools/kernel_id.py) in it; on a mismatch the fields stay null and `counters_stale` says why.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_id import kernel_source_id
+    kid = kernel_source_id("ntt")
+    roof["kernel_source_id"] = kid
+    stale = []
     try:
         import glob
         latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*ntt_pmc_summary.json")))[-1]
         pm = json.load(open(latest))
-        if pm.get("algorithmic_bytes_per_transform") == 16 * n * batch:
+        if pm.get("kernel_source_id") != kid:
+            stale.append(os.path.relpath(latest, ROOT))
+        elif pm.get("algorithmic_bytes_per_transform") == 16 * n * batch:
             roof["traffic"] = pm["hbm_bytes_per_transform"]
             roof["traffic_source"] = os.path.relpath(latest, ROOT)
     except Exception:
@@ -93,12 +105,16 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
     try:
         latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*ntt_valu_summary.json")))[-1]
         vs = json.load(open(latest))
-        if vs.get("elements_per_transform") == n * batch:
+        if vs.get("kernel_source_id") != kid:
+            stale.append(os.path.relpath(latest, ROOT))
+        elif vs.get("elements_per_transform") == n * batch:
             roof["valu_insts_per_element"] = vs["valu_insts_per_element"]
             roof["valu_issue_frac"] = vs["valu_issue_frac"]
             roof["valu_source"] = os.path.relpath(latest, ROOT)
     except Exception:
         pass
+    if stale:
+        roof["counters_stale"] = "not reported: measured on other NTT kernel sources than this library's (" + ", ".join(stale) + ")"
     ok = bool(torch.equal(z, x))
     return gbs, roof, ok, x[0].cpu().numpy().view(np.uint64), y[0].cpu().numpy().view(np.uint64)
 
@@ -147,7 +163,7 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (default long enough that the pool's ramp and drain are < 2 % of the window)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree-bits", type=int, default=13)
     ap.add_argument("--batch-degree-bits", type=int, default=16, help="rows of the private / public batch circuits of the tree leg")
@@ -157,6 +173,8 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the per-stage, witness-generation and end-to-end legs (profiling the timed region)")
     ap.add_argument("--no-tree", action="store_true", help="skip the 64-leaf aggregation-tree leg (BASELINE configs[4])")
+    ap.add_argument("--all-gather", action="store_true", help="every rank receives every rank's proof bytes (all_gather) instead of the default gather to rank 0, "
+                                                               "the rank that consumes them (SURVEY.md 8e)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -200,7 +218,7 @@ def main():
     # ---- synthetic leaf-shaped circuit + witness (setup, untimed: reference builds the circuit in the bench's
     # setup closure too, wormhole/prover/benches/prover.rs:35-37) ----
     d = args.degree_bits
-    pack, wires, pis = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000 + rank, poseidon=True, base_sum=True)
+    pack, wires, pis = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000 + rank, poseidon=True, base_sum=True, poseidon2=True)
     circs = [pkg.Circuit(g, pack) for g in gpus]                    # per-stream workspace, no allocation while proving
     circ = circs[0]
     w_t = torch.from_numpy(wires.view(np.int64)).to(dev)            # witness resident in HBM
@@ -252,7 +270,8 @@ def main():
         # what the step's collective sends (sharding.ProofBlockGather: no per-proof copies on the host)
         nonlocal gathered, step_gather
         if step_gather is None or len(step_gather.send) < ring:
-            step_gather = pkg.sharding.ProofBlockGather(S, proof_len, dist if world > 1 else None, coll_dev, blocks=AHEAD + 1)
+            step_gather = pkg.sharding.ProofBlockGather(S, proof_len, dist if world > 1 else None, coll_dev, blocks=AHEAD + 1,
+                                                        root=None if args.all_gather or world == 1 else 0)
         sg = step_gather
 
         def submit_step(j):
@@ -268,7 +287,7 @@ def main():
                     raise SystemExit("bench.py: a proof of unexpected length")
             if world > 1:
                 _tg = time.perf_counter()
-                gathered = sg.gather(j % ring)        # [world][S][proof_len] on the host
+                gathered = sg.gather(j % ring)        # [world][S][proof_len] on the host (rank 0; every rank with --all-gather)
                 gather_ms.append((time.perf_counter() - _tg) * 1e3)
             last = sg.slot(j % ring, 0).tobytes()
             step_done.append(time.perf_counter())
@@ -295,6 +314,12 @@ def main():
         dt = float(t.item())
         if rank == 0:   # every rank's S proofs arrived; rank 0's own are unchanged
             assert tuple(gathered.shape) == (world, S, proof_len) and gathered[0, 0].numpy().tobytes() == proof
+        gm = torch.tensor([float(np.mean(gather_ms)) if gather_ms else 0.0], dtype=torch.float64, device=coll_dev)
+        gml = [torch.zeros_like(gm) for _ in range(world)]
+        dist.all_gather(gml, gm)
+        gather_ms_per_rank = [round(float(x.item()), 2) for x in gml]
+    else:
+        gather_ms_per_rank = []
     value = args.steps * S * world / dt
 
     extra = {}
@@ -314,7 +339,7 @@ def main():
         # (reference common/src/circuit.rs:396-402), public batch: standard_recursion_config
         rec = dict(poseidon=True, base_sum=True, ext_arith=True, recursion=True)
         NB_PIS = 21 * 8 + 8
-        tleaf = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000, poseidon=True, base_sum=True)
+        tleaf = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000, poseidon=True, base_sum=True, poseidon2=True)
         tpriv = pkg.synth_circuit(args.batch_degree_bits, num_wires=135, num_routed=60, num_public_inputs=NB_PIS, seed=78, **rec)
         tpriv[0][14] = 1
         tpub = None
@@ -322,12 +347,18 @@ def main():
             tpub = pkg.synth_circuit(args.batch_degree_bits, num_wires=135, num_routed=80, num_public_inputs=agg.public_batch_pi_len(8, 8), seed=77, **rec)
         atree = agg.AggregationTree(pkg, gpus[0], rank, world, tleaf, tpriv, tpub, leaf_batch=64)
         dd = dist if world > 1 else None
-        atree.run(dd, coll_dev)
+        tree_exchange = "all" if args.all_gather else "root"
+        atree.run(dd, coll_dev, exchange=tree_exchange)
         barrier()
         t2 = time.perf_counter()
-        t_leaves, t_batches, t_root = atree.run(dd, coll_dev)
+        t_leaves, t_batches, t_root = atree.run(dd, coll_dev, exchange=tree_exchange)
         barrier()
         tdt = time.perf_counter() - t2
+        if world > 1 and tree_exchange == "root":   # untimed: the checker below wants every rank's leaf proofs on rank 0
+            mine = [p_ for p_ in t_leaves if p_ is not None]
+            got_ = pkg.sharding.gather_proof_bytes(mine, dd, coll_dev, root=0)
+            if got_ is not None:
+                t_leaves = [p_ for r_ in got_ for p_ in r_]
         if world > 1:
             tt = torch.tensor([tdt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -511,7 +542,7 @@ def main():
             extra["end_to_end_with_witness_generation"] = e2e
             # the leaf circuit's degree is "12 or 13" (SURVEY.md section 8): the same measurement at 2^12 rows
             try:
-                p12, w12, pi12 = pkg.synth_circuit(12, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000, poseidon=True, base_sum=True)
+                p12, w12, pi12 = pkg.synth_circuit(12, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000, poseidon=True, base_sum=True, poseidon2=True)
                 pool12 = pkg.ProvingPool(p12, workers=WORKERS, device=local_rank, max_batch=LOCKSTEP)
                 d12 = gpu.to_device(w12)
                 o12 = [np.empty(pool12.proof_size(), dtype=np.uint8) for _ in range(S)]
@@ -611,9 +642,12 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_proof": round(dt / (args.steps * S) * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "window_proofs_per_s": windows, "step_ms_rank0": step_ms, "gather_ms_rank0": [round(x, 2) for x in gather_ms[-16:]],
+            "gather_ms_mean_per_rank": gather_ms_per_rank,
+            "proof_exchange": "none (one rank)" if world == 1 else ("all_gather of every step's proof bytes" if args.all_gather else "gather of every step's proof bytes to rank 0, the consuming rank"),
+            "host_threads_per_rank": {"library_proving_workers": WORKERS, "python_threads": __import__("threading").active_count(), "cpus_visible": os.cpu_count()},
             "config": {"workload": "BASELINE configs[2]/[3]: full proof (LDE + Poseidon Merkle commit + quotient + FRI) of a "
                                    "shape-equivalent synthetic leaf circuit, proofs_per_step_per_gpu different witnesses per GPU per step, resident in HBM",
-                       "degree_bits": d, "gates": "PublicInput, Constant, BaseSum<2>(63 limbs), Arithmetic(20 ops), Poseidon(123 constraints), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
+                       "degree_bits": d, "gates": "PublicInput, Constant, BaseSum<2>(63 limbs), Arithmetic(20 ops), Poseidon(123 constraints), Poseidon2 gate (123 constraints; 61 sponge rows of the leaf's 8 hash call sites + 4 free-standing; wire layout = pack table, unpinned), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
                        "num_query_rounds": 28, "proof_of_work_bits": 16, "fri_arity_bits": 4, "proof_bytes": proof_len, "proofs_in_flight_per_gpu": S, "proofs_per_step_per_gpu": S, "workers": WORKERS, "lockstep_batch": LOCKSTEP,
                        "multi_gpu": ("independent proofs per rank + one all_gather of each step's proof bytes (%s)" % ("RCCL" if backend == "nccl" else backend + " rehearsal, ranks share the visible GPUs")) if world > 1 else "single GPU"},
         }

@@ -398,8 +398,12 @@ class AggregationTree:
             v.close()
         self.verifiers = {}
 
-    def run(self, dist=None, device=None, blinding_seed=None, keep=None, shuffle_seed=None, aggregator_address=bytes(32)):
+    def run(self, dist=None, device=None, blinding_seed=None, keep=None, shuffle_seed=None, aggregator_address=bytes(32), exchange="all"):
         """One pass over the tree. Returns (all leaf proofs, all private-batch proofs, root proof or None).
+        exchange: "all" = every level's proof bytes reach every rank (all_gather); "root" = what the next level needs and no
+        more: a rank's private batches consume the leaves the same rank proved, so the leaf level exchanges
+        nothing, and the private-batch proofs are gathered to the root rank only — the returned lists then hold None for proofs
+        this rank neither made nor received.
         blinding_seed / shuffle_seed (32 bytes): make the zero-knowledge salts / the private batches' slot order and dummy
         preimages reproducible (tests; default: operating-system entropy); keep: a dict that receives, per level, this
         rank's (index, public inputs, full witness) triples for an external checker (costs a device download each)."""
@@ -416,7 +420,12 @@ class AggregationTree:
                 for j, i in enumerate(chunk):
                     keep.setdefault("leaf", []).append((i, pis[j].copy(), all_w[j].copy()))
             mine_leaf += self.leaf.prove_many()
-        leaves = [p for r in self.sharding.gather_proof_bytes(mine_leaf, d, device) for p in r]
+        if exchange == "root" and d is not None:
+            leaves = [None] * (self.num_batches * self.slots)
+            for i, p_ in zip(ids, mine_leaf):
+                leaves[i] = p_
+        else:
+            leaves = [p for r in self.sharding.gather_proof_bytes(mine_leaf, d, device) for p in r]
         t1 = time.perf_counter()
         mine_priv = []
         # this rank's private batches in lockstep, in runs of consecutive batch numbers (proof j of a run is blinded with
@@ -439,7 +448,16 @@ class AggregationTree:
                     keep.setdefault("private", []).append((b, pis[j].copy(), self.private.witness(j)))
             mine_priv += self.private.prove_many()
             k += len(run)
-        batches = [p for r in self.sharding.gather_proof_bytes(mine_priv, d, device) for p in r]
+        if exchange == "root" and d is not None:
+            got = self.sharding.gather_proof_bytes(mine_priv, d, device, root=self.plan["root"])
+            if got is not None:
+                batches = [p for r in got for p in r]
+            else:
+                batches = [None] * self.num_batches
+                for b, p_ in zip(pb, mine_priv):
+                    batches[b] = p_
+        else:
+            batches = [p for r in self.sharding.gather_proof_bytes(mine_priv, d, device) for p in r]
         t2 = time.perf_counter()
         root = None
         if self.public is not None:

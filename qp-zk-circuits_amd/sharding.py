@@ -31,11 +31,13 @@ def aggregation_schedule(num_leaves=64, leaves_per_private_batch=8, world=8):
     return plan
 
 
-def gather_proof_bytes(proofs, dist=None, device=None, layout=None):
+def gather_proof_bytes(proofs, dist=None, device=None, layout=None, root=None):
     """All ranks contribute a list of proofs (bytes); every rank receives the list of all ranks' lists, in rank
     order. Fixed-size padded uint8 buffers + a length vector, one all_gather each (payload is latency-bound).
     `layout`: a dict the caller keeps between calls when every call has the same proof counts and sizes on every rank
-    (proofs of one circuit have a fixed size): the two metadata collectives then run once, not per call."""
+    (proofs of one circuit have a fixed size): the two metadata collectives then run once, not per call.
+    `root`: gather to that rank only (SURVEY.md 8e: the proof bytes of a level go to the rank that proves the next one);
+    every other rank gets None and neither receives nor decodes anything."""
     import os
     import torch
     if dist is None or not dist.is_initialized():
@@ -71,8 +73,14 @@ def gather_proof_bytes(proofs, dist=None, device=None, layout=None):
     for i, p in enumerate(proofs):
         staged[i * max_len:i * max_len + len(p)] = np.frombuffer(p, dtype=np.uint8)
     payload = torch.from_numpy(staged).to(dev)
-    recv = [torch.zeros_like(payload) for _ in range(world)]
-    dist.all_gather(recv, payload)
+    if root is not None:
+        recv = [torch.zeros_like(payload) for _ in range(world)] if dist.get_rank() == root else None
+        dist.gather(payload, gather_list=recv, dst=root)
+        if recv is None:
+            return None
+    else:
+        recv = [torch.zeros_like(payload) for _ in range(world)]
+        dist.all_gather(recv, payload)
     out = []
     for r in range(world):
         buf = recv[r].cpu().numpy()
@@ -88,20 +96,26 @@ class ProofBlockGather:
     gather_proof_bytes spends ~160 ms per step in host copies, which is most of a step). `blocks`: how many steps' blocks are
     kept (a ring; the bench submits steps ahead of the one it collects)."""
 
-    def __init__(self, count, proof_len, dist, device, blocks=1):
+    def __init__(self, count, proof_len, dist, device, blocks=1, root=None):
+        """root: None = every rank receives every rank's block (all_gather); a rank number = only that rank does (gather):
+        the next aggregation level runs on one rank, and at 8 ranks x 192 proofs the all_gather form moves 8 x 25 MB into
+        every rank and a 200 MB device-to-host copy per rank and step for bytes only the root reads."""
         import torch
         self.count, self.proof_len, self.dist, self.device = count, proof_len, dist, device
+        self.root = root
         import os
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         self.force = os.environ.get("QPGPU_FORCE_COLLECTIVE") == "1" and dist is not None and dist.is_initialized()   # test hook
         cuda = getattr(device, "type", "cpu") == "cuda"
         mk = (lambda *shape: torch.empty(*shape, dtype=torch.uint8).pin_memory()) if cuda else (lambda *shape: torch.empty(*shape, dtype=torch.uint8))
         self.send = [mk(count, proof_len) for _ in range(blocks)]
-        self.recv_host = mk(self.world, count, proof_len)
+        self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+        self.receives = root is None or self.rank == root
+        self.recv_host = mk(self.world if self.receives else 1, count, proof_len)
         for t in self.send + [self.recv_host]:      # touch every page now, from this thread: left to the proving threads' first
             t.zero_()                                # writes, the two-rank gloo rehearsal of the bench lost 13 % of its rate
         self.send_np = [t.numpy() for t in self.send]
-        self.recv_dev = torch.empty(self.world, count, proof_len, dtype=torch.uint8, device=device) if cuda else self.recv_host
+        self.recv_dev = torch.empty(self.world if self.receives else 1, count, proof_len, dtype=torch.uint8, device=device) if cuda else self.recv_host
         self.send_dev = torch.empty(count, proof_len, dtype=torch.uint8, device=device) if cuda else None
 
     def slot(self, block, i):
@@ -109,11 +123,22 @@ class ProofBlockGather:
         return self.send_np[block][i]
 
     def gather(self, block):
-        """all ranks' blocks -> uint8 host tensor [world][count][proof_len] (valid until the next gather)"""
+        """all ranks' blocks -> uint8 host tensor [world][count][proof_len] (valid until the next gather); with a root, None on
+        the other ranks"""
         import torch
         if self.world == 1 and not self.force:
             self.recv_host[0].copy_(self.send[block])
             return self.recv_host
+        if self.root is not None:
+            if self.send_dev is not None:
+                self.send_dev.copy_(self.send[block], non_blocking=True)
+                self.dist.gather(self.send_dev, gather_list=list(self.recv_dev.unbind(0)) if self.receives else None, dst=self.root)
+                if self.receives:
+                    self.recv_host.copy_(self.recv_dev, non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+            else:
+                self.dist.gather(self.send[block], gather_list=list(self.recv_host.unbind(0)) if self.receives else None, dst=self.root)
+            return self.recv_host if self.receives else None
         if self.send_dev is not None:
             self.send_dev.copy_(self.send[block], non_blocking=True)
             self.dist.all_gather(list(self.recv_dev.unbind(0)), self.send_dev)

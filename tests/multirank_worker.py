@@ -70,7 +70,7 @@ def main():
         # ---- configs[4]: 64 leaves -> 8 zero-knowledge private batches -> 1 public batch, small degrees ----
         dl, db = int(os.environ.get("QP_TEST_LEAF_BITS", "7")), int(os.environ.get("QP_TEST_BATCH_BITS", "8"))
         rec = dict(poseidon=True, base_sum=True, ext_arith=True, recursion=True)
-        leaf = pkg.synth_circuit(dl, num_wires=135, num_routed=80, num_public_inputs=21, seed=11, poseidon=True, base_sum=True)
+        leaf = pkg.synth_circuit(dl, num_wires=135, num_routed=80, num_public_inputs=21, seed=11, poseidon=True, base_sum=True, poseidon2=True)
         priv = pkg.synth_circuit(db, num_wires=135, num_routed=60, num_public_inputs=21 * 8 + 8, seed=12, **rec)
         priv[0][14] = 1                                          # standard_recursion_zk_config: salted leaves
         pub = pkg.synth_circuit(db, num_wires=135, num_routed=80, num_public_inputs=agg.public_batch_pi_len(8, 8), seed=13, **rec)
@@ -78,8 +78,13 @@ def main():
         keep = {}
         SEED = 7000
         ADDRESS = b"".join(v.to_bytes(8, "little") for v in (0xA661, 2, 3, 4))
-        leaves, batches, root = tree.run(dist, None, blinding_seed=SEED, keep=keep, shuffle_seed=bytes(range(32)), aggregator_address=ADDRESS)
+        exchange = os.environ.get("QP_TEST_EXCHANGE", "all")     # "root": proof bytes travel to the consuming rank only
+        leaves, batches, root = tree.run(dist, None, blinding_seed=SEED, keep=keep, shuffle_seed=bytes(range(32)), aggregator_address=ADDRESS, exchange=exchange)
         ok = len(leaves) == 64 and len(batches) == 8
+        if exchange == "root" and world > 1:
+            mine = tree.plan["ranks"][rank]
+            ok = ok and all((leaves[i] is not None) == (i in mine["leaves"]) for i in range(64))
+            ok = ok and all((batches[b] is not None) == (rank == tree.plan["root"] or b in mine["private_batches"]) for b in range(8))
         # every proof this rank produced, against the oracle
         for (i, pis, w) in keep["leaf"]:
             ok = ok and oracle_equal(leaf[0], w, pis, leaves[i])
@@ -102,7 +107,8 @@ def main():
                 want, nulls = {}, []
                 for j in range(8):
                     lp = agg.leaf_public_inputs(8 * b + j)
-                    ok = ok and np.array_equal(agg.proof_public_inputs(leaves[8 * b + j], 21), lp)
+                    if leaves[8 * b + j] is not None:
+                        ok = ok and np.array_equal(agg.proof_public_inputs(leaves[8 * b + j], 21), lp)
                     nulls.append(tuple(lp[4:8].tolist()))
                     for acct, amt in ((tuple(lp[8:12].tolist()), int(lp[1])), (tuple(lp[12:16].tolist()), int(lp[2]))):
                         want[acct] = want.get(acct, 0) + amt

@@ -61,6 +61,16 @@ def test_aggregation_tree_over_two_ranks(tmp_path):
 
 
 @pytest.mark.gpu
+def test_aggregation_tree_gathers_to_the_consuming_rank_only(tmp_path):
+    """The same tree with exchange="root" (what bench.py times): the leaf level exchanges nothing — a rank's private batches
+    consume its own leaves — and the private-batch proofs travel to the root rank alone; every proof still byte-equal to the
+    oracle's and the root's public inputs unchanged."""
+    res = _run_ranks("tree", 2, tmp_path, extra_env={"QP_TEST_EXCHANGE": "root"})
+    assert all(r["ok"] for r in res)
+    assert res[0]["root_bytes"] > 0 and res[1]["root_bytes"] == 0
+
+
+@pytest.mark.gpu
 def test_leaf_proofs_single_rank_matches(tmp_path):
     """The same 8 proofs from one rank: sharding does not change any proof."""
     res = _run_ranks("leaves", 1, tmp_path)

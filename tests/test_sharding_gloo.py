@@ -52,6 +52,24 @@ def _worker(rank, world, port, ret):
         got = blk.gather(b)
         ok = ok and tuple(got.shape) == (world, count, plen)
         ok = ok and all(np.array_equal(got[r, i].numpy(), want[r][i] ^ np.uint8(step)) for r in range(world) for i in range(count))
+    # gather to the consuming rank only: the root gets everything, the others nothing
+    g3 = sh.gather_proof_bytes(mine, dist, root=1)
+    ok = ok and ((g3 is None) if rank != 1 else [p for r in g3 for p in r] == all_proofs)
+    lay3 = {}
+    for _ in range(2):
+        g3 = sh.gather_proof_bytes(mine, dist, None, lay3, root=0)
+        ok = ok and ((g3 is None) if rank != 0 else [len(r) for r in g3] == [3, 2] and [p for r in g3 for p in r] == all_proofs)
+    blk = sh.ProofBlockGather(count, plen, dist, torch.device("cpu"), blocks=2, root=0)
+    for step in range(3):
+        b = step % 2
+        for i in range(count):
+            blk.slot(b, i)[:] = want[rank][i] ^ np.uint8(7 + step)
+        got = blk.gather(b)
+        if rank == 0:
+            ok = ok and tuple(got.shape) == (world, count, plen)
+            ok = ok and all(np.array_equal(got[r, i].numpy(), want[r][i] ^ np.uint8(7 + step)) for r in range(world) for i in range(count))
+        else:
+            ok = ok and got is None
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
