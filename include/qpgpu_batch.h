@@ -115,6 +115,55 @@ int qpgpu_dummy_private_batch_template_check(const uint64_t *pis, size_t n, char
 int qpgpu_public_batch_outputs(const uint64_t *inner_pis, size_t m, size_t n_leaf, const uint8_t aggregator_address[32],
                                uint64_t *out, char *err);
 
+/* ---- inner-proof targets: the witness of a recursive wrapper circuit -----------------
+ * fill_private_batch_witness (wormhole/aggregator/src/private_batch/prover/witness.rs:15-77) assigns N complete inner proofs
+ * to the wrapper's proof targets with `pw.set_proof_with_pis_target`, after ensure_proof_shape_matches_targets
+ * (wormhole/aggregator/src/common/utils.rs:295-540) has compared every vector length of the proof with its target, and then the
+ * N x 4 dummy-nullifier preimage elements. A proof target is one virtual target per field element of a proof of the INNER
+ * circuit (`add_virtual_proof_with_pis(common_data)`); here the tree is flattened into LOGICAL TARGETS 0 .. T-1 per proof slot,
+ * in this order (the order `set_proof_with_pis_target` visits them in upstream plonky2; any enumeration would do, the exporter
+ * and this header only have to agree):
+ *     public_inputs[ ]
+ *     wires_cap, plonk_zs_partial_products_cap, quotient_polys_cap                  (4 elements per digest)
+ *     openings at zeta:  constants, plonk_sigmas, wires, plonk_zs, partial_products, quotient_polys   (2 per extension element)
+ *     openings at g*zeta: plonk_zs_next                                                       (lookup vectors are empty)
+ *     opening_proof.pow_witness
+ *     opening_proof.final_poly coefficients                                                     (2 each)
+ *     opening_proof.commit_phase_merkle_caps
+ *     per query round: per initial oracle: evals (base elements), siblings (digests); per reduction step: evals (extension), siblings
+ * The id of target j of the proof in slot i is i * T + j; the preimage element `limb` of slot i is N * T + 4 i + limb. The
+ * circuit-pack exporter records which wire cell each logical target became (integration/qpgpu_backend.rs: target map), as for
+ * the leaf circuit (include/qpgpu_leaf.h): qpgpu_leaf_map_targets turns (id, value) pairs into the (cell, value) list of
+ * qpgpu_generate_witness_partial_dev.
+ *
+ * A SHAPE is the list of a proof's vector lengths as 32-bit words, in the order the reference's check visits them:
+ *   public_inputs, wires_cap, plonk_zs_partial_products_cap, quotient_polys_cap, openings.{constants, plonk_sigmas, wires,
+ *   plonk_zs, plonk_zs_next, partial_products, quotient_polys, lookup_zs, lookup_zs_next}, number of commit-phase caps and each
+ *   cap's length, number of query rounds and per round { number of initial oracles, (evals, siblings) each, number of steps,
+ *   (evals, siblings) each }, final_poly. */
+/* the shape of the proof targets of `inner_pack`'s circuit; out may be NULL to ask for the word count */
+int qpgpu_proof_target_shape(const uint64_t *inner_pack, size_t n_words, uint32_t *out, size_t cap, size_t *count, char *err);
+/* the shape `ProofWithPublicInputs::from_bytes(bytes, common_data)` yields: the bytes carry only two kinds of length, the Merkle
+ * paths' (one byte each) and, implicitly, the number of public inputs (whatever follows pow_witness); -1 when the bytes end
+ * inside a vector or hold a non-canonical element */
+int qpgpu_proof_shape_of_bytes(const uint64_t *inner_pack, size_t n_words, const uint8_t *proof, size_t len, uint32_t *out, size_t cap,
+                               size_t *count, char *err);
+/* ensure_proof_shape_matches_targets: 0, or -1 with the reference's message
+ * "{label} at slot {slot} is malformed: {what} has length {actual}, but the circuit expects {expected}" for the first mismatch */
+int qpgpu_ensure_proof_shape_matches_targets(const uint32_t *target_shape, size_t n_target, const uint32_t *proof_shape, size_t n_proof,
+                                             size_t slot, const char *label, char *err);
+size_t qpgpu_proof_target_count(const uint64_t *inner_pack, size_t n_words);      /* T; 0 for a bad pack */
+/* one proof's values in logical-target order (shape-checked first); values_out may be NULL to ask for the count */
+int qpgpu_proof_target_values(const uint64_t *inner_pack, size_t n_words, const uint8_t *proof, size_t len, size_t slot, const char *label,
+                              uint64_t *values_out, size_t cap, size_t *count, char *err);
+/* fill_private_batch_witness: its three count checks with its messages (num_proof_targets / num_preimage_targets are what the
+ * wrapper circuit was built for), the shape check of every proof, then the assignments: num_proofs * (T + 4) pairs
+ * (logical target id, value) in the reference's order — all proofs, then all preimages (4 canonical elements per slot).
+ * targets_out / values_out may be NULL to ask for the count. */
+int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, const uint8_t *const *proofs, const size_t *proof_lens, size_t num_proofs,
+                                   size_t num_proof_targets, const uint64_t *dummy_nullifier_preimages, size_t num_preimages, size_t num_preimage_targets,
+                                   const char *label, uint32_t *targets_out, uint64_t *values_out, size_t cap, size_t *count, char *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,11 +177,16 @@ template <int V, int MODE> __global__ __launch_bounds__(256) void k(u64 *out, co
     u64 s[12];
     const u64 t = threadIdx.x + blockIdx.x * (u64)blockDim.x;
     for (int i = 0; i < 12; i++) s[i] = t * 0x9E3779B97F4A7C15ull + i;
-    for (int it = 0; it < iters; it++) { if (MODE == 0) mds<V>(s); else perm<V>(s, rc); }
+    for (int it = 0; it < iters; it++) {
+        if (MODE == 0) mds<V>(s);
+        else if (MODE == 1) perm<V>(s, rc);
+        else if (MODE == 2) poseidon::permute(s, rc);              // the library's permutation: partial rounds in the spectral domain (round 3)
+        else poseidon::permute_layerwise(s, rc);                   // the library's permutation of rounds 1-2: one MDS layer per round
+    }
     u64 x = 0; for (int i = 0; i < 12; i++) x ^= s[i];
     out[t] = x;
 }
-template <int W> __global__ __launch_bounds__(256) void leafk(const u64 *src, u64 stride, u64 n, u64 *dig, const u64 *rc) {
+template <int W, int LIB = 0> __global__ __launch_bounds__(256) void leafk(const u64 *src, u64 stride, u64 n, u64 *dig, const u64 *rc) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (j >= n) return;
     u64 s[12];
@@ -190,7 +195,7 @@ template <int W> __global__ __launch_bounds__(256) void leafk(const u64 *src, u6
     for (int c = 0; c < W; c += 8) {
 #pragma unroll
         for (int i = 0; i < 8; i++) if (c + i < W) s[i] = src[(u64)(c + i) * stride + j];
-        perm<0>(s, rc);
+        if (LIB) poseidon::permute(s, rc); else perm<0>(s, rc);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) dig[j * 4 + i] = s[i];
@@ -222,8 +227,9 @@ template <int W, int PF> void run_leaf(const char *name, u64 n, const u64 *rc) {
     float best = 1e9;
     for (int rep = 0; rep < 4; rep++) {
         hipEventRecord(e0);
-        if (PF) hipLaunchKernelGGL((leafk_pf<W>), dim3((n + 255) / 256), dim3(256), 0, 0, src, n, n, dig, rc);
-        else hipLaunchKernelGGL((leafk<W>), dim3((n + 255) / 256), dim3(256), 0, 0, src, n, n, dig, rc);
+        if (PF == 1) hipLaunchKernelGGL((leafk_pf<W>), dim3((n + 255) / 256), dim3(256), 0, 0, src, n, n, dig, rc);
+        else if (PF == 2) hipLaunchKernelGGL((leafk<W, 1>), dim3((n + 255) / 256), dim3(256), 0, 0, src, n, n, dig, rc);
+        else hipLaunchKernelGGL((leafk<W, 0>), dim3((n + 255) / 256), dim3(256), 0, 0, src, n, n, dig, rc);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -252,9 +258,11 @@ int main() {
     run<0, 0>("mds i64", 2000, rc); run<1, 0>("mds 3x u32", 2000, rc);
     run<2, 0>("mds i64, 33-bit stage 1", 2000, rc);
     run<0, 1>("permute i64", 64, rc); run<2, 1>("permute, 33-bit stage 1", 64, rc); run<1, 1>("permute 3x u32", 64, rc);
+    run<0, 3>("permute, lib layerwise", 64, rc); run<0, 2>("permute, lib spectral", 64, rc);
     hipMemcpyToSymbol(HIP_SYMBOL(c_rc), h, sizeof h);
     runc<1>("permute, __constant__", 64, rc); runc<2>("permute, laundered flat", 64, rc); runc<3>("permute, laundered as4", 64, rc);
     run_leaf<135, 0>("leaf W=135", 1ull << 21, rc); run_leaf<135, 1>("leaf W=135 prefetch", 1ull << 21, rc);
+    run_leaf<135, 2>("leaf W=135 spectral", 1ull << 21, rc); run_leaf<8, 2>("nodes W=8 spectral", 1ull << 20, rc); run_leaf<135, 2>("leaf W=135 spectral", 1ull << 16, rc);
     run_leaf<135, 0>("leaf W=135", 1ull << 16, rc); run_leaf<135, 1>("leaf W=135 prefetch", 1ull << 16, rc);
     run_leaf<8, 0>("nodes W=8", 1ull << 20, rc);
     return 0;
