@@ -84,6 +84,8 @@ fn last_error(ctx: *const QpgpuCtx) -> String {
 // ---------------------------------------------------------------------------------------------------------------------
 const QPCP_MAGIC: u64 = 0x0000_0031_5043_5051;
 const PUBI_MAGIC: u64 = 0x0000_0031_4942_5550;
+const P2GL_MAGIC: u64 = 0x0000_0031_4C47_3250;     // "P2GL1": wire layout of the Poseidon2 gate (csrc/circuit.hpp)
+const P2_NO_SWAP: u64 = 0xFFFF_FFFF;
 
 /// Gate id string -> (type code, param0, param1, param2) of the pack format. An id this table does not know aborts the
 /// export: the backend refuses unknown gates rather than skipping their constraints.
@@ -114,9 +116,29 @@ fn gate_code(id: &str) -> Result<(u64, u64, u64, u64)> {
     else if id.starts_with("ExponentiationGate") { (11, num("num_power_bits")?, 0, 0) }
     else if id.starts_with("PoseidonMdsGate") { (12, 0, 0, 0) }
     else if id.starts_with("CosetInterpolationGate") { (13, num("subgroup_bits")?, num("degree")?, 0) }
-    // FORK: the qp fork's Poseidon2 gate (wormhole/circuit uses `hash_n_to_hash_no_pad_p2::<Poseidon2Hash>`) has no device
-    // evaluator yet: its wire layout and constants are not available to this repository.
+    // FORK: the qp fork's Poseidon2 gate (wormhole/circuit reaches it through `hash_n_to_hash_no_pad_p2::<Poseidon2Hash>`).
+    // The device evaluates it as gate type 14 with the wire layout this exporter writes into the "P2GL1" trailer
+    // (`poseidon2_gate_layout` below); adjust the prefix if the fork's `Gate::id()` renders differently.
+    else if id.starts_with("Poseidon2Gate") { (14, 0, 0, 0) }
     else { bail!("gate `{id}` is not implemented by the MI355X backend") })
+}
+
+/// The ten words of the "P2GL1" trailer, read off the fork's gate: first input wire, first output wire, swap wire (or
+/// P2_NO_SWAP), first delta wire, first S-box-input wire of the first half's full rounds, of the 22 partial rounds, of the
+/// second half's full rounds, whether round 0 of the first half is recorded too, constraint order (0 = swap boolean, deltas,
+/// first-half rounds, partial rounds, second-half rounds, outputs), one past the last wire used.
+/// FORK: written against the accessor names of upstream's `PoseidonGate` (`wire_input`, `wire_output`, `WIRE_SWAP`,
+/// `wire_delta`, `wire_full_sbox_0`, `wire_partial_sbox`, `wire_full_sbox_1`, `end`) carried over to `Poseidon2Gate`; if the
+/// fork names or orders them differently, this function is the single place to change — the device, the host verifier and the
+/// oracle all read the table (`tests/test_poseidon2_gate*.py` exercise a second layout to prove it). If the fork's gate
+/// constrains in another ORDER than upstream's PoseidonGate, add a new `constraint_order` value on both sides.
+fn poseidon2_gate_layout() -> [u64; 10] {
+    use plonky2::gates::poseidon2::Poseidon2Gate;       // FORK: module path
+    type G = Poseidon2Gate<plonky2::field::goldilocks_field::GoldilocksField, 2>;
+    let first_round_recorded = 0u64;                    // upstream PoseidonGate records S-box inputs from round 1 on
+    [G::wire_input(0) as u64, G::wire_output(0) as u64, G::WIRE_SWAP as u64, G::wire_delta(0) as u64,
+     G::wire_full_sbox_0(1, 0) as u64, G::wire_partial_sbox(0) as u64, G::wire_full_sbox_1(0, 0) as u64,
+     first_round_recorded, 0, G::end() as u64]
 }
 
 /// Index of a target in plonky2's flat target space (`Target::index`): wires first, virtual targets after the trace.
@@ -202,6 +224,13 @@ pub fn circuit_pack<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, co
             w.push(cell_of_target(t, p, c, &cells).ok_or_else(|| anyhow!("a public-input target is not routed into the trace"))?);
         }
     }
+    // the Poseidon2 gate's wire layout, when the circuit uses that gate
+    if c.gates.iter().any(|g| g.0.id().starts_with("Poseidon2Gate")) {
+        w.push(P2GL_MAGIC);
+        w.push(10);
+        w.extend(poseidon2_gate_layout());
+        let _ = P2_NO_SWAP;      // (a fork gate without swap wires writes P2_NO_SWAP as word 2)
+    }
     // (the hint trailer — generators that are not attached to a gate — is only needed for stage s1 on the device; without
     // it qpgpu_prove takes the full witness plonky2's own generate_partial_witness produced. See INTEGRATION.md section 2d.)
     Ok(w)
@@ -215,6 +244,46 @@ pub fn leaf_target_map<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>,
 ) -> Vec<u64> {
     let cells = class_cells(&data.prover_only, &data.common);
     flat_targets.iter().map(|&t| cell_of_target(t, &data.prover_only, &data.common, &cells).unwrap_or(u64::MAX)).collect()
+}
+
+/// Target map of a recursive wrapper (private / public batch) for `qpgpu_batch_fill_proof_targets` (include/qpgpu_batch.h):
+/// the cell of every logical target, slot-major, in the header's documented order — per proof target the public inputs, the
+/// three caps, the openings of the zeta batch and of the zeta-next batch, pow_witness, the final polynomial, the commit-phase
+/// caps and the query rounds — followed by the N x 4 dummy-nullifier preimage targets. `proof_targets` are the wrapper's
+/// `ProofWithPublicInputsTarget`s (`PrivateBatchCircuitTargets::leaf_proofs`, private_batch/circuit/circuit_logic.rs),
+/// `preimages` its `dummy_nullifier_pre_images`.
+pub fn proof_target_map<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+    data: &CircuitData<F, C, D>, proof_targets: &[plonky2::plonk::proof::ProofWithPublicInputsTarget<D>], preimages: &[[Target; 4]],
+) -> Vec<u64> {
+    let cells = class_cells(&data.prover_only, &data.common);
+    let mut flat: Vec<Target> = Vec::new();
+    for pt in proof_targets {
+        flat.extend(pt.public_inputs.iter().copied());
+        let p = &pt.proof;
+        for cap in [&p.wires_cap, &p.plonk_zs_partial_products_cap, &p.quotient_polys_cap] {
+            for h in &cap.0 { flat.extend(h.elements); }
+        }
+        let o = &p.openings;
+        for batch in [&o.constants, &o.plonk_sigmas, &o.wires, &o.plonk_zs, &o.partial_products, &o.quotient_polys, &o.plonk_zs_next] {
+            for e in batch.iter() { flat.extend(e.to_target_array()); }
+        }
+        let f = &p.opening_proof;
+        flat.push(f.pow_witness);
+        for e in &f.final_poly.0 { flat.extend(e.to_target_array()); }
+        for cap in &f.commit_phase_merkle_caps { for h in &cap.0 { flat.extend(h.elements); } }
+        for q in &f.query_round_proofs {
+            for (evals, path) in &q.initial_trees_proof.evals_proofs {
+                flat.extend(evals.iter().copied());
+                for h in &path.siblings { flat.extend(h.elements); }
+            }
+            for st in &q.steps {
+                for e in &st.evals { flat.extend(e.to_target_array()); }
+                for h in &st.merkle_proof.siblings { flat.extend(h.elements); }
+            }
+        }
+    }
+    for pre in preimages { flat.extend(pre.iter().copied()); }
+    flat.iter().map(|&t| cell_of_target(t, &data.prover_only, &data.common, &cells).unwrap_or(u64::MAX)).collect()
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
