@@ -31,4 +31,5 @@ hipError_t merkle_leaf_hash_rows(const uint64_t *rows, uint64_t n_leaves, uint32
 hipError_t merkle_reduce_to_cap(uint64_t *levels, uint64_t cnt, uint64_t cap_n, uint32_t batch, uint64_t ps_digests, const HasherDev &h, hipStream_t st);
 hipError_t poseidon_permute_batch(uint64_t *states, uint64_t n, const HasherDev &h, hipStream_t st);
 // `count` preimages of `len` elements (row-major) through the qp fork's Poseidon2 sponge (pad `|| 1 || 0*`, additive absorption)
-hipError_t poseidon2_hash_pad10_batch(const uint64_t *in, uint64_t len, uint64_t count, uint64_t *out, const poseidon2::Params *p2, hipStream_t st);
+// qp_set: p2 is qp-poseidon-core's parameter set (its external block has a multiplication-free form)
+hipError_t poseidon2_hash_pad10_batch(const uint64_t *in, uint64_t len, uint64_t count, uint64_t *out, const poseidon2::Params *p2, bool qp_set, hipStream_t st);

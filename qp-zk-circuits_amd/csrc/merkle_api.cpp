@@ -154,7 +154,7 @@ int qpgpu_poseidon2_hash_pad10_dev(qpgpu_ctx *ctx, const uint64_t *params, size_
     if (!params && n_words == 0) {
         int rc = ctx->ensure_p2_app();
         if (rc) return rc;
-        QP_HIP(ctx, poseidon2_hash_pad10_batch(d_in, len, count, d_out, ctx->d_p2_app, ctx->stream));
+        QP_HIP(ctx, poseidon2_hash_pad10_batch(d_in, len, count, d_out, ctx->d_p2_app, true, ctx->stream));
         return QPGPU_OK;
     }
     poseidon2::Params p;
@@ -162,7 +162,7 @@ int qpgpu_poseidon2_hash_pad10_dev(qpgpu_ctx *ctx, const uint64_t *params, size_
     void *v = nullptr;   // a caller-supplied block: uploaded for this call only
     QP_HIP(ctx, hipMalloc(&v, sizeof p));
     hipError_t e = hipMemcpyAsync(v, &p, sizeof p, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = poseidon2_hash_pad10_batch(d_in, len, count, d_out, (const poseidon2::Params *)v, ctx->stream);
+    if (e == hipSuccess) e = poseidon2_hash_pad10_batch(d_in, len, count, d_out, (const poseidon2::Params *)v, false, ctx->stream);
     const hipError_t e2 = hipStreamSynchronize(ctx->stream);   // `p` and the block outlive the kernel
     (void)hipFree(v);
     if (e != hipSuccess) return ctx->hip_fail(e, "poseidon2_hash_pad10");

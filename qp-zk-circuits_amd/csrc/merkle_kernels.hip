@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256) node_kernel(const u64 *in, u64 *out, u64 
 // wormhole/circuit/src/unspendable_account.rs:87-88, nullifier.rs:119-120, block_header/header.rs:140): preimage i = `len`
 // elements at in + i * len, padded `|| 1 || 0*` to a multiple of the rate 8 (wormhole/circuit/tests/heap_zeroization.rs:133-160),
 // every block ADDED into the rate part of the state, 4 outputs. One thread per preimage.
+template <bool QP>   // QP: p2 is qp-poseidon-core's set (multiplication-free external layers); otherwise a caller's block
 __global__ void __launch_bounds__(256) p2_pad10_sponge_kernel(const u64 *in, u64 len, u64 count, u64 *out, const poseidon2::Params *p2) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(256) p2_pad10_sponge_kernel(const u64 *in, u64
             const u64 v = idx < len ? gl::canon(src[idx]) : (idx == len ? 1 : 0);
             s[k] = gl::add_canonical(s[k], v);
         }
-        poseidon2::permute(s, *p2);
+        if constexpr (QP) poseidon2::permute_qp(s, *p2); else poseidon2::permute(s, *p2);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) out[i * 4 + k] = s[k];
@@ -387,9 +388,11 @@ hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, u32 batch, u64 
     }
     return hipSuccess;
 }
-hipError_t poseidon2_hash_pad10_batch(const u64 *in, u64 len, u64 count, u64 *out, const poseidon2::Params *p2, hipStream_t st) {
+hipError_t poseidon2_hash_pad10_batch(const u64 *in, u64 len, u64 count, u64 *out, const poseidon2::Params *p2, bool qp_set, hipStream_t st) {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(p2_pad10_sponge_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, in, len, count, out, p2);
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (qp_set) hipLaunchKernelGGL((p2_pad10_sponge_kernel<true>), grid, block, 0, st, in, len, count, out, p2);
+    else hipLaunchKernelGGL((p2_pad10_sponge_kernel<false>), grid, block, 0, st, in, len, count, out, p2);
     return hipGetLastError();
 }
 hipError_t poseidon_permute_batch(u64 *states, u64 n, const HasherDev &h, hipStream_t st) {

@@ -234,12 +234,12 @@ __device__ __forceinline__ void ntt_round_b(const NttPassArgs &a, const PassGeom
 // slots one after the other — half the LDS per workgroup, so twice as many wavefronts share a CU, for two more barriers.
 template <int KA, int KB, bool INV, bool SPLIT, int SPARSE = 0>
 __device__ __forceinline__ void ntt_pass_body(const NttPassArgs &a) {
-    constexpr int NA = 1 << KA, NB = 1 << KB, R = 1 << (KA + KB);
+    constexpr int NA = 1 << KA, NB = 1 << KB;
     extern __shared__ __align__(16) u64 lds[];
     PassGeom g;
     g.T = 1 << a.log_t;
     g.tid = threadIdx.x;
-    g.RP = R + NA + 1;  // odd row pitch: the two thread mappings spread over the banks
+    g.RP = (int)a.row_pitch;   // R + NA + a pad chosen for the exchange width and the tile shape (ntt_pass_row_pitch)
     g.lane0 = (u64)blockIdx.x << a.log_t;          // first lane of this tile (global lane index)
     const u64 col = blockIdx.y;
     g.in = a.in + col * a.in_col_stride + (u64)blockIdx.z * a.in_proof_stride;

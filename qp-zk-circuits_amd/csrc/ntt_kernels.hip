@@ -38,9 +38,21 @@ bool ntt_pass_uses_split(int ka, int kb) {
     return split && kb > 0 && ka + kb >= 9;
 }
 
+// Row pitch of a tile's LDS image in exchange words (ntt_kernel_impl.hpp: element s of lane l at l * RP + s + (s >> KB)).
+// Whole 8-byte words: odd, as before. Split exchange (4-byte ds_write_b32 / ds_read_b32: 32 banks, conflicts counted inside a
+// 32-lane half of the wave): a half-wave of the lane-fast thread mappings is T lanes x 32/T consecutive rows of the other
+// index, which land on distinct banks exactly when RP = 32/T (mod 32) (T = 16: banks 2 l + m); the row-fast mappings are
+// conflict-free for any pitch. With the odd pitch of round 2 the lane-fast mappings were two-way conflicted (counters:
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 50 % on the strided pass, 33 % on the natural-order rows pass).
+unsigned ntt_pass_row_pitch(int ka, int kb, int log_t) {
+    const unsigned base = (1u << (ka + kb)) + (1u << ka);       // a multiple of 32 for the split sizes (ka + kb >= 9)
+    static const int tuned = [] { const char *e = getenv("QPGPU_NTT_PITCH"); return e && *e ? atoi(e) : 1; }();   // 0: the odd pitch of round 2
+    if (!ntt_pass_uses_split(ka, kb) || !tuned || log_t >= 5 || base % 32) return base + 1;
+    return base + (32u >> log_t);
+}
 size_t ntt_pass_lds_bytes(int ka, int kb, int log_t) {
     if (kb == 0) return 0;
-    size_t rp = ((size_t)1 << (ka + kb)) + ((size_t)1 << ka) + 1;
+    const size_t rp = ntt_pass_row_pitch(ka, kb, log_t);
     return (rp << log_t) * (ntt_pass_uses_split(ka, kb) ? sizeof(uint32_t) : sizeof(uint64_t));
 }
 
@@ -76,6 +88,7 @@ hipError_t ntt_pass_launch(const NttPassArgs &a_in, uint64_t n_tiles, uint64_t n
     if (kb == 0) block.x = 1u << a.log_t;
     if (block.x < 64) block.x = 64;
     size_t lds = ntt_pass_lds_bytes(ka, kb, a.log_t);
+    a.row_pitch = ntt_pass_row_pitch(ka, kb, a.log_t);
     if (ka == 1 && kb == 0) return ntt_launch_1_0(a, grid, block, lds, st);
     if (ka == 2 && kb == 0) return ntt_launch_2_0(a, grid, block, lds, st);
     if (ka == 3 && kb == 0) return ntt_launch_3_0(a, grid, block, lds, st);

@@ -32,12 +32,14 @@ struct NttPassArgs {
     uint64_t tw_scale;         // non-zero: folded into the running twiddle product (the 1/N of an inverse transform)
     uint32_t tw_mode;          // 0: two table reads per element; 1: per-thread running product; 2: skipped (timing experiments only)
     int32_t sparse_lv;         // set by ntt_pass_launch: >= 0 when only the first 2^sparse_lv inputs of every round-A thread can be non-zero
+    uint32_t row_pitch;        // set by ntt_pass_launch: exchange words between two lanes' LDS rows (ntt_pass_row_pitch)
     uint32_t split_lds;        // set by ntt_pass_launch: exchange the 32-bit halves one after the other (half the LDS per workgroup)
     const uint64_t *in_scale_a;  // coset input scale: x[p, mm] *= a[p] * b[mm]; null: none
     const uint64_t *in_scale_b;
 };
 
 bool ntt_pass_uses_split(int ka, int kb);   // split 32-bit LDS exchange (half the LDS per workgroup) for this pass shape
+unsigned ntt_pass_row_pitch(int ka, int kb, int log_t);
 size_t ntt_pass_lds_bytes(int ka, int kb, int log_t);
 hipError_t ntt_pass_init();
 hipError_t ntt_pass_launch(const NttPassArgs &a, uint64_t n_tiles, uint64_t n_cols, hipStream_t st, uint32_t n_proofs = 1);

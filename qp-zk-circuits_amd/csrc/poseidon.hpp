@@ -305,6 +305,28 @@ GL_HD void ext_layer(u64 (&s)[12], const Params &p) {
         for (int b = 0; b < 3; b++) s[4 * b + i] = gl::add(t[4 * b + i], sum);
     }
 }
+// The same layer for qp-poseidon-core's block MDSMat4 = circ(2, 3, 1, 1), without multiplications: with t = a + b + c + d the
+// four outputs of a block are t + a + 2b, t + b + 2c, t + c + 2d, t + d + 2a. The Poseidon2 GATE and the application sponge
+// always run on that parameter set (poseidon2::qp_params, pinned by the reference's vectors; poseidon_constants.cpp asserts the
+// block), so their kernels use this form; the proof-system hasher plug keeps the general one (caller-supplied blocks).
+GL_HD void ext_layer_qp(u64 (&s)[12]) {
+    u64 t[12];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const u64 a = s[4 * b], bb = s[4 * b + 1], c = s[4 * b + 2], d = s[4 * b + 3];
+        const u64 sum = gl::add(gl::add(a, bb), gl::add(c, d));
+        t[4 * b] = gl::add(gl::add(sum, a), gl::add(bb, bb));
+        t[4 * b + 1] = gl::add(gl::add(sum, bb), gl::add(c, c));
+        t[4 * b + 2] = gl::add(gl::add(sum, c), gl::add(d, d));
+        t[4 * b + 3] = gl::add(gl::add(sum, d), gl::add(a, a));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 sum = gl::add(gl::add(t[i], t[4 + i]), t[8 + i]);
+#pragma unroll
+        for (int b = 0; b < 3; b++) s[4 * b + i] = gl::add(t[4 * b + i], sum);
+    }
+}
 // internal (partial-round) linear layer: s <- (J + diag(diag_m1)) s
 GL_HD void int_layer(u64 (&s)[12], const Params &p) {
     u64 sum = 0;
@@ -312,6 +334,26 @@ GL_HD void int_layer(u64 (&s)[12], const Params &p) {
     for (int i = 0; i < 12; i++) sum = gl::add(sum, s[i]);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::add(gl::mul(s[i], p.diag_m1[i]), sum);
+}
+// qp-poseidon-core's permutation: p must be qp_params() (only the round constants and the diagonal are read from it)
+GL_HD void permute_qp(u64 (&s)[12], const Params &p) {
+    ext_layer_qp(s);
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = poseidon::sbox7(gl::add(s[i], p.rc_ext[r * 12 + i]));
+        ext_layer_qp(s);
+    }
+    for (int r = 0; r < 22; r++) {
+        s[0] = poseidon::sbox7(gl::add(s[0], p.rc_int[r]));
+        int_layer(s, p);
+    }
+    for (int r = 4; r < 8; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = poseidon::sbox7(gl::add(s[i], p.rc_ext[r * 12 + i]));
+        ext_layer_qp(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
 }
 GL_HD void permute(u64 (&s)[12], const Params &p) {
     ext_layer(s, p);

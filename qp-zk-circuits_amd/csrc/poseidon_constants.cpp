@@ -204,6 +204,7 @@ const Params &qp_params() {
                                          0x5daf18bbd996604bULL, 0x6743bc47b9595257ULL, 0x5528b9362c59bb70ULL, 0xac45e25b7127b68bULL,
                                          0xa2077d7dfbb606b5ULL, 0xf3faac6faee378aeULL, 0x0c6388b51545e883ULL, 0xd27dbb6944917b60ULL};
         for (int i = 0; i < 12; i++) p.diag_m1[i] = diag[i];
+        // circ(2, 3, 1, 1): poseidon2::ext_layer_qp (poseidon.hpp) is this block without multiplications
         static const gl::u64 m4[16] = {2, 3, 1, 1, 1, 2, 3, 1, 1, 1, 2, 3, 3, 1, 1, 2};
         for (int i = 0; i < 16; i++) p.m4[i] = m4[i];
     });

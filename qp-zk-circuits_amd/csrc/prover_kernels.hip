@@ -438,7 +438,8 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
 // over: LAYOUT UNPINNED). Structure: optional swap of the first two 4-element groups (boolean + 4 delta constraints), the
 // initial external layer, then per round `add constants -> S-box input equals its wire -> S-box -> linear layer` with the
 // S-box inputs of full rounds [first_round_wires ? 0 : 1 .. 3], the 22 partial rounds (lane 0) and the last four full rounds on
-// wires, and the 12 outputs: 123 constraints of degree 7 with the default layout.
+// wires, and the 12 outputs: 123 constraints of degree 7 with the default layout. The external layers use the multiplication-free
+// form of qp-poseidon-core's block circ(2, 3, 1, 1) (poseidon2::ext_layer_qp).
 template <int NCH>
 __global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a, u32 gi, u32 t0, int finalize) {
     const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a,
     }
 #pragma unroll
     for (int i = 8; i < 12; i++) st[i] = W(lay.w_input + i);
-    poseidon2::ext_layer(st, P2);
+    poseidon2::ext_layer_qp(st);
     u32 wf = lay.w_full0;
     for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -486,7 +487,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a,
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
-        poseidon2::ext_layer(st, P2);
+        poseidon2::ext_layer_qp(st);
     }
     for (int r = 0; r < 22; r++) {
         const u64 in = W(lay.w_partial + r);
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a,
         for (int i = 0; i < 12; i++) { const u64 in = W(lay.w_full1 + 12 * r + i); emit(gl::sub(st[i], in)); st[i] = in; }
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
-        poseidon2::ext_layer(st, P2);
+        poseidon2::ext_layer_qp(st);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) emit(gl::sub(st[i], W(lay.w_output + i)));

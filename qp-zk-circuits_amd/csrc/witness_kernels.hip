@@ -224,7 +224,7 @@ constexpr u32 WITNESS_CONST_WORDS = poseidon::ROUNDS * 12 + poseidon2::PARAM_WOR
 // then s * diag + sum. The S-box inputs go to the wires the layout names; they are what the gate's constraints pin.
 __device__ __forceinline__ void witness_poseidon2_row(WitnessArgs a, const WitnessInst in, const bool live, const u64 *p2w) {
     const P2GateLayout &lay = a.p2_layout;
-    const u64 *rc_ext = p2w, *rc_int = p2w + 96, *diag = p2w + 118, *m4 = p2w + 130;
+    const u64 *rc_ext = p2w, *rc_int = p2w + 96, *diag = p2w + 118;
     const int g = threadIdx.x & 15, lane_base = (threadIdx.x & 63) & ~15;
     const u64 n = a.n;
     const u32 R = a.num_routed, row = in.row;
@@ -240,13 +240,13 @@ __device__ __forceinline__ void witness_poseidon2_row(WitnessArgs a, const Witne
         if (g < 4) { const u64 delta = swap ? gl::canon(gl::sub(partner, s)) : 0; WR(lay.w_delta + g, delta); s = gl::add(s, delta); }
         else if (g < 8) { const u64 delta = swap ? gl::canon(gl::sub(s, partner)) : 0; s = gl::sub(s, delta); }
     }
-    const int blk = lane_base + (g & 12), col = g & 3;
-    const u64 m0 = m4[4 * col], m1 = m4[4 * col + 1], m2 = m4[4 * col + 2], m3 = m4[4 * col + 3];
+    const int lane = threadIdx.x & 63, col = g & 3, nxt = (lane & ~3) | ((col + 1) & 3);
+    // external layer with qp-poseidon-core's block circ(2, 3, 1, 1): row `col` of a block is (sum of the four) + own + 2 * next
     auto ext = [&](u64 v) -> u64 {
-        u64 t = gl::mul(m0, shfl64(v, blk));
-        t = gl::add(t, gl::mul(m1, shfl64(v, blk + 1)));
-        t = gl::add(t, gl::mul(m2, shfl64(v, blk + 2)));
-        t = gl::add(t, gl::mul(m3, shfl64(v, blk + 3)));
+        u64 sum = gl::add(v, shfl64(v, lane ^ 1));
+        sum = gl::add(sum, shfl64(sum, lane ^ 2));
+        const u64 nx = shfl64(v, nxt);
+        const u64 t = gl::add(gl::add(sum, v), gl::add(nx, nx));
         const u64 cs = gl::add(gl::add(shfl64(t, lane_base + col), shfl64(t, lane_base + 4 + col)), shfl64(t, lane_base + 8 + col));
         return act ? gl::add(t, cs) : 0;
     };

@@ -44,7 +44,7 @@ def test_inner_proofs_become_the_wrappers_partial_witness(pkg, gpu, orc, lib):  
         proof = wc.prove_dev(d_w, wpis, out)
         assert oc.verify(proof) == 0
         # "set twice with different values": the same target assigned two values, as two inconsistent inner proofs would
-        c2 = np.concatenate([cells, cells[:1]]); v2 = np.concatenate([vals, [(int(vals[0]) + 1) % pkg.P]]).astype(np.uint64)
+        c2 = np.concatenate([cells, cells[:1]]); v2 = np.concatenate([vals, np.array([(int(vals[0]) + 1) % pkg.P], dtype=np.uint64)])
         with pytest.raises(pkg.QpGpuError) as e:
             wc.generate_witness_partial_dev(c2, v2, wpis, d_w)
         assert e.value.code == -4 and "set twice with different values" in str(e.value)
