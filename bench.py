@@ -109,7 +109,13 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
             stale.append(os.path.relpath(latest, ROOT))
         elif vs.get("elements_per_transform") == n * batch:
             roof["valu_insts_per_element"] = vs["valu_insts_per_element"]
-            roof["valu_issue_frac"] = vs["valu_issue_frac"]
+            roof["valu_issue_frac"] = vs["valu_issue_frac"]            # the 4-cycle-slot convention; kept for comparison with round 2
+            # the VALU roofline with measured prices (tools/r03_collect.py): issue time of the kernels' instruction mix at the
+            # per-class costs measured on this chip, over the launches' measured cycles
+            roof["valu_roofline"] = {"frac": vs.get("valu_roofline_frac"),
+                                     "per_kernel": {k: e.get("valu_roofline") for k, e in vs.get("kernels", {}).items() if e.get("pass", "").startswith("forward")},
+                                     "lds_bank_conflict_share": {k: e.get("lds_bank_conflict_share") for k, e in vs.get("kernels", {}).items() if e.get("pass", "").startswith("forward")},
+                                     "wait_any_share_of_wave_cycles": {k: e.get("wait_any_share_of_wave_cycles") for k, e in vs.get("kernels", {}).items() if e.get("pass", "").startswith("forward")}}
             roof["valu_source"] = os.path.relpath(latest, ROOT)
     except Exception:
         pass

@@ -151,6 +151,36 @@ GL_HD u64 mul(u64 a, u64 b) {
     mul64wide(a, b, lo, hi);
     return reduce128(lo, hi);
 }
+// ---- sums of products with one reduction at the end: acc (lo + hi 2^64 + top 2^128) += a * b ----
+// The quotient kernels weight up to a few hundred constraints per point with powers of alpha: reducing every product costs a
+// reduce128 and a modular addition (about 16 instructions); accumulating the 128-bit products costs a five-instruction carry chain.
+struct Acc192 { u64 lo, hi; u32 top; };
+GL_HD Acc192 acc_zero() { Acc192 a; a.lo = 0; a.hi = 0; a.top = 0; return a; }
+GL_HD void acc_mul(Acc192 &acc, u64 a, u64 b) {
+    u64 l, h;
+    mul64wide(a, b, l, h);
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 l0 = (u32)acc.lo, l1 = (u32)(acc.lo >> 32), h0 = (u32)acc.hi, h1 = (u32)(acc.hi >> 32), t = acc.top;
+    asm("v_add_co_u32 %0, vcc, %0, %5\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %6, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %7, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc"
+        : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1), "+v"(t)
+        : "v"((u32)l), "v"((u32)(l >> 32)), "v"((u32)h), "v"((u32)(h >> 32))
+        : "vcc");
+    acc.lo = ((u64)l1 << 32) | l0; acc.hi = ((u64)h1 << 32) | h0; acc.top = t;
+#else
+    const u64 lo = acc.lo + l;
+    const u64 c0 = lo < l ? 1 : 0;
+    const u64 hi1 = acc.hi + h, c1 = hi1 < h ? 1 : 0;
+    const u64 hi2 = hi1 + c0, c2 = hi2 < c0 ? 1 : 0;
+    acc.lo = lo; acc.hi = hi2; acc.top += (u32)(c1 + c2);
+#endif
+}
+// 2^128 = (2^64)^2 = (2^32 - 1)^2 = 2^64 - 2^33 + 1 = -2^32 (mod p): the carries out of the 128 bits are subtracted, shifted
+GL_HD u64 acc_reduce(const Acc192 &acc) { return sub(reduce128(acc.lo, acc.hi), (u64)acc.top << 32); }
+
 // a + b for a canonical b (< p): one carry fold is exact (a + b - 2^64 < b <= p - 1, so adding 2^32 - 1 cannot wrap)
 GL_HD u64 add_canonical(u64 a, u64 b) {
     const u64 s = a + b;

@@ -135,15 +135,15 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
     const u64 i = brev32((u32)j, logL);
     const u64 jn = brev32((u32)((i + a.rate) & (a.lde_n - 1)), logL);   // slot of the next row g*x
     const u64 x = a.x_coset[j], l0 = a.l0_coset[j], S = a.lde_n;
-    u64 acc[NCH];
+    gl::Acc192 acc[NCH];      // alpha-weighted sums as unreduced 192-bit accumulators (gl64.hpp): one reduction per challenge at the end
 #pragma unroll
-    for (int c = 0; c < NCH; c++) acc[c] = 0;
+    for (int c = 0; c < NCH; c++) acc[c] = gl::acc_zero();
     u32 t = 0;
 #pragma unroll
     for (int k = 0; k < NCH; k++, t++) {
         const u64 term = gl::mul(l0, gl::sub(a.zs_pp[(u64)k * S + j], 1));
 #pragma unroll
-        for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(term, a.alpha_pows[(u64)c * a.nterms + t]));
+        for (int c = 0; c < NCH; c++) gl::acc_mul(acc[c], term, a.alpha_pows[(u64)c * a.nterms + t]);
     }
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
@@ -161,12 +161,12 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotientArgs a) {
             const u64 next = cc == nchunks - 1 ? a.zs_pp[(u64)k * S + jn] : a.zs_pp[((u64)NCH + (u64)k * npp + cc) * S + j];
             const u64 term = gl::sub(gl::mul(prev, pn), gl::mul(next, pd));
 #pragma unroll
-            for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(term, a.alpha_pows[(u64)c * a.nterms + t]));
+            for (int c = 0; c < NCH; c++) gl::acc_mul(acc[c], term, a.alpha_pows[(u64)c * a.nterms + t]);
             prev = next;
         }
     }
 #pragma unroll
-    for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = acc[c];
+    for (int c = 0; c < NCH; c++) a.acc[(u64)c * S + j] = gl::acc_reduce(acc[c]);
 }
 
 // One copy of a RandomAccessGate with 2^BITS list entries: out[0..BITS) the bit constraints, out[BITS] the index
@@ -211,12 +211,12 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
         const GateDev g = a.gates[gi];
         if (g.num_constraints == 0 || g.type == 4 || g.type == 14) continue;   // the hash gates have kernels of their own
         const u64 f = gate_filter(a, gi, a.cs[(u64)g.selector_index * S + j]);
-        u64 sum[NCH];
+        gl::Acc192 sum[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; c++) sum[c] = 0;
+        for (int c = 0; c < NCH; c++) sum[c] = gl::acc_zero();
         auto emit = [&](u32 q, u64 cst) {
 #pragma unroll
-            for (int c = 0; c < NCH; c++) sum[c] = gl::add(sum[c], gl::mul(cst, ap[(u64)c * a.nterms + q]));
+            for (int c = 0; c < NCH; c++) gl::acc_mul(sum[c], cst, ap[(u64)c * a.nterms + q]);
         };
         if (g.type == 1) {            // ConstantGate: const_i - wire_i
             for (u32 q = 0; q < g.param0; q++) emit(q, gl::sub(consts_base[(u64)q * S], a.wires[(u64)q * S + j]));
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) quotient_gates_kernel(QuotientArgs a, u32
             }
         }
 #pragma unroll
-        for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(f, sum[c]));
+        for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(f, gl::acc_reduce(sum[c])));
     }
     if (finalize) {
         const u64 i = brev32((u32)j, a.log_lde);
@@ -365,13 +365,13 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
     const u64 S = a.lde_n;
     const u64 *ap = a.alpha_pows + t0;
     auto W = [&](u32 i) -> u64 { return a.wires[(u64)i * S + j]; };
-    u64 sum[NCH];
+    gl::Acc192 wsum[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) sum[c] = 0;
+    for (int c = 0; c < NCH; c++) wsum[c] = gl::acc_zero();
     u32 q = 0;
     auto emit = [&](u64 cst) {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) sum[c] = gl::add(sum[c], gl::mul(cst, ap[(u64)c * a.nterms + q]));
+        for (int c = 0; c < NCH; c++) gl::acc_mul(wsum[c], cst, ap[(u64)c * a.nterms + q]);
         q++;
     };
     const u64 swap = W(24);
@@ -420,6 +420,9 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
 #pragma unroll
     for (int i = 0; i < 12; i++) emit(gl::sub(st[i], W(12 + i)));
     const u64 f = gate_filter(a, gi, a.cs[(u64)a.gates[gi].selector_index * S + j]);
+    u64 sum[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) sum[c] = gl::acc_reduce(wsum[c]);
     if (finalize) {
         const u64 i = brev32((u32)j, a.log_lde);
         const u64 zi = a.zh_inv[i & (a.rate - 1)];
@@ -450,13 +453,13 @@ __global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a,
     const P2GateLayout &lay = a.p2_layout;
     const poseidon2::Params &P2 = *a.p2_gate;
     auto W = [&](u32 i) -> u64 { return a.wires[(u64)i * S + j]; };
-    u64 sum[NCH];
+    gl::Acc192 wsum[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) sum[c] = 0;
+    for (int c = 0; c < NCH; c++) wsum[c] = gl::acc_zero();
     u32 q = 0;
     auto emit = [&](u64 cst) {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) sum[c] = gl::add(sum[c], gl::mul(cst, ap[(u64)c * a.nterms + q]));
+        for (int c = 0; c < NCH; c++) gl::acc_mul(wsum[c], cst, ap[(u64)c * a.nterms + q]);
         q++;
     };
     u64 st[12];
@@ -507,6 +510,9 @@ __global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a,
 #pragma unroll
     for (int i = 0; i < 12; i++) emit(gl::sub(st[i], W(lay.w_output + i)));
     const u64 f = gate_filter(a, gi, a.cs[(u64)a.gates[gi].selector_index * S + j]);
+    u64 sum[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) sum[c] = gl::acc_reduce(wsum[c]);
     if (finalize) {
         const u64 i = brev32((u32)j, a.log_lde);
         const u64 zi = a.zh_inv[i & (a.rate - 1)];

@@ -23,7 +23,15 @@ PRE = "r03_final"
 PY = sys.executable
 N_ELEMS = (1 << 20) * 128
 SIMDS, XCDS = 256 * 4, 8
-KID = kernel_source_id("ntt")
+# the identity of the library the box measured: written by tools/r03_final.sh on the box (the tree here may have moved on)
+_idf = os.path.join(SRC, "kernel_source_id.txt")
+if os.path.exists(_idf):
+    KID = open(_idf).read().strip()
+else:   # older runs: the bench line of the same run carries it
+    try:
+        KID = json.loads([l for l in open(os.path.join(SRC, "bench.json")).read().strip().split("\n") if l.startswith("{")][-1])["roofline"]["kernel_source_id"]
+    except Exception:
+        KID = kernel_source_id("ntt")
 
 
 def last_json_line(path):

@@ -9,6 +9,7 @@ O=gpurun_out/r03_final
 mkdir -p $O
 R=$GRAFT_REPO_ROOT
 step() { echo "$1 rc=$2" | tee -a $R/$O/summary.txt; [ $2 -eq 0 ] || { echo "STOP: $1 failed"; find $R/$O -name "*kernel_trace.csv" -delete; exit $2; }; }
+python tools/kernel_id.py ntt > $O/kernel_source_id.txt
 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1; rc=$?; tail -3 $O/pytest.txt | tee -a $O/summary.txt; step pytest $rc
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; step smoke $?
 python bench.py > $O/bench.json 2> $O/bench.err; step bench $?
