@@ -146,10 +146,34 @@ GL_HD u64 join_halves(i64 lo, i64 hi) {
     const u32 top = (u32)(ah >> 32) + (low < al ? 1u : 0u);
     return gl::reduce96(low, top);
 }
-// RUN partial rounds (RUN <= 3) starting at round constant rc0[0], rc0[WIDTH], ...: s <- (MDS . S-box on lane 0 . + rc)^RUN s
-template <int RUN>
+// A coefficient of the low-half spectrum and the same coefficient of the high-half spectrum stand for lo + 2^32 hi. After three
+// rounds both have grown to ~2^58; this brings them back below 2^35 WITHOUT leaving the spectral domain: what exceeds 32 bits of
+// lo moves into hi (k 2^32 off lo, k onto hi), what exceeds 32 bits of hi is folded by 2^64 = 2^32 - 1 (m 2^32 off hi, m onto
+// hi, m off lo: the pair changes by -m p). k and m are taken as multiples of 4: every lane of the vector the spectra stand for
+// is (U1 +- Um +- 2F)/4 or (U1 -+ Um +- 2H)/4, and a change of one coefficient by a multiple of 4 changes four lanes by the same
+// integer in both halves — the divisions stay exact and every lane keeps its value mod p.
+GL_HD void renormalize_pair(i64 &lo, i64 &hi) {
+    const i64 k = (lo >> 32) & ~(i64)3;
+    lo -= shl(k, 32); hi += k;
+    const i64 m = (hi >> 32) & ~(i64)3;
+    hi -= shl(m, 32); hi += m; lo -= m;
+}
+GL_HD void renormalize(Spectrum &sl, Spectrum &sh) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        renormalize_pair(sl.U1[b], sh.U1[b]); renormalize_pair(sl.Um[b], sh.Um[b]);
+        renormalize_pair(sl.F[b], sh.F[b]); renormalize_pair(sl.H[b], sh.H[b]);
+    }
+}
+// lo + 2^32 hi for SIGNED halves (|lo|, |hi| < 2^59) -> loose field element. After a renormalisation the lanes the spectra stand
+// for are signed (a lane is (U1 - Um + 2H)/4 of coefficients that were reduced one by one), and three rounds later they reach
+// 2^58. A multiple of p that exceeds that in both halves is added first: 2^28 p = (2^60 + 2^28) + 2^32 (2^60 - 2^29).
+GL_HD u64 join_signed_halves(i64 lo, i64 hi) { return join_halves(lo + (((i64)1 << 60) + ((i64)1 << 28)), hi + (((i64)1 << 60) - ((i64)1 << 29))); }
+
+// All PARTIAL partial rounds in one spectral run: s <- (MDS . S-box on lane 0 . + rc)^PARTIAL s, rc0[k * WIDTH] = round k's lane-0
+// constant. The coefficients are renormalised every third round (bound: below 2^35 after it, lanes below 2^35, growth at most
+// 264 = 2^8.05 per round: below 2^60 before the next one).
 GL_HD void partial_rounds_spectral(u64 (&s)[WIDTH], const u64 *rc0) {
-    static_assert(RUN >= 1 && RUN <= 3, "three rounds is what signed 64-bit lanes hold");
     i64 lo[WIDTH], hi[WIDTH];
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) { lo[i] = (i64)(u32)s[i]; hi[i] = (i64)(s[i] >> 32); }
@@ -158,23 +182,30 @@ GL_HD void partial_rounds_spectral(u64 (&s)[WIDTH], const u64 *rc0) {
     i64 x_lo = lo[0], x_hi = hi[0];      // lane 0 as the spectra hold it (integers), before the rank-one term of the previous round
     i64 d_lo = 0, d_hi = 0;              // 8 * lane 0 of the previous round's S-box output: the diagonal term, not yet in the spectra
     u64 x0 = s[0];
+#pragma unroll 1
+    for (int k0 = 0; k0 < PARTIAL; k0 += 3) {
 #pragma unroll
-    for (int k = 0; k < RUN; k++) {
-        if (k) x0 = join_halves(x_lo + d_lo, x_hi + d_hi);
-        const u64 y = sbox7(gl::add_canonical(x0, rc0[k * WIDTH]));
-        const i64 y_lo = (i64)(u32)y, y_hi = (i64)(y >> 32);
-        // lane 0 becomes y: the spectra take (y - what they hold for lane 0); the pending diagonal term rides along
-        const i64 in_lo = y_lo - x_lo, in_hi = y_hi - x_hi;
-        sl.U1[0] += in_lo; sl.Um[0] += in_lo; sl.F[0] += in_lo;
-        sh.U1[0] += in_hi; sh.Um[0] += in_hi; sh.F[0] += in_hi;
-        spectrum_times_circulant(sl); spectrum_times_circulant(sh);
-        d_lo = shl(y_lo, 3); d_hi = shl(y_hi, 3);
-        if (k + 1 < RUN) { x_lo = spectrum_lane0(sl); x_hi = spectrum_lane0(sh); }
+        for (int kk = 0; kk < 3; kk++) {
+            const int k = k0 + kk;
+            if (k < PARTIAL) {
+                if (k) x0 = join_signed_halves(x_lo + d_lo, x_hi + d_hi);
+                const u64 y = sbox7(gl::add_canonical(x0, rc0[k * WIDTH]));
+                const i64 y_lo = (i64)(u32)y, y_hi = (i64)(y >> 32);
+                // lane 0 becomes y: the spectra take (y - what they hold for lane 0); the pending diagonal term rides along
+                const i64 in_lo = y_lo - x_lo, in_hi = y_hi - x_hi;
+                sl.U1[0] += in_lo; sl.Um[0] += in_lo; sl.F[0] += in_lo;
+                sh.U1[0] += in_hi; sh.Um[0] += in_hi; sh.F[0] += in_hi;
+                spectrum_times_circulant(sl); spectrum_times_circulant(sh);
+                d_lo = shl(y_lo, 3); d_hi = shl(y_hi, 3);
+                if (kk == 2 && k + 1 < PARTIAL) renormalize(sl, sh);
+                x_lo = spectrum_lane0(sl); x_hi = spectrum_lane0(sh);
+            }
+        }
     }
     vector_of(sl, lo); vector_of(sh, hi);
     lo[0] += d_lo; hi[0] += d_hi;
 #pragma unroll
-    for (int i = 0; i < WIDTH; i++) s[i] = join_halves(lo[i], hi[i]);
+    for (int i = 0; i < WIDTH; i++) s[i] = join_signed_halves(lo[i], hi[i]);
 }
 
 // rc: the 360-entry table of host_hash_round_constants(): same layout as the round constants, with the partial rounds'
@@ -191,11 +222,8 @@ GL_HD void permute(u64 (&s)[WIDTH], const u64 *rc) {
     }
 #pragma unroll
     for (int i = 1; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
-    for (int k = 0; k < PARTIAL / 3; k++, r += 3) partial_rounds_spectral<3>(s, rc + r * WIDTH);
-    for (int k = 0; k < PARTIAL % 3; k++, r++) {
-        s[0] = sbox7(gl::add_canonical(s[0], rc[r * WIDTH]));
-        mds_layer(s);
-    }
+    partial_rounds_spectral(s, rc + r * WIDTH);
+    r += PARTIAL;
     for (int k = 0; k < HALF_FULL; k++, r++) {
 #pragma unroll
         for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add_canonical(s[i], rc[r * WIDTH + i]));

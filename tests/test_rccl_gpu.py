@@ -36,6 +36,15 @@ def test_gather_proof_bytes_over_rccl_single_rank():
                 blk.slot(step %% 2, i)[:] = (17 * step + i) %% 251
             got = blk.gather(step %% 2)
             assert tuple(got.shape) == (1, 3, 4096) and all(int(got[0, i, 0]) == (17 * step + i) %% 251 and int(got[0, i, -1]) == (17 * step + i) %% 251 for i in range(3))
+        # what bench.py issues by default from round 3 on: gather to the consuming rank (dist.gather over RCCL, device tensors)
+        got = pkg.sharding.gather_proof_bytes(proofs, dist, dev, {}, root=0)
+        assert got == [proofs], "gather-to-root over RCCL differs"
+        blk = pkg.sharding.ProofBlockGather(3, 4096, dist, dev, blocks=2, root=0)
+        for step in range(3):
+            for i in range(3):
+                blk.slot(step %% 2, i)[:] = (29 * step + i) %% 251
+            got = blk.gather(step %% 2)
+            assert tuple(got.shape) == (1, 3, 4096) and all(int(got[0, i, 7]) == (29 * step + i) %% 251 for i in range(3))
         t = torch.ones(4, device=dev); dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize(dev)
         dist.destroy_process_group()
         print("rccl ok")
