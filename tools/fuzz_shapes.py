@@ -23,6 +23,9 @@ for i in range(cases):
     kw = dict(num_wires=wires_n, num_routed=routed, num_public_inputs=int(rng.integers(0, 9)), seed=1000 + i,
               poseidon=big and bool(rng.integers(0, 2)), base_sum=bool(rng.integers(0, 2)), ext_arith=routed >= 8 and bool(rng.integers(0, 2)),
               recursion=routed >= 48 and wires_n >= 64 and bool(rng.integers(0, 2)), hints=bool(rng.integers(0, 2)))
+    # the qp fork's Poseidon2 gate (needs 135 wires, 40 routed wires, 32 rows), default or alternative wire layout
+    if big and routed >= 40 and d >= 5 and bool(rng.integers(0, 2)):
+        kw.update(poseidon2=True, p2_alt_layout=bool(rng.integers(0, 2)))
     pack, wires, pis = pkg.synth_circuit(d, **kw)
     rate = int(rng.choice([3, 3, 3, 4, 5]))
     knobs = dict(cap_height=int(rng.integers(0, min(7, d + rate) + 1)), pow_bits=int(rng.choice([0, 4, 12, 16])),
@@ -58,5 +61,11 @@ for i in range(cases):
     mask = circ.witness_free_mask(*wires.shape)
     full = circ.generate_witness(np.where(mask == 1, wires, 0).astype(np.uint64), pis)
     assert (full == wires).all(), "WITNESS DIFFERS " + desc
+    if kw.get("poseidon2"):   # the Poseidon2 rows' digests are the KAT-pinned sponge of their preimages
+        for site in pkg.synth_p2_sites(d, kw["num_public_inputs"], poseidon2=True, p2_alt_layout=kw["p2_alt_layout"]):
+            pre, dig = pkg.p2_site_cells(pack, site)
+            x = np.ascontiguousarray([full[c, r] for c, r in pre], dtype=np.uint64); out = np.empty(4, dtype=np.uint64)
+            assert pkg.load_library().qpgpu_poseidon2_hash_pad10(None, 0, x.ctypes.data if x.size else None, x.size, out.ctypes.data) == 0
+            assert [int(full[c, r]) for c, r in dig] == [int(v) for v in out], "POSEIDON2 DIGEST DIFFERS " + desc
     circ.close(); oc.close()
 print(f"{cases} cases ok in {time.time()-t0:.1f} s")

@@ -65,6 +65,45 @@ int main(int argc, char **argv) {
             qpgpu_verifier_free(w);
         } else refused_packs++;
     }
+    // ---- inner-proof targets: shapes and assignments from valid, mutated, truncated and random proofs and packs ----
+    {
+        size_t nt = 0, np_ = 0, nv = 0;
+        std::vector<uint32_t> tshape(8192), pshape(8192);
+        if (qpgpu_proof_target_shape(pack.data(), pack.size(), tshape.data(), tshape.size(), &nt, err)) { fprintf(stderr, "target_shape: %s\n", err); return 1; }
+        const size_t T = qpgpu_proof_target_count(pack.data(), pack.size());
+        std::vector<uint64_t> vals(2 * (T + 4) + 8);
+        std::vector<uint32_t> ids(2 * (T + 4) + 8);
+        if (qpgpu_proof_target_values(pack.data(), pack.size(), proof.data(), proof.size(), 0, "leaf proof", vals.data(), vals.size(), &nv, err) || nv != T) { fprintf(stderr, "target_values on the valid proof: %s\n", err); return 1; }
+        for (int i = 0; i < iters; i++) {
+            std::vector<uint8_t> p = proof;
+            const int kind = i % 5;
+            if (kind == 0) p[rng() % p.size()] ^= (uint8_t)(1u << (rng() % 8));
+            else if (kind == 1) { const size_t at = rng() % p.size(); for (int k = 0; k < 8 && at + k < p.size(); k++) p[at + k] = 0xFF; }
+            else if (kind == 2) p.resize(rng() % p.size());
+            else if (kind == 3) p.resize(p.size() + 8 * (rng() % 5));
+            else for (auto &b : p) b = (uint8_t)rng();
+            if (qpgpu_proof_shape_of_bytes(pack.data(), pack.size(), p.data(), p.size(), pshape.data(), pshape.size(), &np_, err) == 0)
+                (void)qpgpu_ensure_proof_shape_matches_targets(tshape.data(), nt, pshape.data(), np_, (size_t)i, "leaf proof", err);
+            (void)qpgpu_proof_target_values(pack.data(), pack.size(), p.data(), p.size(), 1, nullptr, vals.data(), vals.size(), &nv, err);
+            const uint8_t *two[2] = {proof.data(), p.data()};
+            const size_t lens[2] = {proof.size(), p.size()};
+            uint64_t pre[8];
+            for (auto &x : pre) x = (rng() % 7 == 0) ? rng() : rng() % 0xFFFFFFFF00000001ull;
+            size_t cnt = 0;
+            (void)qpgpu_batch_fill_proof_targets(pack.data(), pack.size(), two, lens, 2, 1 + rng() % 3, pre, 1 + rng() % 3, 1 + rng() % 3, "leaf proof", ids.data(), vals.data(), ids.size(), &cnt, err);
+            (void)qpgpu_batch_fill_proof_targets(pack.data(), pack.size(), two, lens, 2, 2, pre, 2, 2, "leaf proof", ids.data(), vals.data(), ids.size(), &cnt, err);
+            // shape descriptors: mutated and truncated words must be answered, never indexed past
+            std::vector<uint32_t> q(tshape.begin(), tshape.begin() + nt);
+            if (i % 2) q[rng() % q.size()] = (uint32_t)(rng() >> (rng() % 32)); else q.resize(rng() % q.size());
+            (void)qpgpu_ensure_proof_shape_matches_targets(tshape.data(), nt, q.data(), q.size(), 0, "x", err);
+            (void)qpgpu_ensure_proof_shape_matches_targets(q.data(), q.size(), tshape.data(), nt, 0, "x", err);
+            // and a mutated pack as the inner circuit
+            std::vector<uint64_t> qp = pack;
+            if (i % 3 == 0) qp[rng() % std::min<size_t>(qp.size(), 40)] = rng() >> (rng() % 64); else if (i % 3 == 1) qp.resize(rng() % qp.size());
+            (void)qpgpu_proof_target_count(qp.data(), qp.size());
+            (void)qpgpu_proof_target_values(qp.data(), qp.size(), proof.data(), proof.size(), 0, "leaf proof", vals.data(), vals.size(), &nv, err);
+        }
+    }
     // ---- public-input parsers, admission checks and wrapper outputs on random rows ----
     for (int i = 0; i < iters; i++) {
         const size_t n_leaf = 1 + rng() % 64, count = 1 + rng() % n_leaf;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """AddressSanitizer + UndefinedBehaviorSanitizer pass over the host-only sources of the library (CPU build with g++; GPU
-sanitizers are not available on the pool): builds tools/sanitize/driver.cpp with csrc/{batch,wire,leaf_witness,verifier,circuit,
+sanitizers are not available on the pool): builds tools/sanitize/driver.cpp with csrc/{batch,proof_targets,wire,leaf_witness,verifier,circuit,
 poseidon_constants}.cpp, lets the CPU oracle make one valid proof, and runs the driver on it (mutated / truncated / random
 proofs and packs, random public-input rows, random config text). usage: python tools/sanitize_host.py [iterations]"""
 import os, subprocess, sys, tempfile
@@ -13,7 +13,7 @@ import oracle_binding
 iters = sys.argv[1] if len(sys.argv) > 1 else "300"
 pkg = ge.load_package()
 orc = oracle_binding.Oracle()
-pack, wires, pis = pkg.synth_circuit(7, num_wires=135, num_routed=80, num_public_inputs=21, seed=31, poseidon=True, base_sum=True, ext_arith=True, recursion=True)
+pack, wires, pis = pkg.synth_circuit(7, num_wires=135, num_routed=80, num_public_inputs=21, seed=31, poseidon=True, base_sum=True, ext_arith=True, recursion=True, poseidon2=True)
 oc = oracle_binding.OracleCircuit(orc, pack)
 proof = oc.prove(wires, pis)
 oc.close()
@@ -21,7 +21,7 @@ work = tempfile.mkdtemp(prefix="qp_host_asan_")
 np.ascontiguousarray(pack, dtype="<u8").tofile(os.path.join(work, "pack.bin"))
 open(os.path.join(work, "proof.bin"), "wb").write(proof)
 csrc = os.path.join(ROOT, "qp-zk-circuits_amd", "csrc")
-srcs = [os.path.join(csrc, f) for f in ("batch.cpp", "wire.cpp", "leaf_witness.cpp", "verifier.cpp", "circuit.cpp", "poseidon_constants.cpp")]
+srcs = [os.path.join(csrc, f) for f in ("batch.cpp", "proof_targets.cpp", "wire.cpp", "leaf_witness.cpp", "verifier.cpp", "circuit.cpp", "poseidon_constants.cpp")]
 exe = os.path.join(work, "driver")
 cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-pthread",
        "-I", csrc, os.path.join(ROOT, "tools", "sanitize", "driver.cpp")] + srcs + ["-o", exe]
