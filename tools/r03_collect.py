@@ -105,7 +105,9 @@ for db_path in sorted(glob.glob(os.path.join(SRC, "pmc_sq*", "**", "*results.db"
         key = kname.split("(anonymous namespace)::")[-1].split("(")[0]
         per[key][cname].append(val)
         per[key]["_dur_" + os.path.basename(os.path.dirname(db_path))].append(dur)
-        meta[key] = {"vgpr": vgpr, "lds_bytes": lds}
+        # (rocprofv3's vgpr_count column reads 64 for these kernels; the compiler's resource report — 128 VGPRs, 0 AGPRs,
+        # profiles/*kernel_resource_usage.txt and the isa histogram's num_vgpr — is what the occupancy follows)
+        meta[key] = {"vgpr_count_column_of_rocprofv3": vgpr, "lds_bytes": lds}
 if per:
     kernels = {}
     for key, cs in sorted(per.items()):
@@ -126,6 +128,9 @@ if per:
                 e["valu_issue_frac"] = round(wave_insts * 4 / (SIMDS * cyc / XCDS), 3)
                 e["measured_cycles_per_valu_inst_per_simd"] = round(SIMDS * cyc / XCDS / wave_insts, 3)
                 mangled = "ntt_pass_split_kernelILi5ELi5ELb%dELb%dEE" % (1 if inv else 0, 1 if rows else 0)
+                for nm, ee in isa.items():
+                    if mangled in nm:
+                        e["vgpr_compiler"] = ee.get("num_vgpr")
                 avg, shares = mix_cost(mangled)
                 if avg:
                     e["valu_roofline"] = {"modelled_cycles_per_valu_inst": round(avg, 3), "instruction_mix": shares,
