@@ -15,6 +15,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 max_d = int(sys.argv[3]) if len(sys.argv) > 3 else 11
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
+tally = {"poseidon2": 0, "poseidon2_alt_layout": 0, "zero_knowledge": 0, "hints": 0, "recursion_gates": 0, "lockstep_batches": 0, "rejected_at_load": 0}
 for i in range(cases):
     d = int(rng.integers(3, max_d + 1))
     big = bool(rng.integers(0, 2))
@@ -27,6 +28,7 @@ for i in range(cases):
     if big and routed >= 40 and d >= 5 and bool(rng.integers(0, 2)):
         kw.update(poseidon2=True, p2_alt_layout=bool(rng.integers(0, 2)))
     pack, wires, pis = pkg.synth_circuit(d, **kw)
+    tally["poseidon2"] += bool(kw.get("poseidon2")); tally["poseidon2_alt_layout"] += bool(kw.get("p2_alt_layout")); tally["hints"] += kw["hints"]; tally["recursion_gates"] += kw["recursion"]
     rate = int(rng.choice([3, 3, 3, 4, 5]))
     knobs = dict(cap_height=int(rng.integers(0, min(7, d + rate) + 1)), pow_bits=int(rng.choice([0, 4, 12, 16])),
                  num_queries=int(rng.integers(1, 32)), rate_bits=rate)
@@ -37,6 +39,7 @@ for i in range(cases):
     try:
         circ = pkg.Circuit(gpu, pack)
     except pkg.QpGpuError as e:
+        tally["rejected_at_load"] += 1
         print("skip (rejected at load):", desc, e); continue
     oc = oracle_binding.OracleCircuit(orc, pack)
     circ.set_blinding_seed(7 + i)
@@ -49,7 +52,9 @@ for i in range(cases):
     bad = bytearray(got); bad[int(rng.integers(0, len(got)))] ^= 1 << int(rng.integers(0, 8))
     assert not ver.verify(bytes(bad)) and oc.verify(bytes(bad)) != 0, "TAMPERING ACCEPTED " + desc
     ver.close()
+    tally["zero_knowledge"] += zk
     if d <= 9 or i % 4 == 0:      # the lockstep path over the same shape: proof b of the batch is blinded with seed + b
+        tally["lockstep_batches"] += 1
         cb = pkg.Circuit(gpu, pack, max_batch=3)
         cb.set_blinding_seed(7 + i)
         dense = gpu.to_device(np.stack([wires] * 3))
@@ -68,4 +73,4 @@ for i in range(cases):
             assert pkg.load_library().qpgpu_poseidon2_hash_pad10(None, 0, x.ctypes.data if x.size else None, x.size, out.ctypes.data) == 0
             assert [int(full[c, r]) for c, r in dig] == [int(v) for v in out], "POSEIDON2 DIGEST DIFFERS " + desc
     circ.close(); oc.close()
-print(f"{cases} cases ok in {time.time()-t0:.1f} s")
+print(f"{cases} cases ok in {time.time()-t0:.1f} s (seed {sys.argv[2] if len(sys.argv) > 2 else 1}, max degree_bits {max_d}): " + ", ".join(f"{k} {v}" for k, v in tally.items()))
