@@ -1,0 +1,56 @@
+// poseidon_permutation_check.cpp — the library's Poseidon permutation (poseidon.hpp: full rounds + the 22 partial rounds as one
+// spectral run with renormalisation) against its layer-wise form and the textbook schedule, on the host (the same GL_HD code the
+// kernels compile): random states and the extremes of the value range (all ones, p - 1 - small, 32-bit values, multiples of
+// 2^32), loose (non-canonical) inputs included. Also Poseidon2: the multiplication-free external layer against the general one,
+// and the 192-bit accumulator of the quotient kernels against reduce-every-term. Built and run by tests/test_host_checks.py.
+#include <cstdio>
+#include <cstdlib>
+#include "poseidon.hpp"
+using gl::u64;
+int check_poseidon() {
+    const u64 *rc = poseidon::host_hash_round_constants(), *rcp = poseidon::host_round_constants();
+    u64 seed = 12345; auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
+    int bad = 0;
+    for (int t = 0; t < 200000; t++) {
+        u64 a[12], b[12], c[12];
+        for (int i = 0; i < 12; i++) {
+            u64 v = rnd();
+            if (t % 7 == 0) v = (t % 14 == 0) ? 0xFFFFFFFFFFFFFFFFull : gl::P - 1 - (v & 3);      // extremes: loose all-ones, near p
+            if (t % 11 == 0) v &= 0xFFFFFFFFull;
+            if (t % 13 == 0) v = v << 32;
+            a[i] = b[i] = c[i] = v;
+        }
+        poseidon::permute(a, rc); poseidon::permute_layerwise(b, rc);
+        for (int i = 0; i < 12; i++) c[i] = gl::canon(c[i]);
+        poseidon::permute_textbook(c, rcp);
+        for (int i = 0; i < 12; i++) if (a[i] != b[i] || a[i] != c[i]) bad++;
+    }
+    printf("poseidon permutation: mismatches %d\n", bad);
+    return bad;
+}
+int check_poseidon2() {
+    const poseidon2::Params &P = poseidon2::qp_params();
+    u64 seed = 99; auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
+    int bad = 0;
+    for (int t = 0; t < 50000; t++) {
+        u64 a[12], b[12];
+        for (int i = 0; i < 12; i++) { u64 v = rnd(); if (t % 5 == 0) v = ~0ull - (v & 7); a[i] = b[i] = v; }
+        poseidon2::permute(a, P); poseidon2::permute_qp(b, P);
+        for (int i = 0; i < 12; i++) bad += a[i] != b[i];
+    }
+    printf("poseidon2 permute_qp: mismatches %d\n", bad);
+    return bad;
+}
+int check_acc() {
+    u64 seed = 7; auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
+    int bad = 0;
+    for (int t = 0; t < 20000; t++) {
+        gl::Acc192 acc = gl::acc_zero(); u64 ref = 0;
+        const int n = 1 + (int)(rnd() % 300);
+        for (int i = 0; i < n; i++) { u64 a = rnd(), b = rnd(); if (t % 3 == 0) { a = ~0ull; b = ~0ull - (rnd() & 3); } gl::acc_mul(acc, a, b); ref = gl::add(ref, gl::mul(a, b)); }
+        if (gl::canon(gl::acc_reduce(acc)) != gl::canon(ref)) bad++;
+    }
+    printf("192-bit accumulator: mismatches %d\n", bad);
+    return bad;
+}
+int main() { return (check_poseidon() | check_poseidon2() | check_acc()) != 0; }
