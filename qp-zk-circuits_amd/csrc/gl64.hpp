@@ -151,6 +151,72 @@ GL_HD u64 mul(u64 a, u64 b) {
     mul64wide(a, b, lo, hi);
     return reduce128(lo, hi);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- lazy products for throughput builds: the rare folds of a group of independent products behind ONE wave-uniform branch ----
+// reduce128 begins with t = lo - hi_hi, whose borrow (lo < hi_hi < 2^32) random data sees about once in 2^32 products, and spends
+// three of the product's 22 vector instructions on folding it. The lazy form returns t and the wave mask of the lanes whose fold
+// is still due (a scalar register pair); mul_group ORs the masks of N independent products, tests the union once (GL_ANY_RARE: a
+// scalar compare and branch, no vector issue slot; `unlikely` keeps the folds out of line) and finishes the products: 19 vector
+// instructions each. A taken or not-taken scalar branch still costs its wave tens of cycles of latency, which only other resident
+// waves cover — hence one branch per group, and hence the plain forms wherever a launch is small (qpgpu_tp_min_threads).
+// Measured (profiles/r03_rare_fold.txt): Poseidon permutation 2.61 -> 2.81 G/s in registers at full occupancy. The same treatment
+// of the modular sum and difference (5 + 5 instead of 7 + 8 instructions per NTT butterfly) was built and measured too: the
+// radix-32 register block alone ran 1.13-1.26x faster, the NTT pass kernels did not move (+-3 %: four waves per SIMD do not hide
+// the branches, and the passes are not bound by butterfly issue alone), so sums and differences keep their plain forms.
+#define GL_ANY_RARE(mask) __builtin_expect((mask) != 0, 0)
+// a product in two halves: t = lo - hi_hi of the 128-bit product (borrow -> rare) and the word still to be folded in
+struct LazyProd { u32 t0, t1, hl; };
+__device__ __forceinline__ LazyProd mul_lazy(u64 a, u64 b, u64 &rare) {
+    u64 lo, hi;
+    mul64wide(a, b, lo, hi);
+    LazyProd r;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "v_subbrev_co_u32 %1, %2, 0, %4, vcc"
+        : "=&v"(r.t0), "=&v"(r.t1), "=s"(rare)
+        : "v"((u32)lo), "v"((u32)(lo >> 32)), "v"((u32)(hi >> 32))
+        : "vcc");
+    r.hl = (u32)hi;
+    return r;
+}
+__device__ __forceinline__ void mul_fold(LazyProd &r, u64 rare) {
+    u32 m;
+    asm volatile("s_nop 1\n\t"
+                 "v_cndmask_b32 %2, 0, -1, %3\n\t"          // borrow -> - (2^32-1)
+                 "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+                 "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+                 : "+v"(r.t0), "+v"(r.t1), "=&v"(m) : "s"(rare) : "vcc");
+}
+__device__ __forceinline__ u64 mul_finish(const LazyProd &p) {
+    const u64 t = ((u64)p.t1 << 32) | p.t0;
+    u64 r;
+    u32 c;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\t"     // r = hi_lo * (2^32-1) + t, carry in vcc
+        "v_cndmask_b32 %1, 0, -1, vcc"
+        : "=&v"(r), "=&v"(c)
+        : "v"(p.hl), "v"(t)
+        : "vcc");
+    return r + (u64)c;
+}
+// r[i] = a[i] * b[i] for N independent products, one rare-fold branch for the group
+template <int N>
+__device__ __forceinline__ void mul_group(u64 (&r)[N], const u64 (&a)[N], const u64 (&b)[N]) {
+    LazyProd p[N];
+    u64 rare[N], any = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { p[i] = mul_lazy(a[i], b[i], rare[i]); any |= rare[i]; }
+    if (GL_ANY_RARE(any)) {
+#pragma unroll
+        for (int i = 0; i < N; i++) mul_fold(p[i], rare[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = mul_finish(p[i]);
+}
+#elif defined(__HIPCC__)
+// host pass of a .hip unit: device templates that name mul_group must still parse (never called)
+template <int N>
+inline void mul_group(u64 (&r)[N], const u64 (&a)[N], const u64 (&b)[N]) { for (int i = 0; i < N; i++) r[i] = mul(a[i], b[i]); }
+#endif
+
 // ---- sums of products with one reduction at the end: acc (lo + hi 2^64 + top 2^128) += a * b ----
 // The quotient kernels weight up to a few hundred constraints per point with powers of alpha: reducing every product costs a
 // reduce128 and a modular addition (about 16 instructions); accumulating the 128-bit products costs a five-instruction carry chain.

@@ -4,9 +4,8 @@
 // hash_or_noop, two_to_one} (stage s3 of SURVEY.md §8a; reached from PolynomialBatch::from_coeffs inside
 // prove, reference call site wormhole/prover/src/lib.rs:171-175).
 //
-// Layout: the LDE is column-major and already in leaf order (bit-reversed slots), so thread j reads
-// slot j of each column: a wave reads 512 contiguous bytes per column, no transpose in HBM.
-// One thread = one sponge (state in 24 VGPRs). Integer-ALU-bound: ceil(W/8) permutations per leaf.
+// The thread-per-hash kernels live in merkle_hash_impl.hpp and are built twice: here (latency build) and in
+// merkle_kernels_tp.hip (throughput build, taken by launches of qpgpu_tp_min_threads() threads or more).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "merkle.hpp"
@@ -18,51 +17,28 @@ using gl::u64;
 
 __constant__ u64 c_poseidon_rc[poseidon::ROUNDS * poseidon::WIDTH];
 
-hipError_t merkle_upload_constants(const u64 *rc360) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
+// throughput build (merkle_kernels_tp.hip)
+hipError_t merkle_tp_upload_constants(const u64 *rc360);
+hipError_t merkle_tp_leaves(const MerkleLeafArgs &a, u64 total, const HasherDev &h, hipStream_t st);
+hipError_t merkle_tp_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st);
+hipError_t merkle_tp_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const HasherDev &h, hipStream_t st);
+hipError_t merkle_tp_pow(const PowArgs &a, dim3 g, const HasherDev &h, hipStream_t st);
+
+// Launches of at least this many threads (four resident waves per SIMD on 256 CUs) take the throughput build of a hashing kernel,
+// smaller ones the latency build. QPGPU_TP_MIN_THREADS overrides (0: always, a huge value: never).
+uint64_t qpgpu_tp_min_threads() {
+    static const uint64_t v = [] { const char *e = getenv("QPGPU_TP_MIN_THREADS"); return e && *e ? strtoull(e, nullptr, 10) : (uint64_t)1 << 18; }();
+    return v;
 }
+
+hipError_t merkle_upload_constants(const u64 *rc360) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
+    return e != hipSuccess ? e : merkle_tp_upload_constants(rc360);
+}
+
+#include "merkle_hash_impl.hpp"
 
 namespace {
-
-struct PoseidonV1 {
-    static __device__ __forceinline__ void permute(u64 (&s)[12], const poseidon2::Params *) { poseidon::permute(s, c_poseidon_rc); }
-};
-struct Poseidon2P {   // the parameter plug: same sponge and tree code, other permutation; parameters of the caller's context
-    static __device__ __forceinline__ void permute(u64 (&s)[12], const poseidon2::Params *p2) { poseidon2::permute(s, *p2); }
-};
-
-// tree of the batch a global leaf / node index belongs to (counts are powers of two)
-__device__ __forceinline__ u32 ilog2_64(u64 x) { return 63u - (u32)__clzll((long long)x); }
-
-// leaf j = [src0 cols..., src1 cols...] at slot j (each source column-major with its own stride).
-template <class Perm>
-__global__ void __launch_bounds__(256) leaf_hash_kernel(MerkleLeafArgs a, const poseidon2::Params *p2) {
-    const u64 gj = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (gj >= a.n_leaves * a.batch) return;
-    const u64 pr = gj >> ilog2_64(a.n_leaves), j = gj & (a.n_leaves - 1);
-    a.src0 += pr * a.ps_src0; a.src1 += pr * a.ps_src1; a.digests += pr * a.ps_digests;
-    const u32 W = a.ncols0 + a.ncols1;
-    u64 *out = a.digests + j * 4;
-    auto elem = [&](u32 c) -> u64 {
-        return c < a.ncols0 ? a.src0[(u64)c * a.stride0 + j] : a.src1[(u64)(c - a.ncols0) * a.stride1 + j];
-    };
-    if (W <= 4) {  // hash_or_noop: short rows are copied
-        for (u32 c = 0; c < 4; c++) out[c] = c < W ? gl::canon(elem(c)) : 0;
-        return;
-    }
-    u64 s[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = 0;
-    for (u32 c = 0; c < W; c += 8) {
-        // overwrite-mode absorption of up to 8 elements
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (c + i < W) s[i] = elem(c + i);
-        Perm::permute(s, p2);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = s[i];
-}
 
 // ---- lane-cooperative permutation: one state spread over 16 lanes (element g in lane g, 12 used), four states
 // per wave. The S-box layer runs on all elements at once and the MDS layer gathers the other eleven elements with
@@ -191,50 +167,6 @@ __global__ void __launch_bounds__(256) leaf_cols_coop_kernel(MerkleLeafArgs a) {
     if (live && g < 4) a.digests[j * 4 + g] = s;
 }
 
-// row-major leaves (FRI round trees: leaf = 2^arity ext values = contiguous felts)
-template <class Perm>
-__global__ void __launch_bounds__(256) leaf_hash_rows_kernel(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const poseidon2::Params *p2) {
-    const u64 gj = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (gj >= n_leaves * batch) return;
-    const u64 pr = gj >> ilog2_64(n_leaves), j = gj & (n_leaves - 1);
-    rows += pr * ps_rows; digests += pr * ps_digests;
-    const u64 *row = rows + j * width;
-    u64 *out = digests + j * 4;
-    if (width <= 4) {
-        for (u32 c = 0; c < 4; c++) out[c] = c < width ? gl::canon(row[c]) : 0;
-        return;
-    }
-    u64 s[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = 0;
-    for (u32 c = 0; c < width; c += 8) {
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (c + i < width) s[i] = row[c + i];
-        Perm::permute(s, p2);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = s[i];
-}
-
-// one level: out[i] = two_to_one(in[2i], in[2i+1])
-template <class Perm>
-__global__ void __launch_bounds__(256) node_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const poseidon2::Params *p2) {
-    const u64 gi = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (gi >= n_out * batch) return;
-    const u64 pr = gi >> ilog2_64(n_out), i = gi & (n_out - 1);
-    in += pr * ps; out += pr * ps;
-    u64 s[12];
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(in + i * 8);
-    ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
-    s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = c.x; s[5] = c.y; s[6] = d.x; s[7] = d.y;
-    s[8] = s[9] = s[10] = s[11] = 0;
-    Perm::permute(s, p2);
-    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + i * 4);
-    o[0] = make_ulonglong2(s[0], s[1]);
-    o[1] = make_ulonglong2(s[2], s[3]);
-}
-
 // Poseidon2Hash::hash_no_pad of the qp fork (the application hash inside the Wormhole circuits; reference call sites
 // wormhole/circuit/src/unspendable_account.rs:87-88, nullifier.rs:119-120, block_header/header.rs:140): preimage i = `len`
 // elements at in + i * len, padded `|| 1 || 0*` to a multiple of the rate 8 (wormhole/circuit/tests/heap_zeroization.rs:133-160),
@@ -272,41 +204,14 @@ __global__ void permute_kernel(u64 *states, u64 n, const poseidon2::Params *p2) 
     for (int k = 0; k < 12; k++) states[i * 12 + k] = s[k];
 }
 
-// s10 fri_proof_of_work: candidate nonce at `pos` of the pre-absorbed duplex state; accept when the last rate
-// element has >= pow_bits leading zeros; result = minimum accepted nonce in [base, base + count). Workgroups are numbered
-// chunk-major over the proofs of the batch (chunk c of every proof before chunk c + 1 of any), and a workgroup whose
-// candidates are all above a nonce already found for its proof leaves at once: the expected work per proof is about
-// 2^pow_bits permutations plus what is in flight, not the whole span.
-template <class Perm>
-__global__ void __launch_bounds__(256) pow_kernel(PowArgs a, const poseidon2::Params *p2) {
-    // chunk-major over the proofs, and the proof a workgroup serves rotates with the chunk: workgroups go to the 8 XCDs round
-    // robin, so with a fixed assignment (batch a multiple of 8) each proof's candidates would all run on one XCD, and the XCD whose
-    // proofs find their nonce last would finish the launch alone
-    const u32 chunk = blockIdx.x / a.batch, pr = (blockIdx.x % a.batch + chunk) % a.batch;
-    const u64 idx = (u64)chunk * blockDim.x + threadIdx.x;
-    if (idx >= a.count) return;
-    const u64 base = a.bases[pr];
-    if (base == ~0ull) return;                 // this proof already has its nonce
-    const u64 nonce = base + idx;
-    if (__hip_atomic_load(&a.results[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) return;
-    const u64 *st = a.states + 12 * (u64)pr;
-    u64 s[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = (i == (int)a.pos) ? nonce : st[i];
-    Perm::permute(s, p2);
-    if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin((unsigned long long *)&a.results[pr], (unsigned long long)nonce);
-}
-
 }  // namespace
 
 hipError_t pk_pow(const PowArgs &a, const HasherDev &h, hipStream_t st) {
     if (a.count == 0 || a.batch == 0) return hipSuccess;
     const u64 chunks = (a.count + 255) / 256;
     if (chunks * a.batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 b(256), g((unsigned)(chunks * a.batch));
-    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((pow_kernel<Poseidon2P>), g, b, 0, st, a, h.p2);
-    else hipLaunchKernelGGL((pow_kernel<PoseidonV1>), g, b, 0, st, a, h.p2);
-    return hipGetLastError();
+    dim3 g((unsigned)(chunks * a.batch));
+    return chunks * a.batch * 256 >= qpgpu_tp_min_threads() ? merkle_tp_pow(a, g, h, st) : hash_launch_pow(a, g, h, st);
 }
 
 // below this many independent hashes a level is latency-bound and the lane-cooperative form wins. The cooperative form
@@ -330,10 +235,7 @@ hipError_t merkle_leaf_hash(const MerkleLeafArgs &a0, const HasherDev &h, hipStr
         hipLaunchKernelGGL(leaf_cols_coop_kernel, grid, block, 0, st, a);
         return hipGetLastError();
     }
-    dim3 block(256), grid((unsigned)((total + 255) / 256));
-    if (p2) hipLaunchKernelGGL((leaf_hash_kernel<Poseidon2P>), grid, block, 0, st, a, h.p2);
-    else hipLaunchKernelGGL((leaf_hash_kernel<PoseidonV1>), grid, block, 0, st, a, h.p2);
-    return hipGetLastError();
+    return total >= qpgpu_tp_min_threads() ? merkle_tp_leaves(a, total, h, st) : hash_launch_leaves(a, total, h, st);
 }
 hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st) {
     if (n_leaves == 0 || batch == 0) return hipSuccess;
@@ -345,10 +247,8 @@ hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *
         hipLaunchKernelGGL(leaf_rows_coop_kernel, grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests);
         return hipGetLastError();
     }
-    dim3 block(256), grid((unsigned)((total + 255) / 256));
-    if (p2) hipLaunchKernelGGL((leaf_hash_rows_kernel<Poseidon2P>), grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h.p2);
-    else hipLaunchKernelGGL((leaf_hash_rows_kernel<PoseidonV1>), grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h.p2);
-    return hipGetLastError();
+    return total >= qpgpu_tp_min_threads() ? merkle_tp_rows(rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h, st)
+                                           : hash_launch_rows(rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h, st);
 }
 static hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const HasherDev &h, hipStream_t st) {
     if (n_out == 0) return hipSuccess;
@@ -359,11 +259,7 @@ static hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, u32 ba
         hipLaunchKernelGGL(node_coop_kernel, grid, block, 0, st, in, out, n_out, batch, ps);
         return hipGetLastError();
     }
-    unsigned threads = total >= 256 ? 256 : 64;
-    dim3 block(threads), grid((unsigned)((total + threads - 1) / threads));
-    if (p2) hipLaunchKernelGGL((node_kernel<Poseidon2P>), grid, block, 0, st, in, out, n_out, batch, ps, h.p2);
-    else hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out, batch, ps, h.p2);
-    return hipGetLastError();
+    return total >= qpgpu_tp_min_threads() ? merkle_tp_nodes(in, out, n_out, batch, ps, h, st) : hash_launch_nodes(in, out, n_out, batch, ps, h, st);
 }
 // every level from `cnt` digests (at `levels`, the following levels stored behind it) down to the cap
 hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, u32 batch, u64 ps, const HasherDev &h, hipStream_t st) {

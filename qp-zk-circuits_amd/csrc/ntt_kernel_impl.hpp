@@ -77,7 +77,11 @@ __device__ __forceinline__ void dif_level(u64 (&x)[1 << K]) {
 }
 
 template <int K, bool INV>
-__device__ __forceinline__ void dif_regs(u64 (&x)[1 << K]) { dif_level<K, INV, (1 << K)>(x); }
+__device__ __forceinline__ void dif_regs(u64 (&x)[1 << K]) {
+#ifndef NTT_EXPERIMENT_NO_BUTTERFLIES    // timing experiments only: what a pass costs without its register transforms
+    dif_level<K, INV, (1 << K)>(x);
+#endif
+}
 
 // The same transform when only the first V = 2^LV of the 2^K inputs are non-zero (the first pass of a zero-padded LDE: a
 // coefficient vector of length n in a transform of length 8 n). With k = k1 + (2^K / V) k2: X[k] = DFT_V(x[v] w^(k1 v))[k2], so

@@ -79,3 +79,35 @@ def test_merkle_bad_arguments(gpu, pkg):
     with pytest.raises(pkg.QpGpuError):
         gpu.merkle_build_dev(d, 4, 1, 2, 3, d)   # cap above the leaves
     d.free()
+
+
+def test_throughput_build_and_rare_folds_vs_oracle(gpu, orc, pkg):
+    """Launches of 2^18 threads or more run the throughput build of the hashing kernels (merkle_kernels_tp.hip: S-box products
+    as rare-fold groups, gl64.hpp). 2^19 leaves put the leaf kernels and the first tree level there. A sprinkling of leaves
+    is built so that S-box inputs of the first round are multiples of 2^32: their squares have a zero low half and a top
+    word above it, which is exactly the borrow the lazy products fold behind their wave-uniform branch (a random product
+    sees it once in 2^32). Digests, every tree level and the cap must equal the oracle's."""
+    log_leaves, width, cap_h = 19, 9, 4
+    n = 1 << log_leaves
+    rng = np.random.default_rng(2024)
+    leaves = rng.integers(0, P, (n, width), dtype=np.uint64)
+    rc, _ = pkg.poseidon_constants()
+    hit = rng.choice(n, 5000, replace=False)
+    for j in hit:
+        lanes = rng.choice(8, int(rng.integers(1, 9)), replace=False)
+        for i in lanes:
+            m = int(rng.integers(1 << 16, 1 << 32))
+            leaves[j, i] = ((m << 32) - int(rc[i])) % P          # first-round S-box input = m * 2^32
+    dig_want, cap_want = orc.merkle(leaves, cap_h)
+    total = gpu.merkle_digest_count(log_leaves, cap_h)
+    d_dig = gpu.alloc(total * 32)
+    d_rows = gpu.to_device(leaves)
+    cap = gpu.merkle_build_rows_dev(d_rows, width, log_leaves, cap_h, d_dig)
+    assert np.array_equal(cap, cap_want)
+    assert np.array_equal(d_dig.download().reshape(-1, 4), dig_want)
+    d_rows.free()
+    d_cols = gpu.to_device(np.ascontiguousarray(leaves.T))
+    cap = gpu.merkle_build_dev(d_cols, n, width, log_leaves, cap_h, d_dig)
+    assert np.array_equal(cap, cap_want)
+    assert np.array_equal(d_dig.download().reshape(-1, 4), dig_want)
+    d_cols.free(); d_dig.free()

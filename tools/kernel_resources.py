@@ -3,9 +3,9 @@
 (hipcc -Rpass-analysis=kernel-resource-usage). usage: tools/kernel_resources.py > profiles/rNN_kernel_resource_usage.txt"""
 import os, re, subprocess, sys
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qp-zk-circuits_amd", "csrc")
-FILES = ["ntt_inst_0.hip", "ntt_inst_1.hip", "ntt_inst_2.hip", "ntt_inst_3.hip", "ntt_kernels.hip", "merkle_kernels.hip", "prover_kernels.hip", "witness_kernels.hip"]
+FILES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 KEYS = {"VGPRs": "vgpr", "AGPRs": "agpr", "SGPRs": "sgpr", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occ", "LDS Size [bytes/block]": "lds"}
-print(f"{'file':20s} {'kernel':72s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'scratch B/lane':>15s} {'lds B':>7s} {'waves/SIMD':>10s}")
+print(f"{'file':22s} {'kernel':72s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'scratch B/lane':>15s} {'lds B':>7s} {'waves/SIMD':>10s}")
 for f in FILES:
     p = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--offload-device-only", "-c", f, "-o", os.devnull,
                         "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, text=True)
@@ -23,4 +23,4 @@ for f in FILES:
     names = subprocess.run(["/usr/bin/c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.split("\n")
     for r, nm in zip(rows, names):
         nm = re.sub(r"\(anonymous namespace\)::|qpgpu::", "", nm).split("(")[0].replace("void ", "")
-        print(f"{f:20s} {nm[:72]:72s} {r.get('vgpr', 0):5d} {r.get('agpr', 0):5d} {r.get('sgpr', 0):5d} {r.get('scratch', 0):15d} {r.get('lds', 0):7d} {r.get('occ', 0):10d}")
+        print(f"{f:22s} {nm[:72]:72s} {r.get('vgpr', 0):5d} {r.get('agpr', 0):5d} {r.get('sgpr', 0):5d} {r.get('scratch', 0):15d} {r.get('lds', 0):7d} {r.get('occ', 0):10d}")
