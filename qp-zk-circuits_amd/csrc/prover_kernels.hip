@@ -393,8 +393,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
 #pragma unroll
             for (int i = 0; i < 12; i++) { const u64 in = W(29 + 12 * (r - 1) + i); emit(gl::sub(st[i], in)); st[i] = in; }
         }
-#pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+        poseidon::sbox7_layer(st);
         poseidon::mds_layer(st);
     }
     // partial rounds in the textbook schedule: the value fed to the S-box is the same in upstream's fast-partial basis (that
@@ -405,7 +404,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
         for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);
         const u64 in = W(65 + r);
         emit(gl::sub(st[0], in));
-        st[0] = poseidon::sbox7(in);
+        st[0] = poseidon::sbox7_lane(in);
         poseidon::mds_layer(st);
     }
     for (int r = 0; r < 4; r++, rc++) {
@@ -413,8 +412,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon_kernel(QuotientArgs a, 
         for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], a.poseidon_rc[rc * 12 + i]);
 #pragma unroll
         for (int i = 0; i < 12; i++) { const u64 in = W(87 + 12 * r + i); emit(gl::sub(st[i], in)); st[i] = in; }
-#pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+        poseidon::sbox7_layer(st);
         poseidon::mds_layer(st);
     }
 #pragma unroll
@@ -488,14 +486,13 @@ __global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a,
             for (int i = 0; i < 12; i++) { const u64 in = W(wf + i); emit(gl::sub(st[i], in)); st[i] = in; }
             wf += 12;
         }
-#pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+        poseidon::sbox7_layer(st);
         poseidon2::ext_layer_qp(st);
     }
     for (int r = 0; r < 22; r++) {
         const u64 in = W(lay.w_partial + r);
         emit(gl::sub(gl::add(st[0], P2.rc_int[r]), in));
-        st[0] = poseidon::sbox7(in);
+        st[0] = poseidon::sbox7_lane(in);
         poseidon2::int_layer(st, P2);
     }
     for (int r = 0; r < 4; r++) {
@@ -503,8 +500,7 @@ __global__ void __launch_bounds__(256) quotient_poseidon2_kernel(QuotientArgs a,
         for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], P2.rc_ext[(4 + r) * 12 + i]);
 #pragma unroll
         for (int i = 0; i < 12; i++) { const u64 in = W(lay.w_full1 + 12 * r + i); emit(gl::sub(st[i], in)); st[i] = in; }
-#pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = poseidon::sbox7(st[i]);
+        poseidon::sbox7_layer(st);
         poseidon2::ext_layer_qp(st);
     }
 #pragma unroll
