@@ -5,7 +5,8 @@
 // prove, reference call site wormhole/prover/src/lib.rs:171-175).
 //
 // The thread-per-hash kernels live in merkle_hash_impl.hpp and are built twice: here (latency build) and in
-// merkle_kernels_tp.hip (throughput build, taken by launches of qpgpu_tp_min_threads() threads or more).
+// merkle_kernels_tp.hip (throughput build, taken by launches of qpgpu_tp_min_threads() threads or more). Leaf sponges and tree
+// levels of that size under the Poseidon hasher go to a third build, merkle_kernels_mx.hip: partial rounds on the matrix pipe.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "merkle.hpp"
@@ -23,6 +24,10 @@ hipError_t merkle_tp_leaves(const MerkleLeafArgs &a, u64 total, const HasherDev 
 hipError_t merkle_tp_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st);
 hipError_t merkle_tp_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const HasherDev &h, hipStream_t st);
 hipError_t merkle_tp_pow(const PowArgs &a, dim3 g, const HasherDev &h, hipStream_t st);
+// matrix-pipe build (merkle_kernels_mx.hip): plonky2's Poseidon only
+hipError_t merkle_mx_upload_constants(const u64 *rc360);
+hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, hipStream_t st);
+hipError_t merkle_mx_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, hipStream_t st);
 
 // Launches of at least this many threads (four resident waves per SIMD on 256 CUs) take the throughput build of a hashing kernel,
 // smaller ones the latency build. QPGPU_TP_MIN_THREADS overrides (0: always, a huge value: never).
@@ -31,9 +36,15 @@ uint64_t qpgpu_tp_min_threads() {
     return v;
 }
 
+// QPGPU_MX=0 keeps large launches on the throughput build (A/B runs, and the way back should the matrix form misbehave)
+static bool mx_enabled() {
+    static const bool v = [] { const char *e = getenv("QPGPU_MX"); return !(e && *e == '0'); }();
+    return v;
+}
 hipError_t merkle_upload_constants(const u64 *rc360) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
-    return e != hipSuccess ? e : merkle_tp_upload_constants(rc360);
+    if (e == hipSuccess) e = merkle_tp_upload_constants(rc360);
+    return e != hipSuccess ? e : merkle_mx_upload_constants(rc360);
 }
 
 #include "merkle_hash_impl.hpp"
@@ -235,7 +246,8 @@ hipError_t merkle_leaf_hash(const MerkleLeafArgs &a0, const HasherDev &h, hipStr
         hipLaunchKernelGGL(leaf_cols_coop_kernel, grid, block, 0, st, a);
         return hipGetLastError();
     }
-    return total >= qpgpu_tp_min_threads() ? merkle_tp_leaves(a, total, h, st) : hash_launch_leaves(a, total, h, st);
+    if (total < qpgpu_tp_min_threads()) return hash_launch_leaves(a, total, h, st);
+    return (!p2 && a.ncols0 + a.ncols1 > 4 && mx_enabled()) ? merkle_mx_leaves(a, total, st) : merkle_tp_leaves(a, total, h, st);
 }
 hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st) {
     if (n_leaves == 0 || batch == 0) return hipSuccess;
@@ -259,7 +271,8 @@ static hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, u32 ba
         hipLaunchKernelGGL(node_coop_kernel, grid, block, 0, st, in, out, n_out, batch, ps);
         return hipGetLastError();
     }
-    return total >= qpgpu_tp_min_threads() ? merkle_tp_nodes(in, out, n_out, batch, ps, h, st) : hash_launch_nodes(in, out, n_out, batch, ps, h, st);
+    if (total < qpgpu_tp_min_threads()) return hash_launch_nodes(in, out, n_out, batch, ps, h, st);
+    return (!p2 && mx_enabled()) ? merkle_mx_nodes(in, out, n_out, batch, ps, st) : merkle_tp_nodes(in, out, n_out, batch, ps, h, st);
 }
 // every level from `cnt` digests (at `levels`, the following levels stored behind it) down to the cap
 hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, u32 batch, u64 ps, const HasherDev &h, hipStream_t st) {

@@ -1,0 +1,119 @@
+// merkle_kernels_mx.hip — matrix-pipe build of the thread-per-hash kernels of stage s3 (column-major leaf sponges, tree levels):
+// plonky2's Poseidon with its 22 partial rounds as one int8 GEMM on v_mfma_i32_32x32x32_i8 (poseidon_mfma.hpp), the full rounds on
+// the vector ALU with the S-box products as rare-fold groups (gl64.hpp). Same digests as merkle_hash_impl.hpp, bit for bit
+// (tests/test_merkle_gpu.py runs every build on the same inputs). 3.64 against 2.81 G permutations/s in registers
+// (profiles/r03_poseidon_mfma.txt).
+//
+// What the matrix form asks of a kernel: the 61 KB constant table in LDS (workgroups of 512 threads, two per CU: four waves per
+// SIMD at 128 VGPRs), every lane of a wave inside the permutation (MFMA and the half-wave swaps work on whole waves: a thread
+// without work hashes a clamped index and does not store), and enough hashes per workgroup to pay for the table load (a thread of
+// the tree-level kernel takes `per_thread` nodes). merkle_kernels.hip routes launches of qpgpu_tp_min_threads() hashes or more of
+// the Poseidon hasher here; smaller launches and the Poseidon2 plug keep the other builds.
+#define POSEIDON_GROUPED_SBOX 1
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "merkle.hpp"
+#include "poseidon_mfma.hpp"
+#include "prover_kernels.hpp"
+
+using gl::u32;
+using gl::u64;
+
+namespace mx {
+constexpr int WG = 512;
+__constant__ u64 c_poseidon_rc[poseidon::ROUNDS * poseidon::WIDTH];
+__device__ uint4 g_table[pmf::TABLE_BYTES / 16];
+
+#define MX_KERNEL __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
+
+__device__ __forceinline__ const unsigned char *table_to_lds() {
+    extern __shared__ uint4 mx_lds[];
+    for (int i = threadIdx.x; i < pmf::TABLE_BYTES / 16; i += WG) mx_lds[i] = g_table[i];
+    __syncthreads();
+    return (const unsigned char *)mx_lds;
+}
+__device__ __forceinline__ u32 ilog2_64(u64 x) { return 63u - (u32)__clzll((long long)x); }
+
+// leaf j = [src0 cols..., src1 cols...] at slot j, W > 4 (the launcher keeps hash_or_noop's copy case on the other builds)
+MX_KERNEL leaf_hash_kernel(MerkleLeafArgs a) {
+    const unsigned char *lds = table_to_lds();
+    const u64 total = a.n_leaves * a.batch;
+    u64 gj = blockIdx.x * (u64)WG + threadIdx.x;
+    const bool live = gj < total;
+    gj = live ? gj : total - 1;
+    const u64 pr = gj >> ilog2_64(a.n_leaves), j = gj & (a.n_leaves - 1);
+    a.src0 += pr * a.ps_src0; a.src1 += pr * a.ps_src1; a.digests += pr * a.ps_digests;
+    const u32 W = a.ncols0 + a.ncols1;
+    auto elem = [&](u32 c) -> u64 {
+        return c < a.ncols0 ? a.src0[(u64)c * a.stride0 + j] : a.src1[(u64)(c - a.ncols0) * a.stride1 + j];
+    };
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    for (u32 c = 0; c < W; c += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (c + i < W) s[i] = elem(c + i);
+        pmf::permute(s, c_poseidon_rc, lds);
+    }
+    if (live) {
+        u64 *out = a.digests + j * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = s[i];
+    }
+}
+
+// one level: out[i] = two_to_one(in[2i], in[2i+1]); thread t of workgroup b takes nodes (b * per_thread + k) * WG + t
+MX_KERNEL node_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, u32 per_thread) {
+    const unsigned char *lds = table_to_lds();
+    const u64 total = n_out * batch;
+    const u32 sh = ilog2_64(n_out);
+    for (u32 k = 0; k < per_thread; k++) {
+        u64 gi = ((u64)blockIdx.x * per_thread + k) * WG + threadIdx.x;
+        const bool live = gi < total;
+        gi = live ? gi : total - 1;
+        const u64 pr = gi >> sh, i = gi & (n_out - 1);
+        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(in + pr * ps + i * 8);
+        const ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
+        u64 s[12];
+        s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = c.x; s[5] = c.y; s[6] = d.x; s[7] = d.y;
+        s[8] = s[9] = s[10] = s[11] = 0;
+        pmf::permute(s, c_poseidon_rc, lds);
+        if (live) {
+            ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + pr * ps + i * 4);
+            o[0] = make_ulonglong2(s[0], s[1]);
+            o[1] = make_ulonglong2(s[2], s[3]);
+        }
+    }
+}
+}  // namespace mx
+
+hipError_t merkle_mx_upload_constants(const u64 *rc360) {
+    std::vector<unsigned char> tab(pmf::TABLE_BYTES);
+    // the table is a function of the round constants; the integer emulation of the device schedule (same table bytes, same
+    // recombination code) is held against the plain permutation before anything is uploaded
+    if (!pmf::build_tables(rc360, tab.data()) || !pmf::host_selfcheck(rc360, tab.data(), 64)) return hipErrorInvalidValue;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(mx::c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(mx::g_table), tab.data(), pmf::TABLE_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)mx::leaf_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)mx::node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+}
+hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, hipStream_t st) {
+    const u64 blocks = (total + mx::WG - 1) / mx::WG;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mx::leaf_hash_kernel, dim3((unsigned)blocks), dim3(mx::WG), pmf::TABLE_BYTES, st, a);
+    return hipGetLastError();
+}
+hipError_t merkle_mx_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, hipStream_t st) {
+    const u64 total = n_out * batch;
+    // 512 workgroup slots on the chip (two per CU): one node per thread up to 2^18 nodes, then more nodes per thread
+    u64 per_thread = total >> 18;
+    per_thread = per_thread < 1 ? 1 : per_thread > 8 ? 8 : per_thread;
+    const u64 blocks = (total + mx::WG * per_thread - 1) / (mx::WG * per_thread);
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mx::node_kernel, dim3((unsigned)blocks), dim3(mx::WG), pmf::TABLE_BYTES, st, in, out, n_out, batch, ps, (u32)per_thread);
+    return hipGetLastError();
+}

@@ -111,3 +111,25 @@ def test_throughput_build_and_rare_folds_vs_oracle(gpu, orc, pkg):
     assert np.array_equal(cap, cap_want)
     assert np.array_equal(d_dig.download().reshape(-1, 4), dig_want)
     d_cols.free(); d_dig.free()
+
+
+def test_matrix_build_vs_oracle(gpu, orc):
+    """Leaf sponges and tree levels of 2^18 hashes or more under the Poseidon hasher run the matrix-pipe build
+    (merkle_kernels_mx.hip: the 22 partial rounds as one int8 GEMM, poseidon_mfma.hpp). A wires-shaped commitment (135 columns:
+    17 permutations per leaf, the last block ragged) on 2^18 leaves, with runs of extreme elements (0, p - 1, 2^32 - 1, 2^63):
+    digests, every level and the cap equal the oracle's."""
+    log_leaves, width, cap_h = 18, 135, 4
+    n = 1 << log_leaves
+    rng = np.random.default_rng(31337)
+    leaves = rng.integers(0, P, (n, width), dtype=np.uint64)
+    ext = np.array([0, P - 1, 2**32 - 1, 2**63, 2**32, P - 2**32], dtype=np.uint64)
+    for j in rng.choice(n, 4000, replace=False):
+        k = int(rng.integers(1, width))
+        leaves[j, rng.choice(width, k, replace=False)] = rng.choice(ext, k)
+    dig_want, cap_want = orc.merkle(leaves, cap_h)
+    d_dig = gpu.alloc(gpu.merkle_digest_count(log_leaves, cap_h) * 32)
+    d_cols = gpu.to_device(np.ascontiguousarray(leaves.T))
+    cap = gpu.merkle_build_dev(d_cols, n, width, log_leaves, cap_h, d_dig)
+    assert np.array_equal(cap, cap_want)
+    assert np.array_equal(d_dig.download().reshape(-1, 4), dig_want)
+    d_cols.free(); d_dig.free()
