@@ -28,6 +28,7 @@ hipError_t merkle_tp_pow(const PowArgs &a, dim3 g, const HasherDev &h, hipStream
 hipError_t merkle_mx_upload_constants(const u64 *rc360);
 hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, hipStream_t st);
 hipError_t merkle_mx_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, hipStream_t st);
+hipError_t merkle_mx_pow(const PowArgs &a, hipStream_t st);
 
 // Launches of at least this many threads (four resident waves per SIMD on 256 CUs) take the throughput build of a hashing kernel,
 // smaller ones the latency build. QPGPU_TP_MIN_THREADS overrides (0: always, a huge value: never).
@@ -222,7 +223,8 @@ hipError_t pk_pow(const PowArgs &a, const HasherDev &h, hipStream_t st) {
     const u64 chunks = (a.count + 255) / 256;
     if (chunks * a.batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 g((unsigned)(chunks * a.batch));
-    return chunks * a.batch * 256 >= qpgpu_tp_min_threads() ? merkle_tp_pow(a, g, h, st) : hash_launch_pow(a, g, h, st);
+    if (chunks * a.batch * 256 < qpgpu_tp_min_threads()) return hash_launch_pow(a, g, h, st);
+    return (h.kind != hasher::POSEIDON2 && mx_enabled()) ? merkle_mx_pow(a, st) : merkle_tp_pow(a, g, h, st);
 }
 
 // below this many independent hashes a level is latency-bound and the lane-cooperative form wins. The cooperative form

@@ -1,4 +1,5 @@
-// merkle_kernels_mx.hip — matrix-pipe build of the thread-per-hash kernels of stage s3 (column-major leaf sponges, tree levels):
+// merkle_kernels_mx.hip — matrix-pipe build of the thread-per-hash kernels of stages s3 / s10 (column-major leaf sponges, tree
+// levels, proof of work):
 // plonky2's Poseidon with its 22 partial rounds as one int8 GEMM on v_mfma_i32_32x32x32_i8 (poseidon_mfma.hpp), the full rounds on
 // the vector ALU with the S-box products as rare-fold groups (gl64.hpp). Same digests as merkle_hash_impl.hpp, bit for bit
 // (tests/test_merkle_gpu.py runs every build on the same inputs). 3.64 against 2.81 G permutations/s in registers
@@ -47,6 +48,8 @@ MX_KERNEL leaf_hash_kernel(MerkleLeafArgs a) {
     auto elem = [&](u32 c) -> u64 {
         return c < a.ncols0 ? a.src0[(u64)c * a.stride0 + j] : a.src1[(u64)(c - a.ncols0) * a.stride1 + j];
     };
+    // (requesting the next block's columns between the two halves of the permutation was measured: 16 more live registers at the
+    // 128-register cap spill, 3.27 instead of 3.47 G permutations/s on the wires-shaped tree, gpurun_out/mx/leaf_time.txt)
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -86,6 +89,26 @@ MX_KERNEL node_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, u32
         }
     }
 }
+
+// s10 fri_proof_of_work, same contract as pow_kernel of merkle_hash_impl.hpp (minimum accepted nonce per proof by atomicMin;
+// workgroups chunk-major over the proofs, the proof rotating with the chunk). A workgroup leaves BEFORE it loads the table when its
+// proof has its nonce already or when all of its 512 candidates lie above a nonce found in this launch.
+MX_KERNEL pow_kernel(PowArgs a) {
+    const u32 chunk = blockIdx.x / a.batch, pr = (blockIdx.x % a.batch + chunk) % a.batch;
+    const u64 first = (u64)chunk * WG;
+    if (first >= a.count) return;
+    const u64 base = a.bases[pr];
+    if (base == ~0ull) return;
+    if (__hip_atomic_load(&a.results[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + first) return;
+    const unsigned char *lds = table_to_lds();
+    const u64 idx = first + threadIdx.x, nonce = base + idx;
+    const u64 *st = a.states + 12 * (u64)pr;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = (i == (int)a.pos) ? nonce : st[i];
+    pmf::permute(s, c_poseidon_rc, lds);
+    if (idx < a.count && (s[7] >> (64 - a.pow_bits)) == 0) atomicMin((unsigned long long *)&a.results[pr], (unsigned long long)nonce);
+}
 }  // namespace mx
 
 hipError_t merkle_mx_upload_constants(const u64 *rc360) {
@@ -99,7 +122,15 @@ hipError_t merkle_mx_upload_constants(const u64 *rc360) {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)mx::leaf_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)mx::node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+    e = hipFuncSetAttribute((const void *)mx::node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)mx::pow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+}
+hipError_t merkle_mx_pow(const PowArgs &a, hipStream_t st) {
+    const u64 chunks = (a.count + mx::WG - 1) / mx::WG;
+    if (chunks * a.batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mx::pow_kernel, dim3((unsigned)(chunks * a.batch)), dim3(mx::WG), pmf::TABLE_BYTES, st, a);
+    return hipGetLastError();
 }
 hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, hipStream_t st) {
     const u64 blocks = (total + mx::WG - 1) / mx::WG;

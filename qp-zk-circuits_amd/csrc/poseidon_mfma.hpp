@@ -382,9 +382,10 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12], const unsigned char
         for (int o = 0; o < 4; o++) s[4 * f + o] = recombine(Z[o]);
     }
 }
-// poseidon::permute with the partial rounds on the matrix pipe. Every lane of the wave must be here (MFMA and the lane swaps ignore
-// or need the whole wave); lds: the table of build_tables, 16-byte aligned.
-__device__ __forceinline__ void permute(u64 (&s)[12], const u64 *rc, const unsigned char *lds) {
+// poseidon::permute with the partial rounds on the matrix pipe, in two halves so that a caller can place loads between them (the
+// closing full rounds need the fewest registers). Every lane of the wave must be here (MFMA and the lane swaps ignore or need the
+// whole wave); lds: the table of build_tables, 16-byte aligned.
+__device__ __forceinline__ void permute_head(u64 (&s)[12], const u64 *rc, const unsigned char *lds) {
     using namespace poseidon;
     int r = 0;
     for (int k = 0; k < HALF_FULL; k++, r++) {
@@ -394,7 +395,10 @@ __device__ __forceinline__ void permute(u64 (&s)[12], const u64 *rc, const unsig
         mds_layer(s);
     }
     partial_rounds(s, lds);
-    r += 1 + PARTIAL;
+}
+__device__ __forceinline__ void permute_tail(u64 (&s)[12], const u64 *rc) {
+    using namespace poseidon;
+    int r = HALF_FULL + 1 + PARTIAL;
     sbox7_layer(s);
     mds_layer(s);
     for (int k = 1; k < HALF_FULL; k++, r++) {
@@ -406,8 +410,14 @@ __device__ __forceinline__ void permute(u64 (&s)[12], const u64 *rc, const unsig
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
 }
+__device__ __forceinline__ void permute(u64 (&s)[12], const u64 *rc, const unsigned char *lds) {
+    permute_head(s, rc, lds);
+    permute_tail(s, rc);
+}
 #elif defined(__HIPCC__)
-__device__ void permute(u64 (&s)[12], const u64 *rc, const unsigned char *lds);   // host pass of a .hip unit: name only
+__device__ void permute(u64 (&s)[12], const u64 *rc, const unsigned char *lds);   // host pass of a .hip unit: names only
+__device__ void permute_head(u64 (&s)[12], const u64 *rc, const unsigned char *lds);
+__device__ void permute_tail(u64 (&s)[12], const u64 *rc);
 #endif
 
 }  // namespace pmf
