@@ -6,7 +6,7 @@
 // input of every round and the state after the last one are affine in (s, y_0 .. y_{k-1}):
 //     x_k = (e0^T N^k)(s + c') + sum_{j<k} (e0^T N^{k-1-j} m0) y_j + c_k         out = N^22 (s + c') + sum_j y_j N^{21-j} m0 + c''
 // (c' the lanes-1..11 constants before the first partial round, c'' the constants of the full round that follows: both folded into
-// the additive terms). That is one matrix of dense 64-bit field constants with 34 columns; a 64-bit modular matrix product is an
+// the additive terms; and s = M t for the S-box outputs t of the fourth full round, so that round's MDS layer is in the matrix too). That is one matrix of dense 64-bit field constants with 34 columns; a 64-bit modular matrix product is an
 // int8 GEMM on byte digits, and v_mfma_i32_32x32x32_i8 runs beside the vector ALU, which the rest of the permutation saturates:
 //   * B operand = the inputs as 8 signed base-256 digits per element. The state of lane n is column n, an element's 8 digits are 8
 //     consecutive k: the registers already hold the operand, up to one v_permlane32_swap per register pair (lanes 32..63 of a
@@ -41,8 +41,7 @@ constexpr int group_base(int g) { int b = 0; for (int i = 0; i < g; i++) b += gr
 constexpr int N_GROUP_TILES = group_base(N_GROUP);                  // 33
 constexpr int N_TILES = N_GROUP_TILES + N_FIN * FIN_STEPS;          // 60
 constexpr int CINIT_OFF = N_TILES * 1024;
-constexpr int C0_OFF = CINIT_OFF + (N_GROUP + N_FIN) * 128;
-constexpr int TABLE_BYTES = C0_OFF + 16;
+constexpr int TABLE_BYTES = CINIT_OFF + (N_GROUP + N_FIN) * 128;
 static_assert(N_GROUP_TILES == 33 && TABLE_BYTES % 16 == 0, "table layout");
 constexpr u64 DIGIT_BIAS = 0x8080808080808080ull;
 
@@ -182,7 +181,7 @@ inline bool build_tables(const u64 *rc, unsigned char *tab) {
         for (int o = 0; o < 4; o++) {
             const int k = 4 * g + o;
             if (k >= 22) continue;                            // the last group has two rounds
-            for (int e = 0; e < 12; e++) rw.w[o][e] = R[k][e];
+            for (int e = 0; e < 12; e++) { u64 a = 0; for (int i = 0; i < 12; i++) a = fadd(a, fmul(R[k][i], M[i][e])); rw.w[o][e] = a; }   // (e0^T N^k) M
             for (int j = 0; j < 4 * g; j++) rw.w[o][12 + j] = G[k - 1 - j];
             u64 a = rc[(4 + k) * 12];
             for (int e = 0; e < 12; e++) a = fadd(a, fmul(R[k][e], cvec[e]));
@@ -194,7 +193,7 @@ inline bool build_tables(const u64 *rc, unsigned char *tab) {
         Rows rw{};
         for (int o = 0; o < 4; o++) {
             const int i = 4 * f + o;
-            for (int e = 0; e < 12; e++) rw.w[o][e] = NP[i][e];
+            for (int e = 0; e < 12; e++) { u64 a = 0; for (int j = 0; j < 12; j++) a = fadd(a, fmul(NP[i][j], M[j][e])); rw.w[o][e] = a; }   // N^22 M
             for (int j = 0; j < 22; j++) rw.w[o][12 + j] = Q[21 - j][i];
             u64 a = rc[26 * 12 + i];
             for (int e = 0; e < 12; e++) a = fadd(a, fmul(NP[i][e], cvec[e]));
@@ -202,8 +201,6 @@ inline bool build_tables(const u64 *rc, unsigned char *tab) {
         }
         if (!fill_tiles(rw, FIN_STEPS, tab + (size_t)(N_GROUP_TILES + f * FIN_STEPS) * 1024, tab + CINIT_OFF + (N_GROUP + f) * 128)) return false;
     }
-    const u64 c0 = rc[4 * 12];
-    memcpy(tab + C0_OFF, &c0, 8);
     return true;
 }
 // what one MFMA chain computes for one column, from the table bytes (layout assumptions as the device code's)
@@ -231,17 +228,16 @@ inline bool emu_permute(u64 (&s)[12], const u64 *rc, const unsigned char *tab) {
     for (int k = 0; k < HALF_FULL; k++, r++) {
         for (int i = 0; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
         sbox7_layer(s);
-        mds_layer(s);
+        if (k + 1 < HALF_FULL) mds_layer(s);          // the fourth round's MDS layer is part of the matrix
     }
     u64 D[N_ELEM] = {}, y[24];
     for (int e = 0; e < 12; e++) D[e] = to_digits(s[e]);
-    u64 c0; memcpy(&c0, tab + C0_OFF, 8);
     for (int g = 0; g < N_GROUP; g++) {
         u32 Z[4][LIMBS];
         if (!emu_gemm(tab, group_base(g), g, group_steps(g), D, Z)) return false;
         for (int o = 0; o < 4 && 4 * g + o < 22; o++) {
             const int k = 4 * g + o;
-            u64 x = k == 0 ? gl::add_canonical(s[0], c0) : recombine(Z[o]);
+            u64 x = recombine(Z[o]);
             constexpr u32 G[3] = {G0, G1, G2};
             for (int j = 4 * g; j < k; j++) x = gl::add(x, mul_small(y[j], G[k - 1 - j]));
             y[k] = sbox7_lane(x);
@@ -298,7 +294,6 @@ struct Run {
     u32 Dlo[N_ELEM], Dhi[N_ELEM];     // digits, natural layout until their K-step is formed
     v4i B0[FIN_STEPS], B1[FIN_STEPS];  // B operands of the columns of lanes 0..31 / 32..63
     u64 y[24];
-    u64 s0, c0;
     const unsigned char *lds;
 };
 __device__ __forceinline__ void form_step(Run &st, int q) {
@@ -342,14 +337,10 @@ __device__ __forceinline__ void group_step(Run &st) {
 #pragma unroll
     for (int o = 0; o < n; o++) {
         const int k = 4 * G + o;
-        u64 x;
-        if (G == 0 && o == 0) x = gl::add_canonical(st.s0, st.c0);
-        else {
-            x = recombine(Z[o]);
-            constexpr u32 Gc[3] = {G0, G1, G2};
+        u64 x = recombine(Z[o]);
+        constexpr u32 Gc[3] = {G0, G1, G2};
 #pragma unroll
-            for (int j = 4 * G; j < k; j++) x = gl::add(x, mul_small(st.y[j], Gc[k - 1 - j]));
-        }
+        for (int j = 4 * G; j < k; j++) x = gl::add(x, mul_small(st.y[j], Gc[k - 1 - j]));
         st.y[k] = poseidon::sbox7_lane(x);
     }
 #pragma unroll
@@ -362,11 +353,11 @@ __device__ __forceinline__ void group_step(Run &st) {
 template <int... G>
 __device__ __forceinline__ void all_groups(Run &st, std::integer_sequence<int, G...>) { (group_step<G>(st), ...); }
 
-// s: the state after the first four full rounds -> the state the S-box layer of the first closing full round applies to (that
-// round's constants are already in)
+// s: the S-box outputs of the fourth full round (its MDS layer is part of the matrix) -> the state the S-box layer of the first
+// closing full round applies to (that round's constants are already in)
 __device__ __forceinline__ void partial_rounds(u64 (&s)[12], const unsigned char *lds) {
     Run st;
-    st.lds = lds; st.s0 = s[0]; st.c0 = *(const u64 *)(lds + C0_OFF);
+    st.lds = lds;
 #pragma unroll
     for (int e = 0; e < N_ELEM; e++) {
         const u64 t = e < 12 ? to_digits(s[e]) : 0;
@@ -392,7 +383,7 @@ __device__ __forceinline__ void permute_head(u64 (&s)[12], const u64 *rc, const 
 #pragma unroll
         for (int i = 0; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
         sbox7_layer(s);
-        mds_layer(s);
+        if (k + 1 < HALF_FULL) mds_layer(s);
     }
     partial_rounds(s, lds);
 }
