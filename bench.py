@@ -464,18 +464,22 @@ def main():
             perm_rate = 17 * (1 << HL) * hash_n / (hash_ms * 1e-3)
             d_cols.free(); d_dig.free()
             lde_leaves = 1 << (d + 3)
-            extra["poseidon_hashing"] = {"bound": "valu", "permutations_per_s": round(perm_rate / 1e9, 3), "unit": "G/s",
-                                         "kernel": "leaf_hash_kernel<PoseidonV1>, 2^20 leaves x 135 columns",
+            mx_on = os.environ.get("QPGPU_MX", "1") != "0"
+            extra["poseidon_hashing"] = {"bound": "valu (full rounds) beside mfma (the 22 partial rounds as one int8 GEMM)" if mx_on else "valu",
+                                         "permutations_per_s": round(perm_rate / 1e9, 3), "unit": "G/s",
+                                         "kernel": ("mx::leaf_hash_kernel" if mx_on else "tp::leaf_hash_kernel<PoseidonV1>") + ", 2^20 leaves x 135 columns",
                                          "wires_leaf_hash_algorithmic_GBps": round(8.0 * 135 * lde_leaves / 1e9 / (17 * lde_leaves / perm_rate), 1),
                                          "note": "leaf hashing reads 8*W bytes per leaf and runs ceil(W/8) permutations: at the permutation "
                                                  "rate above the wires oracle streams this many GB/s, far below HBM"}
-            try:   # hardware counters of the same kernel, committed (tools/gpurun_scripts/r02_leaf_pmc.sh)
-                with open(os.path.join(ROOT, "profiles", "r02_final_leaf_hash_valu_summary.json")) as f:
-                    lk = json.load(f)["kernels"]["leaf_hash_kernel<PoseidonV1>"]
-                extra["poseidon_hashing"].update(valu_insts_per_permutation=lk["valu_insts_per_permutation"],
-                                                 cycles_per_valu_inst_per_simd=lk["cycles_per_valu_inst_per_simd"],
-                                                 valu_source="profiles/r02_final_leaf_hash_valu_summary.json")
-            except (OSError, KeyError, ValueError):
+            try:   # hardware counters of the same kernel, committed (tools/gpurun_scripts/r03_mx_pmc.sh)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from kernel_id import kernel_source_id
+                with open(os.path.join(ROOT, "profiles", "r03_mx_leaf_hash_counters.json")) as f:
+                    lk = json.load(f)
+                if mx_on and lk.get("kernel_source_id") == kernel_source_id("hash"):
+                    extra["poseidon_hashing"].update({k: lk[k] for k in ("valu_insts_per_permutation", "mfma_insts_per_permutation", "mfma_busy_frac") if k in lk})
+                    extra["poseidon_hashing"]["counters_source"] = "profiles/r03_mx_leaf_hash_counters.json"
+            except (OSError, KeyError, ValueError, ImportError):
                 pass
 
             # stage s1 on the device (separate leg, not part of the headline: the metric is quoted with the witness resident):

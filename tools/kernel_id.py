@@ -10,7 +10,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qp-zk-circuits_amd", "csrc")
 GROUPS = {
     "ntt": ["gl64.hpp", "ntt_pass.hpp", "ntt_kernel_impl.hpp", "ntt_kernels.hip", "ntt_inst_0.hip", "ntt_inst_1.hip", "ntt_inst_2.hip", "ntt_inst_3.hip", "Makefile"],
-    "hash": ["gl64.hpp", "poseidon.hpp", "merkle.hpp", "merkle_kernels.hip", "Makefile"],
+    "hash": ["gl64.hpp", "poseidon.hpp", "poseidon_mfma.hpp", "merkle.hpp", "merkle_hash_impl.hpp", "merkle_kernels.hip", "merkle_kernels_tp.hip", "merkle_kernels_mx.hip", "Makefile"],
 }
 
 
