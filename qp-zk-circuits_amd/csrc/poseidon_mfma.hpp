@@ -32,8 +32,10 @@
 namespace pmf {
 using gl::u32;
 using gl::u64;
+#if defined(__HIPCC__)
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+#endif
 
 constexpr int LIMBS = 8, N_GROUP = 6, N_FIN = 3, FIN_STEPS = 9, N_ELEM = 36;   // 12 state elements + 22 y + 2 zero
 constexpr int group_steps(int g) { return 3 + g; }                  // group g = rounds 4g .. 4g+3: elements 12 + 4g known

@@ -1,6 +1,7 @@
 """Host build (g++) of the arithmetic the kernels share with the host through GL_HD headers: the spectral Poseidon permutation
 against its layer-wise and textbook forms on random and extreme states, the multiplication-free Poseidon2 external layer, the
-quotient kernels' 192-bit accumulators. tools/host_checks/poseidon_permutation_check.cpp; about ten seconds."""
+quotient kernels' 192-bit accumulators, and the matrix form of the partial rounds (poseidon_mfma.hpp: integer emulation of the
+device schedule from the table bytes the kernels load). tools/host_checks/poseidon_permutation_check.cpp; about ten seconds."""
 import os
 import subprocess
 
@@ -14,4 +15,4 @@ def test_shared_arithmetic_on_the_host(tmp_path):
                            os.path.join(csrc, "poseidon_constants.cpp"), "-o", exe, "-lpthread"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("mismatches 0") == 3, r.stdout
+    assert r.stdout.count("mismatches 0") == 4, r.stdout

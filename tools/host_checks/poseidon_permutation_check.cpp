@@ -5,7 +5,9 @@
 // and the 192-bit accumulator of the quotient kernels against reduce-every-term. Built and run by tests/test_host_checks.py.
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "poseidon.hpp"
+#include "poseidon_mfma.hpp"
 using gl::u64;
 int check_poseidon() {
     const u64 *rc = poseidon::host_hash_round_constants(), *rcp = poseidon::host_round_constants();
@@ -53,4 +55,40 @@ int check_acc() {
     printf("192-bit accumulator: mismatches %d\n", bad);
     return bad;
 }
-int main() { return (check_poseidon() | check_poseidon2() | check_acc()) != 0; }
+// the matrix form of the partial rounds (poseidon_mfma.hpp): the integer emulation of the device schedule, computed from the very
+// table bytes the kernels load (digits, accumulator start values, recombination), against the permutation; a limb outside
+// [0, 2^24) fails the emulation
+int check_matrix_form() {
+    const u64 *rc = poseidon::host_hash_round_constants();
+    std::vector<unsigned char> tab(pmf::TABLE_BYTES);
+    if (!pmf::build_tables(rc, tab.data())) { printf("matrix form: table construction failed\n"); return 1; }
+    u64 seed = 4242; auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
+    int bad = 0;
+    for (int t = 0; t < 20000; t++) {
+        u64 a[12], b[12];
+        for (int i = 0; i < 12; i++) {
+            u64 v = rnd();
+            if (t % 7 == 0) v = (t % 14 == 0) ? 0xFFFFFFFFFFFFFFFFull : gl::P - 1 - (v & 3);
+            if (t % 11 == 0) v &= 0xFFFFFFFFull;
+            if (t % 13 == 0) v = v << 32;
+            if (t % 17 == 0) v = 0;
+            a[i] = b[i] = v;
+        }
+        poseidon::permute(a, rc);
+        if (!pmf::host::emu_permute(b, rc, tab.data())) { bad += 12; continue; }
+        for (int i = 0; i < 12; i++) bad += a[i] != b[i];
+    }
+    // digit conversion at the edges of its two cases
+    const u64 edge[] = {0, 1, 0x7F7F7F7F7F7F7F7Full, 0x7F7F7F7F7F7F7F80ull, 0x7F7F7F7F7F7F7F81ull, gl::P - 1, gl::P, ~0ull, 0x8000000000000000ull};
+    for (u64 v : edge) {
+        const u64 t = pmf::to_digits(v);
+        __int128 sum = 0;
+        for (int bq = 7; bq >= 0; bq--) sum = sum * 256 + (signed char)(t >> (8 * bq));
+        const __int128 want = (__int128)(v % gl::P);
+        __int128 got = sum % (__int128)gl::P; if (got < 0) got += gl::P;
+        bad += got != want;
+    }
+    printf("matrix form of the partial rounds: mismatches %d\n", bad);
+    return bad;
+}
+int main() { return (check_poseidon() | check_poseidon2() | check_acc() | check_matrix_form()) != 0; }
