@@ -68,8 +68,11 @@ static bool probe_layout() {
 }
 
 // ---------- kernels ----------
+#ifndef PMF_WPE
+#define PMF_WPE 4
+#endif
 template <int WG, int MODE>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void perm_kernel(u64 *out, const u64 *rc, const uint4 *tables, int iters) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PMF_WPE, PMF_WPE))) void perm_kernel(u64 *out, const u64 *rc, const uint4 *tables, int iters) {
     extern __shared__ uint4 lds[];
     if (MODE == 1) {
         for (int i = threadIdx.x; i < pmf::TABLE_BYTES / 16; i += WG) lds[i] = tables[i];
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 template <int WG, int MODE>
 static void run(const char *name, int iters, const u64 *rc, const uint4 *tables, int waves_per_simd_note) {
     const int total = 256 * 16 * 256;
-    const int blocks = total / WG;
+    const int blocks = (total + WG - 1) / WG;
     u64 *out;
     hipMalloc(&out, (size_t)blocks * WG * 8);
     const size_t shm = MODE == 1 ? pmf::TABLE_BYTES : 0;
@@ -157,5 +160,7 @@ int main(int argc, char **argv) {
     run<256, 1>("permute, partial rounds on MFMA (WG 256)", 64, rc, tables, 0);
     run<512, 1>("permute, partial rounds on MFMA (WG 512)", 64, rc, tables, 0);
     run<1024, 1>("permute, partial rounds on MFMA (WG 1024)", 64, rc, tables, 0);
+    run<384, 1>("permute, partial rounds on MFMA (WG 384)", 64, rc, tables, 0);
+    run<768, 1>("permute, partial rounds on MFMA (WG 768)", 64, rc, tables, 0);
     return 0;
 }

@@ -28,6 +28,7 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU S
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -o ntt -- python3 $R/tools/ntt_only.py 3 > $R/$O/pmc_fetch.log 2>&1; step pmc_fetch $?
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -o ntt -- python3 $R/tools/ntt_only.py 3 > $R/$O/pmc_write.log 2>&1; step pmc_write $?
 cd $R
+bash tools/gpurun_scripts/r03_mx_pmc.sh > $O/mx_pmc.log 2>&1; step mx_pmc $?
 [ -s $O/crash_trace_prof_bench.txt ] && { echo "CRASH TRACE WRITTEN" | tee -a $O/summary.txt; head -60 $O/crash_trace_prof_bench.txt; }
 python tools/profile_summary.py $O/prof_bench $O/sum_bench "python3 bench.py (default command)" >> $O/summary.txt 2>&1
 python tools/profile_summary.py $O/prof_ntt $O/sum_ntt_only "python3 tools/ntt_only.py 40" >> $O/summary.txt 2>&1
