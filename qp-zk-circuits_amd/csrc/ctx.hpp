@@ -35,7 +35,12 @@ struct qpgpu_ctx {
     // constants and the pad-10 sponge), independent of which permutation is the proof-system hasher above
     poseidon2::Params *d_p2_app = nullptr;
     int ensure_p2_app();
-    HasherDev hasher_dev() const { HasherDev h; h.kind = hasher.kind; h.p2 = d_p2; return h; }
+    HasherDev hasher_dev() const {
+        HasherDev h; h.kind = hasher.kind; h.p2 = d_p2;
+        h.qp = hasher.kind == hasher::POSEIDON2 && hasher_is_qp();
+        return h;
+    }
+    bool hasher_is_qp() const;   // the context's Poseidon2 block equals poseidon2::qp_params() (merkle_api.cpp)
 
     // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)
     struct KStat { double ms = 0; uint64_t launches = 0; };

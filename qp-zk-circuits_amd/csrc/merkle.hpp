@@ -10,7 +10,9 @@
 namespace poseidon2 { struct Params; }
 // which permutation the hashing kernels run: plonky2's Poseidon (constants in __constant__ memory, fixed) or Poseidon2 with
 // the context's parameter block (device pointer)
-struct HasherDev { int kind = 0; const poseidon2::Params *p2 = nullptr; };
+// qp: the parameter block is qp-poseidon-core's set (poseidon2::qp_params): its external block has a multiplication-free form and
+// its internal rounds a matrix-pipe form (merkle_kernels_mx.hip); any other block runs the general plug
+struct HasherDev { int kind = 0; const poseidon2::Params *p2 = nullptr; bool qp = false; };
 
 struct MerkleLeafArgs {
     const uint64_t *src0;   // column-major: column c at src0 + c*stride0, leaf j at slot j
@@ -25,6 +27,7 @@ struct MerkleLeafArgs {
 
 uint64_t qpgpu_tp_min_threads();   // launches at least this large take the throughput build of a hashing kernel (merkle_kernels.hip)
 hipError_t merkle_upload_constants(const uint64_t *rc360);   // plonky2 Poseidon round constants, once per device
+hipError_t merkle_upload_p2_tables(const poseidon2::Params &qp);   // matrix-form table of qp-poseidon-core's Poseidon2, once per device
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, const HasherDev &h, hipStream_t st);
 hipError_t merkle_leaf_hash_rows(const uint64_t *rows, uint64_t n_leaves, uint32_t width, uint64_t *digests, uint32_t batch, uint64_t ps_rows, uint64_t ps_digests,
                                  const HasherDev &h, hipStream_t st);

@@ -1,14 +1,21 @@
 // merkle_api.cpp — C ABI for stage s3 (Poseidon hashing, MerkleTree::new).
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <mutex>
 #include "ctx.hpp"
 #include "merkle.hpp"
 #include "poseidon.hpp"
 
+bool qpgpu_ctx::hasher_is_qp() const {
+    const poseidon2::Params &q = poseidon2::qp_params();
+    return memcmp(hasher.p2.rc_ext, q.rc_ext, sizeof q.rc_ext) == 0 && memcmp(hasher.p2.rc_int, q.rc_int, sizeof q.rc_int) == 0 &&
+           memcmp(hasher.p2.diag_m1, q.diag_m1, sizeof q.diag_m1) == 0 && memcmp(hasher.p2.m4, q.m4, sizeof q.m4) == 0;
+}
+
 int merkle_ensure_constants(qpgpu_ctx *ctx) {
     // plonky2's Poseidon round constants live in __constant__ memory, the same for every context: once per device
     static std::mutex mu;
-    static bool uploaded[64] = {false};
+    static bool uploaded[64] = {false}, uploaded_p2[64] = {false};
     {
         std::lock_guard<std::mutex> lk(mu);
         const int dev = ctx->device;
@@ -16,6 +23,10 @@ int merkle_ensure_constants(qpgpu_ctx *ctx) {
         if (!uploaded[dev]) {
             QP_HIP(ctx, merkle_upload_constants(poseidon::host_hash_round_constants()));
             uploaded[dev] = true;
+        }
+        if (ctx->hasher.kind == hasher::POSEIDON2 && ctx->hasher_is_qp() && !uploaded_p2[dev]) {
+            QP_HIP(ctx, merkle_upload_p2_tables(poseidon2::qp_params()));
+            uploaded_p2[dev] = true;
         }
     }
     if (ctx->hasher.kind == hasher::POSEIDON2 && !ctx->d_p2) {   // the context's Poseidon2 parameter block

@@ -13,6 +13,9 @@ struct PoseidonV1 {
 struct Poseidon2P {   // the parameter plug: same sponge and tree code, other permutation; parameters of the caller's context
     static __device__ __forceinline__ void permute(u64 (&s)[12], const poseidon2::Params *p2) { poseidon2::permute(s, *p2); }
 };
+struct Poseidon2QP {  // the plug when the context's block is qp-poseidon-core's set: multiplication-free external layers
+    static __device__ __forceinline__ void permute(u64 (&s)[12], const poseidon2::Params *p2) { poseidon2::permute_qp(s, *p2); }
+};
 
 // tree of the batch a global leaf / node index belongs to (counts are powers of two)
 __device__ __forceinline__ u32 ilog2_64(u64 x) { return 63u - (u32)__clzll((long long)x); }
@@ -119,14 +122,16 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a, const poseidon2::Pa
 
 hipError_t hash_launch_leaves(const MerkleLeafArgs &a, u64 total, const HasherDev &h, hipStream_t st) {
     dim3 block(256), grid((unsigned)((total + 255) / 256));
-    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((leaf_hash_kernel<Poseidon2P>), grid, block, 0, st, a, h.p2);
+    if (h.kind == hasher::POSEIDON2 && h.qp) hipLaunchKernelGGL((leaf_hash_kernel<Poseidon2QP>), grid, block, 0, st, a, h.p2);
+    else if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((leaf_hash_kernel<Poseidon2P>), grid, block, 0, st, a, h.p2);
     else hipLaunchKernelGGL((leaf_hash_kernel<PoseidonV1>), grid, block, 0, st, a, h.p2);
     return hipGetLastError();
 }
 hipError_t hash_launch_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st) {
     const u64 total = n_leaves * batch;
     dim3 block(256), grid((unsigned)((total + 255) / 256));
-    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((leaf_hash_rows_kernel<Poseidon2P>), grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h.p2);
+    if (h.kind == hasher::POSEIDON2 && h.qp) hipLaunchKernelGGL((leaf_hash_rows_kernel<Poseidon2QP>), grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h.p2);
+    else if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((leaf_hash_rows_kernel<Poseidon2P>), grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h.p2);
     else hipLaunchKernelGGL((leaf_hash_rows_kernel<PoseidonV1>), grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h.p2);
     return hipGetLastError();
 }
@@ -134,12 +139,14 @@ hipError_t hash_launch_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 
     const u64 total = n_out * batch;
     unsigned threads = total >= 256 ? 256 : 64;
     dim3 block(threads), grid((unsigned)((total + threads - 1) / threads));
-    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((node_kernel<Poseidon2P>), grid, block, 0, st, in, out, n_out, batch, ps, h.p2);
+    if (h.kind == hasher::POSEIDON2 && h.qp) hipLaunchKernelGGL((node_kernel<Poseidon2QP>), grid, block, 0, st, in, out, n_out, batch, ps, h.p2);
+    else if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((node_kernel<Poseidon2P>), grid, block, 0, st, in, out, n_out, batch, ps, h.p2);
     else hipLaunchKernelGGL((node_kernel<PoseidonV1>), grid, block, 0, st, in, out, n_out, batch, ps, h.p2);
     return hipGetLastError();
 }
 hipError_t hash_launch_pow(const PowArgs &a, dim3 g, const HasherDev &h, hipStream_t st) {
-    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((pow_kernel<Poseidon2P>), g, dim3(256), 0, st, a, h.p2);
+    if (h.kind == hasher::POSEIDON2 && h.qp) hipLaunchKernelGGL((pow_kernel<Poseidon2QP>), g, dim3(256), 0, st, a, h.p2);
+    else if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL((pow_kernel<Poseidon2P>), g, dim3(256), 0, st, a, h.p2);
     else hipLaunchKernelGGL((pow_kernel<PoseidonV1>), g, dim3(256), 0, st, a, h.p2);
     return hipGetLastError();
 }

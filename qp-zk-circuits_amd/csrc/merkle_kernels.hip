@@ -24,11 +24,13 @@ hipError_t merkle_tp_leaves(const MerkleLeafArgs &a, u64 total, const HasherDev 
 hipError_t merkle_tp_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st);
 hipError_t merkle_tp_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const HasherDev &h, hipStream_t st);
 hipError_t merkle_tp_pow(const PowArgs &a, dim3 g, const HasherDev &h, hipStream_t st);
-// matrix-pipe build (merkle_kernels_mx.hip): plonky2's Poseidon only
+// matrix-pipe build (merkle_kernels_mx.hip)
 hipError_t merkle_mx_upload_constants(const u64 *rc360);
-hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, hipStream_t st);
-hipError_t merkle_mx_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, hipStream_t st);
-hipError_t merkle_mx_pow(const PowArgs &a, hipStream_t st);
+hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, const HasherDev &h, hipStream_t st);
+hipError_t merkle_mx_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const HasherDev &h, hipStream_t st);
+hipError_t merkle_mx_pow(const PowArgs &a, const HasherDev &h, hipStream_t st);
+// the matrix build serves plonky2's Poseidon and Poseidon2 with qp-poseidon-core's parameters
+static bool mx_serves(const HasherDev &h) { return h.kind != hasher::POSEIDON2 || h.qp; }
 
 // Launches of at least this many threads (four resident waves per SIMD on 256 CUs) take the throughput build of a hashing kernel,
 // smaller ones the latency build. QPGPU_TP_MIN_THREADS overrides (0: always, a huge value: never).
@@ -224,7 +226,7 @@ hipError_t pk_pow(const PowArgs &a, const HasherDev &h, hipStream_t st) {
     if (chunks * a.batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 g((unsigned)(chunks * a.batch));
     if (chunks * a.batch * 256 < qpgpu_tp_min_threads()) return hash_launch_pow(a, g, h, st);
-    return (h.kind != hasher::POSEIDON2 && mx_enabled()) ? merkle_mx_pow(a, st) : merkle_tp_pow(a, g, h, st);
+    return (mx_serves(h) && mx_enabled()) ? merkle_mx_pow(a, h, st) : merkle_tp_pow(a, g, h, st);
 }
 
 // below this many independent hashes a level is latency-bound and the lane-cooperative form wins. The cooperative form
@@ -249,7 +251,7 @@ hipError_t merkle_leaf_hash(const MerkleLeafArgs &a0, const HasherDev &h, hipStr
         return hipGetLastError();
     }
     if (total < qpgpu_tp_min_threads()) return hash_launch_leaves(a, total, h, st);
-    return (!p2 && a.ncols0 + a.ncols1 > 4 && mx_enabled()) ? merkle_mx_leaves(a, total, st) : merkle_tp_leaves(a, total, h, st);
+    return (mx_serves(h) && a.ncols0 + a.ncols1 > 4 && mx_enabled()) ? merkle_mx_leaves(a, total, h, st) : merkle_tp_leaves(a, total, h, st);
 }
 hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st) {
     if (n_leaves == 0 || batch == 0) return hipSuccess;
@@ -274,7 +276,7 @@ static hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, u32 ba
         return hipGetLastError();
     }
     if (total < qpgpu_tp_min_threads()) return hash_launch_nodes(in, out, n_out, batch, ps, h, st);
-    return (!p2 && mx_enabled()) ? merkle_mx_nodes(in, out, n_out, batch, ps, st) : merkle_tp_nodes(in, out, n_out, batch, ps, h, st);
+    return (mx_serves(h) && mx_enabled()) ? merkle_mx_nodes(in, out, n_out, batch, ps, h, st) : merkle_tp_nodes(in, out, n_out, batch, ps, h, st);
 }
 // every level from `cnt` digests (at `levels`, the following levels stored behind it) down to the cap
 hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, u32 batch, u64 ps, const HasherDev &h, hipStream_t st) {

@@ -1,7 +1,8 @@
 // merkle_kernels_mx.hip — matrix-pipe build of the thread-per-hash kernels of stages s3 / s10 (column-major leaf sponges, tree
 // levels, proof of work):
-// plonky2's Poseidon with its 22 partial rounds as one int8 GEMM on v_mfma_i32_32x32x32_i8 (poseidon_mfma.hpp), the full rounds on
-// the vector ALU with the S-box products as rare-fold groups (gl64.hpp). Same digests as merkle_hash_impl.hpp, bit for bit
+// plonky2's Poseidon — and qp-poseidon-core's Poseidon2 when that is the context's hasher — with the 22 partial (internal) rounds
+// as one int8 GEMM on v_mfma_i32_32x32x32_i8 (poseidon_mfma.hpp), the full rounds on the vector ALU with the S-box products as
+// rare-fold groups (gl64.hpp). Same digests as merkle_hash_impl.hpp, bit for bit
 // (tests/test_merkle_gpu.py runs every build on the same inputs). 3.64 against 2.81 G permutations/s in registers
 // (profiles/r03_poseidon_mfma.txt).
 //
@@ -23,21 +24,34 @@ using gl::u64;
 namespace mx {
 constexpr int WG = 512;
 __constant__ u64 c_poseidon_rc[poseidon::ROUNDS * poseidon::WIDTH];
-__device__ uint4 g_table[pmf::TABLE_BYTES / 16];
+__device__ uint4 g_table[pmf::TABLE_BYTES / 16];        // plonky2's Poseidon
+__device__ uint4 g_table_p2[pmf::TABLE_BYTES / 16];     // qp-poseidon-core's Poseidon2
 
 #define MX_KERNEL __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
+// the two permutations of the build: the matrix table they need and the permutation itself
+struct PoseidonV1 {
+    static __device__ __forceinline__ const uint4 *table() { return g_table; }
+    static __device__ __forceinline__ void permute(u64 (&s)[12], const poseidon2::Params *, const unsigned char *lds) { pmf::permute(s, c_poseidon_rc, lds); }
+};
+struct Poseidon2QP {
+    static __device__ __forceinline__ const uint4 *table() { return g_table_p2; }
+    static __device__ __forceinline__ void permute(u64 (&s)[12], const poseidon2::Params *p2, const unsigned char *lds) { pmf::permute_p2qp(s, *p2, lds); }
+};
+template <class Perm>
 __device__ __forceinline__ const unsigned char *table_to_lds() {
     extern __shared__ uint4 mx_lds[];
-    for (int i = threadIdx.x; i < pmf::TABLE_BYTES / 16; i += WG) mx_lds[i] = g_table[i];
+    const uint4 *t = Perm::table();
+    for (int i = threadIdx.x; i < pmf::TABLE_BYTES / 16; i += WG) mx_lds[i] = t[i];
     __syncthreads();
     return (const unsigned char *)mx_lds;
 }
 __device__ __forceinline__ u32 ilog2_64(u64 x) { return 63u - (u32)__clzll((long long)x); }
 
 // leaf j = [src0 cols..., src1 cols...] at slot j, W > 4 (the launcher keeps hash_or_noop's copy case on the other builds)
-MX_KERNEL leaf_hash_kernel(MerkleLeafArgs a) {
-    const unsigned char *lds = table_to_lds();
+template <class Perm>
+MX_KERNEL leaf_hash_kernel(MerkleLeafArgs a, const poseidon2::Params *p2) {
+    const unsigned char *lds = table_to_lds<Perm>();
     const u64 total = a.n_leaves * a.batch;
     u64 gj = blockIdx.x * (u64)WG + threadIdx.x;
     const bool live = gj < total;
@@ -57,7 +71,7 @@ MX_KERNEL leaf_hash_kernel(MerkleLeafArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if (c + i < W) s[i] = elem(c + i);
-        pmf::permute(s, c_poseidon_rc, lds);
+        Perm::permute(s, p2, lds);
     }
     if (live) {
         u64 *out = a.digests + j * 4;
@@ -67,8 +81,9 @@ MX_KERNEL leaf_hash_kernel(MerkleLeafArgs a) {
 }
 
 // one level: out[i] = two_to_one(in[2i], in[2i+1]); thread t of workgroup b takes nodes (b * per_thread + k) * WG + t
-MX_KERNEL node_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, u32 per_thread) {
-    const unsigned char *lds = table_to_lds();
+template <class Perm>
+MX_KERNEL node_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, u32 per_thread, const poseidon2::Params *p2) {
+    const unsigned char *lds = table_to_lds<Perm>();
     const u64 total = n_out * batch;
     const u32 sh = ilog2_64(n_out);
     for (u32 k = 0; k < per_thread; k++) {
@@ -81,7 +96,7 @@ MX_KERNEL node_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, u32
         u64 s[12];
         s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = c.x; s[5] = c.y; s[6] = d.x; s[7] = d.y;
         s[8] = s[9] = s[10] = s[11] = 0;
-        pmf::permute(s, c_poseidon_rc, lds);
+        Perm::permute(s, p2, lds);
         if (live) {
             ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + pr * ps + i * 4);
             o[0] = make_ulonglong2(s[0], s[1]);
@@ -93,58 +108,70 @@ MX_KERNEL node_kernel(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, u32
 // s10 fri_proof_of_work, same contract as pow_kernel of merkle_hash_impl.hpp (minimum accepted nonce per proof by atomicMin;
 // workgroups chunk-major over the proofs, the proof rotating with the chunk). A workgroup leaves BEFORE it loads the table when its
 // proof has its nonce already or when all of its 512 candidates lie above a nonce found in this launch.
-MX_KERNEL pow_kernel(PowArgs a) {
+template <class Perm>
+MX_KERNEL pow_kernel(PowArgs a, const poseidon2::Params *p2) {
     const u32 chunk = blockIdx.x / a.batch, pr = (blockIdx.x % a.batch + chunk) % a.batch;
     const u64 first = (u64)chunk * WG;
     if (first >= a.count) return;
     const u64 base = a.bases[pr];
     if (base == ~0ull) return;
     if (__hip_atomic_load(&a.results[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + first) return;
-    const unsigned char *lds = table_to_lds();
+    const unsigned char *lds = table_to_lds<Perm>();
     const u64 idx = first + threadIdx.x, nonce = base + idx;
     const u64 *st = a.states + 12 * (u64)pr;
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = (i == (int)a.pos) ? nonce : st[i];
-    pmf::permute(s, c_poseidon_rc, lds);
+    Perm::permute(s, p2, lds);
     if (idx < a.count && (s[7] >> (64 - a.pow_bits)) == 0) atomicMin((unsigned long long *)&a.results[pr], (unsigned long long)nonce);
 }
 }  // namespace mx
 
+template <class Perm>
+static hipError_t allow_table_in_lds() {
+    hipError_t e = hipFuncSetAttribute((const void *)mx::leaf_hash_kernel<Perm>, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)mx::node_kernel<Perm>, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)mx::pow_kernel<Perm>, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+    return e;
+}
+// The tables are functions of the round constants. Before anything is uploaded, the integer emulation of the device schedule
+// (same table bytes, same recombination code) is held against the plain permutation on the host.
 hipError_t merkle_mx_upload_constants(const u64 *rc360) {
     std::vector<unsigned char> tab(pmf::TABLE_BYTES);
-    // the table is a function of the round constants; the integer emulation of the device schedule (same table bytes, same
-    // recombination code) is held against the plain permutation before anything is uploaded
     if (!pmf::build_tables(rc360, tab.data()) || !pmf::host_selfcheck(rc360, tab.data(), 64)) return hipErrorInvalidValue;
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(mx::c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
     if (e != hipSuccess) return e;
     e = hipMemcpyToSymbol(HIP_SYMBOL(mx::g_table), tab.data(), pmf::TABLE_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)mx::leaf_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)mx::node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)mx::pow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+    return e != hipSuccess ? e : allow_table_in_lds<mx::PoseidonV1>();
 }
-hipError_t merkle_mx_pow(const PowArgs &a, hipStream_t st) {
-    const u64 chunks = (a.count + mx::WG - 1) / mx::WG;
-    if (chunks * a.batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mx::pow_kernel, dim3((unsigned)(chunks * a.batch)), dim3(mx::WG), pmf::TABLE_BYTES, st, a);
-    return hipGetLastError();
+hipError_t merkle_upload_p2_tables(const poseidon2::Params &qp) {
+    std::vector<unsigned char> tab(pmf::TABLE_BYTES);
+    if (!pmf::build_tables_p2(qp, tab.data()) || !pmf::host_selfcheck_p2(qp, tab.data(), 64)) return hipErrorInvalidValue;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(mx::g_table_p2), tab.data(), pmf::TABLE_BYTES);
+    return e != hipSuccess ? e : allow_table_in_lds<mx::Poseidon2QP>();
 }
-hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, hipStream_t st) {
+hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, const HasherDev &h, hipStream_t st) {
     const u64 blocks = (total + mx::WG - 1) / mx::WG;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mx::leaf_hash_kernel, dim3((unsigned)blocks), dim3(mx::WG), pmf::TABLE_BYTES, st, a);
+    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL(mx::leaf_hash_kernel<mx::Poseidon2QP>, dim3((unsigned)blocks), dim3(mx::WG), pmf::TABLE_BYTES, st, a, h.p2);
+    else hipLaunchKernelGGL(mx::leaf_hash_kernel<mx::PoseidonV1>, dim3((unsigned)blocks), dim3(mx::WG), pmf::TABLE_BYTES, st, a, h.p2);
     return hipGetLastError();
 }
-hipError_t merkle_mx_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, hipStream_t st) {
+hipError_t merkle_mx_nodes(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const HasherDev &h, hipStream_t st) {
     const u64 total = n_out * batch;
     // 512 workgroup slots on the chip (two per CU): one node per thread up to 2^18 nodes, then more nodes per thread
     u64 per_thread = total >> 18;
     per_thread = per_thread < 1 ? 1 : per_thread > 8 ? 8 : per_thread;
     const u64 blocks = (total + mx::WG * per_thread - 1) / (mx::WG * per_thread);
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mx::node_kernel, dim3((unsigned)blocks), dim3(mx::WG), pmf::TABLE_BYTES, st, in, out, n_out, batch, ps, (u32)per_thread);
+    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL(mx::node_kernel<mx::Poseidon2QP>, dim3((unsigned)blocks), dim3(mx::WG), pmf::TABLE_BYTES, st, in, out, n_out, batch, ps, (u32)per_thread, h.p2);
+    else hipLaunchKernelGGL(mx::node_kernel<mx::PoseidonV1>, dim3((unsigned)blocks), dim3(mx::WG), pmf::TABLE_BYTES, st, in, out, n_out, batch, ps, (u32)per_thread, h.p2);
+    return hipGetLastError();
+}
+hipError_t merkle_mx_pow(const PowArgs &a, const HasherDev &h, hipStream_t st) {
+    const u64 chunks = (a.count + mx::WG - 1) / mx::WG;
+    if (chunks * a.batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (h.kind == hasher::POSEIDON2) hipLaunchKernelGGL(mx::pow_kernel<mx::Poseidon2QP>, dim3((unsigned)(chunks * a.batch)), dim3(mx::WG), pmf::TABLE_BYTES, st, a, h.p2);
+    else hipLaunchKernelGGL(mx::pow_kernel<mx::PoseidonV1>, dim3((unsigned)(chunks * a.batch)), dim3(mx::WG), pmf::TABLE_BYTES, st, a, h.p2);
     return hipGetLastError();
 }

@@ -43,7 +43,8 @@ constexpr int group_base(int g) { int b = 0; for (int i = 0; i < g; i++) b += gr
 constexpr int N_GROUP_TILES = group_base(N_GROUP);                  // 33
 constexpr int N_TILES = N_GROUP_TILES + N_FIN * FIN_STEPS;          // 60
 constexpr int CINIT_OFF = N_TILES * 1024;
-constexpr int TABLE_BYTES = CINIT_OFF + (N_GROUP + N_FIN) * 128;
+constexpr int G_OFF = CINIT_OFF + (N_GROUP + N_FIN) * 128;         // three 64-bit coefficients of the running group's y
+constexpr int TABLE_BYTES = G_OFF + 32;
 static_assert(N_GROUP_TILES == 33 && TABLE_BYTES % 16 == 0, "table layout");
 constexpr u64 DIGIT_BIAS = 0x8080808080808080ull;
 
@@ -153,10 +154,16 @@ inline bool fill_tiles(const Rows &rw, int steps, unsigned char *tiles, unsigned
         }
     return true;
 }
-// rc: the 360-entry table poseidon::permute takes (host_hash_round_constants layout)
-inline bool build_tables(const u64 *rc, unsigned char *tab) {
-    static u64 M[12][12], R[23][12], G[22], Q[22][12], NP[12][12], cvec[12];
-    for (int r = 0; r < 12; r++) for (int j = 0; j < 12; j++) M[r][j] = mds_entry(r, j);
+// The partial-round block of a Poseidon-family permutation as the builder sees it: 22 rounds of `lane 0 <- (lane 0 + c_k)^7, state
+// <- M state`, entered with `pre t + cvec` (t = the S-box outputs of the full round before: that round's linear layer is `pre`)
+// and left with `+ after` (the constants of the full round behind).
+struct Linear {
+    u64 M[12][12], pre[12][12];
+    u64 c_lane0[22], cvec[12], after[12];
+};
+inline bool build_tables(const Linear &L, unsigned char *tab) {
+    static u64 R[23][12], G[22], Q[22][12], NP[12][12];
+    const auto &M = L.M;
     for (int j = 0; j < 12; j++) R[0][j] = j == 0;
     for (int k = 0; k < 22; k++)
         for (int j = 0; j < 12; j++) {
@@ -165,8 +172,7 @@ inline bool build_tables(const u64 *rc, unsigned char *tab) {
             R[k + 1][j] = a;
         }
     for (int d = 0; d < 22; d++) { u64 a = 0; for (int i = 0; i < 12; i++) a = fadd(a, fmul(R[d][i], M[i][0])); G[d] = a; }
-    if (G[0] != G0 || G[1] != G1 || G[2] != G2) return false;
-    for (int i = 0; i < 12; i++) Q[0][i] = M[i][0];
+    for (int i = 0; i < 12; i++) Q[0][i] = M[i][0] % gl::P;
     for (int d = 0; d + 1 < 22; d++)
         for (int i = 0; i < 12; i++) { u64 a = 0; for (int j = 1; j < 12; j++) a = fadd(a, fmul(M[i][j], Q[d][j])); Q[d + 1][i] = a; }
     for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) NP[i][j] = i == j;
@@ -175,18 +181,16 @@ inline bool build_tables(const u64 *rc, unsigned char *tab) {
         for (int i = 0; i < 12; i++) for (int e = 0; e < 12; e++) { u64 a = 0; for (int j = 1; j < 12; j++) a = fadd(a, fmul(M[i][j], NP[j][e])); T[i][e] = a; }
         memcpy(NP, T, sizeof T);
     }
-    cvec[0] = 0;
-    for (int i = 1; i < 12; i++) cvec[i] = rc[4 * 12 + i];
     memset(tab, 0, TABLE_BYTES);
     for (int g = 0; g < N_GROUP; g++) {
         Rows rw{};
         for (int o = 0; o < 4; o++) {
             const int k = 4 * g + o;
             if (k >= 22) continue;                            // the last group has two rounds
-            for (int e = 0; e < 12; e++) { u64 a = 0; for (int i = 0; i < 12; i++) a = fadd(a, fmul(R[k][i], M[i][e])); rw.w[o][e] = a; }   // (e0^T N^k) M
+            for (int e = 0; e < 12; e++) { u64 a = 0; for (int i = 0; i < 12; i++) a = fadd(a, fmul(R[k][i], L.pre[i][e])); rw.w[o][e] = a; }   // (e0^T N^k) pre
             for (int j = 0; j < 4 * g; j++) rw.w[o][12 + j] = G[k - 1 - j];
-            u64 a = rc[(4 + k) * 12];
-            for (int e = 0; e < 12; e++) a = fadd(a, fmul(R[k][e], cvec[e]));
+            u64 a = L.c_lane0[k] % gl::P;
+            for (int e = 0; e < 12; e++) a = fadd(a, fmul(R[k][e], L.cvec[e]));
             rw.addc[o] = a;
         }
         if (!fill_tiles(rw, group_steps(g), tab + (size_t)group_base(g) * 1024, tab + CINIT_OFF + g * 128)) return false;
@@ -195,15 +199,43 @@ inline bool build_tables(const u64 *rc, unsigned char *tab) {
         Rows rw{};
         for (int o = 0; o < 4; o++) {
             const int i = 4 * f + o;
-            for (int e = 0; e < 12; e++) { u64 a = 0; for (int j = 0; j < 12; j++) a = fadd(a, fmul(NP[i][j], M[j][e])); rw.w[o][e] = a; }   // N^22 M
+            for (int e = 0; e < 12; e++) { u64 a = 0; for (int j = 0; j < 12; j++) a = fadd(a, fmul(NP[i][j], L.pre[j][e])); rw.w[o][e] = a; }   // N^22 pre
             for (int j = 0; j < 22; j++) rw.w[o][12 + j] = Q[21 - j][i];
-            u64 a = rc[26 * 12 + i];
-            for (int e = 0; e < 12; e++) a = fadd(a, fmul(NP[i][e], cvec[e]));
+            u64 a = L.after[i] % gl::P;
+            for (int e = 0; e < 12; e++) a = fadd(a, fmul(NP[i][e], L.cvec[e]));
             rw.addc[o] = a;
         }
         if (!fill_tiles(rw, FIN_STEPS, tab + (size_t)(N_GROUP_TILES + f * FIN_STEPS) * 1024, tab + CINIT_OFF + (N_GROUP + f) * 128)) return false;
     }
+    memcpy(tab + G_OFF, G, 3 * sizeof(u64));                  // the running group's coefficients (Poseidon: 25, 5 017, 1 259 209)
     return true;
+}
+// plonky2's Poseidon; rc: the 360-entry table poseidon::permute takes (host_hash_round_constants layout)
+inline bool build_tables(const u64 *rc, unsigned char *tab) {
+    static Linear L;
+    memset(&L, 0, sizeof L);
+    for (int r = 0; r < 12; r++) for (int j = 0; j < 12; j++) L.M[r][j] = L.pre[r][j] = mds_entry(r, j);
+    for (int k = 0; k < 22; k++) L.c_lane0[k] = rc[(4 + k) * 12];
+    for (int i = 1; i < 12; i++) L.cvec[i] = rc[4 * 12 + i];
+    for (int i = 0; i < 12; i++) L.after[i] = rc[26 * 12 + i];
+    if (!build_tables(L, tab)) return false;
+    u64 g[3]; memcpy(g, tab + G_OFF, sizeof g);
+    return g[0] == G0 && g[1] == G1 && g[2] == G2;            // the device code has them as immediates
+}
+// qp-poseidon-core's Poseidon2 (poseidon2::permute_qp): internal layer J + diag, the external layer before it folded in; both
+// matrices are read off the layer functions themselves (columns = images of the unit vectors)
+inline bool build_tables_p2(const poseidon2::Params &p, unsigned char *tab) {
+    static Linear L;
+    memset(&L, 0, sizeof L);
+    for (int j = 0; j < 12; j++) {
+        u64 e[12] = {}, f[12] = {};
+        e[j] = f[j] = 1;
+        poseidon2::int_layer(e, p); poseidon2::ext_layer_qp(f);
+        for (int i = 0; i < 12; i++) { L.M[i][j] = gl::canon(e[i]); L.pre[i][j] = gl::canon(f[i]); }
+    }
+    for (int k = 0; k < 22; k++) L.c_lane0[k] = p.rc_int[k];
+    for (int i = 0; i < 12; i++) L.after[i] = p.rc_ext[4 * 12 + i];
+    return build_tables(L, tab);
 }
 // what one MFMA chain computes for one column, from the table bytes (layout assumptions as the device code's)
 inline bool emu_gemm(const unsigned char *tab, int tile0, int cidx, int steps, const u64 *D, u32 (&Z)[4][LIMBS]) {
@@ -224,15 +256,11 @@ inline bool emu_gemm(const unsigned char *tab, int tile0, int cidx, int steps, c
         }
     return true;
 }
-inline bool emu_permute(u64 (&s)[12], const u64 *rc, const unsigned char *tab) {
-    using namespace poseidon;
-    int r = 0;
-    for (int k = 0; k < HALF_FULL; k++, r++) {
-        for (int i = 0; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
-        sbox7_layer(s);
-        if (k + 1 < HALF_FULL) mds_layer(s);          // the fourth round's MDS layer is part of the matrix
-    }
-    u64 D[N_ELEM] = {}, y[24];
+// the partial-round block as the device runs it: s = S-box outputs of the full round before -> the state the S-box layer of the
+// full round behind applies to
+inline bool emu_partial_rounds(u64 (&s)[12], const unsigned char *tab) {
+    u64 D[N_ELEM] = {}, y[24], G[3];
+    memcpy(G, tab + G_OFF, sizeof G);
     for (int e = 0; e < 12; e++) D[e] = to_digits(s[e]);
     for (int g = 0; g < N_GROUP; g++) {
         u32 Z[4][LIMBS];
@@ -240,9 +268,8 @@ inline bool emu_permute(u64 (&s)[12], const u64 *rc, const unsigned char *tab) {
         for (int o = 0; o < 4 && 4 * g + o < 22; o++) {
             const int k = 4 * g + o;
             u64 x = recombine(Z[o]);
-            constexpr u32 G[3] = {G0, G1, G2};
-            for (int j = 4 * g; j < k; j++) x = gl::add(x, mul_small(y[j], G[k - 1 - j]));
-            y[k] = sbox7_lane(x);
+            for (int j = 4 * g; j < k; j++) x = gl::add(x, G[k - 1 - j] >> 32 ? gl::mul(y[j], G[k - 1 - j]) : mul_small(y[j], (u32)G[k - 1 - j]));
+            y[k] = poseidon::sbox7_lane(x);
         }
         for (int o = 0; o < 4 && 4 * g + o < 22; o++) D[12 + 4 * g + o] = to_digits(y[4 * g + o]);
     }
@@ -251,6 +278,17 @@ inline bool emu_permute(u64 (&s)[12], const u64 *rc, const unsigned char *tab) {
         if (!emu_gemm(tab, N_GROUP_TILES + f * FIN_STEPS, N_GROUP + f, FIN_STEPS, D, Z)) return false;
         for (int o = 0; o < 4; o++) s[4 * f + o] = recombine(Z[o]);
     }
+    return true;
+}
+inline bool emu_permute(u64 (&s)[12], const u64 *rc, const unsigned char *tab) {
+    using namespace poseidon;
+    int r = 0;
+    for (int k = 0; k < HALF_FULL; k++, r++) {
+        for (int i = 0; i < WIDTH; i++) s[i] = gl::add_canonical(s[i], rc[r * WIDTH + i]);
+        sbox7_layer(s);
+        if (k + 1 < HALF_FULL) mds_layer(s);          // the fourth round's MDS layer is part of the matrix
+    }
+    if (!emu_partial_rounds(s, tab)) return false;
     r += 1 + PARTIAL;
     sbox7_layer(s); mds_layer(s);
     for (int k = 1; k < HALF_FULL; k++, r++) {
@@ -261,7 +299,25 @@ inline bool emu_permute(u64 (&s)[12], const u64 *rc, const unsigned char *tab) {
     for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
     return true;
 }
-inline bool selfcheck(const u64 *rc, const unsigned char *tab, int n = 2000) {
+inline bool emu_permute_p2(u64 (&s)[12], const poseidon2::Params &p, const unsigned char *tab) {
+    poseidon2::ext_layer_qp(s);
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], p.rc_ext[r * 12 + i]);
+        poseidon::sbox7_layer(s);
+        if (r < 3) poseidon2::ext_layer_qp(s);        // the fourth round's external layer is part of the matrix
+    }
+    if (!emu_partial_rounds(s, tab)) return false;
+    poseidon::sbox7_layer(s); poseidon2::ext_layer_qp(s);
+    for (int r = 5; r < 8; r++) {
+        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], p.rc_ext[r * 12 + i]);
+        poseidon::sbox7_layer(s);
+        poseidon2::ext_layer_qp(s);
+    }
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+    return true;
+}
+template <class F, class Gf>
+inline bool selfcheck_with(F plain, Gf emu, int n) {
     u64 seed = 0x243F6A8885A308D3ull;
     for (int t = 0; t < n; t++) {
         u64 a[12], b[12];
@@ -272,18 +328,28 @@ inline bool selfcheck(const u64 *rc, const unsigned char *tab, int n = 2000) {
             if (t % 11 == 0) v = gl::P - 1 - (v & 3);
             a[i] = b[i] = v;
         }
-        poseidon::permute(a, rc);
-        if (!emu_permute(b, rc, tab)) return false;
+        plain(a);
+        if (!emu(b)) return false;
         for (int i = 0; i < 12; i++) if (a[i] != b[i]) return false;
     }
     return true;
 }
+inline bool selfcheck(const u64 *rc, const unsigned char *tab, int n = 2000) {
+    return selfcheck_with([&](u64 (&s)[12]) { poseidon::permute(s, rc); }, [&](u64 (&s)[12]) { return emu_permute(s, rc, tab); }, n);
+}
+inline bool selfcheck_p2(const poseidon2::Params &p, const unsigned char *tab, int n = 2000) {
+    return selfcheck_with([&](u64 (&s)[12]) { poseidon2::permute_qp(s, p); }, [&](u64 (&s)[12]) { return emu_permute_p2(s, p, tab); }, n);
+}
 }  // namespace host
 inline bool build_tables(const u64 *rc, unsigned char *tab) { return host::build_tables(rc, tab); }
 inline bool host_selfcheck(const u64 *rc, const unsigned char *tab, int n = 2000) { return host::selfcheck(rc, tab, n); }
+inline bool build_tables_p2(const poseidon2::Params &p, unsigned char *tab) { return host::build_tables_p2(p, tab); }
+inline bool host_selfcheck_p2(const poseidon2::Params &p, const unsigned char *tab, int n = 2000) { return host::selfcheck_p2(p, tab, n); }
 #else
 bool build_tables(const u64 *, unsigned char *);          // host functions: declared only in the device pass
 bool host_selfcheck(const u64 *, const unsigned char *, int n = 2000);
+bool build_tables_p2(const poseidon2::Params &, unsigned char *);
+bool host_selfcheck_p2(const poseidon2::Params &, const unsigned char *, int n = 2000);
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -296,6 +362,7 @@ struct Run {
     u32 Dlo[N_ELEM], Dhi[N_ELEM];     // digits, natural layout until their K-step is formed
     v4i B0[FIN_STEPS], B1[FIN_STEPS];  // B operands of the columns of lanes 0..31 / 32..63
     u64 y[24];
+    u64 Gd[3];                         // the running group's coefficients when they are not Poseidon's three small integers
     const unsigned char *lds;
 };
 __device__ __forceinline__ void form_step(Run &st, int q) {
@@ -331,7 +398,7 @@ __device__ __forceinline__ void gemm(const Run &st, int tile0, int cidx, u32 (&Z
         Z[i >> 3][i & 7] = x; Z[2 + (i >> 3)][i & 7] = yv;
     }
 }
-template <int G>
+template <int G, bool SMALL_G>
 __device__ __forceinline__ void group_step(Run &st) {
     u32 Z[4][LIMBS];
     gemm<group_steps(G)>(st, group_base(G), G, Z);
@@ -342,7 +409,7 @@ __device__ __forceinline__ void group_step(Run &st) {
         u64 x = recombine(Z[o]);
         constexpr u32 Gc[3] = {G0, G1, G2};
 #pragma unroll
-        for (int j = 4 * G; j < k; j++) x = gl::add(x, mul_small(st.y[j], Gc[k - 1 - j]));
+        for (int j = 4 * G; j < k; j++) x = gl::add(x, SMALL_G ? mul_small(st.y[j], Gc[k - 1 - j]) : gl::mul(st.y[j], st.Gd[k - 1 - j]));
         st.y[k] = poseidon::sbox7_lane(x);
     }
 #pragma unroll
@@ -352,21 +419,29 @@ __device__ __forceinline__ void group_step(Run &st) {
     }
     form_step(st, 3 + G);
 }
-template <int... G>
-__device__ __forceinline__ void all_groups(Run &st, std::integer_sequence<int, G...>) { (group_step<G>(st), ...); }
+template <bool SMALL_G, int... G>
+__device__ __forceinline__ void all_groups(Run &st, std::integer_sequence<int, G...>) { (group_step<G, SMALL_G>(st), ...); }
 
 // s: the S-box outputs of the fourth full round (its MDS layer is part of the matrix) -> the state the S-box layer of the first
 // closing full round applies to (that round's constants are already in)
+template <bool SMALL_G = true>
 __device__ __forceinline__ void partial_rounds(u64 (&s)[12], const unsigned char *lds) {
     Run st;
     st.lds = lds;
+    if (!SMALL_G) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {      // wave-uniform: scalar registers
+            const u64 g = *(const u64 *)(lds + G_OFF + 8 * d);
+            st.Gd[d] = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)g);
+        }
+    }
 #pragma unroll
     for (int e = 0; e < N_ELEM; e++) {
         const u64 t = e < 12 ? to_digits(s[e]) : 0;
         st.Dlo[e] = (u32)t; st.Dhi[e] = (u32)(t >> 32);
     }
     form_step(st, 0); form_step(st, 1); form_step(st, 2);
-    all_groups(st, std::make_integer_sequence<int, N_GROUP>{});
+    all_groups<SMALL_G>(st, std::make_integer_sequence<int, N_GROUP>{});
 #pragma unroll
     for (int f = 0; f < N_FIN; f++) {
         u32 Z[4][LIMBS];
@@ -387,7 +462,7 @@ __device__ __forceinline__ void permute_head(u64 (&s)[12], const u64 *rc, const 
         sbox7_layer(s);
         if (k + 1 < HALF_FULL) mds_layer(s);
     }
-    partial_rounds(s, lds);
+    partial_rounds<true>(s, lds);
 }
 __device__ __forceinline__ void permute_tail(u64 (&s)[12], const u64 *rc) {
     using namespace poseidon;
@@ -407,10 +482,33 @@ __device__ __forceinline__ void permute(u64 (&s)[12], const u64 *rc, const unsig
     permute_head(s, rc, lds);
     permute_tail(s, rc);
 }
+// poseidon2::permute_qp (qp-poseidon-core's parameter set) with the 22 internal rounds, the external layer before them and the
+// constants of the external round behind them on the matrix pipe; lds: the table of build_tables_p2 for the same parameters
+__device__ __forceinline__ void permute_p2qp(u64 (&s)[12], const poseidon2::Params &p, const unsigned char *lds) {
+    poseidon2::ext_layer_qp(s);
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], p.rc_ext[r * 12 + i]);
+        poseidon::sbox7_layer(s);
+        if (r < 3) poseidon2::ext_layer_qp(s);
+    }
+    partial_rounds<false>(s, lds);
+    poseidon::sbox7_layer(s);
+    poseidon2::ext_layer_qp(s);
+    for (int r = 5; r < 8; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], p.rc_ext[r * 12 + i]);
+        poseidon::sbox7_layer(s);
+        poseidon2::ext_layer_qp(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+}
 #elif defined(__HIPCC__)
 __device__ void permute(u64 (&s)[12], const u64 *rc, const unsigned char *lds);   // host pass of a .hip unit: names only
 __device__ void permute_head(u64 (&s)[12], const u64 *rc, const unsigned char *lds);
 __device__ void permute_tail(u64 (&s)[12], const u64 *rc);
+__device__ void permute_p2qp(u64 (&s)[12], const poseidon2::Params &p, const unsigned char *lds);
 #endif
 
 }  // namespace pmf

@@ -124,6 +124,29 @@ def test_permute_kernel_chain_reproduces_reference_kats(pkg, gpu_qp):
 
 
 @pytest.mark.gpu
+def test_matrix_build_under_the_pinned_parameters(pkg, gpu_qp, orc_qp):
+    """Launches of 2^18 hashes or more under Poseidon2 with qp-poseidon-core's parameters run the matrix-pipe build
+    (merkle_kernels_mx.hip: the 22 internal rounds, the external layer before them and the constants behind them as one int8 GEMM,
+    pmf::permute_p2qp). A 2^18-leaf tree over 21 columns (three permutations per leaf, the last block ragged) with runs of extreme
+    elements: digests, every level and the cap equal the oracle's tree over orc_p2_qp_params' permutation, the KAT-pinned path."""
+    log_leaves, width, cap_h = 18, 21, 4
+    n = 1 << log_leaves
+    rng = np.random.default_rng(4711)
+    leaves = rng.integers(0, P, (n, width), dtype=np.uint64)
+    ext = np.array([0, P - 1, 2**32 - 1, 2**63, 2**32, P - 2**32], dtype=np.uint64)
+    for j in rng.choice(n, 4000, replace=False):
+        k = int(rng.integers(1, width))
+        leaves[j, rng.choice(width, k, replace=False)] = rng.choice(ext, k)
+    dig_want, cap_want = orc_qp.merkle(leaves, cap_h)
+    d_dig = gpu_qp.alloc(gpu_qp.merkle_digest_count(log_leaves, cap_h) * 32)
+    d_cols = gpu_qp.to_device(np.ascontiguousarray(leaves.T))
+    cap = gpu_qp.merkle_build_dev(d_cols, n, width, log_leaves, cap_h, d_dig)
+    assert np.array_equal(cap, cap_want)
+    assert np.array_equal(d_dig.download().reshape(-1, 4), dig_want)
+    d_cols.free(); d_dig.free()
+
+
+@pytest.mark.gpu
 def test_tree_kernels_under_the_pinned_parameters(pkg, gpu_qp, orc_qp):
     """leaf_hash_kernel<Poseidon2P>, leaf_hash_rows_kernel<Poseidon2P> and node_kernel<Poseidon2P> against the oracle's Merkle
     tree over orc_p2_qp_params' permutation (the KAT-pinned path), through the polynomial-batch and the row-major entries."""

@@ -91,4 +91,29 @@ int check_matrix_form() {
     printf("matrix form of the partial rounds: mismatches %d\n", bad);
     return bad;
 }
-int main() { return (check_poseidon() | check_poseidon2() | check_acc() | check_matrix_form()) != 0; }
+// the same for qp-poseidon-core's Poseidon2 (internal rounds, the external layer before them, the constants behind them): the
+// emulation against the GENERAL form of the permutation (caller-supplied block products), 20 000 states
+int check_matrix_form_p2() {
+    const poseidon2::Params &P = poseidon2::qp_params();
+    std::vector<unsigned char> tab(pmf::TABLE_BYTES);
+    if (!pmf::build_tables_p2(P, tab.data())) { printf("Poseidon2 matrix form: table construction failed\n"); return 1; }
+    u64 seed = 777; auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
+    int bad = 0;
+    for (int t = 0; t < 20000; t++) {
+        u64 a[12], b[12];
+        for (int i = 0; i < 12; i++) {
+            u64 v = rnd();
+            if (t % 7 == 0) v = (t % 14 == 0) ? 0xFFFFFFFFFFFFFFFFull : gl::P - 1 - (v & 3);
+            if (t % 11 == 0) v &= 0xFFFFFFFFull;
+            if (t % 13 == 0) v = v << 32;
+            if (t % 17 == 0) v = 0;
+            a[i] = b[i] = v;
+        }
+        poseidon2::permute(a, P);
+        if (!pmf::host::emu_permute_p2(b, P, tab.data())) { bad += 12; continue; }
+        for (int i = 0; i < 12; i++) bad += a[i] != b[i];
+    }
+    printf("Poseidon2 matrix form of the internal rounds: mismatches %d\n", bad);
+    return bad;
+}
+int main() { return (check_poseidon() | check_poseidon2() | check_acc() | check_matrix_form() | check_matrix_form_p2()) != 0; }

@@ -72,9 +72,9 @@ static bool probe_layout() {
 #define PMF_WPE 4
 #endif
 template <int WG, int MODE>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PMF_WPE, PMF_WPE))) void perm_kernel(u64 *out, const u64 *rc, const uint4 *tables, int iters) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PMF_WPE, PMF_WPE))) void perm_kernel(u64 *out, const u64 *rc, const uint4 *tables, int iters, const poseidon2::Params *p2 = nullptr) {
     extern __shared__ uint4 lds[];
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
         for (int i = threadIdx.x; i < pmf::TABLE_BYTES / 16; i += WG) lds[i] = tables[i];
         __syncthreads();
     }
@@ -83,6 +83,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PMF_WPE, PMF
     for (int i = 0; i < 12; i++) s[i] = t * 0x9E3779B97F4A7C15ull + i;
     for (int it = 0; it < iters; it++) {
         if (MODE == 1) pmf::permute(s, rc, (const unsigned char *)lds);
+        else if (MODE == 2) poseidon2::permute_qp(s, *p2);          // Poseidon2, qp-poseidon-core's set, multiplication-free external layers
+        else if (MODE == 3) pmf::permute_p2qp(s, *p2, (const unsigned char *)lds);
+        else if (MODE == 4) poseidon2::permute(s, *p2);             // Poseidon2 through the general parameter plug
         else poseidon::permute(s, rc);
     }
     if (iters == 1) {
@@ -95,21 +98,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PMF_WPE, PMF
 }
 
 template <int WG, int MODE>
-static void run(const char *name, int iters, const u64 *rc, const uint4 *tables, int waves_per_simd_note) {
+static void run(const char *name, int iters, const u64 *rc, const uint4 *tables, int waves_per_simd_note, const poseidon2::Params *p2 = nullptr) {
     const int total = 256 * 16 * 256;
     const int blocks = (total + WG - 1) / WG;
     u64 *out;
     hipMalloc(&out, (size_t)blocks * WG * 8);
-    const size_t shm = MODE == 1 ? pmf::TABLE_BYTES : 0;
+    const size_t shm = (MODE == 1 || MODE == 3) ? pmf::TABLE_BYTES : 0;
     if (shm) hipFuncSetAttribute((const void *)perm_kernel<WG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((perm_kernel<WG, MODE>), dim3(blocks), dim3(WG), shm, 0, out, rc, tables, 2);
+    hipLaunchKernelGGL((perm_kernel<WG, MODE>), dim3(blocks), dim3(WG), shm, 0, out, rc, tables, 2, p2);
     hipError_t err = hipDeviceSynchronize();
     if (err != hipSuccess) { printf("%s: launch failed: %s\n", name, hipGetErrorString(err)); return; }
     float best = 1e9; u64 chk = 0;
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((perm_kernel<WG, MODE>), dim3(blocks), dim3(WG), shm, 0, out, rc, tables, iters);
+        hipLaunchKernelGGL((perm_kernel<WG, MODE>), dim3(blocks), dim3(WG), shm, 0, out, rc, tables, iters, p2);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -142,6 +145,26 @@ static bool check(const u64 *rc_dev, const u64 *rc_host, const uint4 *tables) {
     return bad == 0;
 }
 
+template <int WG>
+static bool check_p2(const poseidon2::Params *p2_dev, const poseidon2::Params &p2, const uint4 *tables) {
+    const int blocks = 4;
+    u64 *out; hipMalloc(&out, (size_t)blocks * WG * 12 * 8);
+    hipFuncSetAttribute((const void *)perm_kernel<WG, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pmf::TABLE_BYTES);
+    hipLaunchKernelGGL((perm_kernel<WG, 3>), dim3(blocks), dim3(WG), pmf::TABLE_BYTES, 0, out, (const u64 *)nullptr, tables, 1, p2_dev);
+    std::vector<u64> h((size_t)blocks * WG * 12);
+    if (hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { printf("check_p2: copy failed\n"); return false; }
+    int bad = 0;
+    for (int t = 0; t < blocks * WG; t++) {
+        u64 s[12];
+        for (int i = 0; i < 12; i++) s[i] = (u64)t * 0x9E3779B97F4A7C15ull + i;
+        poseidon2::permute(s, p2);                          // the general form on the host
+        for (int i = 0; i < 12; i++) bad += s[i] != h[(size_t)t * 12 + i];
+    }
+    printf("Poseidon2 matrix form vs host poseidon2::permute, %d states (WG %d): %s (%d mismatching words)\n", blocks * WG, WG, bad ? "FAIL" : "bit-exact", bad);
+    hipFree(out);
+    return bad == 0;
+}
+
 int main(int argc, char **argv) {
     u64 h[360];
     for (int i = 0; i < 360; i++) h[i] = (0x123456789ABCDEFull * (i + 1)) % 0xFFFFFFFF00000001ull;
@@ -156,11 +179,22 @@ int main(int argc, char **argv) {
     ok = check<1024>(rc, h, tables) && ok;
     ok = check<512>(rc, h, tables) && ok;
     if (!ok && !(argc > 1 && !strcmp(argv[1], "force"))) return 5;
+    // Poseidon2 with qp-poseidon-core's parameters
+    const poseidon2::Params &P2 = poseidon2::qp_params();
+    std::vector<unsigned char> tab2(pmf::TABLE_BYTES);
+    if (!pmf::build_tables_p2(P2, tab2.data()) || !pmf::host_selfcheck_p2(P2, tab2.data())) { printf("Poseidon2 table construction / self-check failed\n"); return 6; }
+    uint4 *tables2; hipMalloc(&tables2, tab2.size()); hipMemcpy(tables2, tab2.data(), tab2.size(), hipMemcpyHostToDevice);
+    poseidon2::Params *p2d; hipMalloc(&p2d, sizeof P2); hipMemcpy(p2d, &P2, sizeof P2, hipMemcpyHostToDevice);
+    ok = check_p2<512>(p2d, P2, tables2) && ok;
+    ok = check_p2<64>(p2d, P2, tables2) && ok;
+    if (!ok && !(argc > 1 && !strcmp(argv[1], "force"))) return 5;
+    run<256, 4>("Poseidon2 permute, general plug (WG 256)", 64, rc, tables2, 0, p2d);
+    run<256, 2>("Poseidon2 permute_qp (WG 256)", 64, rc, tables2, 0, p2d);
+    run<512, 3>("Poseidon2, internal rounds on MFMA (WG 512)", 64, rc, tables2, 0, p2d);
     run<256, 0>("permute, lib spectral (WG 256)", 64, rc, tables, 0);
     run<256, 1>("permute, partial rounds on MFMA (WG 256)", 64, rc, tables, 0);
     run<512, 1>("permute, partial rounds on MFMA (WG 512)", 64, rc, tables, 0);
     run<1024, 1>("permute, partial rounds on MFMA (WG 1024)", 64, rc, tables, 0);
-    run<384, 1>("permute, partial rounds on MFMA (WG 384)", 64, rc, tables, 0);
-    run<768, 1>("permute, partial rounds on MFMA (WG 768)", 64, rc, tables, 0);
+
     return 0;
 }
