@@ -566,6 +566,37 @@ def main():
                 pool12.close(); d12.free()
             except pkg.QpGpuError as e:
                 extra["degree_bits_12"] = {"error": str(e)}
+            # The same shape at full throughput under the OTHER candidate proof-system hasher: the reference does not tell which
+            # permutation backs PoseidonGoldilocksConfig in the fork, so the hasher is a plug; this is the headline's
+            # counterpart should it be Poseidon2 (qp-poseidon-core's parameters, pinned by the reference's seven vectors). New
+            # contexts take the process default, which is set for this leg only; one proof is held against the oracle.
+            try:
+                qp_ = pkg.poseidon2_qp_params()
+                pkg.set_hasher_poseidon2(*qp_)
+                try:
+                    pq, wq, piq = pkg.synth_circuit(d, num_wires=135, num_routed=80, num_public_inputs=21, seed=1000 + rank, poseidon=True, base_sum=True, poseidon2=True)
+                    poolq = pkg.ProvingPool(pq, workers=WORKERS, device=local_rank, max_batch=LOCKSTEP)
+                    dq = gpu.to_device(wq)
+                    oq = [np.empty(poolq.proof_size(), dtype=np.uint8) for _ in range(S)]
+                    for rep_ in range(2):
+                        tq = time.perf_counter()
+                        tk = [poolq.submit(dq, piq, oq[i % S]) for i in range(6 * S)]
+                        lens_q = [poolq.wait(t_, copy=False) for t_ in tk]
+                        dtq = time.perf_counter() - tq
+                    import oracle_binding as _ob
+                    orq = _ob.Oracle(); orq.select_poseidon2(*qp_)
+                    ocq = _ob.OracleCircuit(orq, pq)
+                    okq = bool(ocq.prove(wq, piq) == oq[0][:poolq.proof_size()].tobytes())
+                    ocq.close(); orq.select_poseidon()
+                    extra["poseidon2_hasher"] = {"proofs_per_s": round(6 * S / dtq, 1), "ms_per_proof": round(dtq / (6 * S) * 1e3, 4), "bytes_equal_oracle": okq,
+                                                 "note": "same circuit shape, workers and lockstep batches as the headline, Merkle trees / challenger / proof of work under Poseidon2 "
+                                                         "with qp-poseidon-core's parameters (large launches on the matrix-pipe build as well)"}
+                    ok = ok and okq
+                    poolq.close(); dq.free()
+                finally:
+                    pkg.set_hasher_poseidon()
+            except pkg.QpGpuError as e:
+                extra["poseidon2_hasher"] = {"error": str(e)}
             extra["witness_generation"] = {"generator_instances": gens, "dependency_levels": levels, "caller_supplied_cells": free,
                                            "single_ms": round(s1_single * 1e3, 3), "batch": WB16,
                                            "batched_ms_per_witness": round(s1_batch16 / WB16 * 1e3, 3), "equals_full_witness": s1_ok,
