@@ -44,6 +44,27 @@ static bool mx_enabled() {
     static const bool v = [] { const char *e = getenv("QPGPU_MX"); return !(e && *e == '0'); }();
     return v;
 }
+// below this many independent hashes a level is latency-bound and the lane-cooperative form wins. The cooperative form
+// does about 3x the work, so the crossover depends on how many proofs share the GPU: QPGPU_COOP_MAX overrides it.
+static u64 coop_max_init() {
+    const char *e = getenv("QPGPU_COOP_MAX");
+    if (e && *e) { const long long v = atoll(e); if (v >= 0) return (u64)v; }
+    return 16384;
+}
+static const u64 COOP_MAX = coop_max_init();
+// Lockstep batches of QPGPU_TPUT_BATCH trees or more (default 8) are throughput work: the device is shared by several such batches
+// and what counts is the work a level costs, not how soon it ends. They skip the lane-cooperative kernels (about 3x the work per
+// hash) and the fused tree top, and run every level on the large-launch builds (thread per hash; matrix-pipe build where it serves
+// the hasher). Measured with six workers x 32 proofs: 2^13-row circuits + 1 %, 2^11-row circuits + 37 % (profiles/r03_poseidon_mfma.txt
+// item 11). Single proofs and small batches keep the latency-oriented routing.
+static u32 tput_batch() {
+    static const u32 v = [] { const char *e = getenv("QPGPU_TPUT_BATCH"); return e && *e ? (u32)strtoul(e, nullptr, 10) : 8u; }();
+    return v;
+}
+static inline bool tput(u32 batch) { return batch >= tput_batch(); }
+static inline u64 coop_max_for(u32 batch) { return tput(batch) ? 0 : COOP_MAX; }
+static inline u64 tp_min_for(u32 batch) { return tput(batch) ? 0 : qpgpu_tp_min_threads(); }
+
 hipError_t merkle_upload_constants(const u64 *rc360) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
     if (e == hipSuccess) e = merkle_tp_upload_constants(rc360);
@@ -225,18 +246,9 @@ hipError_t pk_pow(const PowArgs &a, const HasherDev &h, hipStream_t st) {
     const u64 chunks = (a.count + 255) / 256;
     if (chunks * a.batch > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 g((unsigned)(chunks * a.batch));
-    if (chunks * a.batch * 256 < qpgpu_tp_min_threads()) return hash_launch_pow(a, g, h, st);
+    if (chunks * a.batch * 256 < tp_min_for(a.batch)) return hash_launch_pow(a, g, h, st);
     return (mx_serves(h) && mx_enabled()) ? merkle_mx_pow(a, h, st) : merkle_tp_pow(a, g, h, st);
 }
-
-// below this many independent hashes a level is latency-bound and the lane-cooperative form wins. The cooperative form
-// does about 3x the work, so the crossover depends on how many proofs share the GPU: QPGPU_COOP_MAX overrides it.
-static u64 coop_max_init() {
-    const char *e = getenv("QPGPU_COOP_MAX");
-    if (e && *e) { const long long v = atoll(e); if (v >= 0) return (u64)v; }
-    return 16384;
-}
-static const u64 COOP_MAX = coop_max_init();
 
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a0, const HasherDev &h, hipStream_t st) {
     MerkleLeafArgs a = a0;
@@ -245,12 +257,12 @@ hipError_t merkle_leaf_hash(const MerkleLeafArgs &a0, const HasherDev &h, hipStr
     if (a.n_leaves & (a.n_leaves - 1)) return hipErrorInvalidValue;
     const u64 total = a.n_leaves * a.batch;
     const bool p2 = h.kind == hasher::POSEIDON2;   // the lane-cooperative kernels exist for Poseidon only
-    if (!p2 && total <= COOP_MAX / 2) {
+    if (!p2 && total <= coop_max_for(a.batch) / 2) {
         dim3 block(256), grid((unsigned)((total * 16 + 255) / 256));
         hipLaunchKernelGGL(leaf_cols_coop_kernel, grid, block, 0, st, a);
         return hipGetLastError();
     }
-    if (total < qpgpu_tp_min_threads()) return hash_launch_leaves(a, total, h, st);
+    if (total < tp_min_for(a.batch)) return hash_launch_leaves(a, total, h, st);
     return (mx_serves(h) && a.ncols0 + a.ncols1 > 4 && mx_enabled()) ? merkle_mx_leaves(a, total, h, st) : merkle_tp_leaves(a, total, h, st);
 }
 hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *digests, u32 batch, u64 ps_rows, u64 ps_digests, const HasherDev &h, hipStream_t st) {
@@ -258,24 +270,24 @@ hipError_t merkle_leaf_hash_rows(const u64 *rows, u64 n_leaves, u32 width, u64 *
     if (n_leaves & (n_leaves - 1)) return hipErrorInvalidValue;
     const u64 total = n_leaves * batch;
     const bool p2 = h.kind == hasher::POSEIDON2;
-    if (!p2 && total <= COOP_MAX) {
+    if (!p2 && total <= coop_max_for(batch)) {
         dim3 block(256), grid((unsigned)((total * 16 + 255) / 256));
         hipLaunchKernelGGL(leaf_rows_coop_kernel, grid, block, 0, st, rows, n_leaves, width, digests, batch, ps_rows, ps_digests);
         return hipGetLastError();
     }
-    return total >= qpgpu_tp_min_threads() ? merkle_tp_rows(rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h, st)
+    return total >= tp_min_for(batch) ? merkle_tp_rows(rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h, st)
                                            : hash_launch_rows(rows, n_leaves, width, digests, batch, ps_rows, ps_digests, h, st);
 }
 static hipError_t merkle_reduce_level(const u64 *in, u64 *out, u64 n_out, u32 batch, u64 ps, const HasherDev &h, hipStream_t st) {
     if (n_out == 0) return hipSuccess;
     const u64 total = n_out * batch;
     const bool p2 = h.kind == hasher::POSEIDON2;
-    if (!p2 && total <= COOP_MAX) {
+    if (!p2 && total <= coop_max_for(batch)) {
         dim3 block(256), grid((unsigned)((total * 16 + 255) / 256));
         hipLaunchKernelGGL(node_coop_kernel, grid, block, 0, st, in, out, n_out, batch, ps);
         return hipGetLastError();
     }
-    if (total < qpgpu_tp_min_threads()) return hash_launch_nodes(in, out, n_out, batch, ps, h, st);
+    if (total < tp_min_for(batch)) return hash_launch_nodes(in, out, n_out, batch, ps, h, st);
     return (mx_serves(h) && mx_enabled()) ? merkle_mx_nodes(in, out, n_out, batch, ps, h, st) : merkle_tp_nodes(in, out, n_out, batch, ps, h, st);
 }
 // every level from `cnt` digests (at `levels`, the following levels stored behind it) down to the cap
@@ -289,7 +301,7 @@ hipError_t merkle_reduce_to_cap(u64 *levels, u64 cnt, u64 cap_n, u32 batch, u64 
         // largest subtree (digests per cap entry) handed to the fused kernel: 0 off, 32 (default: the last five levels, all
         // lane-cooperative), up to 512 (larger settings measured within noise of 32 with lockstep batches of 16 and 32).
         static const u32 top_m = [] { const char *e = getenv("QPGPU_TREE_TOP"); const int v = e ? atoi(e) : 32; return (u32)(v < 0 ? 0 : v > 512 ? 512 : v); }();
-        if (top_m >= 2 && h.kind != hasher::POSEIDON2 && m <= top_m && cap_n <= 65535 && batch <= 65535) {
+        if (top_m >= 2 && !tput(batch) && h.kind != hasher::POSEIDON2 && m <= top_m && cap_n <= 65535 && batch <= 65535) {
             if (m <= 32) hipLaunchKernelGGL((tree_top_kernel<32>), dim3((unsigned)cap_n, batch), dim3(256), 0, st, lvl, cnt, (u32)m, ps);
             else if (m <= 256) hipLaunchKernelGGL((tree_top_kernel<256>), dim3((unsigned)cap_n, batch), dim3(256), 0, st, lvl, cnt, (u32)m, ps);
             else hipLaunchKernelGGL((tree_top_kernel<512>), dim3((unsigned)cap_n, batch), dim3(512), 0, st, lvl, cnt, (u32)m, ps);
