@@ -476,7 +476,7 @@ def main():
                 from kernel_id import kernel_source_id
                 with open(os.path.join(ROOT, "profiles", "r03_mx_leaf_hash_counters.json")) as f:
                     lk = json.load(f)
-                if mx_on and lk.get("kernel_source_id") == kernel_source_id("hash"):
+                if mx_on and lk.get("kernel_source_id") == kernel_source_id("hash_mx"):
                     extra["poseidon_hashing"].update({k: lk[k] for k in ("valu_insts_per_permutation", "mfma_insts_per_permutation", "mfma_busy_frac") if k in lk})
                     extra["poseidon_hashing"]["counters_source"] = "profiles/r03_mx_leaf_hash_counters.json"
             except (OSError, KeyError, ValueError, ImportError):

@@ -12,7 +12,7 @@ QPGPU_MX=0 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_C
 cd $R
 python tools/pmc_db_summary.py _kernel $(find $O/p1 $O/p2 -name "*.db") > $O/mx.json
 python tools/pmc_db_summary.py _kernel $(find $O/p3 -name "*.db") > $O/tp.json
-python tools/kernel_id.py hash > $O/kernel_source_id.txt
+python tools/kernel_id.py hash_mx > $O/kernel_source_id.txt
 cat $O/mfma_counters.txt; python -c "
 import json; d=json.load(open('$O/mx.json'))
 for k,v in d.items():
