@@ -1,7 +1,8 @@
 """Randomised differential run: circuit shapes, gate mixes, FRI knobs, zero knowledge and witness hints drawn at random;
 GPU proof bytes against the CPU restatement, the restated verifier and the library's own host verifier, a lockstep batch of
 three against the single-proof bytes, and device witness generation against the full witness.
-usage: fuzz_shapes.py [cases] [seed] [max degree_bits]"""
+usage: fuzz_shapes.py [cases] [seed] [max degree_bits] [poseidon|poseidon2]   (last: the proof-system hasher; poseidon2 = qp-poseidon-core's
+parameters on the context, the process default and the oracle)"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -10,7 +11,14 @@ pkg = g.load_package()
 import oracle_binding
 from test_prove_gpu import _with_fri_config
 orc = oracle_binding.Oracle()
-gpu = pkg.QpGpu(0)
+hasher = sys.argv[4] if len(sys.argv) > 4 else "poseidon"
+if hasher == "poseidon2":
+    qp = pkg.poseidon2_qp_params()
+    pkg.set_hasher_poseidon2(*qp)      # the synthetic generator and the host verifier hash with the process default
+    orc.select_poseidon2(*qp)
+    gpu = pkg.QpGpu(0, hasher=qp)
+else:
+    gpu = pkg.QpGpu(0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 max_d = int(sys.argv[3]) if len(sys.argv) > 3 else 11
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -47,7 +55,7 @@ for i in range(cases):
     want = oc.prove(wires, pis, seed=7 + i)
     assert got == want, "BYTES DIFFER " + desc
     assert oc.verify(got) == 0, "REJECTED " + desc
-    ver = pkg.Verifier(pack, circuit=circ)
+    ver = pkg.Verifier(pack, circuit=circ, hasher=1 if hasher == "poseidon2" else 0)
     assert ver.verify(got), "LIBRARY VERIFIER REJECTED " + desc + " " + ver.reason
     bad = bytearray(got); bad[int(rng.integers(0, len(got)))] ^= 1 << int(rng.integers(0, 8))
     assert not ver.verify(bytes(bad)) and oc.verify(bytes(bad)) != 0, "TAMPERING ACCEPTED " + desc
@@ -73,4 +81,4 @@ for i in range(cases):
             assert pkg.load_library().qpgpu_poseidon2_hash_pad10(None, 0, x.ctypes.data if x.size else None, x.size, out.ctypes.data) == 0
             assert [int(full[c, r]) for c, r in dig] == [int(v) for v in out], "POSEIDON2 DIGEST DIFFERS " + desc
     circ.close(); oc.close()
-print(f"{cases} cases ok in {time.time()-t0:.1f} s (seed {sys.argv[2] if len(sys.argv) > 2 else 1}, max degree_bits {max_d}): " + ", ".join(f"{k} {v}" for k, v in tally.items()))
+print(f"{cases} cases ok under the {hasher} hasher in {time.time()-t0:.1f} s (seed {sys.argv[2] if len(sys.argv) > 2 else 1}, max degree_bits {max_d}): " + ", ".join(f"{k} {v}" for k, v in tally.items()))
