@@ -159,7 +159,7 @@ inline bool fill_tiles(const Rows &rw, int steps, unsigned char *tiles, unsigned
 // and left with `+ after` (the constants of the full round behind).
 struct Linear {
     u64 M[12][12], pre[12][12];
-    u64 c_lane0[22], cvec[12], after[12];
+    u64 rc[22][12], after[12];      // rc[k]: the constants added to the state before round k's S-box (all twelve lanes)
 };
 inline bool build_tables(const Linear &L, unsigned char *tab) {
     static u64 R[23][12], G[22], Q[22][12], NP[12][12];
@@ -181,6 +181,12 @@ inline bool build_tables(const Linear &L, unsigned char *tab) {
         for (int i = 0; i < 12; i++) for (int e = 0; e < 12; e++) { u64 a = 0; for (int j = 1; j < 12; j++) a = fadd(a, fmul(M[i][j], NP[j][e])); T[i][e] = a; }
         memcpy(NP, T, sizeof T);
     }
+    // additive parts: acc_k = what the constants of rounds < k have put into the state before round k (acc_0 = 0,
+    // acc_{k+1} = N (acc_k + rc_k)); round k's S-box input carries acc_k[0] + rc_k[0], the final state acc_22 + after
+    static u64 accv[23][12];
+    memset(accv, 0, sizeof accv);
+    for (int k = 0; k < 22; k++)
+        for (int i = 0; i < 12; i++) { u64 a = 0; for (int j = 1; j < 12; j++) a = fadd(a, fmul(M[i][j], fadd(accv[k][j], L.rc[k][j] % gl::P))); accv[k + 1][i] = a; }
     memset(tab, 0, TABLE_BYTES);
     for (int g = 0; g < N_GROUP; g++) {
         Rows rw{};
@@ -189,9 +195,7 @@ inline bool build_tables(const Linear &L, unsigned char *tab) {
             if (k >= 22) continue;                            // the last group has two rounds
             for (int e = 0; e < 12; e++) { u64 a = 0; for (int i = 0; i < 12; i++) a = fadd(a, fmul(R[k][i], L.pre[i][e])); rw.w[o][e] = a; }   // (e0^T N^k) pre
             for (int j = 0; j < 4 * g; j++) rw.w[o][12 + j] = G[k - 1 - j];
-            u64 a = L.c_lane0[k] % gl::P;
-            for (int e = 0; e < 12; e++) a = fadd(a, fmul(R[k][e], L.cvec[e]));
-            rw.addc[o] = a;
+            rw.addc[o] = fadd(accv[k][0], L.rc[k][0] % gl::P);
         }
         if (!fill_tiles(rw, group_steps(g), tab + (size_t)group_base(g) * 1024, tab + CINIT_OFF + g * 128)) return false;
     }
@@ -201,9 +205,7 @@ inline bool build_tables(const Linear &L, unsigned char *tab) {
             const int i = 4 * f + o;
             for (int e = 0; e < 12; e++) { u64 a = 0; for (int j = 0; j < 12; j++) a = fadd(a, fmul(NP[i][j], L.pre[j][e])); rw.w[o][e] = a; }   // N^22 pre
             for (int j = 0; j < 22; j++) rw.w[o][12 + j] = Q[21 - j][i];
-            u64 a = L.after[i] % gl::P;
-            for (int e = 0; e < 12; e++) a = fadd(a, fmul(NP[i][e], L.cvec[e]));
-            rw.addc[o] = a;
+            rw.addc[o] = fadd(accv[22][i], L.after[i] % gl::P);
         }
         if (!fill_tiles(rw, FIN_STEPS, tab + (size_t)(N_GROUP_TILES + f * FIN_STEPS) * 1024, tab + CINIT_OFF + (N_GROUP + f) * 128)) return false;
     }
@@ -215,12 +217,22 @@ inline bool build_tables(const u64 *rc, unsigned char *tab) {
     static Linear L;
     memset(&L, 0, sizeof L);
     for (int r = 0; r < 12; r++) for (int j = 0; j < 12; j++) L.M[r][j] = L.pre[r][j] = mds_entry(r, j);
-    for (int k = 0; k < 22; k++) L.c_lane0[k] = rc[(4 + k) * 12];
-    for (int i = 1; i < 12; i++) L.cvec[i] = rc[4 * 12 + i];
+    for (int k = 0; k < 22; k++) L.rc[k][0] = rc[(4 + k) * 12];
+    for (int i = 1; i < 12; i++) L.rc[0][i] = rc[4 * 12 + i];
     for (int i = 0; i < 12; i++) L.after[i] = rc[26 * 12 + i];
     if (!build_tables(L, tab)) return false;
     u64 g[3]; memcpy(g, tab + G_OFF, sizeof g);
     return g[0] == G0 && g[1] == G1 && g[2] == G2;            // the device code has them as immediates
+}
+// plonky2's PoseidonGate (quotient kernel): the same matrices with the PLAIN round constants (ALL_ROUND_CONSTANTS: twelve lanes in
+// every partial round), as the gate's constraints are written against the textbook schedule; rcp: poseidon::host_round_constants()
+inline bool build_tables_gate(const u64 *rcp, unsigned char *tab) {
+    static Linear L;
+    memset(&L, 0, sizeof L);
+    for (int r = 0; r < 12; r++) for (int j = 0; j < 12; j++) L.M[r][j] = L.pre[r][j] = mds_entry(r, j);
+    for (int k = 0; k < 22; k++) for (int i = 0; i < 12; i++) L.rc[k][i] = rcp[(4 + k) * 12 + i];
+    for (int i = 0; i < 12; i++) L.after[i] = rcp[26 * 12 + i];
+    return build_tables(L, tab);
 }
 // qp-poseidon-core's Poseidon2 (poseidon2::permute_qp): internal layer J + diag, the external layer before it folded in; both
 // matrices are read off the layer functions themselves (columns = images of the unit vectors)
@@ -233,7 +245,7 @@ inline bool build_tables_p2(const poseidon2::Params &p, unsigned char *tab) {
         poseidon2::int_layer(e, p); poseidon2::ext_layer_qp(f);
         for (int i = 0; i < 12; i++) { L.M[i][j] = gl::canon(e[i]); L.pre[i][j] = gl::canon(f[i]); }
     }
-    for (int k = 0; k < 22; k++) L.c_lane0[k] = p.rc_int[k];
+    for (int k = 0; k < 22; k++) L.rc[k][0] = p.rc_int[k];
     for (int i = 0; i < 12; i++) L.after[i] = p.rc_ext[4 * 12 + i];
     return build_tables(L, tab);
 }
@@ -278,6 +290,26 @@ inline bool emu_partial_rounds(u64 (&s)[12], const unsigned char *tab) {
         if (!emu_gemm(tab, N_GROUP_TILES + f * FIN_STEPS, N_GROUP + f, FIN_STEPS, D, Z)) return false;
         for (int o = 0; o < 4; o++) s[4 * f + o] = recombine(Z[o]);
     }
+    return true;
+}
+// textbook permutation (plain constants) through the gate table: what the PoseidonGate kernel's matrix form computes when every
+// S-box input equals its wire (a satisfied row)
+inline bool emu_permute_textbook(u64 (&s)[12], const u64 *rcp, const unsigned char *tab) {
+    using namespace poseidon;
+    int r = 0;
+    for (int k = 0; k < HALF_FULL; k++, r++) {
+        for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add_canonical(s[i], rcp[r * WIDTH + i]));
+        if (k + 1 < HALF_FULL) mds_layer(s);
+    }
+    if (!emu_partial_rounds(s, tab)) return false;
+    r += 1 + PARTIAL;
+    for (int i = 0; i < WIDTH; i++) s[i] = sbox7(s[i]);
+    mds_layer(s);
+    for (int k = 1; k < HALF_FULL; k++, r++) {
+        for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add_canonical(s[i], rcp[r * WIDTH + i]));
+        mds_layer(s);
+    }
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
     return true;
 }
 inline bool emu_permute(u64 (&s)[12], const u64 *rc, const unsigned char *tab) {
@@ -337,18 +369,26 @@ inline bool selfcheck_with(F plain, Gf emu, int n) {
 inline bool selfcheck(const u64 *rc, const unsigned char *tab, int n = 2000) {
     return selfcheck_with([&](u64 (&s)[12]) { poseidon::permute(s, rc); }, [&](u64 (&s)[12]) { return emu_permute(s, rc, tab); }, n);
 }
+inline bool selfcheck_gate(const u64 *rcp, const unsigned char *tab, int n = 2000) {
+    return selfcheck_with([&](u64 (&s)[12]) { for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]); poseidon::permute_textbook(s, rcp); },
+                          [&](u64 (&s)[12]) { for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]); return emu_permute_textbook(s, rcp, tab); }, n);
+}
 inline bool selfcheck_p2(const poseidon2::Params &p, const unsigned char *tab, int n = 2000) {
     return selfcheck_with([&](u64 (&s)[12]) { poseidon2::permute_qp(s, p); }, [&](u64 (&s)[12]) { return emu_permute_p2(s, p, tab); }, n);
 }
 }  // namespace host
 inline bool build_tables(const u64 *rc, unsigned char *tab) { return host::build_tables(rc, tab); }
 inline bool host_selfcheck(const u64 *rc, const unsigned char *tab, int n = 2000) { return host::selfcheck(rc, tab, n); }
+inline bool build_tables_gate(const u64 *rcp, unsigned char *tab) { return host::build_tables_gate(rcp, tab); }
+inline bool host_selfcheck_gate(const u64 *rcp, const unsigned char *tab, int n = 2000) { return host::selfcheck_gate(rcp, tab, n); }
 inline bool build_tables_p2(const poseidon2::Params &p, unsigned char *tab) { return host::build_tables_p2(p, tab); }
 inline bool host_selfcheck_p2(const poseidon2::Params &p, const unsigned char *tab, int n = 2000) { return host::selfcheck_p2(p, tab, n); }
 #else
 bool build_tables(const u64 *, unsigned char *);          // host functions: declared only in the device pass
 bool host_selfcheck(const u64 *, const unsigned char *, int n = 2000);
 bool build_tables_p2(const poseidon2::Params &, unsigned char *);
+bool build_tables_gate(const u64 *, unsigned char *);
+bool host_selfcheck_gate(const u64 *, const unsigned char *, int n = 2000);
 bool host_selfcheck_p2(const poseidon2::Params &, const unsigned char *, int n = 2000);
 #endif
 
@@ -398,8 +438,11 @@ __device__ __forceinline__ void gemm(const Run &st, int tile0, int cidx, u32 (&Z
         Z[i >> 3][i & 7] = x; Z[2 + (i >> 3)][i & 7] = yv;
     }
 }
-template <int G, bool SMALL_G>
-__device__ __forceinline__ void group_step(Run &st) {
+// what a round does with its S-box input: the permutation sends it through the S-box; a gate's quotient kernel compares it with
+// the wire that holds it and sends the WIRE through (poseidon quotient kernels)
+struct SboxOfInput { __device__ __forceinline__ u64 operator()(int, u64 x) const { return poseidon::sbox7_lane(x); } };
+template <int G, bool SMALL_G, class F>
+__device__ __forceinline__ void group_step(Run &st, F &f) {
     u32 Z[4][LIMBS];
     gemm<group_steps(G)>(st, group_base(G), G, Z);
     constexpr int n = 4 * G + 4 <= 22 ? 4 : 22 - 4 * G;
@@ -410,7 +453,7 @@ __device__ __forceinline__ void group_step(Run &st) {
         constexpr u32 Gc[3] = {G0, G1, G2};
 #pragma unroll
         for (int j = 4 * G; j < k; j++) x = gl::add(x, SMALL_G ? mul_small(st.y[j], Gc[k - 1 - j]) : gl::mul(st.y[j], st.Gd[k - 1 - j]));
-        st.y[k] = poseidon::sbox7_lane(x);
+        st.y[k] = f(k, x);
     }
 #pragma unroll
     for (int o = 0; o < n; o++) {
@@ -419,13 +462,13 @@ __device__ __forceinline__ void group_step(Run &st) {
     }
     form_step(st, 3 + G);
 }
-template <bool SMALL_G, int... G>
-__device__ __forceinline__ void all_groups(Run &st, std::integer_sequence<int, G...>) { (group_step<G, SMALL_G>(st), ...); }
+template <bool SMALL_G, class F, int... G>
+__device__ __forceinline__ void all_groups(Run &st, F &f, std::integer_sequence<int, G...>) { (group_step<G, SMALL_G>(st, f), ...); }
 
 // s: the S-box outputs of the fourth full round (its MDS layer is part of the matrix) -> the state the S-box layer of the first
 // closing full round applies to (that round's constants are already in)
-template <bool SMALL_G = true>
-__device__ __forceinline__ void partial_rounds(u64 (&s)[12], const unsigned char *lds) {
+template <bool SMALL_G, class F>
+__device__ __forceinline__ void partial_rounds(u64 (&s)[12], const unsigned char *lds, F &f) {
     Run st;
     st.lds = lds;
     if (!SMALL_G) {
@@ -441,7 +484,7 @@ __device__ __forceinline__ void partial_rounds(u64 (&s)[12], const unsigned char
         st.Dlo[e] = (u32)t; st.Dhi[e] = (u32)(t >> 32);
     }
     form_step(st, 0); form_step(st, 1); form_step(st, 2);
-    all_groups<SMALL_G>(st, std::make_integer_sequence<int, N_GROUP>{});
+    all_groups<SMALL_G>(st, f, std::make_integer_sequence<int, N_GROUP>{});
 #pragma unroll
     for (int f = 0; f < N_FIN; f++) {
         u32 Z[4][LIMBS];
@@ -462,7 +505,8 @@ __device__ __forceinline__ void permute_head(u64 (&s)[12], const u64 *rc, const 
         sbox7_layer(s);
         if (k + 1 < HALF_FULL) mds_layer(s);
     }
-    partial_rounds<true>(s, lds);
+    SboxOfInput f;
+    partial_rounds<true>(s, lds, f);
 }
 __device__ __forceinline__ void permute_tail(u64 (&s)[12], const u64 *rc) {
     using namespace poseidon;
@@ -492,7 +536,8 @@ __device__ __forceinline__ void permute_p2qp(u64 (&s)[12], const poseidon2::Para
         poseidon::sbox7_layer(s);
         if (r < 3) poseidon2::ext_layer_qp(s);
     }
-    partial_rounds<false>(s, lds);
+    SboxOfInput f;
+    partial_rounds<false>(s, lds, f);
     poseidon::sbox7_layer(s);
     poseidon2::ext_layer_qp(s);
     for (int r = 5; r < 8; r++) {
@@ -509,6 +554,7 @@ __device__ void permute(u64 (&s)[12], const u64 *rc, const unsigned char *lds); 
 __device__ void permute_head(u64 (&s)[12], const u64 *rc, const unsigned char *lds);
 __device__ void permute_tail(u64 (&s)[12], const u64 *rc);
 __device__ void permute_p2qp(u64 (&s)[12], const poseidon2::Params &p, const unsigned char *lds);
+template <bool SMALL_G, class F> __device__ void partial_rounds(u64 (&)[12], const unsigned char *, F &) {}   // body: device pass only
 #endif
 
 }  // namespace pmf

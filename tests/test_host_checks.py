@@ -15,4 +15,4 @@ def test_shared_arithmetic_on_the_host(tmp_path):
                            os.path.join(csrc, "poseidon_constants.cpp"), "-o", exe, "-lpthread"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("mismatches 0") == 5, r.stdout
+    assert r.stdout.count("mismatches 0") == 6, r.stdout

@@ -116,4 +116,14 @@ int check_matrix_form_p2() {
     printf("Poseidon2 matrix form of the internal rounds: mismatches %d\n", bad);
     return bad;
 }
-int main() { return (check_poseidon() | check_poseidon2() | check_acc() | check_matrix_form() | check_matrix_form_p2()) != 0; }
+// the table with the PLAIN round constants (twelve lanes in every partial round: the schedule PoseidonGate's constraints are written
+// against) against the textbook permutation, through the generic builder
+int check_matrix_form_gate() {
+    const u64 *rcp = poseidon::host_round_constants();
+    std::vector<unsigned char> tab(pmf::TABLE_BYTES);
+    if (!pmf::build_tables_gate(rcp, tab.data())) { printf("gate table: construction failed\n"); return 1; }
+    const int bad = pmf::host_selfcheck_gate(rcp, tab.data(), 5000) ? 0 : 1;
+    printf("matrix form with the plain round constants (gate table): mismatches %d\n", bad);
+    return bad;
+}
+int main() { return (check_poseidon() | check_poseidon2() | check_acc() | check_matrix_form() | check_matrix_form_p2() | check_matrix_form_gate()) != 0; }
