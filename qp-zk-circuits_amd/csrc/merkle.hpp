@@ -27,6 +27,7 @@ struct MerkleLeafArgs {
 
 uint64_t qpgpu_tp_min_threads();   // launches at least this large take the throughput build of a hashing kernel (merkle_kernels.hip)
 hipError_t merkle_upload_constants(const uint64_t *rc360);   // plonky2 Poseidon round constants, once per device
+bool merkle_mx_in_use();                                      // false under QPGPU_MX=0
 hipError_t merkle_upload_p2_tables(const poseidon2::Params &qp);   // matrix-form table of qp-poseidon-core's Poseidon2, once per device
 hipError_t merkle_leaf_hash(const MerkleLeafArgs &a, const HasherDev &h, hipStream_t st);
 hipError_t merkle_leaf_hash_rows(const uint64_t *rows, uint64_t n_leaves, uint32_t width, uint64_t *digests, uint32_t batch, uint64_t ps_rows, uint64_t ps_digests,

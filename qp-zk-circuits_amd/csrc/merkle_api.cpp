@@ -24,7 +24,7 @@ int merkle_ensure_constants(qpgpu_ctx *ctx) {
             QP_HIP(ctx, merkle_upload_constants(poseidon::host_hash_round_constants()));
             uploaded[dev] = true;
         }
-        if (ctx->hasher.kind == hasher::POSEIDON2 && ctx->hasher_is_qp() && !uploaded_p2[dev]) {
+        if (ctx->hasher.kind == hasher::POSEIDON2 && ctx->hasher_is_qp() && !uploaded_p2[dev] && merkle_mx_in_use()) {
             QP_HIP(ctx, merkle_upload_p2_tables(poseidon2::qp_params()));
             uploaded_p2[dev] = true;
         }

@@ -65,10 +65,12 @@ static inline bool tput(u32 batch) { return batch >= tput_batch(); }
 static inline u64 coop_max_for(u32 batch) { return tput(batch) ? 0 : COOP_MAX; }
 static inline u64 tp_min_for(u32 batch) { return tput(batch) ? 0 : qpgpu_tp_min_threads(); }
 
+bool merkle_mx_in_use() { return mx_enabled(); }
 hipError_t merkle_upload_constants(const u64 *rc360) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
     if (e == hipSuccess) e = merkle_tp_upload_constants(rc360);
-    return e != hipSuccess ? e : merkle_mx_upload_constants(rc360);
+    if (e != hipSuccess || !mx_enabled()) return e;       // QPGPU_MX=0: no matrix build, no table, no device self-test
+    return merkle_mx_upload_constants(rc360);
 }
 
 #include "merkle_hash_impl.hpp"

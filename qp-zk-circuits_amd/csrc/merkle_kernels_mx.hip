@@ -125,6 +125,19 @@ MX_KERNEL pow_kernel(PowArgs a, const poseidon2::Params *p2) {
     Perm::permute(s, p2, lds);
     if (idx < a.count && (s[7] >> (64 - a.pow_bits)) == 0) atomicMin((unsigned long long *)&a.results[pr], (unsigned long long)nonce);
 }
+
+// device self-test (below): one permutation per thread
+template <class Perm>
+MX_KERNEL selftest_kernel(u64 *states, const poseidon2::Params *p2) {
+    const unsigned char *lds = table_to_lds<Perm>();
+    const u64 t = blockIdx.x * (u64)WG + threadIdx.x;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = states[t * 12 + i];
+    Perm::permute(s, p2, lds);
+#pragma unroll
+    for (int i = 0; i < 12; i++) states[t * 12 + i] = s[i];
+}
 }  // namespace mx
 
 template <class Perm>
@@ -134,6 +147,46 @@ static hipError_t allow_table_in_lds() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)mx::pow_kernel<Perm>, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
     return e;
 }
+// Once per device, right after a table has been uploaded: four workgroups of the matrix-build permutation (eight waves each, two
+// per SIMD: the occupancy at which a mis-scheduled MFMA destination shows, poseidon_mfma.hpp) on 2 048 fixed states incl. extremes,
+// against the plain permutation on the host. A mismatch fails the context's set-up with hipErrorAssert instead of letting a
+// platform on which the matrix form misbehaves hash anything (QPGPU_MX=0 runs without the matrix build and without this test).
+template <class Perm, class HostPerm>
+static hipError_t device_selftest(HostPerm host_perm, const poseidon2::Params *host_p2) {
+    constexpr int N = 4 * mx::WG;
+    std::vector<u64> in((size_t)N * 12), out((size_t)N * 12);
+    u64 seed = 0x9E3779B97F4A7C15ull;
+    for (int t = 0; t < N; t++)
+        for (int i = 0; i < 12; i++) {
+            seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+            u64 v = (seed ^ (seed >> 31)) % gl::P;
+            if (t % 9 == 0) v = (i & 1) ? gl::P - 1 - (v & 3) : (v & 7);
+            in[(size_t)t * 12 + i] = v;
+        }
+    u64 *d = nullptr; poseidon2::Params *dp = nullptr; hipStream_t st = nullptr;
+    hipError_t e = hipMalloc((void **)&d, in.size() * 8);
+    if (e == hipSuccess && host_p2) { e = hipMalloc((void **)&dp, sizeof *host_p2); if (e == hipSuccess) e = hipMemcpy(dp, host_p2, sizeof *host_p2, hipMemcpyHostToDevice); }
+    if (e == hipSuccess) e = hipMemcpy(d, in.data(), in.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)mx::selftest_kernel<Perm>, hipFuncAttributeMaxDynamicSharedMemorySize, pmf::TABLE_BYTES);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mx::selftest_kernel<Perm>, dim3(N / mx::WG), dim3(mx::WG), pmf::TABLE_BYTES, st, d, dp);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out.data(), d, out.size() * 8, hipMemcpyDeviceToHost);
+    if (st) (void)hipStreamDestroy(st);
+    if (d) (void)hipFree(d);
+    if (dp) (void)hipFree(dp);
+    if (e != hipSuccess) return e;
+    for (int t = 0; t < N; t++) {
+        u64 s[12];
+        for (int i = 0; i < 12; i++) s[i] = in[(size_t)t * 12 + i];
+        host_perm(s);
+        for (int i = 0; i < 12; i++) if (s[i] != out[(size_t)t * 12 + i]) return hipErrorAssert;
+    }
+    return hipSuccess;
+}
 // The tables are functions of the round constants. Before anything is uploaded, the integer emulation of the device schedule
 // (same table bytes, same recombination code) is held against the plain permutation on the host.
 hipError_t merkle_mx_upload_constants(const u64 *rc360) {
@@ -142,13 +195,15 @@ hipError_t merkle_mx_upload_constants(const u64 *rc360) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(mx::c_poseidon_rc), rc360, sizeof(u64) * poseidon::ROUNDS * poseidon::WIDTH);
     if (e != hipSuccess) return e;
     e = hipMemcpyToSymbol(HIP_SYMBOL(mx::g_table), tab.data(), pmf::TABLE_BYTES);
-    return e != hipSuccess ? e : allow_table_in_lds<mx::PoseidonV1>();
+    if (e == hipSuccess) e = allow_table_in_lds<mx::PoseidonV1>();
+    return e != hipSuccess ? e : device_selftest<mx::PoseidonV1>([&](u64 (&s)[12]) { poseidon::permute(s, rc360); }, nullptr);
 }
 hipError_t merkle_upload_p2_tables(const poseidon2::Params &qp) {
     std::vector<unsigned char> tab(pmf::TABLE_BYTES);
     if (!pmf::build_tables_p2(qp, tab.data()) || !pmf::host_selfcheck_p2(qp, tab.data(), 64)) return hipErrorInvalidValue;
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(mx::g_table_p2), tab.data(), pmf::TABLE_BYTES);
-    return e != hipSuccess ? e : allow_table_in_lds<mx::Poseidon2QP>();
+    if (e == hipSuccess) e = allow_table_in_lds<mx::Poseidon2QP>();
+    return e != hipSuccess ? e : device_selftest<mx::Poseidon2QP>([&](u64 (&s)[12]) { poseidon2::permute(s, qp); }, &qp);
 }
 hipError_t merkle_mx_leaves(const MerkleLeafArgs &a, u64 total, const HasherDev &h, hipStream_t st) {
     const u64 blocks = (total + mx::WG - 1) / mx::WG;
