@@ -81,4 +81,6 @@ for i in range(cases):
             assert pkg.load_library().qpgpu_poseidon2_hash_pad10(None, 0, x.ctypes.data if x.size else None, x.size, out.ctypes.data) == 0
             assert [int(full[c, r]) for c, r in dig] == [int(v) for v in out], "POSEIDON2 DIGEST DIFFERS " + desc
     circ.close(); oc.close()
+    if (i + 1) % 100 == 0:
+        print(f"  {i + 1} cases so far, {time.time()-t0:.0f} s", flush=True)
 print(f"{cases} cases ok under the {hasher} hasher in {time.time()-t0:.1f} s (seed {sys.argv[2] if len(sys.argv) > 2 else 1}, max degree_bits {max_d}): " + ", ".join(f"{k} {v}" for k, v in tally.items()))
