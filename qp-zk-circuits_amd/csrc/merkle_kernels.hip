@@ -55,7 +55,7 @@ static const u64 COOP_MAX = coop_max_init();
 // Lockstep batches of QPGPU_TPUT_BATCH trees or more (default 8) are throughput work: the device is shared by several such batches
 // and what counts is the work a level costs, not how soon it ends. They skip the lane-cooperative kernels (about 3x the work per
 // hash) and the fused tree top, and run every level on the large-launch builds (thread per hash; matrix-pipe build where it serves
-// the hasher). Measured with six workers x 32 proofs: 2^13-row circuits + 1 %, 2^11-row circuits + 37 % (profiles/r03_poseidon_mfma.txt
+// the hasher). Measured with six workers x 32 proofs: + 1 % on 2^13- and 2^12-row circuits (profiles/r03_poseidon_mfma.txt
 // item 11). Single proofs and small batches keep the latency-oriented routing.
 static u32 tput_batch() {
     static const u32 v = [] { const char *e = getenv("QPGPU_TPUT_BATCH"); return e && *e ? (u32)strtoul(e, nullptr, 10) : 8u; }();
