@@ -396,22 +396,23 @@ GL_HD void int_layer(u64 (&s)[12], const Params &p) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::add(gl::mul(s[i], p.diag_m1[i]), sum);
 }
-// qp-poseidon-core's permutation: p must be qp_params() (only the round constants and the diagonal are read from it)
+// qp-poseidon-core's permutation: p must be qp_params() (only the round constants and the diagonal are read from it; they are
+// canonical, so adding them needs one carry fold)
 GL_HD void permute_qp(u64 (&s)[12], const Params &p) {
     ext_layer_qp(s);
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], p.rc_ext[r * 12 + i]);
+        for (int i = 0; i < 12; i++) s[i] = gl::add_canonical(s[i], p.rc_ext[r * 12 + i]);
         poseidon::sbox7_layer(s);
         ext_layer_qp(s);
     }
     for (int r = 0; r < 22; r++) {
-        s[0] = poseidon::sbox7_lane(gl::add(s[0], p.rc_int[r]));
+        s[0] = poseidon::sbox7_lane(gl::add_canonical(s[0], p.rc_int[r]));
         int_layer(s, p);
     }
     for (int r = 4; r < 8; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], p.rc_ext[r * 12 + i]);
+        for (int i = 0; i < 12; i++) s[i] = gl::add_canonical(s[i], p.rc_ext[r * 12 + i]);
         poseidon::sbox7_layer(s);
         ext_layer_qp(s);
     }

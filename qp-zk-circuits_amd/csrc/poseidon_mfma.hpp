@@ -532,7 +532,7 @@ __device__ __forceinline__ void permute_p2qp(u64 (&s)[12], const poseidon2::Para
     poseidon2::ext_layer_qp(s);
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], p.rc_ext[r * 12 + i]);
+        for (int i = 0; i < 12; i++) s[i] = gl::add_canonical(s[i], p.rc_ext[r * 12 + i]);   // the block's constants are canonical (parse_p2, qp_params)
         poseidon::sbox7_layer(s);
         if (r < 3) poseidon2::ext_layer_qp(s);
     }
@@ -542,7 +542,7 @@ __device__ __forceinline__ void permute_p2qp(u64 (&s)[12], const poseidon2::Para
     poseidon2::ext_layer_qp(s);
     for (int r = 5; r < 8; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], p.rc_ext[r * 12 + i]);
+        for (int i = 0; i < 12; i++) s[i] = gl::add_canonical(s[i], p.rc_ext[r * 12 + i]);   // the block's constants are canonical (parse_p2, qp_params)
         poseidon::sbox7_layer(s);
         poseidon2::ext_layer_qp(s);
     }
