@@ -174,6 +174,45 @@ int qpgpu_zk_proof_from_unsorted(const uint8_t leaf_hash[32], const uint8_t *uns
  * negative tests observe as a failed prove), -1 for malformed inputs (as qpgpu_leaf_fill_witness). */
 int qpgpu_leaf_check_constraints(const qpgpu_leaf_inputs *in, char *err);
 
+/* ---- the leaf circuit itself, natively ----
+ * WormholeCircuit::new(wormhole_leaf_circuit_config()) + build_prover() (wormhole/circuit/src/circuit.rs:115-152,210-212),
+ * restated statement by statement on a native restatement of plonky2's CircuitBuilder (qp-zk-circuits_amd/csrc/builder.hpp,
+ * leaf_circuit.cpp): the five fragments' targets in CircuitTargets::new's order (= the 21 public inputs' order), the
+ * unspendable-account double hash, the 32 / 14 / 48-bit range checks and the fee relation, the leaf hash, the depth bound, the
+ * 16-level 4-ary Merkle walk over position hints and selects, the block-number range check, and connect_shared_targets
+ * (shared secret / transfer count / account, the in-circuit dummy flag, the conditional nullifier / block-hash / tree-root
+ * bindings). Host only. Output: a circuit pack for qpgpu_circuit_load* and target_map_out[QPGPU_LT_COUNT] = the wire cell
+ * (row * num_wires + wire) of every logical target above, for qpgpu_leaf_map_targets / qpgpu_leaf_commit.
+ *   min_degree_bits: NoopGate padding up to 2^min_degree_bits rows (0: the next power of two above the gates used);
+ *   inner_hasher: 0 Poseidon, 1 Poseidon2 — the gate the public-input hash is built from; must be the hasher of the context
+ *     that proves (qpgpu_ctx_set_hasher; for Poseidon2: qp-poseidon-core's parameter set, which is also the gate's);
+ *   p2_layout: the ten words of the pack trailer "P2GL1" (csrc/circuit.hpp), NULL = the default layout. LAYOUT UNPINNED.
+ * What cannot match the fork offline: the order in which qp-plonky2's builder lays gates out, its Poseidon2 sponge wiring and its
+ * circuit_digest (here: a hash of the pack's contents). The STATEMENT proven and the gate set are the reference's; the verifier
+ * data are this builder's.
+ * info_out (QPGPU_LEAF_CIRCUIT_INFO_WORDS words, may be NULL): degree_bits, rows before padding, gates after target creation,
+ * gates added by UnspendableAccount::circuit, by ZkMerkleProofData::circuit, by the block-number range check, by
+ * connect_shared_targets (the reference's GateProfiler checkpoints, wormhole/circuit/src/profile.rs), then rows of
+ * ArithmeticGate, BaseSumGate, Poseidon2 gate, PoseidonGate, ConstantGate, PublicInputGate, NoopGate, free-standing generators,
+ * selector polynomials.
+ * Call with pack_out = NULL to learn the size. Returns 0, or a qpgpu.h error code with a message in err. */
+#define QPGPU_LEAF_CIRCUIT_INFO_WORDS 16
+/* fragment: the whole WormholeCircuit, or one CircuitFragment composed alone with its unconditional binding, the way the
+ * reference's fragment tests build them (wormhole/tests/src/circuit/block_header_tests.rs:8-19, unspendable_account_tests.rs:26-40,
+ * nullifier_tests.rs): BlockHeader::circuit (public inputs: block_hash x4, block_number), UnspendableAccount::circuit (none),
+ * Nullifier::circuit (hash x4). Logical targets a fragment does not have map to UINT64_MAX. */
+#define QPGPU_LEAF_FRAGMENT_FULL 0u
+#define QPGPU_LEAF_FRAGMENT_BLOCK_HEADER 1u
+#define QPGPU_LEAF_FRAGMENT_UNSPENDABLE_ACCOUNT 2u
+#define QPGPU_LEAF_FRAGMENT_NULLIFIER 3u
+int qpgpu_leaf_circuit_build(unsigned fragment, unsigned min_degree_bits, int inner_hasher, const uint64_t *p2_layout, uint64_t *pack_out, size_t pack_cap_words,
+                             size_t *pack_words, uint64_t *target_map_out, uint64_t *info_out, char *err);
+/* WormholeProver::commit (wormhole/prover/src/lib.rs:156-163) against such a circuit: qpgpu_leaf_fill_witness followed by
+ * qpgpu_leaf_map_targets. cells_out / values_out (room for QPGPU_LT_COUNT) are what qpgpu_generate_witness_partial_dev and
+ * qpgpu_pool_submit_partial take. Returns 0 or -1 with the reference's message in err. */
+int qpgpu_leaf_commit(const qpgpu_leaf_inputs *in, const uint64_t *target_map, uint64_t *cells_out, uint64_t *values_out, size_t cap,
+                      size_t *count, uint64_t public_inputs_out[QPGPU_LEAF_PUBLIC_INPUTS], char *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,3 +13,4 @@ from .binding import pack_header, pack_public_input_cells, Verifier, poseidon2_q
 from .binding import pack_p2_layout, pack_trailers, p2_site_cells, P2_NO_SWAP  # noqa: F401
 from . import sharding  # noqa: F401,E402
 from . import aggregation  # noqa: F401,E402
+from . import leaf  # noqa: F401,E402

@@ -86,6 +86,9 @@ class Oracle:
         L.orc_bytes_to_u64s.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         L.orc_bytes_to_digest.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
         L.orc_digest_to_bytes.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.orc_generate_witness.restype = ctypes.c_int
+        L.orc_generate_witness.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         L.orc_set_threads(usable_cpus())
 
     def select_poseidon2(self, rc_ext, rc_int, diag_m1, m4):
@@ -100,6 +103,19 @@ class Oracle:
         self.lib.orc_select_hasher_p2(None); self._p2 = None
     def set_threads(self, n): self.lib.orc_set_threads(int(n))
     def max_threads(self): return int(self.lib.orc_max_threads())
+
+    # ---- stage s1: generate_partial_witness over a pack (oracle/witness.c) ----
+    WIT_OK, WIT_CONFLICT, WIT_INCOMPLETE, WIT_UNSUPPORTED, WIT_BAD_PACK = 0, 1, 2, 3, 4
+    def generate_witness(self, pack_words, cells, values, public_inputs):
+        """(rc, wires[num_wires, n], conflict_cell): rc 0 = every generator ran, 1 = a target was set twice with different values
+        (conflict_cell = row * num_wires + wire), 2 = generators left waiting for unset targets."""
+        pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
+        nw, n = int(pw[2]), 1 << int(pw[1])
+        c = np.ascontiguousarray(cells, dtype=np.uint64); v = np.ascontiguousarray(values, dtype=np.uint64)
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        wires = np.zeros((nw, n), dtype=np.uint64); bad = ctypes.c_uint64()
+        rc = self.lib.orc_generate_witness(_vp(pw), pw.size, _vp(c), _vp(v), c.size, _vp(p), _vp(wires), ctypes.byref(bad))
+        return rc, wires, bad.value
 
     # ---- field ----
     def mul(self, a, b): return self.lib.orc_gl_mul(a, b)
