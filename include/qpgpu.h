@@ -219,6 +219,20 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
  * (wormhole/tests/src/circuit/block_header_tests.rs:34-95, nullifier_tests.rs:53-58). Unassigned free cells stay zero. */
 int qpgpu_generate_witness_partial_dev(qpgpu_circuit *c, const uint64_t *cells, const uint64_t *values, size_t count,
                                        const uint64_t *public_inputs, uint64_t *d_wires);
+/* `batch` PartialWitnesses over the SAME cell list at once (every proof of one circuit assigns the same targets: the 299 of
+ * wormhole/prover/src/lib.rs:187-221): values is batch x count, public_inputs batch x num_public_inputs, d_wires batch wire
+ * matrices back to back. The cell list is resolved against the circuit once and kept (copy classes, which assignments seed a
+ * free class and which land in a generated one); per call the values go up in one piece, the dependency levels are walked
+ * once for all witnesses, and one read-back tells which witnesses had a target set twice with different values — a caller's
+ * assignment against a generated value, two assignments of one class, or two generators of one class that disagree (plonky2
+ * allows several generators per partition as long as they agree: `connect(computed, claimed)`). status (may be NULL): per
+ * witness QPGPU_OK or QPGPU_EUNSAT; the return value is QPGPU_EUNSAT when any witness failed, with the first one's target
+ * in qpgpu_last_error. */
+int qpgpu_generate_witness_partial_batch_dev(qpgpu_circuit *c, const uint64_t *cells, size_t count, const uint64_t *values,
+                                             const uint64_t *public_inputs, uint32_t batch, uint64_t *d_wires, int *status);
+/* Resolve a cell list and size every buffer for up to max_batch witnesses now (on the loading thread), so that the generate
+ * calls themselves neither allocate nor free. Optional: the generate calls do it on first use. */
+int qpgpu_witness_partial_prepare(qpgpu_circuit *c, const uint64_t *cells, size_t count, uint32_t max_batch);
 
 /* ---- stage-level entry points: the circuit-independent parts of prove() ---------------------------------------
  * For a patched `qp-plonky2::plonk::prover::prove` that keeps witness generation, partial products and the quotient

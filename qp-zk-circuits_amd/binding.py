@@ -105,6 +105,8 @@ def load_library():
         "qpgpu_generate_witness": (c.c_int, [vp, u64p, u64p]),
         "qpgpu_generate_witness_batch_dev": (c.c_int, [vp, u64p, c.c_uint32, u64p]),
         "qpgpu_generate_witness_partial_dev": (c.c_int, [vp, u64p, u64p, c.c_size_t, u64p, u64p]),
+        "qpgpu_generate_witness_partial_batch_dev": (c.c_int, [vp, u64p, c.c_size_t, u64p, u64p, c.c_uint32, u64p, vp]),
+        "qpgpu_witness_partial_prepare": (c.c_int, [vp, u64p, c.c_size_t, c.c_uint32]),
         "qpgpu_oracle_commit": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint32,
                                           c.POINTER(vp)]),
         "qpgpu_oracle_free": (None, [vp]),
@@ -393,6 +395,23 @@ class Circuit:
         p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         self.gpu._check(self.gpu.lib.qpgpu_generate_witness_partial_dev(self.h, cl.ctypes.data, vl.ctypes.data, cl.size,
                                                                         p.ctypes.data, _ptr(d_wires)))
+
+    def generate_witness_partial_batch_dev(self, cells, values, public_inputs, d_wires):
+        """`batch` PartialWitnesses over one cell list: values [batch, count], public_inputs [batch, num_pis], d_wires batch
+        matrices back to back. Returns the per-witness status list (0 or -4); never raises for an unsatisfied witness."""
+        cl = np.ascontiguousarray(cells, dtype=np.uint64); vl = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, cl.size)
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        batch = vl.shape[0]
+        status = (ctypes.c_int * batch)()
+        rc = self.gpu.lib.qpgpu_generate_witness_partial_batch_dev(self.h, cl.ctypes.data, cl.size, vl.ctypes.data, p.ctypes.data, batch,
+                                                                   _ptr(d_wires), status)
+        if rc not in (0, -4):
+            self.gpu._check(rc)
+        return list(status)
+
+    def witness_partial_prepare(self, cells, max_batch):
+        cl = np.ascontiguousarray(cells, dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_witness_partial_prepare(self.h, cl.ctypes.data, cl.size, max_batch))
 
     def prove(self, wires, public_inputs):
         """wires: host array [num_wires, n]; returns proof bytes."""
@@ -729,6 +748,9 @@ class QpGpu(_Stage3):
     def _check(self, rc):
         if rc != 0:
             raise QpGpuError(rc, self.lib.qpgpu_last_error(self.ctx).decode())
+
+    def last_error(self):
+        return self.lib.qpgpu_last_error(self.ctx).decode()
 
     def sync(self):
         self._check(self.lib.qpgpu_sync(self.ctx))

@@ -390,7 +390,31 @@ __global__ void __launch_bounds__(256) witness_gather_kernel(const u64 *wires, c
     if (i < count) out[i] = gl::canon(wires[idx[i]]);
 }
 
+// a partition set twice (see witness.hpp)
+__global__ void __launch_bounds__(256) witness_check_pairs_kernel(const u64 *wires, const u32 *own, const u32 *src, u32 count, u64 batch_stride, u32 *err, u32 slot) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64 *w = wires + (u64)blockIdx.y * batch_stride;
+    if (gl::canon(w[own[i]]) != gl::canon(w[src[i]])) atomicMin(&err[2 * blockIdx.y + slot], i);
+}
+__global__ void __launch_bounds__(256) witness_check_vals_kernel(const u64 *wires, const u32 *idx, const u64 *vals, u32 count, u64 batch_stride, u32 val_stride, u32 *err, u32 slot) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    if (gl::canon(wires[(u64)blockIdx.y * batch_stride + idx[i]]) != gl::canon(vals[(u64)blockIdx.y * val_stride + i])) atomicMin(&err[2 * blockIdx.y + slot], i);
+}
+
 }  // namespace
+
+hipError_t wk_check_pairs(const uint64_t *wires, const uint32_t *own, const uint32_t *src, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t *err, uint32_t slot, hipStream_t st) {
+    if (count == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(witness_check_pairs_kernel, dim3((count + 255) / 256, batch), dim3(256), 0, st, wires, own, src, count, batch_stride, err, slot);
+    return hipGetLastError();
+}
+hipError_t wk_check_vals(const uint64_t *wires, const uint32_t *idx, const uint64_t *vals, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t val_stride, uint32_t *err, uint32_t slot, hipStream_t st) {
+    if (count == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(witness_check_vals_kernel, dim3((count + 255) / 256, batch), dim3(256), 0, st, wires, idx, vals, count, batch_stride, val_stride, err, slot);
+    return hipGetLastError();
+}
 
 hipError_t wk_scatter(uint64_t *wires, const uint32_t *idx, const uint64_t *vals, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t val_stride, hipStream_t st) {
     if (count == 0 || batch == 0) return hipSuccess;

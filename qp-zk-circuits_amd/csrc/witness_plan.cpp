@@ -40,6 +40,33 @@ struct WitnessPlan {
     std::vector<uint32_t> h_src_of;          // [n][num_routed] -> flat source cell of the copy class
     std::vector<uint8_t> generated;          // [num_wires][n]: 1 = a generator produces this cell (or its copy class)
     uint32_t *d_pair_idx = nullptr; u64 *d_pair_val = nullptr; size_t pair_cap = 0;
+    // copy classes with more than one producer (plonky2 lets several generators set one partition as long as they agree:
+    // `connect(computed, claimed)` where both sides are generated). One producer is the class's source; the cells the others
+    // write are compared with the source before the copy pass overwrites them (check_own[i] vs check_src[i], flat cells).
+    std::vector<uint32_t> h_check_own, h_check_src;
+    uint32_t *d_check_own = nullptr, *d_check_src = nullptr;
+    uint32_t *d_err = nullptr; uint32_t err_cap = 0;     // [err_cap][2]: first failing pair + 1 (secondary producers; assignments)
+    // a prepared PartialWitness shape (the cells a caller assigns are the same for every proof of a circuit): see PartialPrep
+    struct PartialPrep *prep = nullptr;
+};
+
+// The resolution of one assignment list against the plan: assignment i (public inputs first, then the caller's cells) either
+// seeds a free copy class (scattered into its source cell), or lands in a class a generator produces (compared with the
+// generated value afterwards), or repeats an earlier assignment's class (the two values must agree on the host).
+struct PartialPrep {
+    std::vector<u64> cells;                       // the caller's list this was prepared for
+    std::vector<uint32_t> scatter_from, check_from;   // index into the combined value vector [public inputs..., values...]
+    std::vector<uint32_t> scatter_idx, check_idx; // flat cells
+    std::vector<std::pair<uint32_t, uint32_t>> same;   // (earlier, later) value indices that share a class
+    std::vector<u64> check_cell;                  // cell (row * num_wires + wire) named in messages
+    uint32_t *d_scatter_idx = nullptr, *d_check_idx = nullptr;
+    u64 *d_scatter_val = nullptr, *d_check_val = nullptr;   // [cap][count]
+    uint32_t cap = 0;
+    bool valid = false;
+    void release() {
+        for (void *q : {(void *)d_scatter_idx, (void *)d_check_idx, (void *)d_scatter_val, (void *)d_check_val}) if (q) (void)hipFree(q);
+        d_scatter_idx = d_check_idx = nullptr; d_scatter_val = d_check_val = nullptr; cap = 0;
+    }
 };
 
 void witness_plan_free(WitnessPlan *p) {
@@ -54,6 +81,10 @@ void witness_plan_free(WitnessPlan *p) {
     if (p->d_pi_vals) (void)hipFree(p->d_pi_vals);
     if (p->d_pair_idx) (void)hipFree(p->d_pair_idx);
     if (p->d_pair_val) (void)hipFree(p->d_pair_val);
+    if (p->d_check_own) (void)hipFree(p->d_check_own);
+    if (p->d_check_src) (void)hipFree(p->d_check_src);
+    if (p->d_err) (void)hipFree(p->d_err);
+    if (p->prep) { p->prep->release(); delete p->prep; }
     delete p;
 }
 
@@ -188,10 +219,9 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
         for (uint32_t op = 0, k = num_instances(g); op < k; op++) insts.push_back({(uint32_t)r, (uint32_t)gate_of_row[r], op});
     }
     for (size_t hi = 0; hi < p.hints.size(); hi++) insts.push_back({(uint32_t)hi, WITNESS_HINT, (uint32_t)p.hints[hi].w[0]});
-    // producer of each copy class (by class root), and the source cell every member reads
-    std::vector<int32_t> producer(n * R, -1);           // indexed by class root: instance id
-    std::vector<uint32_t> source(n * R);                // indexed by class root: cell (row * R + col)
-    for (uint32_t i = 0; i < n * R; i++) source[i] = i;
+    // producers of each copy class (by class root). plonky2 lets any number of generators set one partition as long as they
+    // agree; which of them becomes the class's source (the cell every member reads) is decided below, by who can run first.
+    std::vector<std::vector<uint32_t>> producers(n * R);   // indexed by class root: instance ids
     plan.free_mask.assign(NW * n, 1);
     IO tmp;
     CellIO io;
@@ -206,7 +236,7 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
             describe_any(p, insts[id], tmp, io);
             if (pass == 1) {
                 size_t taken = 0;
-                for (const Cell &oc : io.out) if (oc.col < R && producer[find((uint32_t)((u64)oc.row * R + oc.col))] >= 0) taken++;
+                for (const Cell &oc : io.out) if (oc.col < R && !producers[find((uint32_t)((u64)oc.row * R + oc.col))].empty()) taken++;
                 if (taken == io.out.size()) { dropped[id] = 1; continue; }
                 if (taken) return "witness plan: PublicInputGate wires are only partly connected to a hash output (row " + std::to_string(insts[id].row) + ")";
             }
@@ -214,17 +244,77 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
                 if (oc.col >= NW) return "witness plan: generator output beyond num_wires";
                 plan.free_mask[(u64)oc.col * n + oc.row] = 0;
                 if (oc.col >= R) continue;
-                const uint32_t cell = (uint32_t)((u64)oc.row * R + oc.col), root = find(cell);
-                if (producer[root] >= 0) return "witness plan: two generators write one copy class (row " + std::to_string(oc.row) + ")";
-                producer[root] = (int32_t)id; source[root] = cell;
+                producers[find((uint32_t)((u64)oc.row * R + oc.col))].push_back((uint32_t)id);
             }
         }
     if (std::count(dropped.begin(), dropped.end(), 1)) {   // compact, keeping producer ids valid
         std::vector<int32_t> remap(insts.size(), -1);
         std::vector<WitnessInst> kept;
         for (size_t id = 0; id < insts.size(); id++) if (!dropped[id]) { remap[id] = (int32_t)kept.size(); kept.push_back(insts[id]); }
-        for (auto &pr : producer) if (pr >= 0) pr = remap[pr];
+        for (auto &pl : producers) for (auto &pr : pl) pr = (uint32_t)remap[pr];
         insts.swap(kept);
+    }
+
+    // ---- levels, the way generate_partial_witness gets there: a generator runs once every target it watches is set, a
+    // partition is set by the first of its producers to run. Level of an instance = 1 + the latest level at which one of its
+    // input classes becomes known; a class becomes known at the level of its earliest producer (level 0 = caller-supplied).
+    // Instances that never become runnable sit on a dependency cycle. ----
+    std::vector<std::vector<uint32_t>> in_classes(insts.size());     // distinct producer-backed input classes (roots)
+    std::vector<std::vector<uint32_t>> readers(n * R);               // class root -> instances waiting for it
+    for (size_t id = 0; id < insts.size(); id++) {
+        describe_any(p, insts[id], tmp, io);
+        std::vector<uint32_t> &ic = in_classes[id];
+        for (const Cell &c_ : io.in) {
+            if (c_.col >= R) continue;
+            const uint32_t root = find((uint32_t)((u64)c_.row * R + c_.col));
+            const auto &pl = producers[root];
+            if (pl.empty() || (pl.size() == 1 && pl[0] == id)) continue;      // free, or produced by this very instance
+            ic.push_back(root);
+        }
+        std::sort(ic.begin(), ic.end());
+        ic.erase(std::unique(ic.begin(), ic.end()), ic.end());
+        for (uint32_t root : ic) readers[root].push_back((uint32_t)id);
+    }
+    std::vector<int32_t> level(insts.size(), 0), class_level(n * R, -1);
+    std::vector<int32_t> primary(n * R, -1);            // class root -> the producer that is its source
+    std::vector<uint32_t> source(n * R);                // class root -> source cell (row * R + col)
+    for (uint32_t i = 0; i < n * R; i++) source[i] = i;
+    {
+        std::vector<uint32_t> waiting(insts.size());
+        std::vector<std::vector<uint32_t>> bucket(2);   // bucket[l] = instances that run at level l (levels are reached in order)
+        for (size_t id = 0; id < insts.size(); id++) { waiting[id] = (uint32_t)in_classes[id].size(); if (!waiting[id]) { level[id] = 1; bucket[1].push_back((uint32_t)id); } }
+        for (size_t l = 1; l < bucket.size(); l++) {
+            for (size_t k = 0; k < bucket[l].size(); k++) {
+                const uint32_t id = bucket[l][k];
+                describe_any(p, insts[id], tmp, io);
+                for (const Cell &oc : io.out) {
+                    if (oc.col >= R) continue;
+                    const uint32_t cell = (uint32_t)((u64)oc.row * R + oc.col), root = find(cell);
+                    if (class_level[root] >= 0) continue;
+                    class_level[root] = (int32_t)l; primary[root] = (int32_t)id; source[root] = cell;
+                    for (uint32_t rd : readers[root]) {
+                        if (level[rd] > 0) continue;
+                        if (--waiting[rd] == 0) {
+                            level[rd] = (int32_t)l + 1;
+                            if (bucket.size() <= l + 1) bucket.resize(l + 2);
+                            bucket[l + 1].push_back(rd);
+                        }
+                    }
+                }
+            }
+        }
+        for (size_t id = 0; id < insts.size(); id++) if (level[id] == 0) return "witness plan: cyclic generator dependency";
+    }
+    // cells written by a producer that is not its class's source: compared with the source before the copy pass
+    for (size_t id = 0; id < insts.size(); id++) {
+        describe_any(p, insts[id], tmp, io);
+        for (const Cell &oc : io.out) {
+            if (oc.col >= R) continue;
+            const uint32_t cell = (uint32_t)((u64)oc.row * R + oc.col), s = source[find(cell)];
+            if (s == cell) continue;
+            plan.h_check_own.push_back((uint32_t)((u64)oc.col * n + oc.row));
+            plan.h_check_src.push_back((uint32_t)((u64)(s % R) * n + s / R));
+        }
     }
     std::vector<uint32_t> src_of(n * R);
     for (uint32_t cell = 0; cell < n * R; cell++) {
@@ -237,38 +327,9 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     plan.generated.assign(NW * n, 0);
     for (u64 col = 0; col < NW; col++)
         for (u64 r = 0; r < n; r++)
-            plan.generated[col * n + r] = col < R ? (producer[find((uint32_t)(r * R + col))] >= 0) : (plan.free_mask[col * n + r] == 0);
+            plan.generated[col * n + r] = col < R ? !producers[find((uint32_t)(r * R + col))].empty() : (plan.free_mask[col * n + r] == 0);
     plan.h_src_of = src_of;
 
-    // ---- levels: 1 + the deepest producer among the inputs (iterative depth-first, cycles rejected) ----
-    std::vector<int32_t> level(insts.size(), 0);        // 0 = unvisited, -1 = on the stack
-    std::vector<std::pair<uint32_t, uint32_t>> stack;   // (instance, next input position)
-    std::vector<std::vector<uint32_t>> deps(insts.size());
-    for (size_t id = 0; id < insts.size(); id++) {
-        describe_any(p, insts[id], tmp, io);
-        for (const Cell &ic : io.in) {
-            if (ic.col >= R) continue;
-            const int32_t pr = producer[find((uint32_t)((u64)ic.row * R + ic.col))];
-            if (pr >= 0 && (size_t)pr != id) deps[id].push_back((uint32_t)pr);
-        }
-    }
-    for (size_t start = 0; start < insts.size(); start++) {
-        if (level[start] > 0) continue;
-        stack.push_back({(uint32_t)start, 0}); level[start] = -1;
-        while (!stack.empty()) {
-            auto &top = stack.back();
-            if (top.second < deps[top.first].size()) {
-                const uint32_t d = deps[top.first][top.second++];
-                if (level[d] == -1) return "witness plan: cyclic generator dependency";
-                if (level[d] == 0) { level[d] = -1; stack.push_back({d, 0}); }
-            } else {
-                int32_t lv = 1;
-                for (uint32_t d : deps[top.first]) lv = std::max(lv, level[d] + 1);
-                level[top.first] = lv;
-                stack.pop_back();
-            }
-        }
-    }
     int32_t max_level = 0;
     for (int32_t l : level) max_level = std::max(max_level, l);
     std::vector<uint32_t> order(insts.size());
@@ -334,8 +395,13 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     if (!p.hints.empty() && !up(p.hints.data(), p.hints.size() * sizeof(HintOp), (void **)&plan.d_hints)) return "witness plan: device allocation failed";
     if (!p.pi_cells.empty()) {
         std::vector<uint32_t> flat(p.pi_cells.size());
-        for (size_t i = 0; i < flat.size(); i++) flat[i] = (uint32_t)((p.pi_cells[i] % NW) * n + p.pi_cells[i] / NW);
+        // a public input is written where its copy class is read from (the class's source cell)
+        for (size_t i = 0; i < flat.size(); i++) flat[i] = src_of[(p.pi_cells[i] / NW) * R + p.pi_cells[i] % NW];
         if (!up(flat.data(), flat.size() * 4, (void **)&plan.d_pi_idx)) return "witness plan: device allocation failed";
+    }
+    if (!plan.h_check_own.empty()) {
+        if (!up(plan.h_check_own.data(), plan.h_check_own.size() * 4, (void **)&plan.d_check_own)) return "witness plan: device allocation failed";
+        if (!up(plan.h_check_src.data(), plan.h_check_src.size() * 4, (void **)&plan.d_check_src)) return "witness plan: device allocation failed";
     }
     return "";
 }
@@ -382,42 +448,125 @@ int qpgpu_witness_free_mask(qpgpu_circuit *c, uint8_t *mask, size_t mask_len) {
     return QPGPU_OK;
 }
 
-int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs) {
-    if (!c) return QPGPU_EINVAL;
+}  // extern "C"
+
+namespace {
+// Resolve an assignment list against the plan (see PartialPrep). Public inputs come first in the combined value vector.
+std::string prepare_partial(const CircuitPack &p, const WitnessPlan &plan, const uint64_t *cells, size_t count, PartialPrep &pp) {
+    const u64 n = p.n(), NW = p.num_wires, R = p.num_routed_wires;
+    const uint32_t npis = (uint32_t)p.num_public_inputs;
+    pp.cells.assign(cells, cells + count);
+    pp.scatter_from.clear(); pp.check_from.clear(); pp.scatter_idx.clear(); pp.check_idx.clear(); pp.same.clear(); pp.check_cell.clear();
+    std::unordered_map<uint32_t, uint32_t> first;       // class key -> value index of the first assignment
+    first.reserve((count + npis) * 2);
+    auto assign = [&](u64 cell, uint32_t from) -> std::string {
+        if (cell >= NW * n) return "generate_witness_partial: cell " + std::to_string(cell) + " is outside the trace";
+        const u64 row = cell / NW, col = cell % NW;
+        const uint32_t own = (uint32_t)(col * n + row), key = col < R ? plan.h_src_of[row * R + col] : own;
+        auto it = first.find(key);
+        if (it != first.end()) { pp.same.push_back({it->second, from}); return ""; }
+        first.emplace(key, from);
+        if (plan.generated[own]) { pp.check_idx.push_back(key); pp.check_from.push_back(from); pp.check_cell.push_back(cell); }
+        else { pp.scatter_idx.push_back(key); pp.scatter_from.push_back(from); }   // a free class is read through its source cell
+        return "";
+    };
+    for (size_t i = 0; i < p.pi_cells.size(); i++) { const std::string e = assign(p.pi_cells[i], (uint32_t)i); if (!e.empty()) return e; }
+    for (size_t i = 0; i < count; i++) { const std::string e = assign(cells[i], npis + (uint32_t)i); if (!e.empty()) return e; }
+    return "";
+}
+int prep_device(qpgpu_ctx *ctx, PartialPrep &pp, uint32_t batch) {
+    if (pp.cap >= batch && pp.d_scatter_idx) return QPGPU_OK;
+    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pp.release();
+    const size_t ns = std::max<size_t>(pp.scatter_idx.size(), 1), nc = std::max<size_t>(pp.check_idx.size(), 1);
+    QP_HIP(ctx, hipMalloc((void **)&pp.d_scatter_idx, ns * 4));
+    QP_HIP(ctx, hipMalloc((void **)&pp.d_check_idx, nc * 4));
+    QP_HIP(ctx, hipMalloc((void **)&pp.d_scatter_val, ns * 8 * batch));
+    QP_HIP(ctx, hipMalloc((void **)&pp.d_check_val, nc * 8 * batch));
+    if (!pp.scatter_idx.empty()) QP_HIP(ctx, hipMemcpyAsync(pp.d_scatter_idx, pp.scatter_idx.data(), pp.scatter_idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!pp.check_idx.empty()) QP_HIP(ctx, hipMemcpyAsync(pp.d_check_idx, pp.check_idx.data(), pp.check_idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pp.cap = batch;
+    return QPGPU_OK;
+}
+
+// Stage s1 for `batch` witnesses. With `pp`: the wire matrices are cleared and seeded with the prepared assignments first
+// (values: [batch][npis + count] is assembled from public_inputs and part_values). status (may be null): per witness
+// QPGPU_OK / QPGPU_EUNSAT. Returns QPGPU_EUNSAT when any witness failed (the first one's reason in last_error).
+int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs, PartialPrep *pp,
+                          const uint64_t *part_values, int *status) {
     qpgpu_ctx *ctx = c->ctx;
-    QP_DEV(ctx);
-    if (!d_wires || batch == 0 || batch > 65535 || (!public_inputs && c->pack.num_public_inputs)) return ctx->fail(QPGPU_EINVAL, "generate_witness: bad argument");
-    QP_TRY(ensure_plan(c));
     WitnessPlan &plan = *c->wplan;
-    const size_t npis = c->pack.num_public_inputs;
-    if (plan.pi_cap < batch) {
+    const CircuitPack &p = c->pack;
+    const size_t npis = p.num_public_inputs, count = pp ? pp->cells.size() : 0;
+    const u64 NW = p.num_wires, stride = p.num_wires * p.n();
+    auto name = [&](u64 cell) { return "target (row " + std::to_string(cell / NW) + ", wire " + std::to_string(cell % NW) + ")"; };
+    if (status) for (uint32_t b = 0; b < batch; b++) status[b] = QPGPU_OK;
+    int overall = QPGPU_OK;
+    auto flag = [&](uint32_t b, const std::string &why) {
+        if (status) status[b] = QPGPU_EUNSAT;
+        if (overall == QPGPU_OK) { overall = QPGPU_EUNSAT; ctx->err = (batch > 1 ? "witness " + std::to_string(b) + ": " : std::string()) + why; }
+    };
+    // two assignments of one copy class must agree (host check; the later one is not written)
+    if (pp)
+        for (uint32_t b = 0; b < batch; b++) {
+            auto val = [&](uint32_t from) { return gl::canon(from < npis ? public_inputs[(size_t)b * npis + from] : part_values[(size_t)b * count + (from - npis)]); };
+            auto cell_of = [&](uint32_t from) { return from < npis ? p.pi_cells[from] : pp->cells[from - npis]; };
+            for (const auto &sm : pp->same)
+                if (val(sm.first) != val(sm.second)) {
+                    flag(b, name(cell_of(sm.second)) + " set twice with different values (" + std::to_string(val(sm.second)) + " here, " + std::to_string(val(sm.first)) +
+                                " through " + name(cell_of(sm.first)) + ")");
+                    break;
+                }
+        }
+    const bool pair_checks = !plan.h_check_own.empty(), val_checks = pp && !pp->check_idx.empty();
+    if (plan.pi_cap < batch || (plan.err_cap < batch)) {
         QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (plan.d_pi_hash) { (void)hipFree(plan.d_pi_hash); plan.d_pi_hash = nullptr; }
         if (plan.d_pi_vals) { (void)hipFree(plan.d_pi_vals); plan.d_pi_vals = nullptr; }
-        plan.pi_cap = 0;
+        if (plan.d_err) { (void)hipFree(plan.d_err); plan.d_err = nullptr; }
+        plan.pi_cap = 0; plan.err_cap = 0;
         QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_hash, (size_t)batch * 32));
         QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_vals, std::max<size_t>((size_t)batch * npis * 8, 8)));
-        plan.pi_cap = batch;
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_err, (size_t)batch * 8));
+        plan.pi_cap = batch; plan.err_cap = batch;
     }
-    // the public inputs and their hash go up through the context's pinned bounce buffer and a copy kernel (ctx.hpp: read_back)
+    if (pp) QP_TRY(prep_device(ctx, *pp, batch));
+    // everything the host sends goes up through the context's pinned bounce buffer and a copy kernel (ctx.hpp: read_back)
+    const size_t ns = pp ? pp->scatter_idx.size() : 0, nc = pp ? pp->check_idx.size() : 0;
     const size_t pi_bytes = plan.d_pi_idx ? (size_t)batch * npis * 8 : 0, hash_bytes = (size_t)batch * 32;
-    QP_TRY(ctx->reserve_read_back(pi_bytes + hash_bytes));
+    const size_t sc_bytes = (size_t)batch * ns * 8, ck_bytes = (size_t)batch * nc * 8;
+    QP_TRY(ctx->reserve_read_back(pi_bytes + hash_bytes + sc_bytes + ck_bytes + (size_t)batch * 8));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));       // nothing of an earlier call still reads the bounce buffer
     u64 *bounce = (u64 *)ctx->h_pin;
-    if (pi_bytes) {   // PartialWitness::set_target for every public-input target
-        std::memcpy(bounce, public_inputs, pi_bytes);
-        QP_HIP(ctx, pk_copy(plan.d_pi_vals, bounce, pi_bytes, ctx->stream));
-        QP_HIP(ctx, wk_scatter(d_wires, plan.d_pi_idx, plan.d_pi_vals, (uint32_t)npis, batch, c->pack.num_wires * c->pack.n(), (uint32_t)npis, ctx->stream));
-    }
+    if (pp) QP_HIP(ctx, hipMemsetAsync(d_wires, 0, (size_t)batch * stride * 8, ctx->stream));
+    if (pi_bytes) std::memcpy(bounce, public_inputs, pi_bytes);
     u64 *pih = bounce + pi_bytes / 8;
-    for (uint32_t b = 0; b < batch; b++) host_pi_hash(ctx->hasher, public_inputs + (size_t)b * c->pack.num_public_inputs, c->pack.num_public_inputs, pih + 4 * b);
+    for (uint32_t b = 0; b < batch; b++) host_pi_hash(ctx->hasher, public_inputs + (size_t)b * npis, npis, pih + 4 * b);
+    u64 *scv = pih + hash_bytes / 8, *ckv = scv + sc_bytes / 8;
+    if (pp)
+        for (uint32_t b = 0; b < batch; b++) {
+            auto val = [&](uint32_t from) { return gl::canon(from < npis ? public_inputs[(size_t)b * npis + from] : part_values[(size_t)b * count + (from - npis)]); };
+            for (size_t i = 0; i < ns; i++) scv[(size_t)b * ns + i] = val(pp->scatter_from[i]);
+            for (size_t i = 0; i < nc; i++) ckv[(size_t)b * nc + i] = val(pp->check_from[i]);
+        }
+    if (pi_bytes) {   // PartialWitness::set_target for every public-input target
+        QP_HIP(ctx, pk_copy(plan.d_pi_vals, bounce, pi_bytes, ctx->stream));
+        QP_HIP(ctx, wk_scatter(d_wires, plan.d_pi_idx, plan.d_pi_vals, (uint32_t)npis, batch, stride, (uint32_t)npis, ctx->stream));
+    }
     QP_HIP(ctx, pk_copy(plan.d_pi_hash, pih, hash_bytes, ctx->stream));
+    if (ns) {
+        QP_HIP(ctx, pk_copy(pp->d_scatter_val, scv, sc_bytes, ctx->stream));
+        QP_HIP(ctx, wk_scatter(d_wires, pp->d_scatter_idx, pp->d_scatter_val, (uint32_t)ns, batch, stride, (uint32_t)ns, ctx->stream));
+    }
+    if (nc) QP_HIP(ctx, pk_copy(pp->d_check_val, ckv, ck_bytes, ctx->stream));
+    if (pair_checks || val_checks) QP_HIP(ctx, hipMemsetAsync(plan.d_err, 0xFF, (size_t)batch * 8, ctx->stream));
     WitnessArgs a{};
     a.wires = d_wires; a.src_of = plan.d_src_of; a.insts = plan.d_insts; a.gates = c->d_gates; a.cs = c->d_cs_values;
     a.poseidon_rc = c->d_poseidon_rc; a.poseidon_fast = c->d_poseidon_fast; a.pi_hash = plan.d_pi_hash;
     a.p2_gate = c->has_p2_gate ? ctx->d_p2_app : nullptr; a.p2_layout = c->pack.p2_layout;
     a.hints = plan.d_hints; a.num_wires = (uint32_t)c->pack.num_wires;
-    a.n = c->pack.n(); a.batch_stride = c->pack.num_wires * c->pack.n();
+    a.n = c->pack.n(); a.batch_stride = stride;
     a.num_routed = (uint32_t)c->pack.num_routed_wires; a.num_selectors = (uint32_t)c->pack.num_selectors;
     // one launch per dependency level (ordinary instances and PoseidonGate rows side by side); QPGPU_WITNESS_COMBINED=0: two
     static const bool combined = [] { const char *e = getenv("QPGPU_WITNESS_COMBINED"); return !(e && *e == '0'); }();
@@ -432,82 +581,108 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
             QP_HIP(ctx, wk_run_poseidon(a, mid, hi - mid, batch, ctx->stream));
         }
     }
+    // a partition set twice: the cells of producers that are not their class's source, and the caller's assignments inside
+    // generated classes, against the value the class's source holds (before the copy pass makes them equal)
+    if (pair_checks) QP_HIP(ctx, wk_check_pairs(d_wires, plan.d_check_own, plan.d_check_src, (uint32_t)plan.h_check_own.size(), batch, stride, plan.d_err, 0, ctx->stream));
+    if (val_checks) QP_HIP(ctx, wk_check_vals(d_wires, pp->d_check_idx, pp->d_check_val, (uint32_t)nc, batch, stride, (uint32_t)nc, plan.d_err, 1, ctx->stream));
     QP_HIP(ctx, wk_fill_copies(a, batch, ctx->stream));
     ctx->prof_end();
-    return QPGPU_OK;
+    if (pair_checks || val_checks) {
+        std::vector<uint32_t> err((size_t)batch * 2);
+        QP_TRY(ctx->read_back(err.data(), plan.d_err, err.size() * 4));
+        const u64 n = p.n();
+        for (uint32_t b = 0; b < batch; b++) {
+            if (pair_checks && err[2 * b] != 0xFFFFFFFFu) {
+                const uint32_t own = plan.h_check_own[err[2 * b]];
+                flag(b, name((u64)(own % n) * NW + own / n) + " set twice with different values (two generators of one copy class disagree)");
+            } else if (val_checks && err[2 * b + 1] != 0xFFFFFFFFu) {
+                const uint32_t k = err[2 * b + 1], from = pp->check_from[k];
+                const u64 v = gl::canon(from < npis ? public_inputs[(size_t)b * npis + from] : part_values[(size_t)b * count + (from - npis)]);
+                flag(b, name(pp->check_cell[k]) + " set twice with different values (" + std::to_string(v) + " supplied, another value generated)");
+            }
+        }
+    }
+    return overall;
+}
+
+// the plan's prepared assignment list for `cells` (rebuilt when the caller's list changes)
+int ensure_prep(qpgpu_circuit *c, const uint64_t *cells, size_t count, uint32_t batch) {
+    qpgpu_ctx *ctx = c->ctx;
+    WitnessPlan &plan = *c->wplan;
+    if (!plan.prep) plan.prep = new PartialPrep();
+    PartialPrep &pp = *plan.prep;
+    if (!pp.valid || pp.cells.size() != count || (count && std::memcmp(pp.cells.data(), cells, count * 8) != 0)) {
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        pp.release();
+        const std::string err = prepare_partial(c->pack, plan, cells, count, pp);
+        if (!err.empty()) { pp.valid = false; return ctx->fail(QPGPU_EINVAL, err); }
+        pp.valid = true;
+    }
+    return prep_device(ctx, pp, batch);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs) {
+    if (!c) return QPGPU_EINVAL;
+    qpgpu_ctx *ctx = c->ctx;
+    QP_DEV(ctx);
+    if (!d_wires || batch == 0 || batch > 65535 || (!public_inputs && c->pack.num_public_inputs)) return ctx->fail(QPGPU_EINVAL, "generate_witness: bad argument");
+    QP_TRY(ensure_plan(c));
+    return generate_batch(c, d_wires, batch, public_inputs, nullptr, nullptr, nullptr);
 }
 
 int qpgpu_generate_witness_dev(qpgpu_circuit *c, uint64_t *d_wires, const uint64_t *public_inputs) {
     return qpgpu_generate_witness_batch_dev(c, d_wires, 1, public_inputs);
 }
 
-// plonky2's generate_partial_witness on a sparse PartialWitness: (cell, value) assignments instead of a wire matrix.
-// A target that is set twice with different values — two assignments in one copy class, or an assignment that disagrees
-// with what a generator (or the public-input argument) produces for that target — is the reference's
-// "set twice with different values" panic (wormhole/tests/src/circuit/block_header_tests.rs:34-95); here QPGPU_EUNSAT.
-int qpgpu_generate_witness_partial_dev(qpgpu_circuit *c, const uint64_t *cells, const uint64_t *values, size_t count,
-                                       const uint64_t *public_inputs, uint64_t *d_wires) {
+// plonky2's generate_partial_witness on sparse PartialWitnesses: (cell, value) assignments instead of wire matrices.
+// A target that is set twice with different values — two assignments in one copy class, an assignment that disagrees
+// with what a generator (or the public-input argument) produces for that target, or two generators that disagree — is the
+// reference's "set twice with different values" panic (wormhole/tests/src/circuit/block_header_tests.rs:34-95); here
+// QPGPU_EUNSAT.
+int qpgpu_witness_partial_prepare(qpgpu_circuit *c, const uint64_t *cells, size_t count, uint32_t max_batch) {
+    if (!c) return QPGPU_EINVAL;
+    qpgpu_ctx *ctx = c->ctx;
+    QP_DEV(ctx);
+    if ((count && !cells) || max_batch == 0 || max_batch > 65535) return ctx->fail(QPGPU_EINVAL, "witness_partial_prepare: bad argument");
+    QP_TRY(ensure_plan(c));
+    QP_TRY(ensure_prep(c, cells, count, max_batch));
+    WitnessPlan &plan = *c->wplan;
+    // size what generation will need, so that the calls themselves neither allocate nor free
+    if (plan.pi_cap < max_batch || plan.err_cap < max_batch) {
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (plan.d_pi_hash) { (void)hipFree(plan.d_pi_hash); plan.d_pi_hash = nullptr; }
+        if (plan.d_pi_vals) { (void)hipFree(plan.d_pi_vals); plan.d_pi_vals = nullptr; }
+        if (plan.d_err) { (void)hipFree(plan.d_err); plan.d_err = nullptr; }
+        plan.pi_cap = 0; plan.err_cap = 0;
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_hash, (size_t)max_batch * 32));
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_vals, std::max<size_t>((size_t)max_batch * c->pack.num_public_inputs * 8, 8)));
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_err, (size_t)max_batch * 8));
+        plan.pi_cap = max_batch; plan.err_cap = max_batch;
+    }
+    const PartialPrep &pp = *plan.prep;
+    return ctx->reserve_read_back((size_t)max_batch * (c->pack.num_public_inputs + 4 + pp.scatter_idx.size() + pp.check_idx.size() + 1) * 8);
+}
+
+int qpgpu_generate_witness_partial_batch_dev(qpgpu_circuit *c, const uint64_t *cells, size_t count, const uint64_t *values,
+                                             const uint64_t *public_inputs, uint32_t batch, uint64_t *d_wires, int *status) {
     if (!c) return QPGPU_EINVAL;
     qpgpu_ctx *ctx = c->ctx;
     QP_DEV(ctx);
     const CircuitPack &p = c->pack;
-    if (!d_wires || (count && (!cells || !values)) || (!public_inputs && p.num_public_inputs)) return ctx->fail(QPGPU_EINVAL, "generate_witness_partial: null argument");
+    if (!d_wires || batch == 0 || batch > 65535 || (count && (!cells || !values)) || (!public_inputs && p.num_public_inputs))
+        return ctx->fail(QPGPU_EINVAL, "generate_witness_partial: null argument");
     QP_TRY(ensure_plan(c));
-    WitnessPlan &plan = *c->wplan;
-    const u64 n = p.n(), NW = p.num_wires, R = p.num_routed_wires;
-    auto name = [&](u64 cell) { return "target (row " + std::to_string(cell / NW) + ", wire " + std::to_string(cell % NW) + ")"; };
-    // key = the slot plonky2's PartitionWitness would use: the copy class's source cell for routed wires, else the cell
-    struct Slot { u64 value, cell; };
-    std::unordered_map<uint32_t, Slot> set;
-    set.reserve((count + p.num_public_inputs) * 2);
-    std::vector<uint32_t> idx; std::vector<u64> val;          // scatter list (flat cells)
-    std::vector<uint32_t> chk_idx; std::vector<u64> chk_val, chk_cell;   // generator-produced targets to compare afterwards
-    auto assign = [&](u64 cell, u64 v, std::string &err) {
-        if (cell >= NW * n) { err = "generate_witness_partial: cell " + std::to_string(cell) + " is outside the trace"; return; }
-        const u64 row = cell / NW, col = cell % NW;
-        const uint32_t own = (uint32_t)(col * n + row), key = col < R ? plan.h_src_of[row * R + col] : own;
-        v = gl::canon(v);
-        auto it = set.find(key);
-        if (it != set.end()) {
-            if (it->second.value != v) err = name(cell) + " set twice with different values (" + std::to_string(v) + " here, " + std::to_string(it->second.value) + " through " + name(it->second.cell) + ")";
-            return;
-        }
-        set.emplace(key, Slot{v, cell});
-        if (plan.generated[own]) { chk_idx.push_back(key); chk_val.push_back(v); chk_cell.push_back(cell); return; }
-        idx.push_back(key); val.push_back(v);     // a free class is read through its source cell; the copy pass fills the members
-    };
-    std::string err;
-    for (size_t i = 0; i < p.pi_cells.size() && err.empty(); i++) assign(p.pi_cells[i], public_inputs[i], err);
-    for (size_t i = 0; i < count && err.empty(); i++) assign(cells[i], values[i], err);
-    if (!err.empty()) return ctx->fail(err.rfind("generate_witness_partial", 0) == 0 ? QPGPU_EINVAL : QPGPU_EUNSAT, err);
-    const size_t need = std::max(idx.size(), chk_idx.size());
-    if (plan.pair_cap < need) {
-        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (plan.d_pair_idx) (void)hipFree(plan.d_pair_idx);
-        if (plan.d_pair_val) (void)hipFree(plan.d_pair_val);
-        plan.d_pair_idx = nullptr; plan.d_pair_val = nullptr; plan.pair_cap = 0;
-        QP_HIP(ctx, hipMalloc((void **)&plan.d_pair_idx, need * 4));
-        QP_HIP(ctx, hipMalloc((void **)&plan.d_pair_val, need * 8));
-        plan.pair_cap = need;
-    }
-    QP_HIP(ctx, hipMemsetAsync(d_wires, 0, NW * n * 8, ctx->stream));
-    if (!idx.empty()) {
-        QP_HIP(ctx, hipMemcpyAsync(plan.d_pair_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        QP_HIP(ctx, hipMemcpyAsync(plan.d_pair_val, val.data(), val.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        QP_HIP(ctx, wk_scatter(d_wires, plan.d_pair_idx, plan.d_pair_val, (uint32_t)idx.size(), 1, 0, 0, ctx->stream));
-        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    QP_TRY(qpgpu_generate_witness_batch_dev(c, d_wires, 1, public_inputs));
-    if (!chk_idx.empty()) {
-        std::vector<u64> got(chk_idx.size());
-        QP_HIP(ctx, hipMemcpyAsync(plan.d_pair_idx, chk_idx.data(), chk_idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        QP_HIP(ctx, wk_gather(d_wires, plan.d_pair_idx, plan.d_pair_val, (uint32_t)chk_idx.size(), ctx->stream));
-        QP_TRY(ctx->read_back(got.data(), plan.d_pair_val, got.size() * 8));
-        for (size_t i = 0; i < got.size(); i++)
-            if (got[i] != chk_val[i])
-                return ctx->fail(QPGPU_EUNSAT, name(chk_cell[i]) + " set twice with different values (" + std::to_string(chk_val[i]) + " supplied, " + std::to_string(got[i]) + " generated)");
-    }
-    return QPGPU_OK;
+    QP_TRY(ensure_prep(c, cells, count, batch));
+    return generate_batch(c, d_wires, batch, public_inputs, c->wplan->prep, values, status);
+}
+
+int qpgpu_generate_witness_partial_dev(qpgpu_circuit *c, const uint64_t *cells, const uint64_t *values, size_t count,
+                                       const uint64_t *public_inputs, uint64_t *d_wires) {
+    return qpgpu_generate_witness_partial_batch_dev(c, cells, count, values, public_inputs, 1, d_wires, nullptr);
 }
 
 int qpgpu_generate_witness(qpgpu_circuit *c, uint64_t *wires, const uint64_t *public_inputs) {
