@@ -306,16 +306,43 @@ int qpgpu_pool_create(int device, const uint64_t *pack_words, size_t n_words, un
 /* Workers that prove in lockstep: each takes up to max_batch queued proofs at once (qpgpu_prove_batch_dev). Two workers of
  * eight keep the GPU busy while one of them is in a host-side stage. The workers' contexts use the process-default hasher. */
 int qpgpu_pool_create_batched(int device, const uint64_t *pack_words, size_t n_words, unsigned workers, unsigned max_batch, qpgpu_pool **out);
+/* The same over several GPUs of one process — north_star's "proofs shard one-per-GPU across the node ... invoked from Rust
+ * through a thin C-ABI": devices[0..n_devices) (a device may be named twice: two worker sets on one GPU), workers_per_device
+ * workers on each, ONE queue. Proofs are independent, so there is no data-path collective: whichever
+ * worker takes a job writes the proof into the caller's host buffer, which is the whole "gather of proof bytes" inside one
+ * process (RCCL is for bench.py's one-process-per-GPU launch). The level schedule of an aggregation tree
+ * (wormhole/aggregator/src/aggregator.rs:187-227) stays the caller's: submit a level's proofs, wait for them, build the next.
+ * flags: QPGPU_POOL_HOST_WITNESS gives every worker a workspace of max_batch wire matrices, which qpgpu_pool_submit_host needs
+ * (qpgpu_pool_set_partial_cells allocates it too). */
+#define QPGPU_POOL_HOST_WITNESS 1u
+int qpgpu_pool_create_multi(const int *devices, unsigned n_devices, const uint64_t *pack_words, size_t n_words, unsigned workers_per_device,
+                            unsigned max_batch, unsigned flags, qpgpu_pool **out);
 /* A job's arguments are checked at submit (null pointers: QPGPU_EINVAL; out_cap below qpgpu_pool_proof_size:
  * QPGPU_EBUFSIZE). Jobs of different callers share a lockstep batch: when a batch fails, its jobs are proven again one at
  * a time, so only the failing job's wait() returns the error (with that job's own message). */
-void qpgpu_pool_destroy(qpgpu_pool *p);          /* drains the queue first */
+void qpgpu_pool_destroy(qpgpu_pool *p);          /* drains the queue first; witness workspaces are overwritten before release */
 /* qpgpu_circuit_set_witness_check on every worker's circuit; only while no ticket is outstanding (QPGPU_EINVAL otherwise) */
 int qpgpu_pool_set_witness_check(qpgpu_pool *p, int on);
 size_t qpgpu_pool_proof_size(const qpgpu_pool *p);
 unsigned qpgpu_pool_workers(const qpgpu_pool *p);
+unsigned qpgpu_pool_devices(const qpgpu_pool *p);
 const char *qpgpu_pool_last_error(const qpgpu_pool *p);
+/* Three forms of a job's witness. (1) a full wire matrix resident on a device: only that device's workers can read it —
+ * qpgpu_pool_submit_on names the device by its index in `devices` (qpgpu_pool_submit = index 0). */
 int qpgpu_pool_submit(qpgpu_pool *p, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, uint64_t *ticket);
+int qpgpu_pool_submit_on(qpgpu_pool *p, unsigned device_index, const uint64_t *d_wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, uint64_t *ticket);
+/* (2) a full wire matrix in host memory — what a patched qp-plonky2 prove() holds after
+ * `generate_partial_witness(..).full_witness()` — taken by any worker of any device and uploaded on that worker's stream
+ * (about 9 MB per proof at 2^13 rows; over PCIe). The matrix must stay valid until the ticket has been waited for. */
+int qpgpu_pool_submit_host(qpgpu_pool *p, const uint64_t *wires, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, uint64_t *ticket);
+/* (3) a PartialWitness: the values of the cell list set once with qpgpu_pool_set_partial_cells (for the leaf circuit:
+ * qpgpu_leaf_commit's cells / values, i.e. WormholeProver::commit, wormhole/prover/src/lib.rs:156-163). The worker that takes
+ * the job runs stage s1 for its whole lockstep batch (qpgpu_generate_witness_partial_batch_dev) and then stages s2..s12: this
+ * is the reference bench's timed region, `prover.commit(&inputs).unwrap().prove()` (wormhole/prover/benches/prover.rs:38),
+ * from the committed assignments on. `values` (as many words as the cell list) are copied at submit and wiped after use; an
+ * unsatisfiable witness fails its own ticket with QPGPU_EUNSAT and the target's name, the rest of its batch is proven. */
+int qpgpu_pool_set_partial_cells(qpgpu_pool *p, const uint64_t *cells, size_t count);
+int qpgpu_pool_submit_partial(qpgpu_pool *p, const uint64_t *values, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, uint64_t *ticket);
 int qpgpu_pool_wait(qpgpu_pool *p, uint64_t ticket, size_t *out_len);
 
 /* Hash constants the library derives at start-up (host only, no GPU): the 360 Poseidon round constants and plonky2's

@@ -43,6 +43,7 @@ void orc_circuit_free(orc_circuit *c);
 /* returns 0 and writes proof bytes (ProofWithPublicInputs::to_bytes order); -1 buffer too small */
 int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len);
 /* zero-knowledge circuits: salts are drawn from a counter-mode generator keyed by `seed` (the reference uses thread_rng) */
+int orc_prove_many_entry(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len);
 int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint64_t seed, uint8_t *out, size_t cap, size_t *len);
 gl_t orc_salt_value(uint64_t seed, unsigned oracle_index, unsigned column, uint64_t leaf);
 /* 0 = accepted; otherwise a positive stage code saying what failed */

@@ -128,8 +128,13 @@ void orc_poseidon_permute_naive(gl_t s[12]) {
 static const void *g_p2_plug = 0;
 void orc_p2_permute(const void *p, gl_t s[12]);
 void orc_select_hasher_p2(const void *params) { g_p2_plug = params; }   /* NULL: back to Poseidon */
+void orc_poseidon_permute_fast(gl_t s[12]);     /* prove.c: the same map in plonky2's fast-partial-round organisation */
 void orc_poseidon_permute(gl_t s[12]) {
     if (g_p2_plug) { orc_p2_permute(g_p2_plug, s); return; }
+    orc_poseidon_permute_fast(s);
+}
+/* the textbook schedule with the 32-bit-halves MDS layer (kept: the tests hold the three forms against each other) */
+void orc_poseidon_permute_textbook(gl_t s[12]) {
     init_rc();
     int rc = 0;
     for (int r = 0; r < N_FULL_HALF; r++, rc++) {

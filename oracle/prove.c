@@ -20,9 +20,11 @@
 typedef struct { char name[32]; uint64_t *data; size_t len; } trace_item;
 static trace_item g_trace[64];
 static int g_ntrace = 0;
-static void trace_clear(void) { for (int i = 0; i < g_ntrace; i++) free(g_trace[i].data); g_ntrace = 0; }
+static __thread int g_trace_off = 0;     /* set on the threads of orc_prove_many: several proofs at once keep no stage trace */
+static void trace_clear(void) { if (g_trace_off) return; for (int i = 0; i < g_ntrace; i++) free(g_trace[i].data); g_ntrace = 0; }
 static void trace_put(const char *name, const void *data, size_t words) {
     static double t_last = 0; static int timing = -1;
+    if (g_trace_off) return;
     if (timing < 0) timing = getenv("ORC_TIMING") != NULL;
     if (timing) { double t = omp_get_wtime(); fprintf(stderr, "[orc] %-24s +%.3f s\n", name, t_last ? t - t_last : 0.0); t_last = t; }
     if (g_ntrace >= 64) return;
@@ -71,9 +73,10 @@ gl_t orc_salt_value(uint64_t seed, unsigned oracle_index, unsigned column, uint6
     }
     return (((uint64_t)blk[h + 7] << 32) | blk[h + 6]) - GL_P;
 }
-static uint64_t g_seed = 0;
-static int g_blind = 0;
-static unsigned g_oracle_index = 0;
+/* per proving thread (orc_prove_many runs one proof per thread); read into locals before any parallel loop */
+static __thread uint64_t g_seed = 0;
+static __thread int g_blind = 0;
+static __thread unsigned g_oracle_index = 0;
 
 static void batch_from_coeffs(orc_batch *b, gl_t *coeffs /* owned */, size_t ncols, unsigned log_n, unsigned rate_bits, unsigned cap_height) {
     memset(b, 0, sizeof *b);
@@ -91,13 +94,14 @@ static void batch_from_coeffs(orc_batch *b, gl_t *coeffs /* owned */, size_t nco
     }
     const size_t salt = g_blind ? 4 : 0, W = ncols + salt;
     const unsigned oi = g_oracle_index;
+    const uint64_t seed = g_seed;
     b->width = W;
     b->leaves = (gl_t *)malloc(sizeof(gl_t) * W * b->lde_n);
 #pragma omp parallel for schedule(static)
     for (long j = 0; j < (long)b->lde_n; j++) {
         size_t src = bitrev32((uint32_t)j, L);
         for (size_t c = 0; c < ncols; c++) b->leaves[(size_t)j * W + c] = lde[c * b->lde_n + src];
-        for (size_t c = 0; c < salt; c++) b->leaves[(size_t)j * W + ncols + c] = orc_salt_value(g_seed, oi, (unsigned)c, (uint64_t)j);
+        for (size_t c = 0; c < salt; c++) b->leaves[(size_t)j * W + ncols + c] = orc_salt_value(seed, oi, (unsigned)c, (uint64_t)j);
     }
     free(lde);
     b->digests = (gl_t *)malloc(sizeof(gl_t) * 4 * 2 * b->lde_n);
@@ -264,6 +268,51 @@ size_t orc_poseidon_fast_partial(gl_t *out) {
     return k;
 }
 static inline gl_t pg_sbox(gl_t x) { gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2); return gl_mul(gl_mul(x, x2), x4); }
+/* The permutation the way CPU implementations of plonky2 organise it (poseidon.rs: full rounds, then
+ * partial_first_constant_layer + mds_partial_layer_init, 22 x [S-box on lane 0, add the scalar constant, mds_partial_layer_fast],
+ * then full rounds): the same map as the textbook schedule in poseidon.c (tests/test_oracle_poseidon.py holds them against each
+ * other and against the golden vectors), about four times cheaper, which is what makes bench.py's cpu_baseline quotable. Dot
+ * products accumulate the 128-bit products in two 128-bit sums (low and high halves) and reduce once. */
+typedef struct { u128 lo, hi; } acc256;
+static inline void acc_mul(acc256 *a, gl_t x, gl_t y) { const u128 p = (u128)x * y; a->lo += (uint64_t)p; a->hi += (uint64_t)(p >> 64); }
+static inline gl_t acc_reduce(const acc256 *a) { return gl_add(gl_reduce128(a->lo), gl_mul(gl_reduce128(a->hi), GL_EPS)); }   /* lo + hi * 2^64 */
+static inline void fast_mds(gl_t s[12]) {
+    uint64_t lo[24], hi[24];
+    for (int i = 0; i < 12; i++) { lo[i] = lo[i + 12] = (uint32_t)s[i]; hi[i] = hi[i + 12] = s[i] >> 32; }
+    for (int r = 0; r < 12; r++) {
+        uint64_t al = 0, ah = 0;
+        for (int i = 0; i < 12; i++) { al += lo[i + r] * PMDS[i]; ah += hi[i + r] * PMDS[i]; }
+        if (r == 0) { al += lo[0] * 8; ah += hi[0] * 8; }
+        s[r] = gl_reduce128((u128)al + ((u128)ah << 32));
+    }
+}
+void orc_poseidon_permute_fast(gl_t s[12]) {
+    pg_init();
+    int rc = 0;
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) s[i] = pg_sbox(gl_add(s[i], PRC[rc * 12 + i]));
+        fast_mds(s);
+    }
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], FP_FIRST[i]);
+    {
+        gl_t t[11];
+        for (int c = 0; c < 11; c++) { acc256 a = {0, 0}; for (int r = 0; r < 11; r++) acc_mul(&a, FP_INIT[c][r], s[1 + r]); t[c] = acc_reduce(&a); }
+        memcpy(s + 1, t, sizeof t);
+    }
+    for (int r = 0; r < 22; r++) {
+        const gl_t s0 = gl_add(pg_sbox(s[0]), FP_RC[r]);
+        acc256 a = {0, 0};
+        acc_mul(&a, s0, 25);
+        for (int i = 0; i < 11; i++) acc_mul(&a, FP_WH[r][i], s[1 + i]);
+        for (int i = 0; i < 11; i++) s[1 + i] = gl_add(s[1 + i], gl_mul(s0, FP_VS[r][i]));
+        s[0] = acc_reduce(&a);
+    }
+    rc += 22;
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) s[i] = pg_sbox(gl_add(s[i], PRC[rc * 12 + i]));
+        fast_mds(s);
+    }
+}
 /* emits the 123 constraints into out[] */
 static void poseidon_gate_base(const gl_t *w, gl_t *out) {
     pg_init();
@@ -586,6 +635,13 @@ size_t orc_proof_size(const orc_circuit *c) {
 /* ------------------------------------------------------------------ prove */
 int orc_prove(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len) {
     return orc_prove_seeded(c, wires, public_inputs, 0, out, cap, len);
+}
+/* orc_prove on a thread that proves beside others (orc_commit_prove_many): keeps no stage trace */
+int orc_prove_many_entry(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len) {
+    g_trace_off = 1;
+    const int rc = orc_prove_seeded(c, wires, public_inputs, 0, out, cap, len);
+    g_trace_off = 0;
+    return rc;
 }
 int orc_prove_seeded(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint64_t seed, uint8_t *out, size_t cap, size_t *len) {
     trace_clear();

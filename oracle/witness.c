@@ -23,6 +23,7 @@
 enum { ORC_WIT_OK = 0, ORC_WIT_CONFLICT = 1, ORC_WIT_INCOMPLETE = 2, ORC_WIT_UNSUPPORTED = 3, ORC_WIT_BAD_PACK = 4 };
 
 void orc_poseidon_round_constants(gl_t *out);
+int orc_prove_many_entry(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len);   /* prove.c: orc_prove without the stage trace */
 
 typedef struct {
     const orc_circuit *c;
@@ -298,48 +299,55 @@ static uint32_t gate_instances(const orc_gate *g) {
     }
 }
 
-/* cells / values: the PartialWitness (cell = row * num_wires + wire); public_inputs go to the pack's public-input cells
- * ("PUBI1"). wires_out: num_wires x n column-major, unset targets 0. conflict_cell_out: the target that was set twice. */
-int orc_generate_witness(const uint64_t *words, size_t n_words, const uint64_t *cells, const gl_t *values, size_t count,
-                         const gl_t *public_inputs, gl_t *wires_out, uint64_t *conflict_cell_out) {
-    orc_circuit *c = orc_circuit_load(words, n_words);
-    if (!c) return ORC_WIT_BAD_PACK;
+/* ---- a circuit prepared for witness generation: what plonky2 holds in ProverOnlyCircuitData (the partition of the
+ * targets, the generator list); built once per circuit, outside any timed region ---- */
+typedef struct {
+    orc_circuit *c;
+    uint64_t *words; size_t n_words;          /* own copy of the pack (the trailers are read in place) */
+    const uint64_t *hints, *pi_cells; size_t n_hints, n_pi;
+    uint32_t *cls;
+    gen_t *gens; size_t n_gens;
+} orc_witness_plan;
+
+void orc_witness_plan_free(orc_witness_plan *w) {
+    if (!w) return;
+    free(w->cls); free(w->gens); free(w->words);
+    orc_circuit_free(w->c);
+    free(w);
+}
+const orc_circuit *orc_witness_plan_circuit(const orc_witness_plan *w) { return w->c; }
+
+/* returns NULL for a pack the oracle rejects; *rc_out says why (ORC_WIT_BAD_PACK / ORC_WIT_UNSUPPORTED) */
+orc_witness_plan *orc_witness_plan_create(const uint64_t *words_in, size_t n_words, int *rc_out) {
     int rc = ORC_WIT_OK;
+    orc_witness_plan *w = (orc_witness_plan *)calloc(1, sizeof *w);
+    w->words = (uint64_t *)malloc(n_words * 8); w->n_words = n_words;
+    memcpy(w->words, words_in, n_words * 8);
+    const uint64_t *words = w->words;
+    orc_circuit *c = w->c = orc_circuit_load(words, n_words);
+    if (!c) { if (rc_out) *rc_out = ORC_WIT_BAD_PACK; free(w->words); free(w); return NULL; }
     const size_t n = (size_t)1 << c->degree_bits, NW = c->num_wires, R = c->num_routed, ncs = c->num_selectors + c->num_constants + c->num_routed;
-    /* trailers: hints and public-input cells */
-    const uint64_t *hints = NULL, *pi_cells = NULL; size_t n_hints = 0, n_pi = 0;
-    {
+    {   /* trailers: hints and public-input cells */
         size_t q = 18 + c->n_arity + 8 * c->n_gates + R + 4 + ncs * n;
         while (q + 2 <= n_words) {
             const uint64_t magic = words[q], cnt = words[q + 1];
-            if (magic == 0x00000031544E4948ULL) { hints = words + q + 2; n_hints = cnt; q += 2 + 8 * cnt; }
-            else if (magic == 0x0000003149425550ULL) { pi_cells = words + q + 2; n_pi = cnt; q += 2 + cnt; }
+            if (magic == 0x00000031544E4948ULL) { w->hints = words + q + 2; w->n_hints = cnt; q += 2 + 8 * cnt; }
+            else if (magic == 0x0000003149425550ULL) { w->pi_cells = words + q + 2; w->n_pi = cnt; q += 2 + cnt; }
             else q += 2 + cnt;
         }
     }
     for (size_t i = 0; i < c->n_gates; i++) {
         const uint64_t t = c->gates[i].type;
-        if (t == OG_REDUCING || t == OG_REDUCING_EXT || t == OG_EXPONENTIATION || t == OG_COSET_INTERP) { orc_circuit_free(c); return ORC_WIT_UNSUPPORTED; }
+        if (t == OG_REDUCING || t == OG_REDUCING_EXT || t == OG_EXPONENTIATION || t == OG_COSET_INTERP) rc = ORC_WIT_UNSUPPORTED;
     }
     pw_t p;
     memset(&p, 0, sizeof p);
     p.c = c; p.n = n; p.nw = NW; p.r = R;
-    p.cls = (uint32_t *)malloc(sizeof(uint32_t) * NW * n);
-    p.val = (gl_t *)calloc(NW * n, sizeof(gl_t));
-    p.set = (uint8_t *)calloc(NW * n, 1);
-    if (!build_classes(&p)) rc = ORC_WIT_BAD_PACK;
-    gl_t pih[4] = {0, 0, 0, 0};
-    if (rc == ORC_WIT_OK) {
-        if (c->num_pis) orc_hash_no_pad(public_inputs, c->num_pis, pih);
-        for (size_t i = 0; i < n_pi && i < c->num_pis; i++) pw_set(&p, pi_cells[i] / NW, pi_cells[i] % NW, public_inputs[i]);
-        for (size_t i = 0; i < count; i++) {
-            if (cells[i] >= NW * n) { rc = ORC_WIT_BAD_PACK; break; }
-            pw_set(&p, cells[i] / NW, cells[i] % NW, values[i]);
-        }
-    }
+    p.cls = w->cls = (uint32_t *)malloc(sizeof(uint32_t) * NW * n);
+    if (rc == ORC_WIT_OK && !build_classes(&p)) rc = ORC_WIT_BAD_PACK;
     if (rc == ORC_WIT_OK) {
         /* the generator list: per row the selected gate's instances, then the hints */
-        size_t cap = n_hints;
+        size_t cap = w->n_hints;
         int32_t *gate_of_row = (int32_t *)malloc(sizeof(int32_t) * n);
         for (size_t r = 0; r < n; r++) {
             gate_of_row[r] = -1;
@@ -348,30 +356,94 @@ int orc_generate_witness(const uint64_t *words, size_t n_words, const uint64_t *
             if (gate_of_row[r] < 0) { rc = ORC_WIT_BAD_PACK; break; }
             cap += gate_instances(&c->gates[gate_of_row[r]]);
         }
-        gen_t *pending = (gen_t *)malloc(sizeof(gen_t) * (cap ? cap : 1));
-        size_t np = 0;
         if (rc == ORC_WIT_OK) {
+            w->gens = (gen_t *)malloc(sizeof(gen_t) * (cap ? cap : 1));
             for (size_t r = 0; r < n; r++)
-                for (uint32_t op = 0, k = gate_instances(&c->gates[gate_of_row[r]]); op < k; op++) pending[np++] = (gen_t){gate_of_row[r], (uint32_t)r, op};
-            for (size_t h = 0; h < n_hints; h++) pending[np++] = (gen_t){-1, 0, (uint32_t)h};
-            /* generate_partial_witness: run whatever is ready until nothing is */
-            for (;;) {
-                size_t kept = 0;
-                for (size_t i = 0; i < np; i++) {
-                    const int ran = pending[i].gate < 0 ? run_hint(&p, hints + 8 * (size_t)pending[i].op) : run_gate(&p, &pending[i], pih);
-                    if (!ran) pending[kept++] = pending[i];
-                }
-                if (kept == np || kept == 0) { np = kept; break; }
-                np = kept;
-            }
-            if (p.conflict) rc = ORC_WIT_CONFLICT;
-            else if (np) rc = ORC_WIT_INCOMPLETE;    /* generators left waiting: plonky2 would fail on the first unset target */
+                for (uint32_t op = 0, k = gate_instances(&c->gates[gate_of_row[r]]); op < k; op++) w->gens[w->n_gens++] = (gen_t){gate_of_row[r], (uint32_t)r, op};
+            for (size_t h = 0; h < w->n_hints; h++) w->gens[w->n_gens++] = (gen_t){-1, 0, (uint32_t)h};
         }
-        free(pending); free(gate_of_row);
+        free(gate_of_row);
+    }
+    if (rc_out) *rc_out = rc;
+    if (rc != ORC_WIT_OK) { orc_witness_plan_free(w); return NULL; }
+    return w;
+}
+
+/* cells / values: the PartialWitness (cell = row * num_wires + wire); public_inputs go to the pack's public-input cells
+ * ("PUBI1"). wires_out: num_wires x n column-major, unset targets 0. conflict_cell_out: the target that was set twice. */
+int orc_witness_generate(const orc_witness_plan *w, const uint64_t *cells, const gl_t *values, size_t count, const gl_t *public_inputs,
+                         gl_t *wires_out, uint64_t *conflict_cell_out) {
+    const orc_circuit *c = w->c;
+    const size_t n = (size_t)1 << c->degree_bits, NW = c->num_wires;
+    int rc = ORC_WIT_OK;
+    pw_t p;
+    memset(&p, 0, sizeof p);
+    p.c = c; p.n = n; p.nw = NW; p.r = c->num_routed; p.cls = w->cls;
+    p.val = (gl_t *)calloc(NW * n, sizeof(gl_t));
+    p.set = (uint8_t *)calloc(NW * n, 1);
+    gl_t pih[4] = {0, 0, 0, 0};
+    if (c->num_pis) orc_hash_no_pad(public_inputs, c->num_pis, pih);
+    for (size_t i = 0; i < w->n_pi && i < c->num_pis; i++) pw_set(&p, w->pi_cells[i] / NW, w->pi_cells[i] % NW, public_inputs[i]);
+    for (size_t i = 0; i < count; i++) {
+        if (cells[i] >= NW * n) { rc = ORC_WIT_BAD_PACK; break; }
+        pw_set(&p, cells[i] / NW, cells[i] % NW, values[i]);
+    }
+    if (rc == ORC_WIT_OK) {
+        gen_t *pending = (gen_t *)malloc(sizeof(gen_t) * (w->n_gens ? w->n_gens : 1));
+        size_t np = w->n_gens;
+        memcpy(pending, w->gens, sizeof(gen_t) * np);
+        /* generate_partial_witness: run whatever is ready until nothing is */
+        for (;;) {
+            size_t kept = 0;
+            for (size_t i = 0; i < np; i++) {
+                const int ran = pending[i].gate < 0 ? run_hint(&p, w->hints + 8 * (size_t)pending[i].op) : run_gate(&p, &pending[i], pih);
+                if (!ran) pending[kept++] = pending[i];
+            }
+            if (kept == np || kept == 0) { np = kept; break; }
+            np = kept;
+        }
+        if (p.conflict) rc = ORC_WIT_CONFLICT;
+        else if (np) rc = ORC_WIT_INCOMPLETE;    /* generators left waiting: plonky2 would fail on the first unset target */
+        free(pending);
     }
     if (conflict_cell_out) *conflict_cell_out = p.conflict ? p.conflict_cell : ~0ULL;
     if (wires_out) for (size_t i = 0; i < NW * n; i++) { const uint32_t s = p.cls[i]; wires_out[i] = p.set[s] ? p.val[s] : 0; }
-    free(p.cls); free(p.val); free(p.set);
-    orc_circuit_free(c);
+    /* the slots held the spend secret */
+    memset(p.val, 0, NW * n * sizeof(gl_t));
+    free(p.val); free(p.set);
     return rc;
+}
+
+/* one-shot form: plan, generate, free */
+int orc_generate_witness(const uint64_t *words, size_t n_words, const uint64_t *cells, const gl_t *values, size_t count,
+                         const gl_t *public_inputs, gl_t *wires_out, uint64_t *conflict_cell_out) {
+    int rc = ORC_WIT_OK;
+    orc_witness_plan *w = orc_witness_plan_create(words, n_words, &rc);
+    if (!w) { if (conflict_cell_out) *conflict_cell_out = ~0ULL; return rc; }
+    rc = orc_witness_generate(w, cells, values, count, public_inputs, wires_out, conflict_cell_out);
+    orc_witness_plan_free(w);
+    return rc;
+}
+
+/* `commit().prove()` for `nproofs` PartialWitnesses over one cell list, ONE PROOF PER THREAD (bench.py's cpu_baseline): every
+ * thread generates its witness and proves it serially — the inner loops' OpenMP regions are nested and run on the one thread —
+ * which is how independent proofs use a many-core host best (no barrier per loop, no shared cache lines). values:
+ * [nproofs][count], public_inputs: [nproofs][num_pis], outs: nproofs buffers of cap bytes. Returns the number of failures. */
+int orc_commit_prove_many(const orc_witness_plan *w, size_t nproofs, const uint64_t *cells, size_t count, const gl_t *values,
+                          const gl_t *public_inputs, uint8_t *outs, size_t cap) {
+    const orc_circuit *c = w->c;
+    const size_t words = (size_t)c->num_wires << c->degree_bits;
+    int failures = 0;
+#pragma omp parallel for schedule(dynamic) reduction(+ : failures)
+    for (long i = 0; i < (long)nproofs; i++) {
+        gl_t *wires = (gl_t *)malloc(words * sizeof(gl_t));
+        size_t len = 0;
+        const gl_t *pis = public_inputs + (size_t)i * c->num_pis;
+        int rc = orc_witness_generate(w, cells, values + (size_t)i * count, count, pis, wires, NULL);
+        if (rc == ORC_WIT_OK) rc = orc_prove_many_entry(c, wires, pis, outs + (size_t)i * cap, cap, &len);
+        if (rc != 0 || len != cap) failures++;
+        memset(wires, 0, words * sizeof(gl_t));
+        free(wires);
+    }
+    return failures;
 }

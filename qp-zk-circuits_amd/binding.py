@@ -97,6 +97,12 @@ def load_library():
         "qpgpu_pool_submit": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
         "qpgpu_pool_wait": (c.c_int, [vp, c.c_uint64, c.POINTER(c.c_size_t)]),
         "qpgpu_pool_set_witness_check": (c.c_int, [vp, c.c_int]),
+        "qpgpu_pool_create_multi": (c.c_int, [vp, c.c_uint, u64p, c.c_size_t, c.c_uint, c.c_uint, c.c_uint, c.POINTER(vp)]),
+        "qpgpu_pool_devices": (c.c_uint, [vp]),
+        "qpgpu_pool_set_partial_cells": (c.c_int, [vp, u64p, c.c_size_t]),
+        "qpgpu_pool_submit_on": (c.c_int, [vp, c.c_uint, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
+        "qpgpu_pool_submit_host": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
+        "qpgpu_pool_submit_partial": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
         "qpgpu_set_hasher": (c.c_int, [c.c_int, u64p, c.c_size_t]),
         "qpgpu_get_hasher": (c.c_int, []),
         "qpgpu_witness_info": (c.c_int, [vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)]),
@@ -612,11 +618,14 @@ class ProvingPool:
     """Several proofs of one circuit in flight on one GPU (qpgpu_pool_*): worker threads, streams and circuit copies live
     inside the library."""
 
-    def __init__(self, pack_words, workers=4, device=0, max_batch=1):
+    def __init__(self, pack_words, workers=4, device=0, max_batch=1, devices=None, host_witness=False):
+        """devices: a list of HIP devices (one entry may repeat) -> qpgpu_pool_create_multi with `workers` workers on each."""
         self.lib = load_library()
         pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
         h = ctypes.c_void_p()
-        rc = self.lib.qpgpu_pool_create_batched(device, pw.ctypes.data, pw.size, workers, max_batch, ctypes.byref(h))
+        devs = [device] if devices is None else list(devices)
+        arr = (ctypes.c_int * len(devs))(*devs)
+        rc = self.lib.qpgpu_pool_create_multi(arr, len(devs), pw.ctypes.data, pw.size, workers, max_batch, 1 if host_witness else 0, ctypes.byref(h))
         if rc != 0:
             raise QpGpuError(rc, "qpgpu_pool_create failed")
         self.h = h
@@ -657,6 +666,44 @@ class ProvingPool:
             raise QpGpuError(rc, self.lib.qpgpu_pool_last_error(self.h).decode())
         self._keep[t.value] = (p, out, d_wires)
         return t.value
+
+    def _submitted(self, rc, t, keep):
+        if rc != 0:
+            raise QpGpuError(rc, self.lib.qpgpu_pool_last_error(self.h).decode())
+        self._keep[t.value] = keep
+        return t.value
+
+    def submit_on(self, device_index, d_wires, public_inputs, out=None):
+        """A device-resident witness on the pool's device number `device_index` (only that device's workers take it)."""
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        out = np.empty(self.proof_size(), dtype=np.uint8) if out is None else out
+        t = ctypes.c_uint64()
+        rc = self.lib.qpgpu_pool_submit_on(self.h, device_index, _ptr(d_wires), p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(t))
+        return self._submitted(rc, t, (p, out, d_wires))
+
+    def submit_host(self, wires, public_inputs, out=None):
+        """A full wire matrix in host memory (any worker of any device uploads and proves it)."""
+        w = np.ascontiguousarray(wires, dtype=np.uint64); p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        out = np.empty(self.proof_size(), dtype=np.uint8) if out is None else out
+        t = ctypes.c_uint64()
+        rc = self.lib.qpgpu_pool_submit_host(self.h, w.ctypes.data, p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(t))
+        return self._submitted(rc, t, (p, out, w))
+
+    def set_partial_cells(self, cells):
+        cl = np.ascontiguousarray(cells, dtype=np.uint64)
+        rc = self.lib.qpgpu_pool_set_partial_cells(self.h, cl.ctypes.data, cl.size)
+        if rc != 0:
+            raise QpGpuError(rc, self.lib.qpgpu_pool_last_error(self.h).decode())
+        self._ncells = cl.size
+
+    def submit_partial(self, values, public_inputs, out=None):
+        """A PartialWitness over the pool's cell list: stage s1 on the device, then the proof."""
+        v = np.ascontiguousarray(values, dtype=np.uint64); p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        assert v.size == self._ncells
+        out = np.empty(self.proof_size(), dtype=np.uint8) if out is None else out
+        t = ctypes.c_uint64()
+        rc = self.lib.qpgpu_pool_submit_partial(self.h, v.ctypes.data, p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(t))
+        return self._submitted(rc, t, (p, out, None))
 
     def wait(self, ticket, copy=True):
         """The proof of a ticket (bytes); copy=False: only its length — the bytes are in the `out` buffer given to submit()."""

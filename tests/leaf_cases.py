@@ -80,7 +80,7 @@ def real_inputs(L, depth=3, seed=5, secret_index=1):
     x = L.LeafInputs()
     x.asset_id, x.volume_fee_bps = 0, DEFAULT_VOLUME_FEE_BPS
     x.transfer_count, x.input_amount = DEFAULT_TRANSFER_COUNTS[secret_index], DEFAULT_INPUT_AMOUNTS[secret_index]
-    x.output_amount_1, x.output_amount_2 = 200, 97                       # (200 + 97) * 10000 <= 300 * 9990
+    x.output_amount_1, x.output_amount_2 = (200, 97) if secret_index == 1 else (66, 33)    # (200 + 97) * 10000 <= 300 * 9990; (66 + 33) * 10000 <= 100 * 9990
     unsp = L.unspendable_account(secret)
     x.set32("secret", secret).set32("unspendable_account", unsp)
     x.set32("nullifier", L.nullifier(secret, x.transfer_count))

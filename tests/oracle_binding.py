@@ -89,6 +89,16 @@ class Oracle:
         L.orc_generate_witness.restype = ctypes.c_int
         L.orc_generate_witness.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.orc_witness_plan_create.restype = ctypes.c_void_p
+        L.orc_witness_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+        L.orc_witness_plan_free.argtypes = [ctypes.c_void_p]
+        L.orc_witness_plan_circuit.restype = ctypes.c_void_p; L.orc_witness_plan_circuit.argtypes = [ctypes.c_void_p]
+        L.orc_witness_generate.restype = ctypes.c_int
+        L.orc_witness_generate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.POINTER(ctypes.c_uint64)]
+        L.orc_commit_prove_many.restype = ctypes.c_int
+        L.orc_commit_prove_many.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_size_t]
         L.orc_set_threads(usable_cpus())
 
     def select_poseidon2(self, rc_ext, rc_int, diag_m1, m4):
@@ -212,3 +222,34 @@ class OracleCircuit:
         out = np.empty(n, dtype=np.uint64)
         if n: self.orc.lib.orc_trace_get(name.encode(), _vp(out))
         return out
+
+
+class OracleProver:
+    """`commit().prove()` on the CPU for one circuit: the partition and the generator list are prepared once (setup), then
+    PartialWitnesses are turned into proofs one proof per thread (orc_commit_prove_many) — bench.py's cpu_baseline."""
+    def __init__(self, orc, pack_words):
+        self.orc = orc
+        pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
+        rc = ctypes.c_int()
+        self.h = orc.lib.orc_witness_plan_create(_vp(pw), pw.size, ctypes.byref(rc))
+        if not self.h:
+            raise ValueError("oracle rejected the circuit pack for witness generation (%d)" % rc.value)
+        self.proof_len = orc.lib.orc_proof_size(orc.lib.orc_witness_plan_circuit(self.h))
+        self.shape = (int(pw[2]), 1 << int(pw[1]))
+    def close(self):
+        if self.h:
+            self.orc.lib.orc_witness_plan_free(self.h); self.h = None
+    def generate(self, cells, values, public_inputs):
+        c = np.ascontiguousarray(cells, dtype=np.uint64); v = np.ascontiguousarray(values, dtype=np.uint64); p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        wires = np.zeros(self.shape, dtype=np.uint64); bad = ctypes.c_uint64()
+        rc = self.orc.lib.orc_witness_generate(self.h, _vp(c), _vp(v), c.size, _vp(p), _vp(wires), ctypes.byref(bad))
+        return rc, wires, bad.value
+    def commit_prove_many(self, cells, values, public_inputs):
+        """values [nproofs, count], public_inputs [nproofs, num_pis] -> list of proof bytes (raises when any proof fails)."""
+        c = np.ascontiguousarray(cells, dtype=np.uint64); v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, c.size)
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(v.shape[0], -1)
+        outs = np.zeros((v.shape[0], self.proof_len), dtype=np.uint8)
+        bad = self.orc.lib.orc_commit_prove_many(self.h, v.shape[0], _vp(c), c.size, _vp(v), _vp(p), _vp(outs), self.proof_len)
+        if bad:
+            raise RuntimeError("%d of %d CPU proofs failed" % (bad, v.shape[0]))
+        return [o.tobytes() for o in outs]
