@@ -119,6 +119,9 @@ std::string CircuitPack::validate() const {
     for (const auto &g : gates) {
         if (g.type > GATE_POSEIDON2) return "unknown gate type";
         if (g.type == GATE_POSEIDON2) {
+            // fail closed: the gate's wire layout lives in un-vendored qp-plonky2 and is NOT known offline, so a pack that selects
+            // the gate must say where its wires are ("P2GL1"); an assumed default could prove what the fork's verifier rejects
+            if (!has_p2_layout) return "Poseidon2 gate (type 14) without a wire-layout trailer (P2GL1): the layout is not assumed";
             const std::string why = p2_layout.validate(num_wires, num_routed_wires);
             if (!why.empty()) return why;
             if (g.num_constraints != p2_layout.num_constraints()) return "bad poseidon2 gate: constraint count does not match its wire layout";

@@ -41,9 +41,10 @@
 //           inputs and are not recorded, as in upstream's PoseidonGate; 1: all four rounds are recorded), constraint order (0:
 //           swap boolean, deltas, first-half rounds, partial rounds, second-half rounds, outputs), and one past the last wire
 //           the gate uses. The fork's gate lives in un-vendored qp-plonky2 1.5.5 and its layout cannot be read offline: a pack
-//           WITHOUT the trailer gets the default = upstream PoseidonGate's layout carried over to Poseidon2 (135 wires, 123
-//           constraints of degree 7, consistent with reference common/src/circuit.rs:428-431,447-449); the Rust exporter
-//           (integration/qpgpu_backend.rs) fills the trailer from the fork's gate. LAYOUT UNPINNED until then.
+//           that selects gate type 14 WITHOUT the trailer is REFUSED (validate()): no layout is assumed. The synthetic generator
+//           and the native builder write the trailer explicitly with the stand-in layout = upstream PoseidonGate's carried over
+//           to Poseidon2 (135 wires, 123 constraints of degree 7, consistent with reference common/src/circuit.rs:428-431,447-449);
+//           the Rust exporter (integration/qpgpu_backend.rs) fills it from the fork's gate. LAYOUT UNPINNED until then.
 #pragma once
 #include <stdint.h>
 #include <cstring>

@@ -33,6 +33,19 @@ int Stager::put(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return QPGPU_OK;
 }
 
+int Stager::put_rows(qpgpu_ctx *ctx, u64 *dst, size_t dst_pitch, const u64 *src, size_t src_pitch, size_t row_words, size_t rows) {
+    const size_t w = row_words * rows;
+    if (rows <= 1 || !h || pos + w > words) {       // one row, or no room in the ring: row by row through put()
+        for (size_t r = 0; r < rows; r++) QP_TRY(put(ctx, dst + r * dst_pitch, src + r * src_pitch, row_words * 8));
+        return QPGPU_OK;
+    }
+    u64 *slot = h + pos;
+    pos += w;
+    for (size_t r = 0; r < rows; r++) std::memcpy(slot + r * row_words, src + r * src_pitch, row_words * 8);
+    QP_HIP(ctx, pk_unpack_rows(slot, dst_pitch, row_words, rows, dst, ctx->stream));
+    return QPGPU_OK;
+}
+
 int salt_key_random(uint32_t key[8]) {
     size_t got = 0;
     while (got < 32) {
@@ -170,12 +183,12 @@ int fri_prove(qpgpu_ctx *ctx, const FriParams &p, const PolyOracle *const *oracl
     if (max_count == 0 || max_count > w.max_batch_polys) return ctx->fail(QPGPU_EINVAL, "fri_prove: empty batch or workspace too small");
     ctx->prof_begin("prove_fri_batch");
     {   // alpha powers always start at 1: one table per proof, every batch reads a prefix
-        std::vector<e2> apw(max_count);
+        std::vector<e2> apw((size_t)nb * max_count);
         for (uint32_t b = 0; b < nb; b++) {
             e2 a = gl::e2_from(1);
-            for (size_t i = 0; i < max_count; i++) { apw[i] = gl::e2_canon(a); a = gl::e2_mul(a, fri_alpha[b]); }
-            QP_TRY(stage.put(ctx, (u64 *)w.alpha_ext + (size_t)b * w.ws, apw.data(), apw.size() * sizeof(e2)));
+            for (size_t i = 0; i < max_count; i++) { apw[(size_t)b * max_count + i] = gl::e2_canon(a); a = gl::e2_mul(a, fri_alpha[b]); }
         }
+        QP_TRY(stage.put_rows(ctx, (u64 *)w.alpha_ext, w.ws, (const u64 *)apw.data(), 2 * max_count, 2 * max_count, nb));
     }
     for (size_t bi = 0; bi < batches.size(); bi++) {
         const FriBatch &fb = batches[bi];

@@ -242,7 +242,8 @@ GL_HD void acc_mul(Acc192 &acc, u64 a, u64 b) {
         "v_addc_co_u32 %2, vcc, %2, %7, vcc\n\t"
         "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
         "v_addc_co_u32 %4, vcc, 0, %4, vcc"
-        : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1), "+v"(t)
+        // early-clobber: the chain writes %0..%2 before it reads %6..%8, so no input may share a register with an accumulator limb
+        : "+&v"(l0), "+&v"(l1), "+&v"(h0), "+&v"(h1), "+&v"(t)
         : "v"((u32)l), "v"((u32)(l >> 32)), "v"((u32)h), "v"((u32)(h >> 32))
         : "vcc");
     acc.lo = ((u64)l1 << 32) | l0; acc.hi = ((u64)h1 << 32) | h0; acc.top = t;

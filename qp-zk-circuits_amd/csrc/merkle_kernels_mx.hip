@@ -115,7 +115,13 @@ MX_KERNEL pow_kernel(PowArgs a, const poseidon2::Params *p2) {
     if (first >= a.count) return;
     const u64 base = a.bases[pr];
     if (base == ~0ull) return;
-    if (__hip_atomic_load(&a.results[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + first) return;
+    // the exit is decided ONCE per workgroup (one wave's load, broadcast through LDS): waves that each looked at results[pr]
+    // could decide differently while another workgroup lowers it, and the survivors would wait at the table load's barrier for
+    // waves that have left
+    __shared__ u32 s_leave;
+    if (threadIdx.x == 0) s_leave = __hip_atomic_load(&a.results[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + first ? 1u : 0u;
+    __syncthreads();
+    if (s_leave) return;
     const unsigned char *lds = table_to_lds<Perm>();
     const u64 idx = first + threadIdx.x, nonce = base + idx;
     const u64 *st = a.states + 12 * (u64)pr;
@@ -149,7 +155,7 @@ static hipError_t allow_table_in_lds() {
 }
 // Once per device, right after a table has been uploaded: four workgroups of the matrix-build permutation (eight waves each, two
 // per SIMD: the occupancy at which a mis-scheduled MFMA destination shows, poseidon_mfma.hpp) on 2 048 fixed states incl. extremes,
-// against the plain permutation on the host. A mismatch fails the context's set-up with hipErrorAssert instead of letting a
+// against the plain permutation on the host, then the production kernels themselves (see below). A mismatch fails the context's set-up with hipErrorAssert instead of letting a
 // platform on which the matrix form misbehaves hash anything (QPGPU_MX=0 runs without the matrix build and without this test).
 template <class Perm, class HostPerm>
 static hipError_t device_selftest(HostPerm host_perm, const poseidon2::Params *host_p2) {
@@ -175,17 +181,83 @@ static hipError_t device_selftest(HostPerm host_perm, const poseidon2::Params *h
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (e == hipSuccess) e = hipMemcpy(out.data(), d, out.size() * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        for (int t = 0; t < N && e == hipSuccess; t++) {
+            u64 s[12];
+            for (int i = 0; i < 12; i++) s[i] = in[(size_t)t * 12 + i];
+            host_perm(s);
+            for (int i = 0; i < 12; i++) if (s[i] != out[(size_t)t * 12 + i]) e = hipErrorAssert;
+        }
+    // The hazard the test guards against depends on each kernel's own register allocation, so the kernels that SHIP run too,
+    // at the occupancy they ship at (1 024 workgroups: two per CU, four waves per SIMD): one leaf build (2^19 sponges of 5
+    // columns), one tree level over its digests (2^18 nodes) and one proof-of-work launch, each held against the host — for
+    // the two hashing launches one lane of every wave (a mis-scheduled MFMA destination corrupts whole waves), for the proof of
+    // work the minimum nonce itself.
+    constexpr u64 NL = 1ull << 19, NN = NL / 2, POW_COUNT = 1ull << 18;
+    constexpr u32 WCOLS = 5, POW_BITS = 11, POW_BATCH = 2;
+    u64 *d_cols = nullptr, *d_dig = nullptr, *d_pow = nullptr;
+    std::vector<u64> cols((size_t)WCOLS * NL), dig(4 * (NL + NN)), powbuf(12 * POW_BATCH + 2 * POW_BATCH);
+    if (e == hipSuccess) {
+        for (size_t i = 0; i < cols.size(); i++) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; cols[i] = (seed ^ (seed >> 29)) % gl::P; }
+        for (u32 b = 0; b < POW_BATCH; b++) {
+            for (int i = 0; i < 12; i++) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; powbuf[12 * b + i] = (seed ^ (seed >> 29)) % gl::P; }
+            powbuf[12 * POW_BATCH + b] = 1000 * (b + 1);            // bases
+            powbuf[12 * POW_BATCH + POW_BATCH + b] = ~0ull;         // results
+        }
+        e = hipMalloc((void **)&d_cols, cols.size() * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_dig, dig.size() * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_pow, powbuf.size() * 8);
+        if (e == hipSuccess) e = hipMemcpy(d_cols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_pow, powbuf.data(), powbuf.size() * 8, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        MerkleLeafArgs la{};
+        la.src0 = d_cols; la.stride0 = NL; la.ncols0 = WCOLS; la.n_leaves = NL; la.digests = d_dig; la.batch = 1;
+        hipLaunchKernelGGL(mx::leaf_hash_kernel<Perm>, dim3((unsigned)(NL / mx::WG)), dim3(mx::WG), pmf::TABLE_BYTES, st, la, dp);
+        hipLaunchKernelGGL(mx::node_kernel<Perm>, dim3((unsigned)(NN / mx::WG)), dim3(mx::WG), pmf::TABLE_BYTES, st, d_dig, d_dig + 4 * NL, NN, 1u, (u64)0, 1u, dp);
+        PowArgs pa{};
+        pa.states = d_pow; pa.bases = d_pow + 12 * POW_BATCH; pa.results = d_pow + 12 * POW_BATCH + POW_BATCH;
+        pa.pos = 3; pa.pow_bits = POW_BITS; pa.batch = POW_BATCH; pa.count = POW_COUNT;
+        hipLaunchKernelGGL(mx::pow_kernel<Perm>, dim3((unsigned)(POW_COUNT / mx::WG * POW_BATCH)), dim3(mx::WG), pmf::TABLE_BYTES, st, pa, dp);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpy(dig.data(), d_dig, dig.size() * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(powbuf.data(), d_pow, powbuf.size() * 8, hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess) {
+        for (u64 w = 0; w < NL / 64 && e == hipSuccess; w++) {           // one lane of every wave of the leaf build
+            const u64 j = w * 64 + (w * 7) % 64;
+            u64 s[12] = {0};
+            for (u32 c = 0; c < WCOLS; c++) s[c] = cols[(size_t)c * NL + j];
+            host_perm(s);
+            for (int i = 0; i < 4; i++) if (s[i] != dig[4 * j + i]) e = hipErrorAssert;
+        }
+        for (u64 w = 0; w < NN / 64 && e == hipSuccess; w++) {           // one lane of every wave of the tree level
+            const u64 i0 = w * 64 + (w * 11) % 64;
+            u64 s[12] = {0};
+            for (int i = 0; i < 8; i++) s[i] = dig[8 * i0 + i];
+            host_perm(s);
+            for (int i = 0; i < 4; i++) if (s[i] != dig[4 * NL + 4 * i0 + i]) e = hipErrorAssert;
+        }
+        for (u32 b = 0; b < POW_BATCH && e == hipSuccess; b++) {         // the minimum accepted nonce, found again on the host
+            const u64 base = 1000 * (b + 1), got = powbuf[12 * POW_BATCH + POW_BATCH + b];
+            u64 want = ~0ull;
+            for (u64 k = 0; k < POW_COUNT && want == ~0ull; k++) {
+                u64 s[12];
+                for (int i = 0; i < 12; i++) s[i] = i == 3 ? base + k : powbuf[12 * b + i];
+                host_perm(s);
+                if ((s[7] >> (64 - POW_BITS)) == 0) want = base + k;
+            }
+            if (got != want) e = hipErrorAssert;
+        }
+    }
+    if (d_cols) (void)hipFree(d_cols);
+    if (d_dig) (void)hipFree(d_dig);
+    if (d_pow) (void)hipFree(d_pow);
     if (st) (void)hipStreamDestroy(st);
     if (d) (void)hipFree(d);
     if (dp) (void)hipFree(dp);
-    if (e != hipSuccess) return e;
-    for (int t = 0; t < N; t++) {
-        u64 s[12];
-        for (int i = 0; i < 12; i++) s[i] = in[(size_t)t * 12 + i];
-        host_perm(s);
-        for (int i = 0; i < 12; i++) if (s[i] != out[(size_t)t * 12 + i]) return hipErrorAssert;
-    }
-    return hipSuccess;
+    return e;
 }
 // The tables are functions of the round constants. Before anything is uploaded, the integer emulation of the device schedule
 // (same table bytes, same recombination code) is held against the plain permutation on the host.

@@ -369,7 +369,7 @@ static int prove_batch_impl(qpgpu_circuit *c, uint32_t nb, const u64 *d_wires, c
         for (uint32_t k = 0; k < nch; k++) { sm[k] = betas[b][k]; sm[nch + k] = gammas[b][k]; for (u64 j = 0; j < R; j++) sm[2 * nch + k * R + j] = gl::canon(gl::mul(betas[b][k], p.k_is[j])); }
     }
     // (the alpha part of the table is uploaded after the Z commitment; this upload covers betas .. beta_k_is)
-    for (uint32_t b = 0; b < nb; b++) QP_TRY(c->stage.put(ctx, c->d_small + (size_t)b * SW, small.data() + (size_t)b * SW, (2 * nch + (size_t)nch * R) * 8));
+    QP_TRY(c->stage.put_rows(ctx, c->d_small, SW, small.data(), SW, 2 * nch + (size_t)nch * R, nb));
 
     // ---- s5 partial products ----
     ctx->prof_begin("prove_partial_products");
@@ -394,8 +394,8 @@ static int prove_batch_impl(qpgpu_circuit *c, uint32_t nb, const u64 *d_wires, c
         u64 *ap = small.data() + (size_t)b * SW + 2 * nch + (size_t)nch * R;
         for (uint32_t k = 0; k < nch; k++) { u64 a = 1; for (size_t t = 0; t < nterms; t++) { ap[k * nterms + t] = gl::canon(a); a = gl::mul(a, alphas[b][k]); } }
         std::memcpy(ap + (size_t)nch * nterms, pih[b].data(), 32);
-        QP_TRY(c->stage.put(ctx, d_apow + (size_t)b * SW, ap, ((size_t)nch * nterms + 4) * 8));
     }
+    QP_TRY(c->stage.put_rows(ctx, d_apow, SW, small.data() + 2 * nch + (size_t)nch * R, SW, (size_t)nch * nterms + 4, nb));
     if (c->check_witness) {
         // the analogue of plonky2's debug assertions: filtered gate constraints must vanish on every trace row and the
         // permutation product must close; alpha-weighted sums are zero iff every constraint is (alpha is a transcript challenge)

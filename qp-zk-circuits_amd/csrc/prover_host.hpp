@@ -78,6 +78,9 @@ struct Stager {
     gl::u64 *h = nullptr;
     size_t words = 0, pos = 0;
     int put(qpgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
+    // `rows` tables of row_words each (src rows src_pitch words apart on the host) to dst + r * dst_pitch: ONE launch for the
+    // per-proof tables of a lockstep batch
+    int put_rows(qpgpu_ctx *ctx, gl::u64 *dst, size_t dst_pitch, const gl::u64 *src, size_t src_pitch, size_t row_words, size_t rows);
 };
 
 struct FriParams {

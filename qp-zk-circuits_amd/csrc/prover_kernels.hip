@@ -757,6 +757,15 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const u64 *src, u64 pitc
     dst[i] = src[r * pitch + c];
 }
 
+// the inverse: a dense block of `total / width` rows -> rows `pitch` words apart (one upload for the per-proof tables of a lockstep
+// batch instead of one copy launch per proof)
+__global__ void __launch_bounds__(256) unpack_rows_kernel(const u64 *src, u64 pitch, u64 width, u64 total, u64 *dst) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u64 r = i / width, c = i - r * width;
+    dst[r * pitch + c] = src[i];
+}
+
 // dst[0..bytes) = src[0..bytes): the small transfers of the proving path between pinned host memory and device memory (either
 // side may be the pinned one: the device reads and writes it in place). 8-byte words when both ends are aligned, bytes otherwise.
 __global__ void __launch_bounds__(256) copy_words_kernel(u64 *dst, const u64 *src, u64 words, u64 tail_bytes) {
@@ -861,6 +870,11 @@ hipError_t pk_copy(void *dst, const void *src, size_t bytes, hipStream_t st) {
 }
 hipError_t pk_pack_rows(const u64 *src, u64 pitch_words, u64 width_words, u64 rows, u64 *dst, hipStream_t st) {
     LAUNCH_1D(pack_rows_kernel, width_words * rows, 256, st, src, pitch_words, width_words, width_words * rows, dst);
+    return hipGetLastError();
+}
+hipError_t pk_unpack_rows(const u64 *src, u64 pitch_words, u64 width_words, u64 rows, u64 *dst, hipStream_t st) {
+    if (width_words * rows == 0) return hipSuccess;
+    LAUNCH_1D(unpack_rows_kernel, width_words * rows, 256, st, src, pitch_words, width_words, width_words * rows, dst);
     return hipGetLastError();
 }
 hipError_t pk_scale_powers(u64 *data, u64 n, u64 ncols, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits, hipStream_t st) {

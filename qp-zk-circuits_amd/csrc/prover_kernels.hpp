@@ -86,6 +86,8 @@ hipError_t pk_divide_linear(const uint64_t *comp_a, const uint64_t *comp_b, uint
                             uint64_t *fin_a, uint64_t *fin_b, uint32_t batch, uint64_t ps_comp, uint64_t ps_fin, hipStream_t st);
 // device-side copy of a small block; dst or src may be pinned host memory (used in place of the runtime's small-copy path)
 hipError_t pk_copy(void *dst, const void *src, size_t bytes, hipStream_t st);
+// dense rows -> dst + r * pitch_words (the upload-side counterpart)
+hipError_t pk_unpack_rows(const uint64_t *src, uint64_t pitch_words, uint64_t width_words, uint64_t rows, uint64_t *dst, hipStream_t st);
 hipError_t pk_pack_rows(const uint64_t *src, uint64_t pitch_words, uint64_t width_words, uint64_t rows, uint64_t *dst, hipStream_t st);
 hipError_t pk_interleave_ext(const uint64_t *va, const uint64_t *vb, uint64_t n, uint64_t *rows, uint32_t batch, uint64_t ps_vals, uint64_t ps_rows, hipStream_t st);
 hipError_t pk_fri_fold(const uint64_t *ca, const uint64_t *cb, uint64_t new_n, uint32_t arity, const gl::e2 *betas, uint64_t *oa, uint64_t *ob,

@@ -95,9 +95,10 @@ def test_layout_trailer_round_trip_and_validation(pkg):
     trailers = pkg.pack_trailers(pack)
     magic, at, cnt = [t for t in trailers if t[0] == 0x314C473250][0]
     assert cnt == 10 and pack[at:at + 10].tolist() == [0, 12, 24, 25, 29, 65, 87, 0, 0, 135]
-    # without the trailer the default layout applies: same circuit
+    # without the trailer the pack is refused (fail closed): the fork's layout is not known offline, so none is assumed
     cut = np.concatenate([pack[:at - 2], pack[at + cnt:]])
-    assert validate(cut)[0] == 0 and pkg.pack_p2_layout(cut) is None
+    rc, msg = validate(cut)
+    assert rc != 0 and "P2GL1" in msg and pkg.pack_p2_layout(cut) is None
     for field, value, why in ((0, 130, "outside"), (1, 70, "routed"), (4, 60, "overlap"), (7, 2, "first_round_wires"), (8, 1, "constraint order"),
                               (9, 200, "end_wire"), (7, 1, "overlap"), (2, pkg.P2_NO_SWAP, "constraint count")):
         bad = pack.copy(); bad[at + field] = value
