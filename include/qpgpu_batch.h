@@ -164,6 +164,28 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
                                    size_t num_proof_targets, const uint64_t *dummy_nullifier_preimages, size_t num_preimages, size_t num_preimage_targets,
                                    const char *label, uint32_t *targets_out, uint64_t *values_out, size_t cap, size_t *count, char *err);
 
+/* ---- a wrapper circuit that checks the Merkle half of its inner proofs (csrc/wrapper_circuit.cpp) ------------------------
+ * add_recursive_verifiers (wormhole/aggregator/src/common/recursive.rs:74-102) restated on the library's native builder as far
+ * as the commitments go: `num_proofs` proof targets of the circuit `inner_pack` (logical targets in the order above), and for
+ * every proof and every query round the in-circuit Merkle verification of its four opened rows and of every FRI step's coset of
+ * evaluations (hash the row with PoseidonGate rows, one permute_swapped per path level, RandomAccessGate look-up of the cap entry)
+ * against the inner circuit's constants/sigmas cap (`inner_cs_cap`, 4 << cap_height words: qpgpu_circuit_constants_sigmas_cap of the
+ * loaded inner circuit; it becomes constants of the wrapper) and against the caps the proof carries. The inner public inputs are
+ * the wrapper's public inputs (proof 0's first); their hash is computed as verify_proof does.
+ * NOT verified in-circuit (csrc/wrapper_circuit.cpp says so at length): the transcript — the query indices are therefore inputs
+ * (logical targets below; take them from qpgpu_verifier_query_indices) —, the openings at zeta, the folding arithmetic, the proof
+ * of work. A flipped byte in an opened row, an evaluation or a sibling of an inner proof makes the wrapper's witness
+ * unsatisfiable (QPGPU_EUNSAT at witness generation, naming the target).
+ * Logical targets of the wrapper, target_map_out[...] = wire cell or UINT64_MAX: proof slot i target j -> i * T + j (T =
+ * qpgpu_proof_target_count); dummy-nullifier preimage limb -> N * T + 4 i + limb (assigned by fill_private_batch_witness, unused
+ * here); query index q of slot i -> N * (T + 4) + i * Q + q. num_routed_wires: 80 (public batch) or 60 (private batch),
+ * 0 = 80. info_out (QPGPU_WRAPPER_CIRCUIT_INFO_WORDS, may be NULL): degree_bits, rows before padding, T, Q, PoseidonGate rows,
+ * RandomAccessGate rows, BaseSumGate rows, ArithmeticGate rows, ConstantGate rows, public inputs. */
+#define QPGPU_WRAPPER_CIRCUIT_INFO_WORDS 12
+int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, const uint64_t *inner_cs_cap, size_t cap_words, unsigned num_proofs,
+                                unsigned num_routed_wires, unsigned min_degree_bits, int inner_hasher, uint64_t *pack_out, size_t pack_cap_words,
+                                size_t *pack_words, uint64_t *target_map_out, size_t map_cap, size_t *map_count, uint64_t *info_out, char *err);
+
 #ifdef __cplusplus
 }
 #endif

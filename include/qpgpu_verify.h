@@ -45,6 +45,12 @@ int qpgpu_verifier_constants_sigmas_cap(const qpgpu_verifier *v, uint64_t *out, 
  * Merkle path of oracle k at query q, FRI round consistency, final polynomial). Thread-safe on a shared verifier. */
 int qpgpu_verifier_verify(const qpgpu_verifier *v, const uint8_t *proof, size_t len, char *err);
 
+/* The FRI query indices of a proof (num_query_rounds words): the transcript replayed up to and including the proof of work,
+ * everything it absorbs checked on the way; the query rounds themselves are not looked at, so a proof whose opened rows or
+ * Merkle paths were tampered with still yields its indices. They are what a recursive verifier derives in-circuit; a wrapper
+ * circuit that checks the Merkle paths only (qpgpu_wrapper_circuit_build, include/qpgpu_batch.h) takes them as inputs. */
+int qpgpu_verifier_query_indices(const qpgpu_verifier *v, const uint8_t *proof, size_t len, uint64_t *out, size_t cap, char *err);
+
 /* The same for `count` proofs of the circuit on up to `threads` host threads (0 = all cores): results[i] = 0 or
  * QPGPU_EVERIFY per proof; returns 0 when all are accepted, else QPGPU_EVERIFY with the first rejected proof's index and
  * reason in err. What PrivateBatchProver::commit does to its leaf proofs one after the other. */

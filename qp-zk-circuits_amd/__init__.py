@@ -14,3 +14,4 @@ from .binding import pack_p2_layout, pack_trailers, p2_site_cells, P2_NO_SWAP  #
 from . import sharding  # noqa: F401,E402
 from . import aggregation  # noqa: F401,E402
 from . import leaf  # noqa: F401,E402
+from . import recursion  # noqa: F401,E402

@@ -91,6 +91,7 @@ uint32_t Builder::spec_index(uint64_t type, uint64_t p0, uint64_t p1, uint64_t p
     case GATE_ARITHMETIC: s.degree = 3; s.ncons = p0; s.id = "ArithmeticGate { num_ops: " + std::to_string(p0) + " }"; break;
     case GATE_BASE_SUM: s.degree = 2; s.ncons = p0 + 1; s.id = "BaseSumGate { num_limbs: " + std::to_string(p0) + " } + Base: 2"; break;
     case GATE_POSEIDON: s.degree = 7; s.ncons = 123; s.id = "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"; break;
+    case GATE_RANDOM_ACCESS: s.degree = p0 + 1; s.ncons = p1 * (p0 + 2) + p2; s.id = "RandomAccessGate { bits: " + std::to_string(p0) + ", num_copies: " + std::to_string(p1) + " }"; break;
     case GATE_POSEIDON2: s.degree = 7; s.ncons = cfg_.p2_layout.num_constraints(); s.id = "Poseidon2Gate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"; break;
     default: throw std::logic_error("builder: gate type not supported");
     }
@@ -213,13 +214,87 @@ Builder::State Builder::permute_poseidon2(const State &in) {
     return out;
 }
 
+Builder::State Builder::permute_swapped(const State &in, BoolTarget swap) {
+    if (cfg_.inner_hasher != hasher::POSEIDON2) return permute_poseidon(in, swap);
+    const P2GateLayout &l = cfg_.p2_layout;
+    if (!l.has_swap()) {
+        u64 c = 1;
+        if (target_as_constant(swap.target, c) && c == 0) return permute_poseidon2(in);
+        throw std::logic_error("permute_swapped: the Poseidon2 gate layout has no swap wire");
+    }
+    const uint32_t row = add_gate(spec_index(GATE_POSEIDON2, 0, 0, 0));
+    connect(swap.target, wire(row, l.w_swap));
+    for (uint32_t i = 0; i < 12; i++) connect(in[i], wire(row, l.w_input + i));
+    State out;
+    for (uint32_t i = 0; i < 12; i++) out[i] = wire(row, l.w_output + i);
+    return out;
+}
+
+HashOutTarget Builder::hash_or_noop(const std::vector<Target> &inputs) {
+    if (inputs.size() > 4) return hash_n_to_hash_no_pad(inputs);
+    HashOutTarget h;
+    for (size_t i = 0; i < 4; i++) h.elements[i] = i < inputs.size() ? inputs[i] : zero();
+    return h;
+}
+
+Target Builder::random_access(Target access_index, const std::vector<Target> &v) {
+    if (v.size() == 1) return v[0];
+    uint32_t bits = 0;
+    while ((1ull << bits) < v.size()) bits++;
+    if ((1ull << bits) != v.size() || bits > 6) throw std::logic_error("random_access: the vector length must be a power of two up to 64");
+    // RandomAccessGate::new_from_config: as many copies as the routed wires (2 + 2^bits each) and the wires (+ bits each) hold
+    const uint32_t vec = 1u << bits;
+    const uint32_t copies = std::min<uint32_t>(cfg_.num_routed_wires / (2 + vec), cfg_.num_wires / (2 + vec + bits));
+    if (copies == 0) throw std::logic_error("random_access: the gate does not fit the routed wires");
+    const uint32_t extra = std::min<uint32_t>(cfg_.num_routed_wires - (2 + vec) * copies, cfg_.num_constants);
+    auto slot = ra_slots_.find(bits);
+    uint32_t row, copy;
+    if (slot == ra_slots_.end()) { row = add_gate(spec_index(GATE_RANDOM_ACCESS, bits, copies, extra)); copy = 0; }
+    else { row = slot->second.first; copy = slot->second.second; }
+    if (copy + 1 < copies) ra_slots_[bits] = {row, copy + 1};
+    else ra_slots_.erase(bits);
+    const uint32_t b0 = (2 + vec) * copy;
+    const Target claimed = add_virtual_target();
+    for (uint32_t i = 0; i < vec; i++) connect(v[i], wire(row, b0 + 2 + i));
+    connect(access_index, wire(row, b0));
+    connect(claimed, wire(row, b0 + 1));
+    return claimed;
+}
+
+Target Builder::le_sum(const std::vector<BoolTarget> &bits) {
+    if (bits.empty()) return zero();
+    if (bits.size() - 1 > cfg_.num_routed_wires / 4) throw std::logic_error("le_sum: more bits than one ArithmeticGate row of operations (the BaseSumGate form is not restated)");
+    const Target two_ = two();
+    Target sum = bits.back().target;
+    for (size_t i = bits.size() - 1; i-- > 0;) sum = mul_add(two_, sum, bits[i].target);
+    return sum;
+}
+
+void Builder::verify_merkle_proof_to_cap_with_cap_index(const std::vector<Target> &leaf_data, const std::vector<BoolTarget> &leaf_index_bits, Target cap_index,
+                                                        const std::vector<HashOutTarget> &cap, const std::vector<HashOutTarget> &siblings) {
+    if (leaf_index_bits.size() < siblings.size()) throw std::logic_error("verify_merkle_proof: fewer index bits than siblings");
+    const Target z = zero();
+    HashOutTarget state = hash_or_noop(leaf_data);
+    for (size_t l = 0; l < siblings.size(); l++) {
+        State in;
+        for (int i = 0; i < 4; i++) { in[i] = state.elements[i]; in[4 + i] = siblings[l].elements[i]; in[8 + i] = z; }
+        const State out = permute_swapped(in, leaf_index_bits[l]);
+        for (int i = 0; i < 4; i++) state.elements[i] = out[i];
+    }
+    for (int i = 0; i < 4; i++) {
+        std::vector<Target> column(cap.size());
+        for (size_t k = 0; k < cap.size(); k++) column[k] = cap[k].elements[i];
+        connect(random_access(cap_index, column), state.elements[i]);
+    }
+}
+
 HashOutTarget Builder::hash_n_to_hash_no_pad(const std::vector<Target> &inputs) {
     State state;
     state.fill(zero());
     for (size_t i = 0; i < inputs.size(); i += 8) {
         const size_t len = std::min<size_t>(8, inputs.size() - i);
         for (size_t k = 0; k < len; k++) state[k] = inputs[i + k];          // overwrite mode
-        state = cfg_.inner_hasher == hasher::POSEIDON2 ? permute_poseidon2(state) : permute_poseidon(state, _false());
+        state = permute_swapped(state, _false());
     }
     HashOutTarget h;
     for (int i = 0; i < 4; i++) h.elements[i] = state[i];
@@ -271,6 +346,17 @@ std::string Builder::build(CircuitPack &pack) {
             for (uint32_t op = slot.second.second; op < num_ops; op++)
                 for (uint32_t k = 0; k < 3; k++) connect(z, wire(slot.second.first, 4 * op + k));
         arith_slots_.clear();
+        // the copies left over in the last RandomAccessGate row of every width: index 0 into a list of zeros
+        for (const auto &slot : ra_slots_) {
+            const uint32_t bits = slot.first, vec = 1u << bits;
+            const uint32_t copies = std::min<uint32_t>(R / (2 + vec), NW / (2 + vec + bits));
+            for (uint32_t copy = slot.second.second; copy < copies; copy++) {
+                const uint32_t b0 = (2 + vec) * copy;
+                connect(z, wire(slot.second.first, b0));
+                for (uint32_t i = 0; i < vec; i++) connect(z, wire(slot.second.first, b0 + 2 + i));
+            }
+        }
+        ra_slots_.clear();
     }
     // every constant used gets a ConstantGate slot, in the order of the constants' values
     {

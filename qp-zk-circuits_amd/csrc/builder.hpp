@@ -102,6 +102,17 @@ public:
     State permute_poseidon2(const State &in);                     // one row of the fork's Poseidon2 gate, swap wire (if any) = 0
     // hash_n_to_hash_no_pad::<PoseidonHash>: overwrite-mode sponge, no padding (hashing.rs)
     HashOutTarget hash_n_to_hash_no_pad(const std::vector<Target> &inputs);
+    State permute_swapped(const State &in, BoolTarget swap);      // H::permute_swapped for the configured inner hasher
+    // hash_or_noop: at most 4 elements are the digest themselves (zero padded), more are hashed (hashing.rs)
+    HashOutTarget hash_or_noop(const std::vector<Target> &inputs);
+    // gadgets/random_access.rs: v[access_index] on a RandomAccessGate slot (|v| a power of two, at most 2^6)
+    Target random_access(Target access_index, const std::vector<Target> &v);
+    // gadgets/split_base.rs le_sum: sum of bits[i] * 2^i as a chain of mul_add operations (what upstream picks for <= num_ops bits)
+    Target le_sum(const std::vector<BoolTarget> &bits);
+    // hash/merkle_proofs.rs verify_merkle_proof_to_cap_with_cap_index: the leaf's digest walks up `siblings` (one permute_swapped
+    // per level, swap = the index bit) and must equal cap[cap_index] (4 random accesses into the cap)
+    void verify_merkle_proof_to_cap_with_cap_index(const std::vector<Target> &leaf_data, const std::vector<BoolTarget> &leaf_index_bits, Target cap_index,
+                                                   const std::vector<HashOutTarget> &cap, const std::vector<HashOutTarget> &siblings);
     // hash_n_to_hash_no_pad_p2::<Poseidon2Hash> of the fork: `input || 1 || 0*` to a multiple of the rate 8, every block ADDED
     // into the rate part (wormhole/circuit/tests/heap_zeroization.rs:133-160 pins the padding; the block-header vectors the
     // additive absorption, tests/test_leaf_witness.py)
@@ -154,6 +165,7 @@ private:
     std::unordered_map<Target, u64> targets_to_constants_;
     std::map<ArithKey, Target> arith_results_;
     std::map<std::pair<u64, u64>, std::pair<uint32_t, uint32_t>> arith_slots_;   // (c0, c1) -> (row, next free operation)
+    std::map<uint32_t, std::pair<uint32_t, uint32_t>> ra_slots_;                  // bits -> (row, next free copy)
     std::vector<Target> public_inputs_;
     std::vector<EqHint> eq_hints_;
     std::vector<LowHighHint> lh_hints_;

@@ -490,7 +490,18 @@ int qpgpu_verifier_constants_sigmas_cap(const qpgpu_verifier *v, uint64_t *out, 
     return QPGPU_OK;
 }
 
-int qpgpu_verifier_verify(const qpgpu_verifier *v, const uint8_t *proof, size_t len, char *err) {
+static int verify_impl(const qpgpu_verifier *v, const uint8_t *proof, size_t len, char *err, uint64_t *indices_out);
+int qpgpu_verifier_verify(const qpgpu_verifier *v, const uint8_t *proof, size_t len, char *err) { return verify_impl(v, proof, len, err, nullptr); }
+// The FRI query indices of a proof: the transcript replayed up to the proof of work, then num_query_rounds challenges reduced
+// mod the LDE size. Everything the transcript absorbs is checked on the way (sizes, canonical elements, quotient identity,
+// proof of work); the query rounds themselves are NOT looked at, so the indices of a proof whose opened rows or paths were
+// tampered with are still returned (they are what a recursive verifier circuit derives in-circuit, wormhole/aggregator/src/
+// common/recursive.rs:91-97).
+int qpgpu_verifier_query_indices(const qpgpu_verifier *v, const uint8_t *proof, size_t len, uint64_t *out, size_t cap, char *err) {
+    if (!v || !out || cap < v->pack.num_query_rounds) return fail(err, QPGPU_EINVAL, "query_indices: null argument or room for fewer than num_query_rounds indices");
+    return verify_impl(v, proof, len, err, out);
+}
+static int verify_impl(const qpgpu_verifier *v, const uint8_t *proof, size_t len, char *err, uint64_t *indices_out) {
     if (!v || !proof) return fail(err, QPGPU_EINVAL, "null argument");
     const CircuitPack &c = v->pack;
     const Hash H{&v->hash};
@@ -609,8 +620,11 @@ int qpgpu_verifier_verify(const qpgpu_verifier *v, const uint8_t *proof, size_t 
     Reader q{proof, len, queries_pos};
     std::vector<u64> row(ncs + NW + nch * (1 + npp) + nq + 16), path(64 * 4), ev(64);
     const u64 w_lde = gl::root_of_unity(L);
+    std::vector<size_t> x_indices(c.num_query_rounds);      // the loop below does not touch the transcript: draw them all first
+    for (size_t qi = 0; qi < c.num_query_rounds; qi++) x_indices[qi] = (size_t)(ch.get() % lde_n);
+    if (indices_out) { for (size_t qi = 0; qi < c.num_query_rounds; qi++) indices_out[qi] = x_indices[qi]; return QPGPU_OK; }
     for (size_t qi = 0; qi < c.num_query_rounds; qi++) {
-        size_t x_index = (size_t)(ch.get() % lde_n);
+        size_t x_index = x_indices[qi];
         const u64 *rows[4];
         size_t off = 0;
         for (int o = 0; o < 4; o++) {

@@ -1,0 +1,101 @@
+"""A wrapper circuit that checks the Merkle half of its inner proofs (include/qpgpu_batch.h: qpgpu_wrapper_circuit_build,
+csrc/wrapper_circuit.cpp), on the CPU: the library builds the circuit (host code) from the leaf circuit's pack, the ORACLE makes
+the inner leaf proofs, generates the wrapper's witness from them (fill_private_batch_witness's assignments + the query indices of
+the host verifier's transcript replay), proves and verifies. What add_recursive_verifiers
+(wormhole/aggregator/src/common/recursive.rs:74-102) adds per inner proof, as far as the commitments go; the module says what is
+NOT verified in-circuit. tests/test_wrapper_circuit_gpu.py runs the same through the device."""
+import numpy as np
+import pytest
+
+import leaf_cases as lc
+import oracle_binding as ob
+
+
+@pytest.fixture(scope="module")
+def setup(pkg, orc):
+    L = pkg.leaf
+    leaf = L.LeafCircuit()                                  # the restated leaf circuit at its own size (2^8 rows)
+    xs = [lc.real_inputs(L, depth=3), lc.test_inputs(L, 0), lc.dummy_inputs(L)]
+    com = [leaf.commit(x) for x in xs]
+    op = ob.OracleProver(orc, leaf.pack)
+    proofs = op.commit_prove_many(com[0][0], np.stack([c[1] for c in com]), np.stack([c[2] for c in com]))
+    op.close()
+    ver = pkg.Verifier(leaf.pack)                           # verifier data (constants/sigmas cap) computed on the host
+    assert all(ver.verify(p) for p in proofs)
+    w = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2)
+    yield leaf, proofs, ver, w
+    ver.close()
+
+
+def test_shape(pkg, setup):
+    leaf, proofs, ver, w = setup
+    h = pkg.pack_header(leaf.pack)
+    L_ = h["degree_bits"] + h["rate_bits"]
+    path = L_ - h["cap_height"]
+    widths = [h["num_selectors"] + h["num_constants"] + h["num_routed_wires"], 135, 2 * (1 + h["num_partial_products"]), 16]
+    perms = lambda wd: -(-wd // 8)
+    steps = h["num_arity_rounds"]
+    # per query round: hash the four rows, walk four paths, hash every step's coset (2^4 extension values = 32 elements), walk its path
+    per_query = sum(perms(wd) for wd in widths) + 4 * path + sum(4 + (L_ - 4 * (s + 1) - h["cap_height"]) for s in range(steps))
+    pis_hash = perms(21)
+    assert w.info["rows_poseidon"] == 2 * (28 * per_query + pis_hash) + perms(42)      # + the wrapper's own public-input hash
+    assert w.info["rows_random_access"] == 2 * 28 * (4 + steps) * 4 // 4               # 4 look-ups per path, 4 copies per row
+    assert w.info["rows_base_sum"] == 2 * 28 and w.info["public_inputs"] == 42
+    assert w.info["targets_per_proof"] == (len(proofs[0]) - 28 * (4 + steps)) // 8
+    # the targets nothing in the Merkle half consumes have no cell: openings (2 per extension element), pow witness, final polynomial, preimages
+    nopen = 2 * (h["num_selectors"] + h["num_constants"] + 80 + 135 + 2 + 2 * h["num_partial_products"] + 16 + 2)
+    fin = 2 << (h["degree_bits"] - 4 * steps)
+    assert int((w.target_map == pkg.recursion.NO_CELL).sum()) == 2 * (nopen + 1 + fin + 4)
+
+
+def test_valid_inner_proofs_give_a_valid_wrapper_proof(pkg, orc, setup):
+    leaf, proofs, ver, w = setup
+    cells, vals, pis = w.commit(proofs[:2])
+    rc, wires, _ = orc.generate_witness(w.pack, cells, vals, pis)
+    assert rc == orc.WIT_OK
+    assert pis.tolist() == np.concatenate([lc.proof_public_inputs(p, 21) for p in proofs[:2]]).tolist()     # inner public inputs forwarded
+    oc = ob.OracleCircuit(orc, w.pack)
+    proof = oc.prove(wires, pis)
+    assert oc.verify(proof) == 0
+    oc.close()
+    # other inner proofs, same wrapper
+    cells2, vals2, pis2 = w.commit([proofs[2], proofs[0]])
+    assert np.array_equal(cells2, cells) and orc.generate_witness(w.pack, cells2, vals2, pis2)[0] == orc.WIT_OK
+
+
+def test_tampered_inner_proofs_are_unsatisfiable(pkg, orc, setup):
+    leaf, proofs, ver, w = setup
+    h = pkg.pack_header(leaf.pack)
+    base = proofs[1]
+    # byte offsets inside the proof: caps 3 x 16 x 32, openings, commit caps, then the query rounds
+    n_open = (h["num_selectors"] + h["num_constants"] + 80 + 135 + 2 + 2 + 2 * h["num_partial_products"] + 16) * 16
+    q0 = 3 * 16 * 32 + n_open + h["num_arity_rounds"] * 16 * 32
+    ncs = h["num_selectors"] + h["num_constants"] + 80
+    path = h["degree_bits"] + h["rate_bits"] - h["cap_height"]
+    spots = {"constants/sigmas row, first query": q0 + 8 * 3,
+             "its first sibling": q0 + 8 * ncs + 1 + 5,
+             "wires row, first query": q0 + 8 * ncs + 1 + 32 * path + 8 * 100,
+             "a later query round": q0 + 9 * ((len(base) - q0 - 8 * (2 << (h["degree_bits"] - 4 * h["num_arity_rounds"])) - 8 - 8 * 21) // 28) + 40}
+    for what, off in spots.items():
+        bad = bytearray(base); bad[off] ^= 1
+        # the transcript does not absorb query data: the indices are those of the honest proof, the host verifier rejects the proof
+        assert not ver.verify(bytes(bad)), what
+        cells, vals, pis = w.commit([proofs[0], bytes(bad)])
+        rc, _, cell = orc.generate_witness(w.pack, cells, vals, pis)
+        assert rc == orc.WIT_CONFLICT, what
+    # a wrong query index: the rows are committed, but not at that leaf
+    qi = [w.query_indices(p) for p in proofs[:2]]
+    qi[0] = qi[0].copy(); qi[0][5] ^= 1
+    cells, vals, pis = w.commit(proofs[:2], query_indices=qi)
+    assert orc.generate_witness(w.pack, cells, vals, pis)[0] == orc.WIT_CONFLICT
+    # a cap of the proof itself tampered with: the transcript changes, so do the indices; whatever they are, the paths no longer close
+    bad = bytearray(base); bad[40] ^= 1
+    try:
+        cells, vals, pis = w.commit([proofs[0], bytes(bad)])
+        assert orc.generate_witness(w.pack, cells, vals, pis)[0] == orc.WIT_CONFLICT
+    except ValueError:
+        pass        # (or the replay already fails: proof of work / quotient identity)
+    # a proof of the wrong shape is refused before any assignment, with the reference's message (common/utils.rs:295-317)
+    with pytest.raises(ValueError) as e:
+        w.commit([proofs[0], base[:-8]])
+    assert "malformed" in str(e.value)

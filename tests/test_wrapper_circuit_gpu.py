@@ -1,0 +1,55 @@
+"""The wrapper circuit that checks the Merkle half of its inner proofs, on the device: leaf proofs made by the device prover from
+CircuitInputs, the wrapper's witness generated on the device from them (stage s1: 23 626 assignments -> 3 820 PoseidonGate rows,
+280 RandomAccessGate rows), the wrapper proof byte-equal to the oracle's and accepted by both verifiers; a byte flipped in an
+inner proof's opened row or path -> QPGPU_EUNSAT naming the target. See tests/test_wrapper_circuit.py for what is and is not
+verified in-circuit (csrc/wrapper_circuit.cpp)."""
+import numpy as np
+import pytest
+
+import leaf_cases as lc
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def test_leaf_proofs_verified_in_a_wrapper(pkg, gpu, orc):
+    L = pkg.leaf
+    leaf = L.LeafCircuit()
+    lp = L.LeafProver(pkg, gpu, leaf)
+    xs = [lc.real_inputs(L, depth=5, seed=3), lc.test_inputs(L, 1), lc.dummy_inputs(L)]
+    proofs = [lp.prove(x)[0] for x in xs]
+    ver = pkg.Verifier(leaf.pack, circuit=lp.circ)           # verifier data from the GPU handle's commitment
+    assert all(ver.verify(p) for p in proofs)
+    w = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2)
+    assert w.info["degree_bits"] == 13 and w.info["rows_poseidon"] == 3820
+    wc = pkg.Circuit(gpu, w.pack)
+    nw, n = 135, 1 << w.info["degree_bits"]
+    d = gpu.alloc(nw * n * 8)
+    cells, vals, pis = w.commit(proofs[:2])
+    wc.generate_witness_partial_dev(cells, vals, pis, d)
+    rc, want_wires, _ = orc.generate_witness(w.pack, cells, vals, pis)
+    assert rc == orc.WIT_OK and np.array_equal(d.download().reshape(nw, n), want_wires)
+    wc.set_witness_check(True)
+    proof = wc.prove_dev(d, pis)
+    oc = ob.OracleCircuit(orc, w.pack)
+    assert proof == oc.prove(want_wires, pis) and oc.verify(proof) == 0
+    wv = pkg.Verifier(w.pack, circuit=wc)
+    assert wv.verify(proof)
+    assert lc.proof_public_inputs(proof, 42).tolist() == np.concatenate([lc.proof_public_inputs(p, 21) for p in proofs[:2]]).tolist()
+    # other inner proofs through the same handle (the prepared assignment list is reused)
+    cells2, vals2, pis2 = w.commit([proofs[2], proofs[1]])
+    wc.generate_witness_partial_dev(cells2, vals2, pis2, d)
+    assert wv.verify(wc.prove_dev(d, pis2))
+    # tampering with an inner proof: the host verifier rejects it, and the wrapper's witness cannot be generated
+    h = pkg.pack_header(leaf.pack)
+    n_open = (h["num_selectors"] + h["num_constants"] + 80 + 135 + 2 + 2 + 2 * h["num_partial_products"] + 16) * 16
+    q0 = 3 * 16 * 32 + n_open + h["num_arity_rounds"] * 16 * 32
+    for off in (q0 + 24, q0 + 8 * (h["num_selectors"] + h["num_constants"] + 80) + 6, len(proofs[1]) - 8 * 21 - 8 - 8 * 2 * 16 - 300):
+        bad = bytearray(proofs[1]); bad[off] ^= 1
+        assert not ver.verify(bytes(bad))
+        c3, v3, p3 = w.commit([proofs[0], bytes(bad)])
+        with pytest.raises(pkg.QpGpuError) as e:
+            wc.generate_witness_partial_dev(c3, v3, p3, d)
+        assert e.value.code == -4 and "set twice with different values" in str(e.value), off
+    wv.close(); wc.close(); ver.close(); lp.close(); oc.close()
+    d.free(scrub=True)
