@@ -453,7 +453,37 @@ def main():
                                "nullifiers in rank order and every batch's exit slots are its leaves' amounts merged per account") if ok_t else "FAILED"
             tree_check = ok_t
         atree.close()
+    # The same 64-leaf shape with circuits that CHECK something (single GPU leg): leaves of the restated Wormhole leaf circuit from
+    # CircuitInputs, 8 first-level wrappers over 8 leaf proofs each, 1 second-level wrapper over the 8 first-level proofs; every
+    # wrapper verifies the Merkle half of its inner proofs in-circuit (qpgpu_wrapper_circuit_build; what that leaves out is listed in
+    # csrc/wrapper_circuit.cpp) and forwards their public inputs.
+    attest = None
+    if not args.no_tree and rank == 0 and world == 1:
+        try:
+            at = pkg.recursion.AttestingTree(pkg, gpu, per_batch=8, batches=8)
+            at_inputs = [inputs_all[i % S] for i in range(64)]
+            at.run(at_inputs)
+            gpu.sync()
+            ta = time.perf_counter()
+            a_leaves, a_l1, a_root = at.run(at_inputs)
+            adt = time.perf_counter() - ta
+            ok_a = bool(at.w2_ver.verify(a_root)) and bool(at.w1_ver.verify(a_l1[7])) and bool(at.leaf_ver.verify(a_leaves[63]))
+            root_pis = np.frombuffer(a_root[-8 * 21 * 64:], dtype=np.uint64)
+            ok_a = ok_a and bool(np.array_equal(root_pis, np.concatenate([np.frombuffer(p_[-8 * 21:], dtype=np.uint64) for p_ in a_leaves])))
+            attest = {"leaves": 64, "first_level": 8, "second_level": 1, "seconds": round(adt, 4), "levels": dict(at.times),
+                      "degree_bits": {"leaf": at.leaf.info["degree_bits"], "first_level": at.w1.info["degree_bits"], "second_level": at.w2.info["degree_bits"]},
+                      "poseidon_gate_rows": {"first_level": at.w1.info["rows_poseidon"], "second_level": at.w2.info["rows_poseidon"]},
+                      "checked": "the library's verifier accepts the root, a first-level proof and a leaf; the root's public inputs are the 64 leaves' in order" if ok_a else "FAILED",
+                      "note": "every wrapper checks in-circuit, for each inner proof and each of its 28 query rounds, that the four opened rows and every FRI step's coset of "
+                              "evaluations hash up their Merkle paths to the committed caps (PoseidonGate + RandomAccessGate rows); NOT in-circuit yet: the transcript (query "
+                              "indices are witness inputs from the host verifier's replay), openings at zeta, folding arithmetic, proof of work, the batch-specific logic, "
+                              "zero-knowledge blinding of the private layer. Times include commit on the host (fill_witness; fill_private_batch_witness + transcript replay per inner proof)."}
+            ok = ok and ok_a
+            at.close()
+        except pkg.QpGpuError as e:
+            attest = {"error": str(e)}
     if rank == 0:
+        extra["attesting_tree"] = attest
         extra["aggregation_tree"] = tree
         ok = ok and tree_check is not False
         def extra_legs():

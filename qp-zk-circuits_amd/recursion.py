@@ -93,3 +93,58 @@ class WrapperCircuit:
         npis = int(self.inner_pack[9])
         pis = np.concatenate([np.frombuffer(p[-8 * npis:], dtype=np.uint64) if npis else np.zeros(0, dtype=np.uint64) for p in proofs])
         return cells[:k].copy(), vals[:k].copy(), pis
+
+
+class AttestingTree:
+    """BASELINE configs[4]'s shape with circuits that check something: `batches` x `per_batch` leaf proofs of the restated
+    Wormhole leaf circuit (from CircuitInputs), one first-level wrapper per `per_batch` leaves, one second-level wrapper over the
+    first-level proofs (wormhole/aggregator/src/aggregator.rs:187-227's two layers). Every wrapper is a WrapperCircuit: it checks
+    the Merkle half of each inner proof in-circuit (csrc/wrapper_circuit.cpp says what that leaves out: transcript, openings,
+    folding arithmetic, proof of work; the batch-specific logic and the private layer's zero-knowledge blinding are not part of it
+    either) and forwards the inner public inputs. One GPU, one process; every level is one lockstep batch."""
+
+    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0):
+        self.pkg, self.gpu, self.per_batch, self.batches = pkg, gpu, per_batch, batches
+        L = pkg.leaf
+        self.leaf = L.LeafCircuit(min_degree_bits=leaf_min_degree_bits)
+        n_leaves = per_batch * batches
+        self.leaf_circ = pkg.Circuit(gpu, self.leaf.pack, max_batch=n_leaves)
+        self.leaf_ver = pkg.Verifier(self.leaf.pack, circuit=self.leaf_circ)
+        self.w1 = WrapperCircuit(self.leaf.pack, self.leaf_ver, per_batch)
+        self.w1_circ = pkg.Circuit(gpu, self.w1.pack, max_batch=batches)
+        self.w1_ver = pkg.Verifier(self.w1.pack, circuit=self.w1_circ)
+        self.w2 = WrapperCircuit(self.w1.pack, self.w1_ver, batches)
+        self.w2_circ = pkg.Circuit(gpu, self.w2.pack)
+        self.w2_ver = pkg.Verifier(self.w2.pack, circuit=self.w2_circ)
+        self.words = [135 << c.info["degree_bits"] for c in (self.leaf, self.w1, self.w2)]
+        self.d_wires = gpu.alloc(8 * max(n_leaves * self.words[0], batches * self.words[1], self.words[2]))
+        self.times = {}
+
+    def close(self):
+        self.d_wires.free(scrub=True)
+        for x in (self.leaf_ver, self.w1_ver, self.w2_ver, self.leaf_circ, self.w1_circ, self.w2_circ):
+            x.close()
+
+    def _level(self, circ, words, cells, values, pis):
+        st = circ.generate_witness_partial_batch_dev(cells, values, pis, self.d_wires)
+        if any(st):
+            raise QpGpuError(-4, self.gpu.last_error())
+        nb = len(values)
+        return circ.prove_batch_dev([self.d_wires.ptr + 8 * k * words for k in range(nb)], list(pis))
+
+    def run(self, inputs):
+        """inputs: batches * per_batch LeafInputs. Returns (leaf proofs, first-level proofs, root proof)."""
+        import time
+        assert len(inputs) == self.per_batch * self.batches
+        t0 = time.perf_counter()
+        com = [self.leaf.commit(x) for x in inputs]
+        leaves = self._level(self.leaf_circ, self.words[0], com[0][0], np.stack([c[1] for c in com]), np.stack([c[2] for c in com]))
+        t1 = time.perf_counter()
+        com1 = [self.w1.commit(leaves[b * self.per_batch:(b + 1) * self.per_batch]) for b in range(self.batches)]
+        level1 = self._level(self.w1_circ, self.words[1], com1[0][0], np.stack([c[1] for c in com1]), np.stack([c[2] for c in com1]))
+        t2 = time.perf_counter()
+        c2 = self.w2.commit(level1)
+        root = self._level(self.w2_circ, self.words[2], c2[0], c2[1][None], c2[2][None])[0]
+        t3 = time.perf_counter()
+        self.times = {"leaf_level_s": round(t1 - t0, 4), "first_level_s": round(t2 - t1, 4), "second_level_s": round(t3 - t2, 4)}
+        return leaves, level1, root

@@ -53,3 +53,26 @@ def test_leaf_proofs_verified_in_a_wrapper(pkg, gpu, orc):
         assert e.value.code == -4 and "set twice with different values" in str(e.value), off
     wv.close(); wc.close(); ver.close(); lp.close(); oc.close()
     d.free(scrub=True)
+
+
+def test_two_level_tree_attests_its_leaves(pkg, gpu, orc):
+    """4 leaves -> 2 first-level wrappers of 2 -> 1 second-level wrapper of 2 (the 64-leaf shape of BASELINE configs[4] at test
+    size): every proof accepted by the library's verifier and by the oracle's, the root's public inputs are the four leaves' in
+    order, and a root built over a tampered first-level proof cannot be generated."""
+    L = pkg.leaf
+    tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=2)
+    xs = [lc.real_inputs(L, depth=2 + i, seed=40 + i, secret_index=i % 2) for i in range(4)]
+    leaves, level1, root = tree.run(xs)
+    assert all(tree.leaf_ver.verify(p) for p in leaves) and all(tree.w1_ver.verify(p) for p in level1) and tree.w2_ver.verify(root)
+    for pack, proof in ((tree.w1.pack, level1[1]), (tree.w2.pack, root)):
+        oc = ob.OracleCircuit(orc, pack)
+        assert oc.verify(proof) == 0
+        oc.close()
+    want = np.concatenate([lc.proof_public_inputs(p, 21) for p in leaves])
+    assert lc.proof_public_inputs(root, 84).tolist() == want.tolist()
+    assert lc.proof_public_inputs(level1[1], 42).tolist() == want[42:].tolist()
+    bad = bytearray(level1[0]); bad[len(bad) // 2] ^= 1
+    c2 = tree.w2.commit([bytes(bad), level1[1]])
+    st = tree.w2_circ.generate_witness_partial_batch_dev(c2[0], c2[1][None], c2[2][None], tree.d_wires)
+    assert st == [-4] and "set twice with different values" in gpu.last_error()
+    tree.close()
