@@ -36,15 +36,20 @@ STAGES = ["prove_commit_wires", "prove_partial_products", "prove_commit_zs", "pr
           "prove_openings", "prove_fri_batch", "prove_fri_commit", "prove_pow", "prove_queries"]
 
 
-def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
-    """BASELINE configs[1]: fwd + inverse NTT over `batch` columns of 2^log_n. Returns (GB/s, roofline dict, ok)."""
+def ntt_leg(pkg, gpu, log_n, batch, steps):
+    """BASELINE configs[1]: fwd + inverse NTT over `batch` columns of 2^log_n. Returns (GB/s, roofline dict, ok, column in, column out).
+    Device memory through the library's own allocator (no torch in a one-rank run: one ROCm runtime stack in the process)."""
     n = 1 << log_n
-    g = torch.Generator(device=dev); g.manual_seed(99)
-    hi = torch.randint(0, 0xFFFFFFFF, (batch, n), dtype=torch.int64, device=dev, generator=g)
-    lo = torch.randint(0, 1 << 32, (batch, n), dtype=torch.int64, device=dev, generator=g)
-    x = (hi << 32) | lo
-    del hi, lo
-    y = torch.empty_like(x); z = torch.empty_like(x)
+    x = gpu.alloc(batch * n * 8); y = gpu.alloc(batch * n * 8); z = gpu.alloc(batch * n * 8)
+    rng = np.random.default_rng(99)
+    base = rng.integers(0, pkg.P, n, dtype=np.uint64)
+    col0 = None
+    for c in range(batch):                       # 128 different columns: a seeded column, multiplied column by column on the host
+        col = (base * np.uint64(2 * c + 1)) % np.uint64(pkg.P) if c else base      # (wrapping product mod 2^64, reduced: any canonical values do)
+        col = np.ascontiguousarray(col % np.uint64(pkg.P))
+        if c == 0:
+            col0 = col.copy()
+        gpu._check(gpu.lib.qpgpu_memcpy_h2d(gpu.ctx, x.ptr + c * n * 8, col.ctypes.data, n * 8))
 
     def step():
         gpu.ntt_dev(x, y, log_n, batch)
@@ -52,11 +57,11 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
 
     for _ in range(2):
         step()
-    torch.cuda.synchronize(dev)
+    gpu.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    torch.cuda.synchronize(dev)
+    gpu.sync()
     dt = time.perf_counter() - t0
     gbs = 32.0 * n * batch * steps / dt / 1e9
     gpu.profile(True)
@@ -120,8 +125,18 @@ def ntt_leg(torch, pkg, gpu, dev, log_n, batch, steps):
         pass
     if stale:
         roof["counters_stale"] = "not reported: measured on other NTT kernel sources than this library's (" + ", ".join(stale) + ")"
-    ok = bool(torch.equal(z, x))
-    return gbs, roof, ok, x[0].cpu().numpy().view(np.uint64), y[0].cpu().numpy().view(np.uint64)
+    # round trip on every column, forward output of column 0 handed back for the oracle's check
+    ok = True
+    back = np.empty(n, dtype=np.uint64); orig = np.empty(n, dtype=np.uint64)
+    for c in range(batch):
+        gpu._check(gpu.lib.qpgpu_memcpy_d2h(gpu.ctx, back.ctypes.data, z.ptr + c * n * 8, n * 8))
+        gpu._check(gpu.lib.qpgpu_memcpy_d2h(gpu.ctx, orig.ctypes.data, x.ptr + c * n * 8, n * 8))
+        ok = ok and bool(np.array_equal(back, orig))
+    out0 = np.empty(n, dtype=np.uint64)
+    gpu._check(gpu.lib.qpgpu_memcpy_d2h(gpu.ctx, out0.ctypes.data, y.ptr, n * 8))
+    for b_ in (x, y, z):
+        b_.free()
+    return gbs, roof, ok, col0, out0
 
 
 def launch_ranks(n):
@@ -185,40 +200,53 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus))       # this process never touches a GPU: the ranks are fresh interpreters
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    if os.environ.get("QPGPU_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < (int(os.environ.get("LOCAL_WORLD_SIZE", world))):
-        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible (one rank per GPU)")
-    # rehearsal on a one-GPU box: QPGPU_BENCH_BACKEND=gloo puts every rank on the visible GPUs round-robin and does
-    # the gather on host tensors; the driver's multi-GPU runs use the default (nccl = RCCL over xGMI)
+    # PyTorch is plumbing for the multi-rank launch only (torch.distributed over RCCL). A one-rank run imports no torch: the process
+    # then holds ONE ROCm runtime stack (libqpgpu.so's /opt/rocm libamdhip64 + libhsa-runtime64) instead of torch's bundled HIP next
+    # to whatever HSA a profiler preloads. QPGPU_BENCH_TORCH=1 forces the torch path on one rank.
+    use_torch = world > 1 or os.environ.get("QPGPU_BENCH_TORCH") == "1"
+    torch = dist = dev = coll_dev = None
     backend = os.environ.get("QPGPU_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
+    if use_torch:
+        import torch
+        import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+        if backend == "nccl" and torch.cuda.device_count() < (int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+            raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible (one rank per GPU)")
+        # rehearsal on a one-GPU box: QPGPU_BENCH_BACKEND=gloo puts every rank on the visible GPUs round-robin and does
+        # the gather on host tensors; the driver's multi-GPU runs use the default (nccl = RCCL over xGMI)
+        local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        coll_dev = dev if backend == "nccl" else torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend=backend)
 
     import __graft_entry__ as ge
     pkg = ge.load_package()
     from concurrent.futures import ThreadPoolExecutor
     WORKERS, LOCKSTEP = max(1, args.streams), max(1, args.batch)
     S = WORKERS * LOCKSTEP                                          # proofs in flight per GPU = proofs per step per GPU
-    stream = torch.cuda.current_stream(dev)
-    gpu = pkg.QpGpu(local_rank, stream=stream.cuda_stream)          # shares torch's stream (NTT leg, profiling)
+    try:
+        gpu = pkg.QpGpu(local_rank, stream=torch.cuda.current_stream(dev).cuda_stream) if use_torch else pkg.QpGpu(local_rank)
+    except pkg.QpGpuError as e:
+        raise SystemExit(f"bench.py needs an MI355X: the product path has no CPU fallback ({e})")
     gpus = [gpu]
+    # which runtime libraries this process ended up with (one line on stderr; the evidence scripts keep it)
+    try:
+        libs = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if any(k in ln for k in ("libamdhip64", "libhsa-runtime64", "librocprofiler-sdk"))})
+        print("bench.py runtime stack: " + " ".join(libs), file=sys.stderr)
+    except OSError:
+        pass
 
     # ---- the leaf circuit (setup, untimed: the reference builds the circuit in the bench's setup closure too,
     # wormhole/prover/benches/prover.rs:35-37): WormholeCircuit::new restated natively (qpgpu_leaf_circuit_build), padded with NoopGate
@@ -241,6 +269,9 @@ def main():
     step_gather = None
 
     def barrier():
+        if not use_torch:
+            gpu.sync()          # (the pool's proofs have been waited for by then; this covers the context's own stream)
+            return
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -286,8 +317,11 @@ def main():
         # what the step's collective sends (sharding.ProofBlockGather: no per-proof copies on the host)
         nonlocal gathered, step_gather
         if step_gather is None or len(step_gather.send) < ring:
-            step_gather = pkg.sharding.ProofBlockGather(S, proof_len, dist if world > 1 else None, coll_dev, blocks=AHEAD + 1,
-                                                        root=None if args.all_gather or world == 1 else 0)
+            if use_torch:
+                step_gather = pkg.sharding.ProofBlockGather(S, proof_len, dist if world > 1 else None, coll_dev, blocks=AHEAD + 1,
+                                                            root=None if args.all_gather or world == 1 else 0)
+            else:
+                step_gather = pkg.sharding.LocalProofBlocks(S, proof_len, blocks=AHEAD + 1)
         sg = step_gather
 
         def submit_step(j):
@@ -358,7 +392,7 @@ def main():
     wires0 = np.empty((nw_, n_), dtype=np.uint64)                # witness 0 as proved, for the oracle's byte-parity check below
     gpu._check(gpu.lib.qpgpu_memcpy_d2h(gpu.ctx, wires0.ctypes.data, w_all.ptr, mat_bytes))
     wires, pis = wires0, pis0
-    w_t = torch.from_numpy(wires0.view(np.int64)).to(dev)
+    w_t = gpu.to_device(wires0)
     rs = max(6, min(args.steps, 20))
     run_steps(2, resident=w_all)
     barrier()
@@ -458,19 +492,28 @@ def main():
     # wrapper verifies the Merkle half of its inner proofs in-circuit (qpgpu_wrapper_circuit_build; what that leaves out is listed in
     # csrc/wrapper_circuit.cpp) and forwards their public inputs.
     attest = None
-    if not args.no_tree and rank == 0 and world == 1:
+    if not args.no_tree:
         try:
-            at = pkg.recursion.AttestingTree(pkg, gpu, per_batch=8, batches=8)
-            at_inputs = [inputs_all[i % S] for i in range(64)]
-            at.run(at_inputs)
-            gpu.sync()
+            at = pkg.recursion.AttestingTree(pkg, gpu, per_batch=8, batches=8, rank=rank, world=world)
+            # the same 64 inputs on every rank (rank 0's list when there are several)
+            at_inputs = [inputs_all[0]] + [leaf_cases.real_inputs(L, depth=1 + (i % 16), seed=i, secret_index=i % 2) for i in range(1, 64)]
+            dd_ = dist if world > 1 else None
+            at.run(at_inputs, dd_, coll_dev)
+            barrier()
             ta = time.perf_counter()
-            a_leaves, a_l1, a_root = at.run(at_inputs)
+            a_leaves, a_l1, a_root = at.run(at_inputs, dd_, coll_dev)
+            barrier()
             adt = time.perf_counter() - ta
-            ok_a = bool(at.w2_ver.verify(a_root)) and bool(at.w1_ver.verify(a_l1[7])) and bool(at.leaf_ver.verify(a_leaves[63]))
-            root_pis = np.frombuffer(a_root[-8 * 21 * 64:], dtype=np.uint64)
-            ok_a = ok_a and bool(np.array_equal(root_pis, np.concatenate([np.frombuffer(p_[-8 * 21:], dtype=np.uint64) for p_ in a_leaves])))
-            attest = {"leaves": 64, "first_level": 8, "second_level": 1, "seconds": round(adt, 4), "levels": dict(at.times),
+            if world > 1:
+                tt_ = torch.tensor([adt], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                adt = float(tt_.item())
+            ok_a = all(at.leaf_ver.verify(p_) for p_ in a_leaves[-1:])
+            if rank == 0:
+                ok_a = ok_a and bool(at.w2_ver.verify(a_root)) and bool(at.w1_ver.verify(a_l1[7]))
+                root_pis = np.frombuffer(a_root[-8 * 21 * 64:], dtype=np.uint64)
+                ok_a = ok_a and bool(np.array_equal(root_pis, np.concatenate([at.leaf.commit(x_)[2] for x_ in at_inputs])))
+            attest = {"leaves": 64, "first_level": 8, "second_level": 1, "seconds": round(adt, 4), "levels_rank0": dict(at.times), "ranks": world,
                       "degree_bits": {"leaf": at.leaf.info["degree_bits"], "first_level": at.w1.info["degree_bits"], "second_level": at.w2.info["degree_bits"]},
                       "poseidon_gate_rows": {"first_level": at.w1.info["rows_poseidon"], "second_level": at.w2.info["rows_poseidon"]},
                       "checked": "the library's verifier accepts the root, a first-level proof and a leaf; the root's public inputs are the 64 leaves' in order" if ok_a else "FAILED",
@@ -545,15 +588,29 @@ def main():
                                          "wires_leaf_hash_algorithmic_GBps": round(8.0 * 135 * lde_leaves / 1e9 / (17 * lde_leaves / perm_rate), 1),
                                          "note": "leaf hashing reads 8*W bytes per leaf and runs ceil(W/8) permutations: at the permutation "
                                                  "rate above the wires oracle streams this many GB/s, far below HBM"}
-            try:   # hardware counters of the same kernel, committed (tools/gpurun_scripts/r03_mx_pmc.sh)
+            try:   # hardware counters of the same kernel, committed (tools/gpurun_scripts/mx_pmc.sh -> tools/collect_mx_counters.py)
+                import glob as _glob
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 from kernel_id import kernel_source_id
-                with open(os.path.join(ROOT, "profiles", "r03_mx_leaf_hash_counters.json")) as f:
+                latest_mx = sorted(_glob.glob(os.path.join(ROOT, "profiles", "*mx_leaf_hash_counters.json")))[-1]
+                with open(latest_mx) as f:
                     lk = json.load(f)
                 if mx_on and lk.get("kernel_source_id") == kernel_source_id("hash_mx"):
-                    extra["poseidon_hashing"].update({k: lk[k] for k in ("valu_insts_per_permutation", "mfma_insts_per_permutation", "mfma_busy_frac") if k in lk})
-                    extra["poseidon_hashing"]["counters_source"] = "profiles/r03_mx_leaf_hash_counters.json"
-            except (OSError, KeyError, ValueError, ImportError):
+                    ph = extra["poseidon_hashing"]
+                    ph.update({k: lk[k] for k in ("valu_insts_per_permutation", "mfma_insts_per_permutation", "mfma_busy_frac") if k in lk})
+                    ph["counters_source"] = os.path.relpath(latest_mx, ROOT)
+                    # the VALU issue bound of this instruction count: a wave instruction serves 64 permutations, a SIMD issues one VALU
+                    # instruction per 3.5 cycles at this mix (measured: 3.51, `cycles_per_valu_inst_per_simd` in the counters file),
+                    # 1024 SIMDs at the 2.4 GHz peak engine clock
+                    bound = 1024 * 64 / (lk["valu_insts_per_permutation"] * 3.5) * 2.4
+                    ph["valu_issue_bound_G_per_s"] = round(bound, 3)
+                    ph["frac"] = round(perm_rate / 1e9 / bound, 3)
+                    ph["frac_note"] = ("measured permutations/s over the VALU issue bound of the kernel's own instruction count (valu_insts_per_permutation x 3.5 cycles per wave "
+                                       "instruction per SIMD, 1024 SIMDs, 2.4 GHz); the rest is the clock under load, 40 bytes per lane of spilled registers at the 128-register cap "
+                                       "(four waves per SIMD; the register file is unified on this chip: no spare AGPRs) and the sponge's column loads")
+                else:
+                    extra["poseidon_hashing"]["counters_stale"] = "not reported: measured on other hashing kernel sources than this library's (" + os.path.relpath(latest_mx, ROOT) + ")"
+            except (OSError, KeyError, ValueError, ImportError, IndexError):
                 pass
 
             # stage s1 alone: PartialWitness (299 assignments + 21 public inputs) -> full witness, one at a time and a lockstep batch
@@ -717,7 +774,7 @@ def main():
         extra["cpu_baseline"] = cpu_baseline
         oc.close()
         if not args.no_ntt:
-            gbs, roof, ntt_ok, col_in, col_out = ntt_leg(torch, pkg, gpu, dev, 20, 128, 10)
+            gbs, roof, ntt_ok, col_in, col_out = ntt_leg(pkg, gpu, 20, 128, 10)
             ok = ok and ntt_ok and bool(np.array_equal(col_out, orc.fft(col_in, 20)))
             extra["roofline"] = roof
             extra["ntt_2p20_fwd_inv_GBps"] = round(gbs, 1)

@@ -72,8 +72,56 @@ extern "C" {
                                  hasher_params: *const u64, n_params: usize, out: *mut *mut QpgpuVerifier, err: *mut c_char) -> i32;
     pub fn qpgpu_verifier_free(v: *mut QpgpuVerifier);
     pub fn qpgpu_verifier_verify(v: *const QpgpuVerifier, proof: *const u8, len: usize, err: *mut c_char) -> i32;
+    // include/qpgpu.h — the proving pool over one GPU or several: one queue, a worker set per device,
+    // proofs written into the caller's host buffers
+    pub fn qpgpu_pool_create_multi(devices: *const i32, n_devices: u32, pack: *const u64, n_words: usize, workers_per_device: u32,
+                                   max_batch: u32, flags: u32, out: *mut *mut QpgpuPool) -> i32;
+    pub fn qpgpu_pool_destroy(p: *mut QpgpuPool);
+    pub fn qpgpu_pool_proof_size(p: *const QpgpuPool) -> usize;
+    pub fn qpgpu_pool_last_error(p: *const QpgpuPool) -> *const c_char;
+    pub fn qpgpu_pool_submit_host(p: *mut QpgpuPool, wires: *const u64, public_inputs: *const u64, out: *mut u8, out_cap: usize, ticket: *mut u64) -> i32;
+    pub fn qpgpu_pool_set_partial_cells(p: *mut QpgpuPool, cells: *const u64, count: usize) -> i32;
+    pub fn qpgpu_pool_submit_partial(p: *mut QpgpuPool, values: *const u64, public_inputs: *const u64, out: *mut u8, out_cap: usize, ticket: *mut u64) -> i32;
+    pub fn qpgpu_pool_wait(p: *mut QpgpuPool, ticket: u64, out_len: *mut usize) -> i32;
 }
 #[repr(C)] pub struct QpgpuVerifier { _private: [u8; 0] }
+#[repr(C)] pub struct QpgpuPool { _private: [u8; 0] }
+pub const QPGPU_POOL_HOST_WITNESS: u32 = 1;
+
+/// All the GPUs of a node behind one handle: what `ProvingContext` (wormhole/aggregator/src/aggregator.rs:187-227) or a miner's
+/// leaf-proving loop holds instead of a `ProverCircuitData`. Proofs are independent, so there is no collective: any worker of any
+/// device takes the next job and writes the proof bytes into the caller's buffer.
+pub struct GpuProvingPool { pool: *mut QpgpuPool, proof_size: usize }
+unsafe impl Send for GpuProvingPool {}
+unsafe impl Sync for GpuProvingPool {}      // submit / wait lock inside the library
+
+impl GpuProvingPool {
+    /// `devices`: HIP device ordinals, e.g. `&[0, 1, 2, 3, 4, 5, 6, 7]`; three workers of 32 lockstep proofs per device saturate one.
+    pub fn new(pack: &[u64], devices: &[i32], workers_per_device: u32, lockstep: u32) -> Result<Self> {
+        let mut pool = std::ptr::null_mut();
+        let rc = unsafe { qpgpu_pool_create_multi(devices.as_ptr(), devices.len() as u32, pack.as_ptr(), pack.len(), workers_per_device, lockstep,
+                                                  QPGPU_POOL_HOST_WITNESS, &mut pool) };
+        if rc != 0 { bail!("qpgpu_pool_create_multi failed ({rc})") }
+        Ok(Self { pool, proof_size: unsafe { qpgpu_pool_proof_size(pool) } })
+    }
+    /// `full_witness`: the wire matrix `generate_partial_witness(..).full_witness()` holds (num_wires x n, column-major, canonical u64).
+    /// Returns a ticket; the matrix and `out` must outlive `wait`.
+    pub fn submit(&self, full_witness: &[u64], public_inputs: &[u64], out: &mut [u8]) -> Result<u64> {
+        let mut ticket = 0u64;
+        let rc = unsafe { qpgpu_pool_submit_host(self.pool, full_witness.as_ptr(), public_inputs.as_ptr(), out.as_mut_ptr(), out.len(), &mut ticket) };
+        if rc != 0 { bail!("qpgpu_pool_submit_host: {}", unsafe { std::ffi::CStr::from_ptr(qpgpu_pool_last_error(self.pool)).to_string_lossy() }) }
+        Ok(ticket)
+    }
+    /// Blocks until that proof is written; an unsatisfied witness fails its own ticket only ("Failed to prove: ...").
+    pub fn wait(&self, ticket: u64) -> Result<usize> {
+        let mut len = 0usize;
+        let rc = unsafe { qpgpu_pool_wait(self.pool, ticket, &mut len) };
+        if rc != 0 { bail!("Failed to prove: {}", unsafe { std::ffi::CStr::from_ptr(qpgpu_pool_last_error(self.pool)).to_string_lossy() }) }
+        Ok(len)
+    }
+    pub fn proof_size(&self) -> usize { self.proof_size }
+}
+impl Drop for GpuProvingPool { fn drop(&mut self) { unsafe { qpgpu_pool_destroy(self.pool) } } }
 
 fn last_error(ctx: *const QpgpuCtx) -> String {
     unsafe { std::ffi::CStr::from_ptr(qpgpu_last_error(ctx)).to_string_lossy().into_owned() }

@@ -430,7 +430,9 @@ __device__ __forceinline__ void gemm(const Run &st, int tile0, int cidx, u32 (&Z
         a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, st.B0[q], a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, st.B1[q], a1, 0, 0, 0);
     }
+#ifndef PMF_NO_KEEPALIVE   // (defined only by tools/mfma_hazard_check.py --first-layout, to show what the compiler does without it)
     asm volatile("" : "+v"(a0), "+v"(a1));    // both destinations stay allocated as a whole until the chain has been issued
+#endif
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         u32 x = (u32)a0[i], yv = (u32)a1[i];

@@ -103,21 +103,25 @@ class AttestingTree:
     folding arithmetic, proof of work; the batch-specific logic and the private layer's zero-knowledge blinding are not part of it
     either) and forwards the inner public inputs. One GPU, one process; every level is one lockstep batch."""
 
-    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0):
+    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0, rank=0, world=1):
+        """rank / world: with several ranks (one per GPU) a rank proves the leaves and the first-level wrapper of batches
+        b = rank, rank + world, ..; the first-level proofs travel to rank 0, which proves the second level."""
         self.pkg, self.gpu, self.per_batch, self.batches = pkg, gpu, per_batch, batches
+        self.rank, self.world = rank, world
+        self.my_batches = list(range(rank, batches, world))
         L = pkg.leaf
         self.leaf = L.LeafCircuit(min_degree_bits=leaf_min_degree_bits)
-        n_leaves = per_batch * batches
+        n_leaves = per_batch * max(1, len(self.my_batches))
         self.leaf_circ = pkg.Circuit(gpu, self.leaf.pack, max_batch=n_leaves)
         self.leaf_ver = pkg.Verifier(self.leaf.pack, circuit=self.leaf_circ)
         self.w1 = WrapperCircuit(self.leaf.pack, self.leaf_ver, per_batch)
-        self.w1_circ = pkg.Circuit(gpu, self.w1.pack, max_batch=batches)
+        self.w1_circ = pkg.Circuit(gpu, self.w1.pack, max_batch=max(1, len(self.my_batches)))
         self.w1_ver = pkg.Verifier(self.w1.pack, circuit=self.w1_circ)
         self.w2 = WrapperCircuit(self.w1.pack, self.w1_ver, batches)
         self.w2_circ = pkg.Circuit(gpu, self.w2.pack)
         self.w2_ver = pkg.Verifier(self.w2.pack, circuit=self.w2_circ)
         self.words = [135 << c.info["degree_bits"] for c in (self.leaf, self.w1, self.w2)]
-        self.d_wires = gpu.alloc(8 * max(n_leaves * self.words[0], batches * self.words[1], self.words[2]))
+        self.d_wires = gpu.alloc(8 * max(n_leaves * self.words[0], max(1, len(self.my_batches)) * self.words[1], self.words[2]))
         self.times = {}
 
     def close(self):
@@ -132,19 +136,35 @@ class AttestingTree:
         nb = len(values)
         return circ.prove_batch_dev([self.d_wires.ptr + 8 * k * words for k in range(nb)], list(pis))
 
-    def run(self, inputs):
-        """inputs: batches * per_batch LeafInputs. Returns (leaf proofs, first-level proofs, root proof)."""
+    def run(self, inputs, dist=None, device=None):
+        """inputs: batches * per_batch LeafInputs (every rank holds the list; a rank reads its own batches' inputs). Returns
+        (this rank's leaf proofs in batch order, the first-level proofs — all of them on rank 0, this rank's otherwise —, the root
+        proof on rank 0 / None elsewhere). dist / device: torch.distributed and the device of its tensors when world > 1."""
         import time
         assert len(inputs) == self.per_batch * self.batches
         t0 = time.perf_counter()
-        com = [self.leaf.commit(x) for x in inputs]
-        leaves = self._level(self.leaf_circ, self.words[0], com[0][0], np.stack([c[1] for c in com]), np.stack([c[2] for c in com]))
+        mine = [x for b in self.my_batches for x in inputs[b * self.per_batch:(b + 1) * self.per_batch]]
+        leaves, level1 = [], []
+        if mine:
+            com = [self.leaf.commit(x) for x in mine]
+            leaves = self._level(self.leaf_circ, self.words[0], com[0][0], np.stack([c[1] for c in com]), np.stack([c[2] for c in com]))
         t1 = time.perf_counter()
-        com1 = [self.w1.commit(leaves[b * self.per_batch:(b + 1) * self.per_batch]) for b in range(self.batches)]
-        level1 = self._level(self.w1_circ, self.words[1], com1[0][0], np.stack([c[1] for c in com1]), np.stack([c[2] for c in com1]))
+        if mine:
+            com1 = [self.w1.commit(leaves[k * self.per_batch:(k + 1) * self.per_batch]) for k in range(len(self.my_batches))]
+            level1 = self._level(self.w1_circ, self.words[1], com1[0][0], np.stack([c[1] for c in com1]), np.stack([c[2] for c in com1]))
+        if self.world > 1:       # the one exchange of the tree: first-level proof bytes to the rank that proves the second level
+            from . import sharding
+            got = sharding.gather_proof_bytes(level1, dist, device, root=0)
+            if got is not None:
+                level1 = [None] * self.batches
+                for r, lst in enumerate(got):
+                    for k, p in enumerate(lst):
+                        level1[r + k * self.world] = p
         t2 = time.perf_counter()
-        c2 = self.w2.commit(level1)
-        root = self._level(self.w2_circ, self.words[2], c2[0], c2[1][None], c2[2][None])[0]
+        root = None
+        if self.rank == 0:
+            c2 = self.w2.commit(level1)
+            root = self._level(self.w2_circ, self.words[2], c2[0], c2[1][None], c2[2][None])[0]
         t3 = time.perf_counter()
         self.times = {"leaf_level_s": round(t1 - t0, 4), "first_level_s": round(t2 - t1, 4), "second_level_s": round(t3 - t2, 4)}
         return leaves, level1, root

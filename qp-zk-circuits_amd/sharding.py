@@ -39,9 +39,9 @@ def gather_proof_bytes(proofs, dist=None, device=None, layout=None, root=None):
     `root`: gather to that rank only (SURVEY.md 8e: the proof bytes of a level go to the rank that proves the next one);
     every other rank gets None and neither receives nor decodes anything."""
     import os
-    import torch
     if dist is None or not dist.is_initialized():
         return [list(proofs)]
+    import torch
     if dist.get_world_size() == 1 and os.environ.get("QPGPU_FORCE_COLLECTIVE") != "1":   # the test hook runs the collectives on one rank
         return [list(proofs)]
     world = dist.get_world_size()
@@ -86,6 +86,21 @@ def gather_proof_bytes(proofs, dist=None, device=None, layout=None, root=None):
         buf = recv[r].cpu().numpy()
         out.append([buf[i * max_len:i * max_len + all_lens[r][i]].tobytes() for i in range(counts[r])])
     return out
+
+
+class LocalProofBlocks:
+    """The one-rank form of ProofBlockGather without torch: `blocks` blocks of `count` proof slots in plain host memory (a one-rank
+    run has nothing to send, and importing torch would put a second ROCm runtime into the process)."""
+
+    def __init__(self, count, proof_len, blocks=1):
+        self.count, self.proof_len = count, proof_len
+        self.send = [np.zeros((count, proof_len), dtype=np.uint8) for _ in range(blocks)]      # zeros: every page touched from this thread
+
+    def slot(self, block, i):
+        return self.send[block][i]
+
+    def gather(self, block):
+        return self.send[block][None]
 
 
 class ProofBlockGather:

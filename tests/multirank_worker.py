@@ -119,6 +119,27 @@ def main():
             ok = ok and root is None
         tree.close()
         res.update(ok=bool(ok), leaves=len(leaves), batches=len(batches), root_bytes=len(root) if root else 0)
+    elif mode == "attest":
+        # ---- configs[4] with circuits that check their inner proofs: 8 leaves (restated leaf circuit, from CircuitInputs) -> 4
+        # first-level wrappers of 2 -> 1 second-level wrapper, batches round-robin over the ranks, first-level proofs to rank 0 ----
+        import leaf_cases as lc
+        L = pkg.leaf
+        tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=4, rank=rank, world=world)
+        xs = [lc.real_inputs(L, depth=1 + i, seed=60 + i, secret_index=i % 2) for i in range(8)]
+        leaves, level1, root = tree.run(xs, dist, None)
+        ok = len(leaves) == 2 * len(tree.my_batches) and all(tree.leaf_ver.verify(p) for p in leaves)
+        if rank == 0:
+            ok = ok and len(level1) == 4 and all(tree.w1_ver.verify(p) for p in level1) and tree.w2_ver.verify(root)
+            oc = oracle_binding.OracleCircuit(orc, tree.w2.pack)
+            ok = ok and oc.verify(root) == 0
+            oc.close()
+            # the root forwards the eight leaves' public inputs in leaf order, whichever rank proved them
+            want = np.concatenate([tree.leaf.commit(x)[2] for x in xs])
+            ok = ok and np.array_equal(np.frombuffer(root[-8 * 21 * 8:], dtype=np.uint64), want)
+        else:
+            ok = ok and root is None
+        tree.close()
+        res.update(ok=bool(ok), root_bytes=len(root) if root else 0)
     else:
         raise SystemExit("unknown mode " + mode)
     gpu.close()

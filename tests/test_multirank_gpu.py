@@ -75,3 +75,12 @@ def test_leaf_proofs_single_rank_matches(tmp_path):
     """The same 8 proofs from one rank: sharding does not change any proof."""
     res = _run_ranks("leaves", 1, tmp_path)
     assert res[0]["ok"] and res[0]["proofs"] == 8
+
+
+@pytest.mark.gpu
+def test_attesting_tree_over_two_ranks(tmp_path):
+    """The two-level tree whose wrappers check the Merkle half of their inner proofs, sharded: a rank proves its batches' leaves
+    and first-level wrappers, the first-level proofs travel to rank 0 (the one exchange), rank 0 proves the root; the library's
+    and the oracle's verifiers accept it and its public inputs are the eight leaves' in order."""
+    res = _run_ranks("attest", 2, tmp_path)
+    assert all(r["ok"] for r in res) and res[0]["root_bytes"] > 0 and res[1]["root_bytes"] == 0

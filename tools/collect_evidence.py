@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Turns the output of tools/r03_final.sh (gpurun_out/r03_final) into the tracked files under profiles/ (prefix r03_final_):
+"""Turns the output of the round's evidence script (tools/r04_final.sh -> gpurun_out/<round>_final) into the tracked files under profiles/
+(prefix <round>_final_; round 3's files were made by this script under its earlier name tools/r03_collect.py):
   _bench.json / _bench_2rank_gloo.json / _bench_6rank_gloo.json   bench lines (default command; self-launched gloo rehearsals)
   _bench_kernel_stats.csv, _bench_ntt_2p20_launches.json          rocprofv3 --kernel-trace --stats of the default command
   _ntt_only_*, _headline_*, _single_worker_*                       the same for the NTT loop alone, the headline leg, one worker
@@ -9,7 +10,7 @@
                              chip at their occupancy (profiles/r01_b_valu_rates.txt, 4 waves per SIMD), against measured cycles
   _ntt_isa_hist.json         static instruction mix of the compiled NTT kernels (tools/isa_hist.py)
 Every counter summary carries kernel_source_id (tools/kernel_id.py): bench.py reports its figures only while the id matches.
-usage: python tools/r03_collect.py [src_dir]"""
+usage: python tools/collect_evidence.py <round, e.g. r04> [src_dir]"""
 import glob, json, os, re, shutil, sqlite3, subprocess, sys
 from collections import defaultdict
 
@@ -17,13 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from kernel_id import kernel_source_id  # noqa: E402
 
-SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03_final")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+SRC = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", ROUND + "_final")
 DST = os.path.join(ROOT, "profiles")
-PRE = "r03_final"
+PRE = ROUND + "_final"
 PY = sys.executable
 N_ELEMS = (1 << 20) * 128
 SIMDS, XCDS = 256 * 4, 8
-# the identity of the library the box measured: written by tools/r03_final.sh on the box (the tree here may have moved on)
+# the identity of the library the box measured: written by the evidence script on the box (the tree here may have moved on)
 _idf = os.path.join(SRC, "kernel_source_id.txt")
 if os.path.exists(_idf):
     KID = open(_idf).read().strip()
@@ -142,7 +144,7 @@ if per:
             e["wait_any_share_of_wave_cycles"] = round(e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3)
         kernels[key] = e
     fwd = [e for e in kernels.values() if e["pass"].startswith("forward")]
-    out = {"source": "rocprofv3 --kernel-trace --pmc <SQ set 1 | SQ set 2 + GRBM_GUI_ACTIVE> -- python3 tools/ntt_only.py 3 (tools/r03_final.sh), MI355X",
+    out = {"source": "rocprofv3 --kernel-trace --pmc <SQ set 1 | SQ set 2 + GRBM_GUI_ACTIVE> -- python3 tools/ntt_only.py 3 (the evidence script), MI355X",
            "kernel_source_id": KID, "workload": "2^20 points x 128 columns", "elements_per_transform": N_ELEMS,
            "definitions": {"valu_insts_per_element": "SQ_INSTS_VALU (wave instructions) x 64 lanes / (2^20 x 128 elements), summed over the strided and the rows launch of one forward transform",
                            "valu_issue_frac": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): a CONVENTION (one wave64 instruction per SIMD per 4 cycles), not a ceiling",
@@ -160,7 +162,7 @@ if per:
     json.dump(out, open(os.path.join(DST, f"{PRE}_ntt_valu_summary.json"), "w"), indent=1)
     print("wrote", f"{PRE}_ntt_valu_summary.json", out.get("valu_insts_per_element"), out.get("valu_issue_frac"), out.get("valu_roofline_frac"))
 
-for extra in ("crash_trace_prof_bench.txt", "summary.txt", "poseidon_microbench.txt"):
+for extra in ("crash_trace_prof_bench.txt", "summary.txt", "poseidon_microbench.txt", "runtime_stacks.txt", "leaf_driver_headline.txt", "leaf_driver_single_worker.txt"):
     p = os.path.join(SRC, extra)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, f"{PRE}_{extra}"))

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r03_mx_leaf_hash_counters.json from the rocprofv3 --pmc passes of tools/gpurun_scripts/r03_mx_pmc.sh
+"""profiles/<round>_mx_leaf_hash_counters.json (usage: collect_mx_counters.py <round>) from the rocprofv3 --pmc passes of tools/gpurun_scripts/mx_pmc.sh
 (gpurun_out/mx_pmc/{mx,tp}.json + kernel_source_id.txt): per-permutation instruction counts of the matrix-pipe leaf-hash kernel,
 the throughput build beside it."""
-import glob, json, os, sqlite3
+import glob, json, os, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "mx_pmc")
 mx = json.load(open(os.path.join(O, "mx.json")))
@@ -34,7 +34,7 @@ for path in glob.glob(os.path.join(O, "p3", "**", "*.db"), recursive=True):
                                       "'%tp::%leaf_hash_kernel%' and grid_size = 2097152 group by counter_name"):
         tk[cname] = val; tk["duration_ns_under_pmc"] = dur
 t = derive(tk, PERMS)
-out = {"source": "rocprofv3 --kernel-trace --pmc ... -- python3 tools/hash_probe.py (tools/gpurun_scripts/r03_mx_pmc.sh), MI355X; "
+out = {"source": "rocprofv3 --kernel-trace --pmc ... -- python3 tools/hash_probe.py (tools/gpurun_scripts/mx_pmc.sh), MI355X; "
                  "2^21 leaves x 135 columns = 17 permutations per leaf (one lockstep batch's wires commitment)",
        "kernel_source_id": kid,
        "definitions": {"valu_insts_per_permutation": "SQ_INSTS_VALU (wave instructions) x 64 lanes / permutations of the launch",
@@ -44,6 +44,6 @@ out = {"source": "rocprofv3 --kernel-trace --pmc ... -- python3 tools/hash_probe
        "valu_insts_per_permutation": m["valu_insts_per_permutation"], "mfma_insts_per_permutation": m["mfma_insts_per_permutation"],
        "mfma_busy_frac": m["mfma_busy_frac"],
        "mx::leaf_hash_kernel": m, "tp::leaf_hash_kernel<PoseidonV1> (QPGPU_MX=0)": t}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r03_mx_leaf_hash_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", (sys.argv[1] if len(sys.argv) > 1 else "r04") + "_mx_leaf_hash_counters.json"), "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("valu_insts_per_permutation", "mfma_insts_per_permutation", "mfma_busy_frac")}),
       m["cycles_per_valu_inst_per_simd"], m["G_permutations_per_s_under_pmc"], "| tp:", t["valu_insts_per_permutation"], t["cycles_per_valu_inst_per_simd"], t["G_permutations_per_s_under_pmc"])

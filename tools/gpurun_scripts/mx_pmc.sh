@@ -1,6 +1,6 @@
 #!/bin/bash
 # hardware counters of the matrix-pipe leaf-hash kernel (and of the throughput build beside it): rocprofv3 --pmc passes over
-# tools/hash_probe.py (a 2^21-leaf x 135-column tree = one lockstep batch's wires commitment); -> tools/r03_mx_collect.py
+# tools/hash_probe.py (a 2^21-leaf x 135-column tree = one lockstep batch's wires commitment); -> tools/collect_mx_counters.py
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/mx_pmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
