@@ -83,6 +83,7 @@ int main(int argc, char **argv) {
     qpgpu_pool *pool = NULL;
     if (qpgpu_pool_create_multi(devices, n_devices, pack, words, workers, lockstep, 0, &pool)) { fprintf(stderr, "no gfx950 device (the library has no CPU fallback) or pool creation failed\n"); return 2; }
     print_runtime_stack();
+    if (qpgpu_pool_serialized(pool)) printf("pool: a queue-intercepting profiler is loaded, the workers take turns on the device\n");
     if (qpgpu_pool_set_partial_cells(pool, cells, count)) { fprintf(stderr, "set_partial_cells: %s\n", qpgpu_pool_last_error(pool)); return 3; }
     const size_t cap = qpgpu_pool_proof_size(pool);
     const unsigned per_step = n_devices * workers * lockstep;

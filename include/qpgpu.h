@@ -326,6 +326,9 @@ int qpgpu_pool_set_witness_check(qpgpu_pool *p, int on);
 size_t qpgpu_pool_proof_size(const qpgpu_pool *p);
 unsigned qpgpu_pool_workers(const qpgpu_pool *p);
 unsigned qpgpu_pool_devices(const qpgpu_pool *p);
+/* 1 when the pool's workers take turns on the device: a queue-intercepting profiler (rocprofv3) was found in the process at creation
+ * (its interceptor has faulted under concurrent submission from several threads), or QPGPU_POOL_SERIALIZE=1 */
+int qpgpu_pool_serialized(const qpgpu_pool *p);
 const char *qpgpu_pool_last_error(const qpgpu_pool *p);
 /* Three forms of a job's witness. (1) a full wire matrix resident on a device: only that device's workers can read it —
  * qpgpu_pool_submit_on names the device by its index in `devices` (qpgpu_pool_submit = index 0). */

@@ -99,6 +99,7 @@ def load_library():
         "qpgpu_pool_set_witness_check": (c.c_int, [vp, c.c_int]),
         "qpgpu_pool_create_multi": (c.c_int, [vp, c.c_uint, u64p, c.c_size_t, c.c_uint, c.c_uint, c.c_uint, c.POINTER(vp)]),
         "qpgpu_pool_devices": (c.c_uint, [vp]),
+        "qpgpu_pool_serialized": (c.c_int, [vp]),
         "qpgpu_pool_set_partial_cells": (c.c_int, [vp, u64p, c.c_size_t]),
         "qpgpu_pool_submit_on": (c.c_int, [vp, c.c_uint, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
         "qpgpu_pool_submit_host": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),

@@ -51,24 +51,38 @@ uint64_t parse_hex(const char *&p) {
     return v;
 }
 
-// the /proc/self/maps line whose range holds `addr` (streamed through a small buffer: no allocation in a signal handler)
+// the /proc/self/maps line whose range holds `addr` (streamed through a small buffer: no allocation in a signal handler); when
+// no mapping holds it, the nearest mapping below and the nearest above — that tells an access one past the end of a live buffer
+// (the mapping below ends exactly at the address) from an access into a region that has been released (a gap on both sides)
 void put_mapping_of(uint64_t addr) {
     const int fd = open("/proc/self/maps", O_RDONLY);
     if (fd < 0) { put("  (cannot read /proc/self/maps)\n"); return; }
-    static char line[512];
+    static char line[512], below[512], above[512];
     size_t len = 0;
     char ch;
-    bool found = false;
+    bool found = false, have_above = false;
+    uint64_t below_hi = 0;
+    below[0] = above[0] = 0;
     while (read(fd, &ch, 1) == 1) {
         if (ch != '\n') { if (len + 1 < sizeof line) line[len++] = ch; continue; }
         line[len] = 0;
         const char *p = line;
         const uint64_t lo = parse_hex(p);
-        if (*p == '-') { p++; const uint64_t hi = parse_hex(p); if (addr >= lo && addr < hi) { put("  mapping: "); put(line); put("\n"); found = true; break; } }
+        if (*p == '-') {
+            p++;
+            const uint64_t hi = parse_hex(p);
+            if (addr >= lo && addr < hi) { put("  mapping: "); put(line); put("\n"); found = true; break; }
+            if (hi <= addr) { memcpy(below, line, len + 1); below_hi = hi; }          // maps are sorted: the last one below wins
+            else if (lo > addr && !have_above) { memcpy(above, line, len + 1); have_above = true; break; }
+        }
         len = 0;
     }
     close(fd);
-    if (!found) put("  mapping: the address is not mapped in this process\n");
+    if (found) return;
+    put("  mapping: the address is not mapped in this process\n");
+    if (below[0]) { put("    nearest mapping below: "); put(below); put(below_hi == addr ? "   <- ends exactly at the faulting address (one past its end)\n" : "\n");
+                    if (below_hi != addr) { put("      gap between its end and the address: "); put_hex(addr - below_hi); put(" bytes\n"); } }
+    if (above[0]) { put("    nearest mapping above: "); put(above); put("\n"); }
 }
 
 void handler(int sig, siginfo_t *si, void *uc) {

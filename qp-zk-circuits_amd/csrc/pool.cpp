@@ -13,6 +13,7 @@
 // PartialWitness values of a prepared cell list (WormholeProver::commit's output, wormhole/prover/src/lib.rs:156-163): the
 // worker then runs stage s1 for its whole lockstep batch before stages s2..s12.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
@@ -56,6 +57,13 @@ struct qpgpu_pool {
     size_t wit_words = 0, num_pis = 0;    // words of one wire matrix; public inputs per proof
     std::vector<uint64_t> cells;     // the prepared PartialWitness cell list (qpgpu_pool_set_partial_cells)
     bool host_witness = false;       // workers own a witness workspace of max_batch matrices
+    // Under a profiler that intercepts the HSA queues (rocprofv3) the workers take turns on the device: one thread submits at a
+    // time. rocprofiler-sdk's queue-write interceptor has faulted (a read one AQL packet slot past a mapping) in multi-worker
+    // runs of rounds 2-4, also with a single consistent ROCm 7.2 stack and no torch in the process (profiles/r04_crash_trace_*.txt,
+    // DESIGN.md section 8); it has never faulted with one submitting thread. Per-kernel statistics are unaffected; what a profiled
+    // run then does not show is the overlap between workers. QPGPU_POOL_SERIALIZE=0 / 1 overrides the detection.
+    bool serialize = false;
+    std::mutex device_turn;
     std::string err;
 };
 
@@ -102,6 +110,8 @@ void worker(qpgpu_pool *p, size_t wi) {
             }
         }
         const uint32_t nb = (uint32_t)js.size();
+        std::unique_lock<std::mutex> turn(p->device_turn, std::defer_lock);
+        if (p->serialize) turn.lock();
         std::vector<int> rcs(nb, QPGPU_OK);
         std::vector<std::string> errs(nb);
         std::vector<size_t> lens(nb, 0);
@@ -251,6 +261,12 @@ int qpgpu_pool_create_multi(const int *devices, unsigned n_devices, const uint64
     p->devices.assign(devices, devices + n_devices);
     p->max_batch = max_batch;
     p->done.resize(4096);
+    {
+        // a queue-intercepting profiler in the process? (rocprofv3 preloads librocprofiler-sdk-tool and sets ROCP_TOOL_LIBRARIES)
+        const char *force = getenv("QPGPU_POOL_SERIALIZE");
+        if (force && (force[0] == '0' || force[0] == '1')) p->serialize = force[0] == '1';
+        else p->serialize = getenv("ROCP_TOOL_LIBRARIES") != nullptr || dlsym(RTLD_DEFAULT, "rocprofiler_configure") != nullptr;
+    }
     p->workers.resize((size_t)n_devices * workers_per_device);
     for (size_t i = 0; i < p->workers.size(); i++) {
         Worker &w = p->workers[i];
@@ -270,6 +286,7 @@ int qpgpu_pool_create_multi(const int *devices, unsigned n_devices, const uint64
 size_t qpgpu_pool_proof_size(const qpgpu_pool *p) { return p && !p->workers.empty() ? qpgpu_proof_size(p->workers[0].circ) : 0; }
 unsigned qpgpu_pool_workers(const qpgpu_pool *p) { return p ? (unsigned)p->workers.size() : 0; }
 unsigned qpgpu_pool_devices(const qpgpu_pool *p) { return p ? (unsigned)p->devices.size() : 0; }
+int qpgpu_pool_serialized(const qpgpu_pool *p) { return p && p->serialize ? 1 : 0; }
 const char *qpgpu_pool_last_error(const qpgpu_pool *p) { return p ? p->err.c_str() : "null pool"; }
 
 // qpgpu_circuit_set_witness_check for every worker; call while no job is queued or running
