@@ -218,6 +218,15 @@ __device__ __forceinline__ void ntt_round_b(const NttPassArgs &a, const PassGeom
             if (r + 1 < NB) t = gl::mul(t, step);
         }
     }
+    if (a.tw_lo && a.tw_mode == 3) {
+        // the full table: one load and one product per element instead of two products (the running one and the element's)
+        const u64 *T = a.tw_full + mm;
+#pragma unroll
+        for (int jb = 0; jb < NB; jb++) {
+            const u32 k = ka + ((u32)brev(jb, KB) << KA);
+            y[jb] = gl::mul(y[jb], T[(u64)k << a.log_m]);
+        }
+    }
 #pragma unroll
     for (int jb = 0; jb < NB; jb++) {
         const u32 k = ka + ((u32)brev(jb, KB) << KA);

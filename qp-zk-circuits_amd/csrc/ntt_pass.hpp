@@ -30,7 +30,9 @@ struct NttPassArgs {
     uint32_t tw_lo_bits;
     uint32_t out_loose;        // 1: the output is an intermediate of the transform and need not be canonical
     uint64_t tw_scale;         // non-zero: folded into the running twiddle product (the 1/N of an inverse transform)
-    uint32_t tw_mode;          // 0: two table reads per element; 1: per-thread running product; 2: skipped (timing experiments only)
+    uint32_t tw_mode;          // 0: two table reads per element; 1: per-thread running product; 2: skipped (timing experiments only);
+                               // 3: one read per element from the full table tw_full[k << log_m | mm] = w^(mm k) (x tw_scale), one product
+    const uint64_t *tw_full;
     int32_t sparse_lv;         // set by ntt_pass_launch: >= 0 when only the first 2^sparse_lv inputs of every round-A thread can be non-zero
     uint32_t row_pitch;        // set by ntt_pass_launch: exchange words between two lanes' LDS rows (ntt_pass_row_pitch)
     uint32_t split_lds;        // set by ntt_pass_launch: exchange the 32-bit halves one after the other (half the LDS per workgroup)

@@ -312,9 +312,32 @@ int ntt_core(qpgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log
         if (rc) return rc;
         // inter-pass twiddle w_N^(mm*k): e < N, split at lo_bits
         p.tw_lo_bits = (L + 1) / 2;
-        { static const int tw_mode = env_int("QPGPU_NTT_TW", 1); p.tw_mode = (uint32_t)tw_mode; }
+        // inter-pass twiddle of the strided pass: one read per element from the full table w_N^(mm k) (N words per transform size and
+        // direction: 8 MB at 2^20, 512 KB at 2^16) and one product, instead of a running product per thread plus the element's
+        // product (mode 1). Measured on the 2^20 x 128 transform, alternated in one call: strided launch 0.763 -> 0.715 ms, transform
+        // 1.404 -> 1.354 ms, same outputs (profiles/r04_notes.txt item 6). QPGPU_NTT_TW=1 keeps the running product.
+        { static const int tw_mode = env_int("QPGPU_NTT_TW", 3); p.tw_mode = (uint32_t)tw_mode; }
         p.out_loose = 1;      // the rows pass reduces whatever representative it is handed
-        if (inverse && p.tw_mode == 1) p.tw_scale = out_scale;   // 1/N rides on the running twiddle product: one product per thread
+        if (inverse && (p.tw_mode == 1 || p.tw_mode == 3)) p.tw_scale = out_scale;   // 1/N rides on the running twiddle product (mode 3: in the table)
+        if (p.tw_mode == 3) {
+            const std::string key = "full" + dir + std::to_string(L) + "_" + std::to_string(L2) + "_" + std::to_string(p.tw_scale);   // (the scale of an inner transform of a three-pass size is the outer 1/N)
+            auto it = ctx->ntt_tables.find(key);
+            if (it == ctx->ntt_tables.end()) {
+                std::vector<u64> tab((size_t)R1 * M1);
+                u64 wk = 1;                                      // wN^k
+                for (u64 k = 0; k < R1; k++) {
+                    u64 v = p.tw_scale ? p.tw_scale : 1;
+                    for (u64 mm = 0; mm < M1; mm++) { tab[(size_t)k * M1 + mm] = gl::canon(v); v = gl::mul(v, wk); }
+                    wk = gl::mul(wk, wN);
+                }
+                auto t = std::make_shared<NttTables>();
+                rc = ctx->upload(tab, &t->d);
+                if (rc) return rc;
+                ctx->ntt_tables[key] = t;
+                it = ctx->ntt_tables.find(key);
+            }
+            p.tw_full = it->second->d;
+        }
         rc = cached(ctx, "lo" + dir + std::to_string(L), wN, 1ull << p.tw_lo_bits, (uint64_t **)&p.tw_lo);
         if (rc) return rc;
         rc = cached(ctx, "hi" + dir + std::to_string(L), gl::pow(wN, 1ull << p.tw_lo_bits), 1ull << (L - p.tw_lo_bits), (uint64_t **)&p.tw_hi);
