@@ -518,9 +518,10 @@ def main():
                       "poseidon_gate_rows": {"first_level": at.w1.info["rows_poseidon"], "second_level": at.w2.info["rows_poseidon"]},
                       "checked": "the library's verifier accepts the root, a first-level proof and a leaf; the root's public inputs are the 64 leaves' in order" if ok_a else "FAILED",
                       "note": "every wrapper checks in-circuit, for each inner proof and each of its 28 query rounds, that the four opened rows and every FRI step's coset of "
-                              "evaluations hash up their Merkle paths to the committed caps (PoseidonGate + RandomAccessGate rows); NOT in-circuit yet: the transcript (query "
-                              "indices are witness inputs from the host verifier's replay), openings at zeta, folding arithmetic, proof of work, the batch-specific logic, "
-                              "zero-knowledge blinding of the private layer. Times include commit on the host (fill_witness; fill_private_batch_witness + transcript replay per inner proof)."}
+                              "evaluations hash up their Merkle paths to the committed caps (PoseidonGate + RandomAccessGate rows), replays the inner proof's Fiat-Shamir transcript "
+                              "in-circuit (query indices derived there, proof-of-work response range-checked); NOT in-circuit yet: the openings against the vanishing polynomial at "
+                              "zeta, the folding arithmetic, the batch-specific logic, zero-knowledge blinding of the private layer. Times include commit on the host (fill_witness; "
+                              "fill_private_batch_witness per inner proof)."}
             ok = ok and ok_a
             at.close()
         except pkg.QpGpuError as e:

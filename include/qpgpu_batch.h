@@ -182,8 +182,15 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
  * 0 = 80. info_out (QPGPU_WRAPPER_CIRCUIT_INFO_WORDS, may be NULL): degree_bits, rows before padding, T, Q, PoseidonGate rows,
  * RandomAccessGate rows, BaseSumGate rows, ArithmeticGate rows, ConstantGate rows, public inputs. */
 #define QPGPU_WRAPPER_CIRCUIT_INFO_WORDS 12
+/* flags: QPGPU_WRAPPER_TRANSCRIPT — the Fiat-Shamir transcript of every inner proof is replayed IN-CIRCUIT (RecursiveChallenger on
+ * PoseidonGate rows: circuit digest, public-input hash, caps, openings, FRI caps, final polynomial, proof-of-work witness, in the
+ * prover's order), the proof-of-work response is range-checked (fri_verify_proof_of_work) and the 28 query indices are the low
+ * bits of the transcript's challenges instead of inputs: the query-index logical targets then map to UINT64_MAX and need no
+ * assignment. Still not in-circuit with this flag: the openings against the vanishing polynomial at zeta and the folding
+ * arithmetic (the Plonk / FRI challenges are derived but not yet consumed). */
+#define QPGPU_WRAPPER_TRANSCRIPT 1u
 int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, const uint64_t *inner_cs_cap, size_t cap_words, unsigned num_proofs,
-                                unsigned num_routed_wires, unsigned min_degree_bits, int inner_hasher, uint64_t *pack_out, size_t pack_cap_words,
+                                unsigned num_routed_wires, unsigned min_degree_bits, int inner_hasher, unsigned flags, uint64_t *pack_out, size_t pack_cap_words,
                                 size_t *pack_words, uint64_t *target_map_out, size_t map_cap, size_t *map_count, uint64_t *info_out, char *err);
 
 #ifdef __cplusplus

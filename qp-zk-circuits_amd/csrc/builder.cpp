@@ -171,16 +171,24 @@ std::vector<BoolTarget> Builder::split_le(Target integer, unsigned num_bits) {
     if (num_bits == 0) return bits;
     const unsigned limbs = std::min<unsigned>(63, cfg_.num_routed_wires - 1);
     const unsigned k = (num_bits + limbs - 1) / limbs;
-    if (k != 1) throw std::logic_error("split_le: more than one BaseSumGate row (num_bits > 63) is not supported; use split_low_high");
-    const uint32_t row = add_gate(spec_index(GATE_BASE_SUM, limbs, 2, 0));
-    for (unsigned i = 0; i < limbs; i++) {
-        const Target b = wire(row, 1 + i);
-        if (i < num_bits) bits.push_back({b});
-        else assert_zero(b);
-    }
-    // acc = mul_const_add(2^limbs, zero, sum) = sum for one gate; the sum wire is a copy of the integer (the
-    // WireSplitGenerator's write and the copy constraint agree), the gate's own generator splits it into limbs
-    connect(wire(row, 0), integer);
+    if (num_bits > 64) throw std::logic_error("split_le: more than 64 bits");
+    std::vector<uint32_t> gates(k);
+    for (unsigned g = 0; g < k; g++) gates[g] = add_gate(spec_index(GATE_BASE_SUM, limbs, 2, 0));
+    for (unsigned g = 0; g < k; g++)
+        for (unsigned i = 0; i < limbs; i++) {
+            const Target b = wire(gates[g], 1 + i);
+            if (g * limbs + i < num_bits) bits.push_back({b});
+            else assert_zero(b);
+        }
+    // acc = sum_{k-1} * 2^(limbs (k-1)) + .. + sum_0, connected to the integer. One gate: the sum wire is a copy of the integer (the
+    // WireSplitGenerator's write and the copy constraint agree) and the gate's own generator splits it into limbs; several gates
+    // (a 64-bit split: upstream does not exclude the non-canonical decomposition there, and neither does this): every gate's sum
+    // wire is filled by its WireSplitGenerator (hint trailer)
+    if (k == 1) { connect(wire(gates[0], 0), integer); return bits; }
+    Target acc = zero();
+    for (unsigned g = k; g-- > 0;) acc = mul_const_add(1ull << limbs, acc, wire(gates[g], 0));
+    connect(acc, integer);
+    for (unsigned g = 0; g < k; g++) split_hints_.push_back({integer, wire(gates[g], 0), g * limbs, limbs});
     return bits;
 }
 
@@ -465,6 +473,8 @@ std::string Builder::build(CircuitPack &pack) {
     };
     for (const EqHint &h : eq_hints_)
         pack.hints.push_back({{HINT_EQUALITY, need_cell(h.x, "input"), need_cell(h.y, "input"), need_cell(h.equal, "output"), need_cell(h.inv, "output"), 0, 0, 0}});
+    for (const SplitHint &h : split_hints_)
+        pack.hints.push_back({{HINT_WIRE_SPLIT, need_cell(h.integer, "input"), need_cell(h.sum, "output"), h.shift, h.bits, 0, 0, 0}});
     for (const LowHighHint &h : lh_hints_)
         pack.hints.push_back({{HINT_LOW_HIGH, need_cell(h.x, "input"), need_cell(h.low, "output"), need_cell(h.high, "output"), h.n_log, 0, 0, 0}});
     pack.pi_cells.resize(public_inputs_.size());

@@ -147,6 +147,7 @@ private:
     };
     struct EqHint { Target x, y, equal, inv; };
     struct LowHighHint { Target x, low, high; unsigned n_log; };
+    struct SplitHint { Target integer, sum; unsigned shift, bits; };
 
     Target new_node(u64 cell);
     Target wire(uint32_t row, uint32_t col);
@@ -169,6 +170,7 @@ private:
     std::vector<Target> public_inputs_;
     std::vector<EqHint> eq_hints_;
     std::vector<LowHighHint> lh_hints_;
+    std::vector<SplitHint> split_hints_;
     bool built_ = false;
     size_t rows_before_padding_ = 0;
     std::vector<u64> class_cell_;                            // after build(): representative wire cell per class root

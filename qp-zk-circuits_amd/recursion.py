@@ -19,7 +19,7 @@ def _lib():
         c = ctypes
         vp, sz, cp = c.c_void_p, c.c_size_t, c.c_char_p
         L.qpgpu_wrapper_circuit_build.restype = c.c_int
-        L.qpgpu_wrapper_circuit_build.argtypes = [vp, sz, vp, sz, c.c_uint, c.c_uint, c.c_uint, c.c_int, vp, sz, c.POINTER(sz), vp, sz, c.POINTER(sz), vp, cp]
+        L.qpgpu_wrapper_circuit_build.argtypes = [vp, sz, vp, sz, c.c_uint, c.c_uint, c.c_uint, c.c_int, c.c_uint, vp, sz, c.POINTER(sz), vp, sz, c.POINTER(sz), vp, cp]
         L.qpgpu_batch_fill_proof_targets.argtypes = [vp, sz, vp, vp, sz, sz, vp, sz, sz, cp, vp, vp, sz, c.POINTER(sz), cp]
         L.qpgpu_proof_target_count.argtypes = [vp, sz]; L.qpgpu_proof_target_count.restype = sz
         L.qpgpu_verifier_query_indices.restype = c.c_int
@@ -35,17 +35,20 @@ class WrapperCircuit:
     verifier: a binding.Verifier of the INNER circuit (its constants/sigmas cap becomes constants of the wrapper; it also replays
     the transcript for the query indices)."""
 
-    def __init__(self, inner_pack, verifier, num_proofs, num_routed_wires=80, min_degree_bits=0, inner_hasher=0):
+    def __init__(self, inner_pack, verifier, num_proofs, num_routed_wires=80, min_degree_bits=0, inner_hasher=0, transcript=True):
+        """transcript=True (QPGPU_WRAPPER_TRANSCRIPT): the inner proofs' Fiat-Shamir transcripts are replayed in-circuit, the query
+        indices are derived there and the proof-of-work response is range-checked; False: the query indices are witness inputs."""
         L = _lib()
         self.inner_pack = np.ascontiguousarray(inner_pack, dtype=np.uint64)
-        self.verifier, self.num_proofs = verifier, num_proofs
+        self.verifier, self.num_proofs, self.transcript = verifier, num_proofs, transcript
         cap_h = int(self.inner_pack[11])
         cap = np.empty(4 << cap_h, dtype=np.uint64)
         if L.qpgpu_verifier_constants_sigmas_cap(verifier.h, cap.ctypes.data, cap.size) != 0:
             raise QpGpuError(-1, "verifier has no constants/sigmas cap")
         n, m = ctypes.c_size_t(), ctypes.c_size_t()
         err = ctypes.create_string_buffer(200)
-        args = (self.inner_pack.ctypes.data, self.inner_pack.size, cap.ctypes.data, cap.size, num_proofs, num_routed_wires, min_degree_bits, inner_hasher)
+        args = (self.inner_pack.ctypes.data, self.inner_pack.size, cap.ctypes.data, cap.size, num_proofs, num_routed_wires, min_degree_bits, inner_hasher,
+                1 if transcript else 0)
         rc = L.qpgpu_wrapper_circuit_build(*args, None, 0, ctypes.byref(n), None, 0, ctypes.byref(m), None, err)
         if rc != 0:
             raise QpGpuError(rc, err.value.decode())
@@ -85,7 +88,10 @@ class WrapperCircuit:
             raise ValueError(err.value.decode())
         assert cnt.value == total
         for i, p in enumerate(proofs):
-            qi = self.query_indices(p) if query_indices is None else np.asarray(query_indices[i], dtype=np.uint64)
+            if self.transcript:       # derived in-circuit: the targets have no cell, any value is dropped by the target map
+                qi = np.zeros(self.Q, dtype=np.uint64)
+            else:
+                qi = self.query_indices(p) if query_indices is None else np.asarray(query_indices[i], dtype=np.uint64)
             t[total + i * self.Q:total + (i + 1) * self.Q] = total + i * self.Q + np.arange(self.Q, dtype=np.uint32)
             v[total + i * self.Q:total + (i + 1) * self.Q] = qi
         cells = np.empty(t.size, dtype=np.uint64); vals = np.empty(t.size, dtype=np.uint64)
@@ -99,9 +105,10 @@ class AttestingTree:
     """BASELINE configs[4]'s shape with circuits that check something: `batches` x `per_batch` leaf proofs of the restated
     Wormhole leaf circuit (from CircuitInputs), one first-level wrapper per `per_batch` leaves, one second-level wrapper over the
     first-level proofs (wormhole/aggregator/src/aggregator.rs:187-227's two layers). Every wrapper is a WrapperCircuit: it checks
-    the Merkle half of each inner proof in-circuit (csrc/wrapper_circuit.cpp says what that leaves out: transcript, openings,
-    folding arithmetic, proof of work; the batch-specific logic and the private layer's zero-knowledge blinding are not part of it
-    either) and forwards the inner public inputs. One GPU, one process; every level is one lockstep batch."""
+    the Merkle half of each inner proof in-circuit (csrc/wrapper_circuit.cpp says what that leaves out: openings at zeta and the
+    folding arithmetic; the batch-specific logic and the private layer's zero-knowledge blinding are not part of it
+    either) and forwards the inner public inputs; the inner proofs' transcripts are replayed in-circuit (query indices derived,
+    proof of work checked). One lockstep batch per level and rank."""
 
     def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0, rank=0, world=1):
         """rank / world: with several ranks (one per GPU) a rank proves the leaves and the first-level wrapper of batches

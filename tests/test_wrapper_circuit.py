@@ -22,13 +22,14 @@ def setup(pkg, orc):
     op.close()
     ver = pkg.Verifier(leaf.pack)                           # verifier data (constants/sigmas cap) computed on the host
     assert all(ver.verify(p) for p in proofs)
-    w = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2)
-    yield leaf, proofs, ver, w
+    w = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2)                       # transcript in-circuit (the default)
+    w0 = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, transcript=False)    # the Merkle checks alone: query indices are inputs
+    yield leaf, proofs, ver, w, w0
     ver.close()
 
 
 def test_shape(pkg, setup):
-    leaf, proofs, ver, w = setup
+    leaf, proofs, ver, wt, w = setup
     h = pkg.pack_header(leaf.pack)
     L_ = h["degree_bits"] + h["rate_bits"]
     path = L_ - h["cap_height"]
@@ -46,10 +47,19 @@ def test_shape(pkg, setup):
     nopen = 2 * (h["num_selectors"] + h["num_constants"] + 80 + 135 + 2 + 2 * h["num_partial_products"] + 16 + 2)
     fin = 2 << (h["degree_bits"] - 4 * steps)
     assert int((w.target_map == pkg.recursion.NO_CELL).sum()) == 2 * (nopen + 1 + fin + 4)
+    # with the transcript in-circuit: the openings, the final polynomial and the proof-of-work witness are absorbed (they have cells now),
+    # the query indices are derived (no cells), and the transcript costs one PoseidonGate row per 8 absorbed elements plus the squeezes
+    assert int((wt.target_map == pkg.recursion.NO_CELL).sum()) == 2 * (4 + 28)
+    absorbed = [8 + 64, 64, 64, nopen] + [64] * steps + [fin + 1]            # between two challenges: digest + pi hash + cap | cap | cap | openings | FRI caps | final poly + pow witness
+    squeezes = 28 // 8                                                        # 28 indices after the proof-of-work response: the buffer of 8 refills three more times
+    assert wt.info["rows_poseidon"] == w.info["rows_poseidon"] + 2 * (sum(-(-a // 8) for a in absorbed) + squeezes)
+    assert wt.info["rows_base_sum"] == 2 * (28 * 2 + 1)                       # 64-bit splits of the 28 challenges (two gates each) + the proof-of-work range check
 
 
 def test_valid_inner_proofs_give_a_valid_wrapper_proof(pkg, orc, setup):
-    leaf, proofs, ver, w = setup
+    leaf, proofs, ver, w, w0 = setup
+    c0 = w0.commit(proofs[:2])
+    assert orc.generate_witness(w0.pack, *c0)[0] == orc.WIT_OK                 # indices from the host verifier's replay
     cells, vals, pis = w.commit(proofs[:2])
     rc, wires, _ = orc.generate_witness(w.pack, cells, vals, pis)
     assert rc == orc.WIT_OK
@@ -64,7 +74,7 @@ def test_valid_inner_proofs_give_a_valid_wrapper_proof(pkg, orc, setup):
 
 
 def test_tampered_inner_proofs_are_unsatisfiable(pkg, orc, setup):
-    leaf, proofs, ver, w = setup
+    leaf, proofs, ver, w, w0 = setup
     h = pkg.pack_header(leaf.pack)
     base = proofs[1]
     # byte offsets inside the proof: caps 3 x 16 x 32, openings, commit caps, then the query rounds
@@ -80,21 +90,26 @@ def test_tampered_inner_proofs_are_unsatisfiable(pkg, orc, setup):
         bad = bytearray(base); bad[off] ^= 1
         # the transcript does not absorb query data: the indices are those of the honest proof, the host verifier rejects the proof
         assert not ver.verify(bytes(bad)), what
-        cells, vals, pis = w.commit([proofs[0], bytes(bad)])
-        rc, _, cell = orc.generate_witness(w.pack, cells, vals, pis)
-        assert rc == orc.WIT_CONFLICT, what
-    # a wrong query index: the rows are committed, but not at that leaf
-    qi = [w.query_indices(p) for p in proofs[:2]]
+        for wr in (w, w0):
+            cells, vals, pis = wr.commit([proofs[0], bytes(bad)])
+            rc, _, cell = orc.generate_witness(wr.pack, cells, vals, pis)
+            assert rc == orc.WIT_CONFLICT, what
+    # a wrong query index (indices as inputs): the rows are committed, but not at that leaf
+    qi = [w0.query_indices(p) for p in proofs[:2]]
     qi[0] = qi[0].copy(); qi[0][5] ^= 1
-    cells, vals, pis = w.commit(proofs[:2], query_indices=qi)
-    assert orc.generate_witness(w.pack, cells, vals, pis)[0] == orc.WIT_CONFLICT
-    # a cap of the proof itself tampered with: the transcript changes, so do the indices; whatever they are, the paths no longer close
-    bad = bytearray(base); bad[40] ^= 1
-    try:
+    cells, vals, pis = w0.commit(proofs[:2], query_indices=qi)
+    assert orc.generate_witness(w0.pack, cells, vals, pis)[0] == orc.WIT_CONFLICT
+    # with the transcript in-circuit, everything the transcript absorbs is bound too: a cap, an opening, the final polynomial, the
+    # proof-of-work witness — the indices (or the proof-of-work response) change and the paths no longer close
+    final_poly_at = len(base) - 8 * 21 - 8 - 8 * (2 << (h["degree_bits"] - 4 * h["num_arity_rounds"]))
+    for what, off in (("a cap", 40), ("an opening", 3 * 16 * 32 + 8 * 50 + 2), ("the final polynomial", final_poly_at + 9), ("the proof-of-work witness", len(base) - 8 * 21 - 8)):
+        bad = bytearray(base); bad[off] ^= 1
         cells, vals, pis = w.commit([proofs[0], bytes(bad)])
-        assert orc.generate_witness(w.pack, cells, vals, pis)[0] == orc.WIT_CONFLICT
-    except ValueError:
-        pass        # (or the replay already fails: proof of work / quotient identity)
+        assert orc.generate_witness(w.pack, cells, vals, pis)[0] == orc.WIT_CONFLICT, what
+    # (without the transcript an opening is not looked at by the Merkle half)
+    bad = bytearray(base); bad[3 * 16 * 32 + 8 * 50 + 2] ^= 1
+    c0 = w0.commit([proofs[0], bytes(bad)], query_indices=[w0.query_indices(proofs[0]), w0.query_indices(base)])
+    assert orc.generate_witness(w0.pack, *c0)[0] == orc.WIT_OK
     # a proof of the wrong shape is refused before any assignment, with the reference's message (common/utils.rs:295-317)
     with pytest.raises(ValueError) as e:
         w.commit([proofs[0], base[:-8]])

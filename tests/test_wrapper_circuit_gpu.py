@@ -1,6 +1,6 @@
 """The wrapper circuit that checks the Merkle half of its inner proofs, on the device: leaf proofs made by the device prover from
-CircuitInputs, the wrapper's witness generated on the device from them (stage s1: 23 626 assignments -> 3 820 PoseidonGate rows,
-280 RandomAccessGate rows), the wrapper proof byte-equal to the oracle's and accepted by both verifiers; a byte flipped in an
+CircuitInputs, the wrapper's witness generated on the device from them (stage s1: 24 664 assignments -> 4 032 PoseidonGate rows,
+280 RandomAccessGate rows; the inner proofs' transcripts replayed in-circuit), the wrapper proof byte-equal to the oracle's and accepted by both verifiers; a byte flipped in an
 inner proof's opened row or path -> QPGPU_EUNSAT naming the target. See tests/test_wrapper_circuit.py for what is and is not
 verified in-circuit (csrc/wrapper_circuit.cpp)."""
 import numpy as np
@@ -21,7 +21,7 @@ def test_leaf_proofs_verified_in_a_wrapper(pkg, gpu, orc):
     ver = pkg.Verifier(leaf.pack, circuit=lp.circ)           # verifier data from the GPU handle's commitment
     assert all(ver.verify(p) for p in proofs)
     w = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2)
-    assert w.info["degree_bits"] == 13 and w.info["rows_poseidon"] == 3820
+    assert w.info["degree_bits"] == 13 and w.info["rows_poseidon"] == 4032
     wc = pkg.Circuit(gpu, w.pack)
     nw, n = 135, 1 << w.info["degree_bits"]
     d = gpu.alloc(nw * n * 8)
