@@ -487,16 +487,26 @@ def main():
                                "nullifiers in rank order and every batch's exit slots are its leaves' amounts merged per account") if ok_t else "FAILED"
             tree_check = ok_t
         atree.close()
-    # The same 64-leaf shape with circuits that CHECK something (single GPU leg): leaves of the restated Wormhole leaf circuit from
-    # CircuitInputs, 8 first-level wrappers over 8 leaf proofs each, 1 second-level wrapper over the 8 first-level proofs; every
-    # wrapper verifies the Merkle half of its inner proofs in-circuit (qpgpu_wrapper_circuit_build; what that leaves out is listed in
-    # csrc/wrapper_circuit.cpp) and forwards their public inputs.
+    # The same 64-leaf shape with circuits that CHECK something: leaves of the restated Wormhole leaf circuit from CircuitInputs,
+    # 8 first-level circuits over 8 leaf proofs each carrying the PRIVATE-BATCH logic, 1 second-level circuit over the 8 first-level
+    # proofs carrying the PUBLIC-BATCH logic; every wrapper also verifies the Merkle half of its inner proofs in-circuit and replays
+    # their transcripts (qpgpu_wrapper_circuit_build; what that leaves out is listed in csrc/wrapper_circuit.cpp).
     attest = None
     if not args.no_tree:
         try:
-            at = pkg.recursion.AttestingTree(pkg, gpu, per_batch=8, batches=8, rank=rank, world=world)
-            # the same 64 inputs on every rank (rank 0's list when there are several)
-            at_inputs = [inputs_all[0]] + [leaf_cases.real_inputs(L, depth=1 + (i % 16), seed=i, secret_index=i % 2) for i in range(1, 64)]
+            at = pkg.recursion.AttestingTree(pkg, gpu, per_batch=8, batches=8, rank=rank, world=world, aggregator_address=bytes([3] * 32))
+            # the same 64 inputs on every rank: 48 real spends of ONE block (their leaves in one 4-ary tree of depth 3), every spend
+            # with its own exit accounts, 6 per batch; the reference's dummy in the two other slots of a batch, at moving positions
+            rng_a = np.random.default_rng(4)
+            def acct():
+                b_ = rng_a.integers(0, 256, 32, dtype=np.uint8); b_[7::8] &= 0x7F
+                return b_.tobytes()
+            spends = leaf_cases.shared_tree_inputs(L, 48, depth=3, seed=9, exits=[(acct(), acct()) for _ in range(48)])
+            at_inputs = []
+            for b_ in range(8):
+                slots_ = spends[6 * b_:6 * b_ + 6]
+                slots_.insert(b_ % 7, inputs_all[0]); slots_.insert((3 * b_ + 1) % 8, inputs_all[0])
+                at_inputs += slots_
             dd_ = dist if world > 1 else None
             at.run(at_inputs, dd_, coll_dev)
             barrier()
@@ -509,18 +519,29 @@ def main():
                 dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                 adt = float(tt_.item())
             ok_a = all(at.leaf_ver.verify(p_) for p_ in a_leaves[-1:])
+            parsed = None
             if rank == 0:
                 ok_a = ok_a and bool(at.w2_ver.verify(a_root)) and bool(at.w1_ver.verify(a_l1[7]))
-                root_pis = np.frombuffer(a_root[-8 * 21 * 64:], dtype=np.uint64)
-                ok_a = ok_a and bool(np.array_equal(root_pis, np.concatenate([at.leaf.commit(x_)[2] for x_ in at_inputs])))
-            attest = {"leaves": 64, "first_level": 8, "second_level": 1, "seconds": round(adt, 4), "levels_rank0": dict(at.times), "ranks": world,
+                n_root = pkg.aggregation.public_batch_pi_len(8, 8)
+                root_pis = np.frombuffer(a_root[-8 * n_root:], dtype=np.uint64)
+                want_root = at.expected_root_public_inputs(np.stack([at.leaf.commit(x_)[2] for x_ in at_inputs]))
+                ok_a = ok_a and bool(np.array_equal(root_pis, want_root))
+                hdr_, slots_, nulls_ = pkg.aggregation.parse_public_batch_public_inputs(root_pis, 8, 8)
+                parsed = {"total_exit_slots": hdr_["total_exit_slots"], "block_number": hdr_["block_number"], "nonzero_exit_slots": sum(1 for s_ in slots_ if s_[0]),
+                          "summed_output_amount": sum(s_[0] for s_ in slots_), "nullifiers": len(nulls_)}
+                ok_a = ok_a and parsed["nonzero_exit_slots"] == 96 and parsed["summed_output_amount"] == 48 * 297 and hdr_["aggregator_address"] == bytes([3] * 32)
+            attest = {"leaves": 64, "real_spends": 48, "first_level": 8, "second_level": 1, "seconds": round(adt, 4), "levels_rank0": dict(at.times), "ranks": world,
                       "degree_bits": {"leaf": at.leaf.info["degree_bits"], "first_level": at.w1.info["degree_bits"], "second_level": at.w2.info["degree_bits"]},
                       "poseidon_gate_rows": {"first_level": at.w1.info["rows_poseidon"], "second_level": at.w2.info["rows_poseidon"]},
-                      "checked": "the library's verifier accepts the root, a first-level proof and a leaf; the root's public inputs are the 64 leaves' in order" if ok_a else "FAILED",
-                      "note": "every wrapper checks in-circuit, for each inner proof and each of its 28 query rounds, that the four opened rows and every FRI step's coset of "
-                              "evaluations hash up their Merkle paths to the committed caps (PoseidonGate + RandomAccessGate rows), replays the inner proof's Fiat-Shamir transcript "
-                              "in-circuit (query indices derived there, proof-of-work response range-checked); NOT in-circuit yet: the openings against the vanishing polynomial at "
-                              "zeta, the folding arithmetic, the batch-specific logic, zero-knowledge blinding of the private layer. Times include commit on the host (fill_witness; "
+                      "root_public_inputs": parsed,
+                      "checked": "the library's verifier accepts the root, a first-level proof and a leaf; the root's public inputs are the PublicBatchPublicInputs the host "
+                                 "restatement of the two layers' logic computes from the 64 leaves' public inputs, and parse (96 paid exit slots, 64 nullifiers)" if ok_a else "FAILED",
+                      "note": "first level = the private-batch circuit's own constraints (dummy flags, block / asset / fee consistency, exit-account grouping, distinct real "
+                              "nullifiers, dummy nullifiers = H(H(preimage)), sorting network), second level = the public-batch circuit's, both restated on the native builder "
+                              "(circuit_logic.rs of each layer); every wrapper also checks in-circuit, for each inner proof and each of its 28 query rounds, that the four opened "
+                              "rows and every FRI step's coset of evaluations hash up their Merkle paths to the committed caps, and replays the inner proof's Fiat-Shamir "
+                              "transcript (query indices derived there, proof-of-work response range-checked); NOT in-circuit yet: the openings against the vanishing "
+                              "polynomial at zeta, the folding arithmetic, zero-knowledge blinding of the private layer. Times include commit on the host (fill_witness; "
                               "fill_private_batch_witness per inner proof)."}
             ok = ok and ok_a
             at.close()

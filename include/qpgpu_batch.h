@@ -189,6 +189,17 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
  * assignment. Still not in-circuit with this flag: the openings against the vanishing polynomial at zeta and the folding
  * arithmetic (the Plonk / FRI challenges are derived but not yet consumed). */
 #define QPGPU_WRAPPER_TRANSCRIPT 1u
+/* QPGPU_WRAPPER_PRIVATE_BATCH — the private-batch layer's own logic on top (build_private_batch_constraints,
+ * wormhole/aggregator/src/private_batch/circuit/circuit_logic.rs:171-477): the inner circuit must have the leaf's 21 public inputs;
+ * dummy flags from the zero block hash, references from the first real slot, block / asset / fee consistency, exit-account
+ * grouping with duplicates zeroed and sums range-checked, pairwise distinct real nullifiers, dummy nullifiers replaced by
+ * H(H(preimage)) (Poseidon2 gate rows), all nullifiers through the sorting network. The circuit's public inputs are then the
+ * 21 N + 8 words qpgpu_private_batch_outputs computes on the host (the witness is unsatisfiable when they differ).
+ * QPGPU_WRAPPER_PUBLIC_BATCH — the public-batch layer's (build_public_batch_constraints, public_batch/circuit/circuit_logic.rs:
+ * 167-317): the inner circuit's public inputs are a private batch's (21 N + 8); the aggregator address is assigned through the
+ * FIRST preimage slot's four targets; public inputs = what qpgpu_public_batch_outputs computes. The two exclude each other. */
+#define QPGPU_WRAPPER_PRIVATE_BATCH 2u
+#define QPGPU_WRAPPER_PUBLIC_BATCH 4u
 int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, const uint64_t *inner_cs_cap, size_t cap_words, unsigned num_proofs,
                                 unsigned num_routed_wires, unsigned min_degree_bits, int inner_hasher, unsigned flags, uint64_t *pack_out, size_t pack_cap_words,
                                 size_t *pack_words, uint64_t *target_map_out, size_t map_cap, size_t *map_count, uint64_t *info_out, char *err);

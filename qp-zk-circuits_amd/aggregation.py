@@ -50,7 +50,10 @@ def _lib():
         for name, argt in {"qpgpu_private_batch_preflight": [vp, sz, sz, cp], "qpgpu_dummy_leaf_template_check": [vp, sz, cp],
                            "qpgpu_private_batch_arrange": [sz, sz, cp, vp, vp, cp], "qpgpu_private_batch_outputs": [vp, sz, vp, vp, cp],
                            "qpgpu_public_batch_preflight": [vp, sz, sz, sz, cp], "qpgpu_dummy_private_batch_template_check": [vp, sz, cp],
-                           "qpgpu_public_batch_outputs": [vp, sz, sz, cp, vp, cp]}.items():
+                           "qpgpu_public_batch_outputs": [vp, sz, sz, cp, vp, cp],
+                           "qpgpu_private_batch_public_inputs_parse": [vp, sz, vp, vp, vp, cp],
+                           "qpgpu_public_batch_public_inputs_parse": [vp, sz, ctypes.c_uint64, ctypes.c_uint64, vp, vp, vp, cp],
+                           "qpgpu_poseidon2_hash_bytes": [vp, sz, vp, sz, cp]}.items():
             getattr(L, name).argtypes = argt
             getattr(L, name).restype = ctypes.c_int
         L.qpgpu_private_batch_pi_len.argtypes = [sz]; L.qpgpu_private_batch_pi_len.restype = sz
@@ -94,6 +97,53 @@ def public_batch_outputs(inner_rows, num_leaf_proofs, aggregator_address):
     out = np.zeros(public_batch_pi_len(rows.shape[0], num_leaf_proofs), dtype=np.uint64)
     _call(_lib().qpgpu_public_batch_outputs, rows.ctypes.data, rows.shape[0], num_leaf_proofs, bytes(aggregator_address), out.ctypes.data)
     return out
+
+
+def _parse(fn, hdr_fields, pis, n_slots, n_nulls, *counts):
+    import ctypes
+    u32, b32 = ctypes.c_uint32, ctypes.c_uint8 * 32
+
+    class Hdr(ctypes.Structure):
+        _fields_ = [(k, b32 if k in ("block_hash", "aggregator_address") else u32) for k in hdr_fields]
+
+    class Slot(ctypes.Structure):
+        _fields_ = [("summed_output_amount", u32), ("exit_account", b32)]
+
+    pis = np.ascontiguousarray(pis, dtype=np.uint64)
+    hdr = Hdr(); slots = (Slot * max(n_slots, 1))(); nulls = ctypes.create_string_buffer(32 * max(n_nulls, 1))
+    _call(fn, pis.ctypes.data, pis.size, *counts, ctypes.byref(hdr), slots, nulls)
+    h = {k: (bytes(getattr(hdr, k)) if k in ("block_hash", "aggregator_address") else int(getattr(hdr, k))) for k in hdr_fields}
+    return (h, [(int(slots[i].summed_output_amount), bytes(slots[i].exit_account)) for i in range(n_slots)],
+            [nulls.raw[32 * i:32 * i + 32] for i in range(n_nulls)])
+
+
+def parse_private_batch_public_inputs(pis):
+    """PrivateBatchPublicInputs::try_from_u64_slice: (header dict, [(summed_output_amount, exit_account)] x 2N, [nullifier] x N);
+    ValueError with the reference's message for a malformed slice."""
+    n = (len(pis) - 8) // LEAF_PUBLIC_INPUTS if len(pis) >= 8 else 0
+    return _parse(_lib().qpgpu_private_batch_public_inputs_parse, ("num_exit_slots", "asset_id", "volume_fee_bps", "block_hash", "block_number", "n_leaf"),
+                  pis, 2 * n, n)
+
+
+def parse_public_batch_public_inputs(pis, num_private_batch_proofs, num_leaf_proofs):
+    """PublicBatchPublicInputs::try_from_u64_slice."""
+    m, n = num_private_batch_proofs, num_leaf_proofs
+    return _parse(_lib().qpgpu_public_batch_public_inputs_parse, ("aggregator_address", "asset_id", "volume_fee_bps", "block_hash", "block_number", "total_exit_slots"),
+                  pis, m * 2 * n, m * n, m, n)
+
+
+def dummy_nullifier(preimage):
+    """hash_dummy_nullifier_pre_image (private_batch/circuit/circuit_logic.rs:479-488): H(H(preimage)) with the fork's
+    Poseidon2Hash::hash_no_pad, as the 32 bytes the parsers hand out."""
+    import ctypes
+    pre = np.ascontiguousarray(preimage, dtype=np.uint64)
+    out = ctypes.create_string_buffer(32)
+    if _lib().qpgpu_poseidon2_hash_bytes(None, 0, pre.ctypes.data, 4, out) != 0:
+        raise ValueError("dummy_nullifier: hash failed")
+    inner = np.frombuffer(out.raw, dtype=np.uint64).copy()
+    if _lib().qpgpu_poseidon2_hash_bytes(None, 0, inner.ctypes.data, 4, out) != 0:
+        raise ValueError("dummy_nullifier: hash failed")
+    return out.raw
 
 
 class TemplateProver:

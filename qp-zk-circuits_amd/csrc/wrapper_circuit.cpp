@@ -24,6 +24,7 @@
 // Plonk and FRI challenges are derived in-circuit but not consumed yet. A wrapper proof therefore attests "a proof-shaped
 // object with a valid proof of work whose transcript-chosen rows and cosets are committed under its caps", not yet "the inner
 // proofs verify". The wrapper-specific logic of the private / public batch (circuit_logic.rs) is not part of it either.
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -120,6 +121,183 @@ struct RecursiveChallenger {
     }
 };
 
+// ---- the wrapper-specific logic of the two batch layers, over the inner proofs' public-input targets -------------------------
+using Digest = std::array<Target, 4>;
+
+// bytes_digest_eq (common/src/gadgets.rs:144-157): limb-wise is_equal, and-ed pairwise
+BoolTarget digest_eq(Builder &b, const Digest &a, const Digest &c) {
+    const BoolTarget e0 = b.is_equal(a[0], c[0]), e1 = b.is_equal(a[1], c[1]), e2 = b.is_equal(a[2], c[2]), e3 = b.is_equal(a[3], c[3]);
+    const BoolTarget e01 = b.and_(e0, e1), e23 = b.and_(e2, e3);
+    return b.and_(e01, e23);
+}
+Digest digest_at(const std::vector<Target> &pis, size_t off) { return {pis[off], pis[off + 1], pis[off + 2], pis[off + 3]}; }
+
+// u32_lt (gadgets.rs:187-199): x < y for range-checked 32-bit values; bit 32 of x + 2^32 - y is x >= y
+BoolTarget u32_lt(Builder &b, Target x, Target y) {
+    const Target t = b.sub(b.add(x, b.constant(1ull << 32)), y);
+    Target low, ge;
+    b.split_low_high(t, 32, 33, low, ge);
+    return b.not_({ge});
+}
+// split_canonical_u32_halves (gadgets.rs:211-226): (lo, hi) of the CANONICAL representative — the region hi == 2^32 - 1 && lo >= 1
+// (the integers >= p) is excluded
+void split_canonical_u32_halves(Builder &b, Target x, Target &lo, Target &hi) {
+    b.split_low_high(x, 32, 64, lo, hi);
+    const BoolTarget hi_is_max = b.is_equal(hi, b.constant((1ull << 32) - 1));
+    const Target zero = b.zero();
+    const BoolTarget lo_is_zero = b.is_equal(lo, zero);
+    const BoolTarget in_wraparound = b.and_(hi_is_max, b.not_(lo_is_zero));
+    b.connect(in_wraparound.target, zero);
+}
+// halves8_lt (gadgets.rs:239-254): lexicographic lhs < rhs over 8 half-limbs, most significant first
+BoolTarget halves8_lt(Builder &b, const std::array<Target, 8> &lhs, const std::array<Target, 8> &rhs) {
+    BoolTarget lt = b._false();
+    for (int i = 7; i >= 0; i--) {
+        const BoolTarget lt_i = u32_lt(b, lhs[i], rhs[i]);
+        const BoolTarget eq_i = b.is_equal(lhs[i], rhs[i]);
+        const BoolTarget carry = b.and_(eq_i, lt);
+        lt = b.or_(lt_i, carry);
+    }
+    return lt;
+}
+// sort_digests4 (gadgets.rs:285-334): odd-even transposition network over digests split once into canonical 32-bit halves
+std::vector<Digest> sort_digests4(Builder &b, const std::vector<Digest> &values) {
+    const size_t n = values.size();
+    if (n <= 1) return values;
+    std::vector<std::array<Target, 8>> v(n);
+    for (size_t i = 0; i < n; i++)
+        for (int j = 0; j < 4; j++) { Target lo, hi; split_canonical_u32_halves(b, values[i][j], lo, hi); v[i][2 * j] = hi; v[i][2 * j + 1] = lo; }
+    for (size_t round = 0; round < n; round++)
+        for (size_t i = round % 2; i + 1 < n; i += 2) {
+            const std::array<Target, 8> lhs = v[i], rhs = v[i + 1];
+            const BoolTarget lhs_lt = halves8_lt(b, lhs, rhs);
+            for (int j = 0; j < 8; j++) { v[i][j] = b.select(lhs_lt, lhs[j], rhs[j]); v[i + 1][j] = b.select(lhs_lt, rhs[j], lhs[j]); }
+        }
+    std::vector<Digest> out(n);
+    for (size_t i = 0; i < n; i++) for (int j = 0; j < 4; j++) out[i][j] = b.mul_const_add(1ull << 32, v[i][2 * j], v[i][2 * j + 1]);
+    return out;
+}
+
+// leaf public inputs (wormhole/inputs: asset_id, output_amount_1, output_amount_2, volume_fee_bps, nullifier(4), exit_account_1(4),
+// exit_account_2(4), block_hash(4), block_number)
+enum : size_t { LEAF_ASSET = 0, LEAF_OUT_1 = 1, LEAF_OUT_2 = 2, LEAF_FEE = 3, LEAF_NULLIFIER = 4, LEAF_EXIT_1 = 8, LEAF_EXIT_2 = 12, LEAF_BLOCK_HASH = 16, LEAF_BLOCK_NUMBER = 20, LEAF_PI_LEN = 21 };
+
+// build_private_batch_constraints (wormhole/aggregator/src/private_batch/circuit/circuit_logic.rs:171-477): the public inputs the
+// private-batch circuit registers, [num_exit_slots, asset_id, volume_fee_bps, block_hash(4), block_number, (sum, exit(4)) x 2N,
+// nullifier(4) x N sorted, zero padding to 21 N + 8]
+std::vector<Target> private_batch_logic(Builder &b, const std::vector<std::vector<Target>> &pis, const std::vector<std::vector<Target>> &preimages) {
+    const size_t n = pis.size();
+    const Target one = b.one(), zero = b.zero();
+    const Target num_exit_slots_t = b.constant(2 * n);
+    const Target asset_ref = pis[0][LEAF_ASSET];
+    const Digest sentinel = {zero, zero, zero, zero};
+    std::vector<BoolTarget> is_dummy; std::vector<Digest> block_hashes;
+    for (size_t i = 0; i < n; i++) { block_hashes.push_back(digest_at(pis[i], LEAF_BLOCK_HASH)); is_dummy.push_back(digest_eq(b, block_hashes[i], sentinel)); }
+    // the references come from the first non-dummy slot (prefix scan)
+    BoolTarget found_real = b._false();
+    Digest block_ref = sentinel; Target block_number_ref = zero, fee_ref = zero;
+    for (size_t i = 0; i < n; i++) {
+        const BoolTarget is_real = b.not_(is_dummy[i]), not_found_yet = b.not_(found_real), take = b.and_(is_real, not_found_yet);
+        for (int j = 0; j < 4; j++) block_ref[j] = b.select(take, block_hashes[i][j], block_ref[j]);
+        block_number_ref = b.select(take, pis[i][LEAF_BLOCK_NUMBER], block_number_ref);
+        fee_ref = b.select(take, pis[i][LEAF_FEE], fee_ref);
+        found_real = b.or_(found_real, is_real);
+    }
+    std::vector<Target> out = {num_exit_slots_t, asset_ref, fee_ref};
+    for (size_t i = 0; i < n; i++) {
+        const BoolTarget matches_ref = digest_eq(b, block_hashes[i], block_ref);
+        b.connect(b.or_(is_dummy[i], matches_ref).target, one);
+        b.connect(pis[i][LEAF_ASSET], asset_ref);
+        const BoolTarget fee_matches = b.is_equal(pis[i][LEAF_FEE], fee_ref);
+        b.connect(b.or_(is_dummy[i], fee_matches).target, one);
+    }
+    out.insert(out.end(), block_ref.begin(), block_ref.end());
+    out.push_back(block_number_ref);
+    // exit-account grouping: dummy slots masked to (zero account, 0) at ingress, amounts summed per account, duplicates zeroed
+    const size_t slots = 2 * n;
+    std::vector<Digest> slot_exits(slots); std::vector<Target> slot_amounts(slots);
+    for (size_t s = 0; s < slots; s++) {
+        const std::vector<Target> &p = pis[s / 2];
+        const Digest exit_raw = digest_at(p, s % 2 == 0 ? LEAF_EXIT_1 : LEAF_EXIT_2);
+        const Target amount_raw = p[s % 2 == 0 ? LEAF_OUT_1 : LEAF_OUT_2];
+        for (int j = 0; j < 4; j++) slot_exits[s][j] = b.select(is_dummy[s / 2], zero, exit_raw[j]);
+        slot_amounts[s] = b.select(is_dummy[s / 2], zero, amount_raw);
+    }
+    for (size_t s = 0; s < slots; s++) {
+        const Digest exit_slot = slot_exits[s];
+        BoolTarget is_duplicate = b._false();
+        for (size_t e = 0; e < s; e++) is_duplicate = b.or_(is_duplicate, digest_eq(b, slot_exits[e], exit_slot));
+        Target acc = zero;
+        for (size_t e = 0; e < slots; e++) {
+            const BoolTarget m = digest_eq(b, slot_exits[e], exit_slot);
+            acc = b.add(acc, b.select(m, slot_amounts[e], zero));
+        }
+        const Target final_sum = b.select(is_duplicate, zero, acc);
+        Digest final_exit;
+        for (int j = 0; j < 4; j++) final_exit[j] = b.select(is_duplicate, zero, exit_slot[j]);
+        b.range_check(final_sum, 32);
+        out.push_back(final_sum);
+        out.insert(out.end(), final_exit.begin(), final_exit.end());
+    }
+    // pairwise distinct nullifiers among the real slots
+    std::vector<Digest> real_nullifiers;
+    for (size_t i = 0; i < n; i++) real_nullifiers.push_back(digest_at(pis[i], LEAF_NULLIFIER));
+    for (size_t i = 0; i < n; i++) {
+        const BoolTarget is_real_i = b.not_(is_dummy[i]);
+        for (size_t j = i + 1; j < n; j++) {
+            const BoolTarget is_real_j = b.not_(is_dummy[j]), both_real = b.and_(is_real_i, is_real_j);
+            const BoolTarget equal = digest_eq(b, real_nullifiers[i], real_nullifiers[j]);
+            b.connect(b.and_(both_real, equal).target, zero);
+        }
+    }
+    // dummy slots' nullifiers replaced by H(H(preimage)), the selected nullifiers emitted in sorted order
+    std::vector<Digest> selected(n);
+    for (size_t i = 0; i < n; i++) {
+        const HashOutTarget inner = b.hash_n_to_hash_no_pad_p2(preimages[i]);
+        const HashOutTarget dummy_null = b.hash_n_to_hash_no_pad_p2(std::vector<Target>(inner.elements, inner.elements + 4));
+        for (int j = 0; j < 4; j++) selected[i][j] = b.select(is_dummy[i], dummy_null.elements[j], real_nullifiers[i][j]);
+    }
+    for (const Digest &d : sort_digests4(b, selected)) out.insert(out.end(), d.begin(), d.end());
+    out.resize(LEAF_PI_LEN * n + 8, zero);
+    return out;
+}
+
+// build_public_batch_constraints (wormhole/aggregator/src/public_batch/circuit/circuit_logic.rs:167-317): [aggregator_address(4),
+// asset_id, volume_fee_bps, block_hash(4), block_number, total_exit_slots, (sum, exit(4)) x m * 2N, nullifier(4) x m * N], the
+// segments of dummy inner proofs zeroed; no shuffle, no grouping across inner proofs
+std::vector<Target> public_batch_logic(Builder &b, const std::vector<std::vector<Target>> &pis, size_t n_leaf, const std::vector<Target> &aggregator_address) {
+    enum : size_t { PB_ASSET = 1, PB_FEE = 2, PB_BLOCK_HASH = 3, PB_BLOCK_NUMBER = 7, PB_EXIT_SLOTS = 8 };
+    const size_t m = pis.size();
+    const Target one = b.one(), zero = b.zero();
+    const Digest sentinel = {zero, zero, zero, zero};
+    std::vector<BoolTarget> is_dummy; std::vector<Digest> block_hashes;
+    for (size_t i = 0; i < m; i++) { block_hashes.push_back(digest_at(pis[i], PB_BLOCK_HASH)); is_dummy.push_back(digest_eq(b, block_hashes[i], sentinel)); }
+    BoolTarget found_real = b._false();
+    Digest block_ref = sentinel; Target block_number_ref = zero, asset_ref = zero, fee_ref = zero;
+    for (size_t i = 0; i < m; i++) {
+        const BoolTarget is_real = b.not_(is_dummy[i]), not_found_yet = b.not_(found_real), take = b.and_(is_real, not_found_yet);
+        for (int j = 0; j < 4; j++) block_ref[j] = b.select(take, block_hashes[i][j], block_ref[j]);
+        block_number_ref = b.select(take, pis[i][PB_BLOCK_NUMBER], block_number_ref);
+        asset_ref = b.select(take, pis[i][PB_ASSET], asset_ref);
+        fee_ref = b.select(take, pis[i][PB_FEE], fee_ref);
+        found_real = b.or_(found_real, is_real);
+    }
+    std::vector<Target> out(aggregator_address);
+    out.push_back(asset_ref); out.push_back(fee_ref);
+    for (size_t i = 0; i < m; i++) {
+        b.connect(b.or_(is_dummy[i], b.is_equal(pis[i][PB_ASSET], asset_ref)).target, one);
+        b.connect(b.or_(is_dummy[i], b.is_equal(pis[i][PB_FEE], fee_ref)).target, one);
+        b.connect(b.or_(is_dummy[i], digest_eq(b, block_hashes[i], block_ref)).target, one);
+    }
+    out.insert(out.end(), block_ref.begin(), block_ref.end());
+    out.push_back(block_number_ref);
+    out.push_back(b.constant(m * 2 * n_leaf));
+    const size_t nullifiers_start = PB_EXIT_SLOTS + 2 * n_leaf * 5;
+    for (size_t i = 0; i < m; i++) for (size_t k = PB_EXIT_SLOTS; k < nullifiers_start; k++) out.push_back(b.select(is_dummy[i], zero, pis[i][k]));
+    for (size_t i = 0; i < m; i++) for (size_t k = nullifiers_start; k < nullifiers_start + 4 * n_leaf; k++) out.push_back(b.select(is_dummy[i], zero, pis[i][k]));
+    return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -130,11 +308,21 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
     auto fail = [&](int code, const std::string &m) { if (err) std::snprintf(err, QPGPU_BATCH_ERR_CAP, "%s", m.c_str()); return code; };
     if (err) err[0] = 0;
     if (!inner_pack || !inner_cs_cap || !pack_words || num_proofs == 0 || num_proofs > 64) return fail(QPGPU_EINVAL, "wrapper_circuit_build: null argument or proof count outside 1..64");
-    if (flags & ~QPGPU_WRAPPER_TRANSCRIPT) return fail(QPGPU_EINVAL, "wrapper_circuit_build: unknown flag");
-    const bool transcript = (flags & QPGPU_WRAPPER_TRANSCRIPT) != 0;
+    if (flags & ~(QPGPU_WRAPPER_TRANSCRIPT | QPGPU_WRAPPER_PRIVATE_BATCH | QPGPU_WRAPPER_PUBLIC_BATCH)) return fail(QPGPU_EINVAL, "wrapper_circuit_build: unknown flag");
+    const bool transcript = (flags & QPGPU_WRAPPER_TRANSCRIPT) != 0, private_batch = (flags & QPGPU_WRAPPER_PRIVATE_BATCH) != 0, public_batch = (flags & QPGPU_WRAPPER_PUBLIC_BATCH) != 0;
+    if (private_batch && public_batch) return fail(QPGPU_EINVAL, "wrapper_circuit_build: a circuit is the private-batch or the public-batch layer, not both");
     CircuitPack inner;
     { const std::string why = inner.parse(inner_pack, inner_words); if (!why.empty()) return fail(QPGPU_EINVAL, "wrapper_circuit_build: inner pack: " + why); }
     if (cap_words != ((size_t)4 << inner.cap_height)) return fail(QPGPU_EINVAL, "wrapper_circuit_build: the inner constants/sigmas cap has the wrong size");
+    // the shape checks of PrivateBatchCircuit::new / PublicBatchCircuit::new (circuit_logic.rs:94-104 / :74-87), with their messages
+    size_t n_leaf_inner = 0;
+    if (private_batch && inner.num_public_inputs != LEAF_PI_LEN)
+        return fail(QPGPU_EINVAL, "leaf_common.num_public_inputs (" + std::to_string(inner.num_public_inputs) + ") != expected wormhole leaf PI len (21); refusing to build a private-batch circuit over a non-leaf-shaped inner circuit");
+    if (public_batch) {
+        if (inner.num_public_inputs < 8 + LEAF_PI_LEN || (inner.num_public_inputs - 8) % LEAF_PI_LEN || (inner.num_public_inputs - 8) / LEAF_PI_LEN > 64)
+            return fail(QPGPU_EINVAL, "private_batch_common.num_public_inputs (" + std::to_string(inner.num_public_inputs) + ") is not a private-batch PI len 21 N + 8 for an N in 1..=64");
+        n_leaf_inner = (size_t)(inner.num_public_inputs - 8) / LEAF_PI_LEN;
+    }
     const size_t T = qpgpu_proof_target_count(inner_pack, inner_words), Q = inner.num_query_rounds;
     const size_t total = (size_t)num_proofs * (T + 4 + Q);
     if (map_count) *map_count = total;
@@ -159,7 +347,7 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
         size_t rows_hash = 0;
         for (unsigned i = 0; i < num_proofs; i++) {
             const ProofTargets &p = proofs[i];
-            for (Target t : p.public_inputs) b.register_public_input(t);                // forwarded
+            if (!private_batch && !public_batch) for (Target t : p.public_inputs) b.register_public_input(t);                // forwarded
             const HashOutTarget pih = b.hash_n_to_hash_no_pad(p.public_inputs);         // verify_proof's public_inputs_hash
             if (transcript) {
                 // get_challenges (plonk/get_challenges.rs) + fri_challenges: the prover's transcript replayed in-circuit, in the order
@@ -200,6 +388,13 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
                 }
             }
             rows_hash = b.num_gates();
+        }
+        if (private_batch || public_batch) {
+            std::vector<std::vector<Target>> pis;
+            for (const ProofTargets &p : proofs) pis.push_back(p.public_inputs);
+            // public batch: the aggregator address takes the first four "preimage" targets
+            const std::vector<Target> outs = private_batch ? private_batch_logic(b, pis, preimages) : public_batch_logic(b, pis, n_leaf_inner, preimages[0]);
+            for (Target t : outs) b.register_public_input(t);
         }
         CircuitPack pack;
         const std::string why = b.build(pack);

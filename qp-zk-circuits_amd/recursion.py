@@ -35,10 +35,15 @@ class WrapperCircuit:
     verifier: a binding.Verifier of the INNER circuit (its constants/sigmas cap becomes constants of the wrapper; it also replays
     the transcript for the query indices)."""
 
-    def __init__(self, inner_pack, verifier, num_proofs, num_routed_wires=80, min_degree_bits=0, inner_hasher=0, transcript=True):
+    FLAGS = {None: 0, "private_batch": 2, "public_batch": 4}          # QPGPU_WRAPPER_PRIVATE_BATCH / _PUBLIC_BATCH
+
+    def __init__(self, inner_pack, verifier, num_proofs, num_routed_wires=80, min_degree_bits=0, inner_hasher=0, transcript=True, logic=None):
         """transcript=True (QPGPU_WRAPPER_TRANSCRIPT): the inner proofs' Fiat-Shamir transcripts are replayed in-circuit, the query
-        indices are derived there and the proof-of-work response is range-checked; False: the query indices are witness inputs."""
+        indices are derived there and the proof-of-work response is range-checked; False: the query indices are witness inputs.
+        logic: None (inner public inputs forwarded), "private_batch" (build_private_batch_constraints over leaf proofs) or
+        "public_batch" (build_public_batch_constraints over private-batch proofs): the layer's own constraints and public inputs."""
         L = _lib()
+        self.logic = logic
         self.inner_pack = np.ascontiguousarray(inner_pack, dtype=np.uint64)
         self.verifier, self.num_proofs, self.transcript = verifier, num_proofs, transcript
         cap_h = int(self.inner_pack[11])
@@ -48,7 +53,7 @@ class WrapperCircuit:
         n, m = ctypes.c_size_t(), ctypes.c_size_t()
         err = ctypes.create_string_buffer(200)
         args = (self.inner_pack.ctypes.data, self.inner_pack.size, cap.ctypes.data, cap.size, num_proofs, num_routed_wires, min_degree_bits, inner_hasher,
-                1 if transcript else 0)
+                (1 if transcript else 0) | self.FLAGS[logic])
         rc = L.qpgpu_wrapper_circuit_build(*args, None, 0, ctypes.byref(n), None, 0, ctypes.byref(m), None, err)
         if rc != 0:
             raise QpGpuError(rc, err.value.decode())
@@ -70,12 +75,19 @@ class WrapperCircuit:
             raise ValueError(err.value.decode())
         return out
 
-    def commit(self, proofs, preimages=None, query_indices=None):
-        """fill_private_batch_witness + the query indices: (cells, values, public_inputs) of the wrapper's PartialWitness.
-        Raises ValueError with the reference's message for a malformed proof."""
+    def commit(self, proofs, preimages=None, query_indices=None, aggregator_address=None, public_inputs=None):
+        """fill_private_batch_witness / fill_public_batch_witness + the query indices: (cells, values, public_inputs) of the
+        wrapper's PartialWitness. Raises ValueError with the reference's message for a malformed proof. preimages: the dummy-nullifier
+        preimages (private batch, N x 4 felts); aggregator_address: 32 bytes (public batch). With a batch logic the public inputs
+        are the ones the layer's circuit computes (aggregation.private_batch_outputs / public_batch_outputs on the host; QpGpuError
+        -4 there when the slots violate a constraint the host restatement sees); public_inputs overrides them (tests: what the
+        CIRCUIT says to slots the host restatement refuses)."""
         L = _lib()
         N = self.num_proofs
-        pre = np.zeros(4 * N, dtype=np.uint64) if preimages is None else np.ascontiguousarray(preimages, dtype=np.uint64)
+        pre = np.zeros(4 * N, dtype=np.uint64) if preimages is None else np.ascontiguousarray(preimages, dtype=np.uint64).reshape(-1).copy()
+        if self.logic == "public_batch":
+            addr = bytes(32) if aggregator_address is None else bytes(aggregator_address)
+            pre[:4] = np.frombuffer(addr, dtype=np.uint64)
         bufs = [ctypes.create_string_buffer(bytes(p), len(p)) for p in proofs]
         ptrs = (ctypes.c_void_p * len(proofs))(*[ctypes.addressof(b) for b in bufs])
         lens = (ctypes.c_size_t * len(proofs))(*[len(p) for p in proofs])
@@ -98,6 +110,14 @@ class WrapperCircuit:
         k = L.qpgpu_leaf_map_targets(t.ctypes.data, v.ctypes.data, t.size, self.target_map.ctypes.data, self.target_map.size, cells.ctypes.data, vals.ctypes.data)
         npis = int(self.inner_pack[9])
         pis = np.concatenate([np.frombuffer(p[-8 * npis:], dtype=np.uint64) if npis else np.zeros(0, dtype=np.uint64) for p in proofs])
+        if public_inputs is not None:
+            pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        elif self.logic == "private_batch":
+            from . import aggregation
+            pis = aggregation.private_batch_outputs(pis.reshape(N, npis), pre.reshape(N, 4))
+        elif self.logic == "public_batch":
+            from . import aggregation
+            pis = aggregation.public_batch_outputs(pis.reshape(N, npis), (npis - 8) // 21, addr)
         return cells[:k].copy(), vals[:k].copy(), pis
 
 
@@ -106,11 +126,14 @@ class AttestingTree:
     Wormhole leaf circuit (from CircuitInputs), one first-level wrapper per `per_batch` leaves, one second-level wrapper over the
     first-level proofs (wormhole/aggregator/src/aggregator.rs:187-227's two layers). Every wrapper is a WrapperCircuit: it checks
     the Merkle half of each inner proof in-circuit (csrc/wrapper_circuit.cpp says what that leaves out: openings at zeta and the
-    folding arithmetic; the batch-specific logic and the private layer's zero-knowledge blinding are not part of it
-    either) and forwards the inner public inputs; the inner proofs' transcripts are replayed in-circuit (query indices derived,
-    proof of work checked). One lockstep batch per level and rank."""
+    folding arithmetic; the private layer's zero-knowledge blinding is not part of it either), replays the inner proofs'
+    transcripts in-circuit (query indices derived, proof of work checked) and, with batch_logic (the default), carries its
+    layer's own constraints: the first level is the private-batch circuit's logic over its leaves' public inputs, the second the
+    public-batch circuit's over the first level's — the root proof's public inputs are a PublicBatchPublicInputs. The leaves
+    of one tree must then be what the reference's layers accept (real spends of ONE block, dummies elsewhere). One lockstep batch
+    per level and rank."""
 
-    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0, rank=0, world=1):
+    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0, rank=0, world=1, batch_logic=True, aggregator_address=bytes(32), seed=1):
         """rank / world: with several ranks (one per GPU) a rank proves the leaves and the first-level wrapper of batches
         b = rank, rank + world, ..; the first-level proofs travel to rank 0, which proves the second level."""
         self.pkg, self.gpu, self.per_batch, self.batches = pkg, gpu, per_batch, batches
@@ -121,15 +144,34 @@ class AttestingTree:
         n_leaves = per_batch * max(1, len(self.my_batches))
         self.leaf_circ = pkg.Circuit(gpu, self.leaf.pack, max_batch=n_leaves)
         self.leaf_ver = pkg.Verifier(self.leaf.pack, circuit=self.leaf_circ)
-        self.w1 = WrapperCircuit(self.leaf.pack, self.leaf_ver, per_batch)
+        self.batch_logic, self.aggregator_address = batch_logic, bytes(aggregator_address)
+        self.seed = seed
+        self.w1 = WrapperCircuit(self.leaf.pack, self.leaf_ver, per_batch, logic="private_batch" if batch_logic else None)
         self.w1_circ = pkg.Circuit(gpu, self.w1.pack, max_batch=max(1, len(self.my_batches)))
         self.w1_ver = pkg.Verifier(self.w1.pack, circuit=self.w1_circ)
-        self.w2 = WrapperCircuit(self.w1.pack, self.w1_ver, batches)
+        self.w2 = WrapperCircuit(self.w1.pack, self.w1_ver, batches, logic="public_batch" if batch_logic else None)
         self.w2_circ = pkg.Circuit(gpu, self.w2.pack)
         self.w2_ver = pkg.Verifier(self.w2.pack, circuit=self.w2_circ)
         self.words = [135 << c.info["degree_bits"] for c in (self.leaf, self.w1, self.w2)]
         self.d_wires = gpu.alloc(8 * max(n_leaves * self.words[0], max(1, len(self.my_batches)) * self.words[1], self.words[2]))
         self.times = {}
+
+    def preimages(self, batch):
+        """The dummy-nullifier preimages of first-level batch `batch` (per_batch x 4 felts). The reference draws them from the
+        operating system per proof (private_batch/prover/lib.rs); here they are a function of (seed, batch) so that a test can
+        recompute the public inputs any rank's batch must carry."""
+        return np.random.default_rng([self.seed, batch]).integers(0, 1 << 63, (self.per_batch, 4), dtype=np.uint64)
+
+    def expected_root_public_inputs(self, leaf_public_inputs):
+        """The public inputs the root proof must carry for these leaves (batches * per_batch rows of 21 felts, in leaf order),
+        from the HOST restatements of the two layers' logic (aggregation.private_batch_outputs per batch, then
+        public_batch_outputs) — or, without batch_logic, the leaves' public inputs forwarded."""
+        rows = np.ascontiguousarray(leaf_public_inputs, dtype=np.uint64).reshape(self.batches, self.per_batch, 21)
+        if not self.batch_logic:
+            return rows.reshape(-1)
+        from . import aggregation
+        inner = np.stack([aggregation.private_batch_outputs(rows[b], self.preimages(b)) for b in range(self.batches)])
+        return aggregation.public_batch_outputs(inner, self.per_batch, self.aggregator_address)
 
     def close(self):
         self.d_wires.free(scrub=True)
@@ -157,7 +199,8 @@ class AttestingTree:
             leaves = self._level(self.leaf_circ, self.words[0], com[0][0], np.stack([c[1] for c in com]), np.stack([c[2] for c in com]))
         t1 = time.perf_counter()
         if mine:
-            com1 = [self.w1.commit(leaves[k * self.per_batch:(k + 1) * self.per_batch]) for k in range(len(self.my_batches))]
+            pre = [self.preimages(b) for b in self.my_batches]
+            com1 = [self.w1.commit(leaves[k * self.per_batch:(k + 1) * self.per_batch], preimages=pre[k]) for k in range(len(self.my_batches))]
             level1 = self._level(self.w1_circ, self.words[1], com1[0][0], np.stack([c[1] for c in com1]), np.stack([c[2] for c in com1]))
         if self.world > 1:       # the one exchange of the tree: first-level proof bytes to the rank that proves the second level
             from . import sharding
@@ -170,7 +213,7 @@ class AttestingTree:
         t2 = time.perf_counter()
         root = None
         if self.rank == 0:
-            c2 = self.w2.commit(level1)
+            c2 = self.w2.commit(level1, aggregator_address=self.aggregator_address)
             root = self._level(self.w2_circ, self.words[2], c2[0], c2[1][None], c2[2][None])[0]
         t3 = time.perf_counter()
         self.times = {"leaf_level_s": round(t1 - t0, 4), "first_level_s": round(t2 - t1, 4), "second_level_s": round(t3 - t2, 4)}

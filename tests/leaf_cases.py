@@ -121,3 +121,55 @@ def digest_felts(b32):
 
 def proof_public_inputs(proof, n):
     return np.frombuffer(proof[-8 * n:], dtype=np.uint64) if n else np.zeros(0, dtype=np.uint64)
+
+
+def shared_tree_inputs(L, count, depth=2, seed=11, exits=None, outputs=None):
+    """`count` real spends of ONE block: different random secrets, their leaves in one 4-ary tree of `depth` levels (the other
+    leaves random), one header committing to that tree's root — what a private batch aggregates (every real slot carries the
+    same block hash, distinct nullifiers). exits: per spend (exit_account_1, exit_account_2) as 32 bytes each; outputs: per spend
+    (output_amount_1, output_amount_2) under the fee rule for an input of 300."""
+    rng = np.random.default_rng(seed)
+    assert 1 <= count <= 4 ** depth
+
+    def canon32():
+        b = rng.integers(0, 256, 32, dtype=np.uint8); b[7::8] &= 0x7F
+        return b.tobytes()
+
+    spends = []
+    for i in range(count):
+        secret = canon32()
+        tc = int(rng.integers(1, 1000))
+        unsp = L.unspendable_account(secret)
+        spends.append((secret, tc, unsp, L.zk_leaf_hash(unsp, tc, 0, 300)))
+    level = [s[3] for s in spends] + [canon32() for _ in range(4 ** depth - count)]
+    levels = [level]
+    for _ in range(depth):
+        level = [L.zk_proof_from_unsorted(level[g], [level[g + 1:g + 4]])[2] for g in range(0, len(level), 4)]
+        levels.append(level)
+    root = levels[-1][0]
+    hk = header_kat(1)
+    bh = L.block_hash(hk[0], hk[1], hk[2], hk[3], root, hk[5])
+    out = []
+    for i, (secret, tc, unsp, leaf) in enumerate(spends):
+        x = L.LeafInputs()
+        x.asset_id, x.volume_fee_bps, x.transfer_count, x.input_amount = 0, DEFAULT_VOLUME_FEE_BPS, tc, 300
+        x.output_amount_1, x.output_amount_2 = outputs[i] if outputs else (200, 97)
+        x.set32("secret", secret).set32("unspendable_account", unsp).set32("nullifier", L.nullifier(secret, tc))
+        e1, e2 = exits[i] if exits else (bytes([4] * 32), bytes([7] * 32))
+        x.set32("exit_account_1", e1).set32("exit_account_2", e2)
+        sibs, idx = [], i
+        for l in range(depth):
+            g = idx - idx % 4
+            sibs.append([levels[l][k] for k in range(g, g + 4) if k != idx])
+            idx //= 4
+        sorted_sibs, positions, r = L.zk_proof_from_unsorted(leaf, sibs)
+        assert r == root
+        x.zk_merkle_depth = depth
+        ctypes.memmove(x.zk_merkle_siblings, sorted_sibs, len(sorted_sibs))
+        for l, p in enumerate(positions):
+            x.zk_merkle_positions[l] = p
+        x.set32("zk_tree_root", root).set32("parent_hash", hk[0]).set32("state_root", hk[2]).set32("extrinsics_root", hk[3]).set32("block_hash", bh)
+        x.block_number = hk[1]
+        ctypes.memmove(x.digest, hk[5], 110)
+        out.append(x)
+    return out

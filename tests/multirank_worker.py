@@ -124,8 +124,11 @@ def main():
         # first-level wrappers of 2 -> 1 second-level wrapper, batches round-robin over the ranks, first-level proofs to rank 0 ----
         import leaf_cases as lc
         L = pkg.leaf
-        tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=4, rank=rank, world=world)
-        xs = [lc.real_inputs(L, depth=1 + i, seed=60 + i, secret_index=i % 2) for i in range(8)]
+        # (each level with its layer's own logic: private batch over the leaves, public batch over the first level)
+        tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=4, rank=rank, world=world, aggregator_address=bytes([6] * 32))
+        sp = lc.shared_tree_inputs(L, 5, seed=60)
+        dm = lc.dummy_inputs(L)
+        xs = [sp[0], sp[1], dm, sp[2], sp[3], dm, dm, sp[4]]
         leaves, level1, root = tree.run(xs, dist, None)
         ok = len(leaves) == 2 * len(tree.my_batches) and all(tree.leaf_ver.verify(p) for p in leaves)
         if rank == 0:
@@ -133,9 +136,11 @@ def main():
             oc = oracle_binding.OracleCircuit(orc, tree.w2.pack)
             ok = ok and oc.verify(root) == 0
             oc.close()
-            # the root forwards the eight leaves' public inputs in leaf order, whichever rank proved them
-            want = np.concatenate([tree.leaf.commit(x)[2] for x in xs])
-            ok = ok and np.array_equal(np.frombuffer(root[-8 * 21 * 8:], dtype=np.uint64), want)
+            # the root carries the PublicBatchPublicInputs of the eight leaves, whichever rank proved which batch
+            want = tree.expected_root_public_inputs(np.stack([tree.leaf.commit(x)[2] for x in xs]))
+            ok = ok and np.array_equal(np.frombuffer(root[-8 * want.size:], dtype=np.uint64), want)
+            hdr, slots, nulls = pkg.aggregation.parse_public_batch_public_inputs(want, 4, 2)
+            ok = ok and hdr["total_exit_slots"] == 16 and sum(s[0] for s in slots) == 2 * 297 + 2 * 297 + 297 and len(set(nulls)) == 8
         else:
             ok = ok and root is None
         tree.close()

@@ -60,7 +60,7 @@ def test_two_level_tree_attests_its_leaves(pkg, gpu, orc):
     size): every proof accepted by the library's verifier and by the oracle's, the root's public inputs are the four leaves' in
     order, and a root built over a tampered first-level proof cannot be generated."""
     L = pkg.leaf
-    tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=2)
+    tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=2, batch_logic=False)
     xs = [lc.real_inputs(L, depth=2 + i, seed=40 + i, secret_index=i % 2) for i in range(4)]
     leaves, level1, root = tree.run(xs)
     assert all(tree.leaf_ver.verify(p) for p in leaves) and all(tree.w1_ver.verify(p) for p in level1) and tree.w2_ver.verify(root)
@@ -75,4 +75,47 @@ def test_two_level_tree_attests_its_leaves(pkg, gpu, orc):
     c2 = tree.w2.commit([bytes(bad), level1[1]])
     st = tree.w2_circ.generate_witness_partial_batch_dev(c2[0], c2[1][None], c2[2][None], tree.d_wires)
     assert st == [-4] and "set twice with different values" in gpu.last_error()
+    tree.close()
+
+
+def test_two_level_tree_with_the_batch_layers_logic(pkg, gpu, orc):
+    """The same tree with each level's OWN constraints (private-batch logic over the leaves, public-batch logic over the first
+    level; tests/test_batch_circuits.py on the CPU): witnesses generated and proofs made on the device; the root's public inputs
+    are the PublicBatchPublicInputs the host restatement predicts, the oracle's verifier accepts every level, and leaves the
+    layers do not accept (a replayed spend; spends of two blocks) have no witness on the device either."""
+    L = pkg.leaf
+    A = pkg.aggregation
+    addr = bytes([5] * 32)
+    tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=2, aggregator_address=addr)
+    e1, e2 = bytes([4] * 32), bytes([7] * 32)
+    sp = lc.shared_tree_inputs(L, 3, exits=[(e1, e2), (e1, e1), (e2, e1)], outputs=[(200, 97), (1, 2), (30, 40)])
+    xs = [sp[0], lc.dummy_inputs(L), sp[1], sp[2]]
+    leaves, level1, root = tree.run(xs)
+    assert all(tree.leaf_ver.verify(p) for p in leaves) and all(tree.w1_ver.verify(p) for p in level1) and tree.w2_ver.verify(root)
+    for pack, proof in ((tree.w1.pack, level1[0]), (tree.w2.pack, root)):
+        oc = ob.OracleCircuit(orc, pack)
+        assert oc.verify(proof) == 0
+        oc.close()
+    rows = np.stack([lc.proof_public_inputs(p, 21) for p in leaves])
+    n_root = A.public_batch_pi_len(2, 2)
+    got = lc.proof_public_inputs(root, n_root)
+    assert got.tolist() == tree.expected_root_public_inputs(rows).tolist()
+    assert lc.proof_public_inputs(level1[1], 50).tolist() == A.private_batch_outputs(rows[2:], tree.preimages(1)).tolist()
+    hdr, slots, nulls = A.parse_public_batch_public_inputs(got, 2, 2)
+    assert hdr["aggregator_address"] == addr and hdr["block_hash"] == bytes(sp[0].block_hash) and hdr["total_exit_slots"] == 8
+    # batch 0: (200 -> e1, 97 -> e2), the dummy's two slots masked; batch 1: e1 gets 1 + 2 + 40, e2 gets 30, the repeats zeroed
+    assert slots == [(200, e1), (97, e2), (0, bytes(32)), (0, bytes(32)), (43, e1), (0, bytes(32)), (30, e2), (0, bytes(32))]
+    assert sorted(nulls[:2]) == sorted([bytes(sp[0].nullifier), A.dummy_nullifier(tree.preimages(0)[1])]) and sorted(nulls[2:]) == sorted([bytes(sp[1].nullifier), bytes(sp[2].nullifier)])
+    # slots the private-batch layer does not accept: the host restatement says why, and the device witness generator finds no witness
+    good1 = lc.proof_public_inputs(level1[1], 50)
+    lp = L.LeafProver(pkg, gpu, tree.leaf)
+    other = lp.prove(lc.real_inputs(L, depth=2))[0]            # a spend of another block
+    lp.close()
+    for bad_slots, needle in (([leaves[2], leaves[2]], "nullifier"), ([leaves[2], other], "block")):
+        with pytest.raises(pkg.QpGpuError) as e:
+            tree.w1.commit(bad_slots, preimages=tree.preimages(1))
+        assert e.value.code == -4 and needle in str(e.value)
+        c = tree.w1.commit(bad_slots, preimages=tree.preimages(1), public_inputs=good1)
+        st = tree.w1_circ.generate_witness_partial_batch_dev(c[0], c[1][None], c[2][None], tree.d_wires)
+        assert st == [-4] and "set twice with different values" in gpu.last_error()
     tree.close()
