@@ -200,6 +200,14 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
  * FIRST preimage slot's four targets; public inputs = what qpgpu_public_batch_outputs computes. The two exclude each other. */
 #define QPGPU_WRAPPER_PRIVATE_BATCH 2u
 #define QPGPU_WRAPPER_PUBLIC_BATCH 4u
+/* QPGPU_WRAPPER_VERIFY (needs QPGPU_WRAPPER_TRANSCRIPT) — the arithmetic half of verify_proof in-circuit as well, on
+ * ArithmeticExtensionGate rows: the openings against the vanishing polynomial at zeta (every gate of the inner circuit, the
+ * permutation argument, Z(1) = 1; the same generic expressions the host verifier evaluates, csrc/verify_math.hpp) equal to
+ * Z_H(zeta) * quotient(zeta) for every challenge; per query round the opened rows reduced with the FRI alpha and divided by
+ * (x - zeta) / (x - g zeta), every reduction step's coset interpolated at its beta (and holding the previous evaluation at the
+ * index's position), the final polynomial at the last point. With it the wrapper enforces everything
+ * VerifierCircuitData::verify checks on an inner proof (not built for zero-knowledge inner circuits). */
+#define QPGPU_WRAPPER_VERIFY 8u
 int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, const uint64_t *inner_cs_cap, size_t cap_words, unsigned num_proofs,
                                 unsigned num_routed_wires, unsigned min_degree_bits, int inner_hasher, unsigned flags, uint64_t *pack_out, size_t pack_cap_words,
                                 size_t *pack_words, uint64_t *target_map_out, size_t map_cap, size_t *map_count, uint64_t *info_out, char *err);

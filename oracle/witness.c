@@ -277,6 +277,24 @@ static int run_gate(pw_t *p, const gen_t *g, const gl_t pih[4]) {
         for (size_t i = 0; i < bits; i++) pw_set(p, row, routed + g->op * bits + i, (idx >> i) & 1);
         return 1;
     }
+    case OG_REDUCING: case OG_REDUCING_EXT: {
+        /* ReducingGenerator (gates/reducing.rs, reducing_extension.rs): output 0..2, alpha 2..4, old_acc 4..6, coefficients from 6,
+         * the running accumulators after them; acc <- acc * alpha + coefficient, the last one is the output */
+        const int ext = gt->type == OG_REDUCING_EXT;
+        const size_t nc = gt->param0, accs = 6 + (ext ? 2 * nc : nc);
+        gl_t al[2], ac[2], co[2] = {0, 0};
+        for (int e = 0; e < 2; e++) if (!pw_get(p, row, 2 + e, &al[e]) || !pw_get(p, row, 4 + e, &ac[e])) return 0;
+        for (size_t i = 0; i < (ext ? 2 * nc : nc); i++) { gl_t t; if (!pw_get(p, row, 6 + i, &t)) return 0; }
+        gl2_t acc = gl2_make(ac[0], ac[1]);
+        const gl2_t alpha = gl2_make(al[0], al[1]);
+        for (size_t i = 0; i < nc; i++) {
+            if (ext) { pw_get(p, row, 6 + 2 * i, &co[0]); pw_get(p, row, 7 + 2 * i, &co[1]); } else { pw_get(p, row, 6 + i, &co[0]); co[1] = 0; }
+            acc = gl2_add(gl2_mul(acc, alpha), gl2_make(co[0], co[1]));
+            if (i + 1 < nc) { pw_set(p, row, accs + 2 * i, acc.c[0]); pw_set(p, row, accs + 2 * i + 1, acc.c[1]); }
+            else { pw_set(p, row, 0, acc.c[0]); pw_set(p, row, 1, acc.c[1]); }
+        }
+        return 1;
+    }
     case OG_POSEIDON_MDS: {
         for (int i = 0; i < 24; i++) if (!pw_get(p, row, i, &in[i])) return 0;
         for (int comp = 0; comp < 2; comp++) {
@@ -338,7 +356,7 @@ orc_witness_plan *orc_witness_plan_create(const uint64_t *words_in, size_t n_wor
     }
     for (size_t i = 0; i < c->n_gates; i++) {
         const uint64_t t = c->gates[i].type;
-        if (t == OG_REDUCING || t == OG_REDUCING_EXT || t == OG_EXPONENTIATION || t == OG_COSET_INTERP) rc = ORC_WIT_UNSUPPORTED;
+        if (t == OG_EXPONENTIATION || t == OG_COSET_INTERP) rc = ORC_WIT_UNSUPPORTED;
     }
     pw_t p;
     memset(&p, 0, sizeof p);

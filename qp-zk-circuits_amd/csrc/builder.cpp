@@ -89,6 +89,9 @@ uint32_t Builder::spec_index(uint64_t type, uint64_t p0, uint64_t p1, uint64_t p
     case GATE_CONSTANT: s.degree = 1; s.ncons = p0; s.id = "ConstantGate { num_consts: " + std::to_string(p0) + " }"; break;
     case GATE_PUBLIC_INPUT: s.degree = 1; s.ncons = 4; s.id = "PublicInputGate"; break;
     case GATE_ARITHMETIC: s.degree = 3; s.ncons = p0; s.id = "ArithmeticGate { num_ops: " + std::to_string(p0) + " }"; break;
+    case GATE_ARITHMETIC_EXT: s.degree = 3; s.ncons = 2 * p0; s.id = "ArithmeticExtensionGate { num_ops: " + std::to_string(p0) + " }"; break;
+    case GATE_REDUCING: s.degree = 2; s.ncons = 2 * p0; s.id = "ReducingGate { num_coeffs: " + std::to_string(p0) + " }"; break;
+    case GATE_REDUCING_EXT: s.degree = 2; s.ncons = 2 * p0; s.id = "ReducingExtensionGate { num_coeffs: " + std::to_string(p0) + " }"; break;
     case GATE_BASE_SUM: s.degree = 2; s.ncons = p0 + 1; s.id = "BaseSumGate { num_limbs: " + std::to_string(p0) + " } + Base: 2"; break;
     case GATE_POSEIDON: s.degree = 7; s.ncons = 123; s.id = "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"; break;
     case GATE_RANDOM_ACCESS: s.degree = p0 + 1; s.ncons = p1 * (p0 + 2) + p2; s.id = "RandomAccessGate { bits: " + std::to_string(p0) + ", num_copies: " + std::to_string(p1) + " }"; break;
@@ -148,6 +151,92 @@ Target Builder::arithmetic(u64 c0, u64 c1, Target m0, Target m1, Target ad) {
     out = wire(row, 4 * op + 3);
     arith_results_.emplace(key, out);
     return out;
+}
+
+// gadgets/arithmetic_extension.rs: arithmetic_extension. Operands that are all constants fold; a vanishing product term with
+// const_1 = 1 is the addend; a vanishing addend term with const_0 * (a constant multiplicand) = 1 is the other multiplicand.
+ExtTarget Builder::arithmetic_ext(u64 c0, u64 c1, ExtTarget m0, ExtTarget m1, ExtTarget ad) {
+    c0 = gl::canon(c0); c1 = gl::canon(c1);
+    u64 a0, a1, b0, b1, d0, d1;
+    const bool m0c = ext_as_constant(m0, a0, a1), m1c = ext_as_constant(m1, b0, b1), adc = ext_as_constant(ad, d0, d1);
+    const bool first_zero = c0 == 0 || (m0c && a0 == 0 && a1 == 0) || (m1c && b0 == 0 && b1 == 0);
+    const bool second_zero = c1 == 0 || (adc && d0 == 0 && d1 == 0);
+    if ((first_zero || (m0c && m1c)) && (second_zero || adc)) {
+        gl::e2 r = gl::e2_make(0, 0);
+        if (!first_zero) r = gl::e2_scale(gl::e2_mul(gl::e2_make(a0, a1), gl::e2_make(b0, b1)), c0);
+        if (!second_zero) r = gl::e2_add(r, gl::e2_scale(gl::e2_make(d0, d1), c1));
+        r = gl::e2_canon(r);
+        return constant_ext(r.a, r.b);
+    }
+    if (first_zero && c1 == 1) return ad;
+    if (second_zero) {
+        if (m0c && a1 == 0 && gl::canon(gl::mul(a0, c0)) == 1) return m1;
+        if (m1c && b1 == 0 && gl::canon(gl::mul(b0, c0)) == 1) return m0;
+    }
+    const ExtKey key{c0, c1, {m0.t[0], m0.t[1], m1.t[0], m1.t[1], ad.t[0], ad.t[1]}};
+    auto it = ext_results_.find(key);
+    if (it != ext_results_.end()) return it->second;
+    const uint32_t num_ops = cfg_.num_routed_wires / 8;
+    auto slot = ext_slots_.find({c0, c1});
+    uint32_t row, op;
+    if (slot == ext_slots_.end()) { row = add_gate(spec_index(GATE_ARITHMETIC_EXT, num_ops, 0, 0), c0, c1); op = 0; }
+    else { row = slot->second.first; op = slot->second.second; }
+    if (op + 1 < num_ops) ext_slots_[{c0, c1}] = {row, op + 1};
+    else ext_slots_.erase({c0, c1});
+    const ExtTarget in[3] = {m0, m1, ad};
+    for (uint32_t k = 0; k < 3; k++) for (uint32_t e = 0; e < 2; e++) connect(in[k].t[e], wire(row, 8 * op + 2 * k + e));
+    const ExtTarget out = {{wire(row, 8 * op + 6), wire(row, 8 * op + 7)}};
+    ext_results_.emplace(key, out);
+    return out;
+}
+
+ExtTarget Builder::reduce_base(ExtTarget alpha, const std::vector<Target> &terms) {
+    const uint32_t n = std::min<uint32_t>((cfg_.num_wires - 6) / 3, cfg_.num_routed_wires - 6);      // ReducingGate::max_coeffs_len
+    std::vector<Target> rev(terms);
+    while (rev.size() % n) rev.push_back(zero());
+    std::reverse(rev.begin(), rev.end());
+    ExtTarget acc = zero_ext();
+    for (size_t at = 0; at < rev.size(); at += n) {
+        const uint32_t row = add_gate(spec_index(GATE_REDUCING, n, 0, 0));
+        for (uint32_t e = 0; e < 2; e++) { connect(alpha.t[e], wire(row, 2 + e)); connect(acc.t[e], wire(row, 4 + e)); }
+        for (uint32_t i = 0; i < n; i++) connect(rev[at + i], wire(row, 6 + i));
+        acc = {{wire(row, 0), wire(row, 1)}};
+    }
+    return acc;
+}
+ExtTarget Builder::reduce_ext(ExtTarget alpha, const std::vector<ExtTarget> &terms) {
+    const uint32_t n = std::min<uint32_t>((cfg_.num_wires - 6) / 4, (cfg_.num_routed_wires - 6) / 2);  // ReducingExtensionGate::max_coeffs_len
+    std::vector<ExtTarget> rev(terms);
+    while (rev.size() % n) rev.push_back(zero_ext());
+    std::reverse(rev.begin(), rev.end());
+    ExtTarget acc = zero_ext();
+    for (size_t at = 0; at < rev.size(); at += n) {
+        const uint32_t row = add_gate(spec_index(GATE_REDUCING_EXT, n, 0, 0));
+        for (uint32_t e = 0; e < 2; e++) { connect(alpha.t[e], wire(row, 2 + e)); connect(acc.t[e], wire(row, 4 + e)); }
+        for (uint32_t i = 0; i < n; i++) for (uint32_t e = 0; e < 2; e++) connect(rev[at + i].t[e], wire(row, 6 + 2 * i + e));
+        acc = {{wire(row, 0), wire(row, 1)}};
+    }
+    return acc;
+}
+
+ExtTarget Builder::div_ext(ExtTarget x, ExtTarget y) {
+    const ExtTarget q = {{add_virtual_target(), add_virtual_target()}};
+    quot_hints_.push_back({x, y, q});
+    connect_ext(mul_ext(q, y), x);
+    return q;
+}
+
+// gadgets/arithmetic.rs exp_from_bits_const_base: prod_i (bit_i ? base^(2^i) : 1), two factors folded per operation where
+// upstream does (mul_many over select-by-constant terms; the product is the same field element)
+Target Builder::exp_from_bits_const_base(u64 base, const std::vector<BoolTarget> &bits) {
+    Target acc = one();
+    u64 pw = gl::canon(base);
+    for (const BoolTarget &b : bits) {
+        // factor = 1 + bit * (pw - 1); acc' = acc * factor = (pw - 1) * acc * bit + acc
+        acc = arithmetic(gl::sub(pw, 1), 1, acc, b.target, acc);
+        pw = gl::canon(gl::mul(pw, pw));
+    }
+    return acc;
 }
 
 // gadgets/arithmetic.rs: is_equal, with its EqualityGenerator (equal = [x == y], inv = 1 / (x - y) or 0)
@@ -354,6 +443,10 @@ std::string Builder::build(CircuitPack &pack) {
             for (uint32_t op = slot.second.second; op < num_ops; op++)
                 for (uint32_t k = 0; k < 3; k++) connect(z, wire(slot.second.first, 4 * op + k));
         arith_slots_.clear();
+        for (const auto &slot : ext_slots_)
+            for (uint32_t op = slot.second.second; op < R / 8; op++)
+                for (uint32_t k = 0; k < 6; k++) connect(z, wire(slot.second.first, 8 * op + k));
+        ext_slots_.clear();
         // the copies left over in the last RandomAccessGate row of every width: index 0 into a list of zeros
         for (const auto &slot : ra_slots_) {
             const uint32_t bits = slot.first, vec = 1u << bits;
@@ -477,6 +570,9 @@ std::string Builder::build(CircuitPack &pack) {
         pack.hints.push_back({{HINT_WIRE_SPLIT, need_cell(h.integer, "input"), need_cell(h.sum, "output"), h.shift, h.bits, 0, 0, 0}});
     for (const LowHighHint &h : lh_hints_)
         pack.hints.push_back({{HINT_LOW_HIGH, need_cell(h.x, "input"), need_cell(h.low, "output"), need_cell(h.high, "output"), h.n_log, 0, 0, 0}});
+    for (const QuotHint &h : quot_hints_)
+        pack.hints.push_back({{HINT_QUOTIENT_EXT, need_cell(h.num.t[0], "input"), need_cell(h.num.t[1], "input"), need_cell(h.den.t[0], "input"), need_cell(h.den.t[1], "input"),
+                               need_cell(h.quot.t[0], "output"), need_cell(h.quot.t[1], "output"), 0}});
     pack.pi_cells.resize(public_inputs_.size());
     for (size_t i = 0; i < public_inputs_.size(); i++) pack.pi_cells[i] = need_cell(public_inputs_[i], "public input");
 

@@ -28,6 +28,7 @@ constexpr Target NO_TARGET = 0xFFFFFFFFu;
 constexpr u64 NO_CELL = ~0ull;
 struct BoolTarget { Target target; };
 struct HashOutTarget { Target elements[4]; };
+struct ExtTarget { Target t[2]; };                  // ExtensionTarget<2>: an element of F[x] / (x^2 - 7)
 
 // CircuitConfig (plonk/circuit_data.rs) + FriConfig: the values of standard_recursion_config unless changed
 struct Config {
@@ -118,6 +119,29 @@ public:
     // additive absorption, tests/test_leaf_witness.py)
     HashOutTarget hash_n_to_hash_no_pad_p2(const std::vector<Target> &inputs);
 
+    // ---- extension-field arithmetic (gadgets/arithmetic_extension.rs) on ArithmeticExtensionGate rows ----
+    ExtTarget constant_ext(u64 a, u64 b = 0) { return {{constant(a), constant(b)}}; }
+    ExtTarget zero_ext() { return constant_ext(0); }
+    ExtTarget one_ext() { return constant_ext(1); }
+    ExtTarget to_ext(Target x) { return {{x, zero()}}; }                       // convert_to_ext
+    // const_0 * multiplicand_0 * multiplicand_1 + const_1 * addend, with the special cases and the per-(const_0, const_1) slot packing
+    ExtTarget arithmetic_ext(u64 const_0, u64 const_1, ExtTarget multiplicand_0, ExtTarget multiplicand_1, ExtTarget addend);
+    ExtTarget mul_ext(ExtTarget a, ExtTarget b) { return arithmetic_ext(1, 0, a, b, zero_ext()); }
+    ExtTarget mul_add_ext(ExtTarget a, ExtTarget b, ExtTarget c) { return arithmetic_ext(1, 1, a, b, c); }
+    ExtTarget mul_sub_ext(ExtTarget a, ExtTarget b, ExtTarget c) { return arithmetic_ext(1, gl::P - 1, a, b, c); }
+    ExtTarget add_ext(ExtTarget a, ExtTarget b) { return arithmetic_ext(1, 1, one_ext(), a, b); }
+    ExtTarget sub_ext(ExtTarget a, ExtTarget b) { return arithmetic_ext(1, gl::P - 1, one_ext(), a, b); }
+    // x / y with its QuotientGeneratorExtension: q is a hint output, q * y is connected to x (div_extension)
+    ExtTarget div_ext(ExtTarget x, ExtTarget y);
+    void connect_ext(ExtTarget a, ExtTarget b) { connect(a.t[0], b.t[0]); connect(a.t[1], b.t[1]); }
+    bool ext_as_constant(ExtTarget x, u64 &a, u64 &b) const { return target_as_constant(x.t[0], a) && target_as_constant(x.t[1], b); }
+    // ReducingFactorTarget::reduce_base / reduce (util/reducing.rs): sum_i terms[i] alpha^i on ReducingGate / ReducingExtensionGate
+    // rows of max_coeffs_len coefficients each (highest power first, zero-padded at the front, rows chained through old_acc)
+    ExtTarget reduce_base(ExtTarget alpha, const std::vector<Target> &terms);
+    ExtTarget reduce_ext(ExtTarget alpha, const std::vector<ExtTarget> &terms);
+    // base^(sum bits[i] 2^i) for a CONSTANT base, as a product of select(bit, base^(2^i), 1) factors (exp_from_bits_const_base)
+    Target exp_from_bits_const_base(u64 base, const std::vector<BoolTarget> &exponent_bits);
+
     size_t num_gates() const { return rows_.size(); }
 
     // ---- build ----
@@ -148,6 +172,16 @@ private:
     struct EqHint { Target x, y, equal, inv; };
     struct LowHighHint { Target x, low, high; unsigned n_log; };
     struct SplitHint { Target integer, sum; unsigned shift, bits; };
+    struct QuotHint { ExtTarget num, den, quot; };
+    struct ExtKey {
+        u64 c0, c1; Target v[6];
+        bool operator<(const ExtKey &o) const {
+            if (c0 != o.c0) return c0 < o.c0;
+            if (c1 != o.c1) return c1 < o.c1;
+            for (int i = 0; i < 6; i++) if (v[i] != o.v[i]) return v[i] < o.v[i];
+            return false;
+        }
+    };
 
     Target new_node(u64 cell);
     Target wire(uint32_t row, uint32_t col);
@@ -171,6 +205,9 @@ private:
     std::vector<EqHint> eq_hints_;
     std::vector<LowHighHint> lh_hints_;
     std::vector<SplitHint> split_hints_;
+    std::vector<QuotHint> quot_hints_;
+    std::map<ExtKey, ExtTarget> ext_results_;
+    std::map<std::pair<u64, u64>, std::pair<uint32_t, uint32_t>> ext_slots_;     // (c0, c1) -> (row, next free operation)
     bool built_ = false;
     size_t rows_before_padding_ = 0;
     std::vector<u64> class_cell_;                            // after build(): representative wire cell per class root

@@ -16,6 +16,7 @@
 #include "circuit.hpp"
 #include "gl64.hpp"
 #include "poseidon.hpp"
+#include "verify_math.hpp"
 
 using gl::e2;
 using gl::u64;
@@ -34,14 +35,8 @@ int fail(char *err, int code, const char *fmt, ...) {
 
 // ---- extension-field shorthands (F[x]/(x^2 - 7)) ----
 inline e2 E(u64 a) { return gl::e2_from(a); }
-inline e2 operator+(e2 x, e2 y) { return gl::e2_add(x, y); }
-inline e2 operator-(e2 x, e2 y) { return gl::e2_sub(x, y); }
-inline e2 operator*(e2 x, e2 y) { return gl::e2_mul(x, y); }
-inline e2 scale(e2 x, u64 s) { return gl::e2_scale(x, s); }
+using gl::scale;       // + - * scale sadd madd on e2: verify_math.hpp
 inline bool same(e2 x, e2 y) { x = gl::e2_canon(x); y = gl::e2_canon(y); return x.a == y.a && x.b == y.b; }
-// the extension ALGEBRA over the extension (wire pairs of the *Extension gates at zeta): c0 + c1 X, X^2 = 7, coefficients in e2
-struct Alg { e2 c0, c1; };
-inline Alg alg_mul(Alg a, Alg b) { return {a.c0 * b.c0 + scale(a.c1 * b.c1, 7), a.c0 * b.c1 + a.c1 * b.c0}; }
 
 // ---- hashing under the proof system's permutation ----
 struct Hash {
@@ -108,253 +103,8 @@ void ntt(std::vector<u64> &a, unsigned log_n, u64 root) {
     }
 }
 
-// ---- gate constraints at one point of the extension field ----
-e2 sbox7(e2 x) { const e2 x2 = x * x, x4 = x2 * x2; return (x * x2) * x4; }
-void mds_ext(e2 (&s)[12]) {   // the MDS matrix has base-field entries: it acts on the two coordinates separately
-    u64 a[12], b[12];
-    for (int i = 0; i < 12; i++) { a[i] = gl::canon(s[i].a); b[i] = gl::canon(s[i].b); }
-    poseidon::mds_layer(a); poseidon::mds_layer(b);
-    for (int i = 0; i < 12; i++) s[i] = gl::e2_make(a[i], b[i]);
-}
-
-// PoseidonGate (plonky2::gates::poseidon): wires 0..11 input, 12..23 output, 24 swap, 25..28 delta, 29..64 S-box inputs of
-// full rounds 1..3, 65..86 of the 22 partial rounds, 87..134 of the last four full rounds; 123 constraints.
-void poseidon_gate(const e2 *w, e2 *out) {
-    const u64 *rc = poseidon::host_round_constants(), *fp = poseidon::host_fast_partial();
-    size_t k = 0;
-    const e2 swap = w[24];
-    e2 st[12];
-    out[k++] = swap * (swap - E(1));
-    for (int i = 0; i < 4; i++) out[k++] = swap * (w[i + 4] - w[i]) - w[25 + i];
-    for (int i = 0; i < 4; i++) { st[i] = w[i] + w[25 + i]; st[i + 4] = w[i + 4] - w[25 + i]; }
-    for (int i = 8; i < 12; i++) st[i] = w[i];
-    int r_idx = 0;
-    for (int r = 0; r < 4; r++, r_idx++) {
-        for (int i = 0; i < 12; i++) st[i] = st[i] + E(rc[r_idx * 12 + i]);
-        if (r) for (int i = 0; i < 12; i++) { const e2 in = w[29 + 12 * (r - 1) + i]; out[k++] = st[i] - in; st[i] = in; }
-        for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
-        mds_ext(st);
-    }
-    for (int i = 0; i < 12; i++) st[i] = st[i] + E(fp[poseidon::FP_FIRST + i]);                       // partial_first_constant_layer
-    {
-        e2 t[11];
-        for (int c = 0; c < 11; c++) { e2 acc = E(0); for (int r = 0; r < 11; r++) acc = acc + scale(st[1 + r], fp[poseidon::FP_INIT + c * 11 + r]); t[c] = acc; }
-        for (int c = 0; c < 11; c++) st[1 + c] = t[c];                                                // mds_partial_layer_init
-    }
-    for (int r = 0; r < 22; r++) {
-        const e2 in = w[65 + r];
-        out[k++] = st[0] - in;
-        const e2 s0 = sbox7(in) + E(fp[poseidon::FP_RC + r]);
-        e2 d = scale(s0, poseidon::MDS_00);
-        for (int i = 0; i < 11; i++) d = d + scale(st[1 + i], fp[poseidon::FP_WHATS + r * 11 + i]);
-        for (int i = 0; i < 11; i++) st[1 + i] = st[1 + i] + scale(s0, fp[poseidon::FP_VS + r * 11 + i]);
-        st[0] = d;                                                                                    // mds_partial_layer_fast
-    }
-    r_idx += 22;
-    for (int r = 0; r < 4; r++, r_idx++) {
-        for (int i = 0; i < 12; i++) st[i] = st[i] + E(rc[r_idx * 12 + i]);
-        for (int i = 0; i < 12; i++) { const e2 in = w[87 + 12 * r + i]; out[k++] = st[i] - in; st[i] = in; }
-        for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
-        mds_ext(st);
-    }
-    for (int i = 0; i < 12; i++) out[k++] = st[i] - w[12 + i];
-}
-
-// The qp fork's Poseidon2 gate (type 14) at one extension point, verifier side: wires as the pack's layout table places them
-// (circuit.hpp P2GateLayout; default = upstream PoseidonGate's layout carried over, LAYOUT UNPINNED), permutation =
-// qp-poseidon-core's Poseidon2 (pinned by the reference's known-answer vectors). The linear layers have base-field entries, so
-// they act on an extension element coefficient-wise (scale); only the S-boxes multiply extension elements.
-void p2_external(e2 (&s)[12], const poseidon2::Params &P) {
-    e2 t[12];
-    for (int b = 0; b < 3; b++)
-        for (int i = 0; i < 4; i++) {
-            e2 acc = E(0);
-            for (int j = 0; j < 4; j++) acc = acc + scale(s[4 * b + j], P.m4[4 * i + j]);
-            t[4 * b + i] = acc;
-        }
-    for (int i = 0; i < 4; i++) {
-        const e2 colsum = t[i] + t[4 + i] + t[8 + i];
-        for (int b = 0; b < 3; b++) s[4 * b + i] = t[4 * b + i] + colsum;
-    }
-}
-void p2_internal(e2 (&s)[12], const poseidon2::Params &P) {
-    e2 total = E(0);
-    for (int i = 0; i < 12; i++) total = total + s[i];
-    for (int i = 0; i < 12; i++) s[i] = scale(s[i], P.diag_m1[i]) + total;
-}
-size_t poseidon2_gate(const P2GateLayout &lay, const e2 *w, e2 *out) {
-    const poseidon2::Params &P = poseidon2::qp_params();
-    size_t k = 0;
-    e2 st[12];
-    for (int i = 0; i < 12; i++) st[i] = w[lay.w_input + i];
-    if (lay.has_swap()) {
-        const e2 swap = w[lay.w_swap];
-        out[k++] = swap * (swap - E(1));
-        for (int i = 0; i < 4; i++) {
-            const e2 delta = w[lay.w_delta + i];
-            out[k++] = swap * (st[i + 4] - st[i]) - delta;
-            st[i] = st[i] + delta; st[i + 4] = st[i + 4] - delta;
-        }
-    }
-    p2_external(st, P);
-    uint32_t rec = lay.w_full0;
-    for (int r = 0; r < 8; r++) {
-        if (r == 4) {   // the 22 internal rounds sit between the two halves
-            for (int q = 0; q < 22; q++) {
-                const e2 in = w[lay.w_partial + q];
-                out[k++] = st[0] + E(P.rc_int[q]) - in;
-                st[0] = sbox7(in);
-                p2_internal(st, P);
-            }
-            rec = lay.w_full1;
-        }
-        for (int i = 0; i < 12; i++) st[i] = st[i] + E(P.rc_ext[r * 12 + i]);
-        if (r != 0 || lay.first_round_wires) {
-            for (int i = 0; i < 12; i++) { const e2 in = w[rec + i]; out[k++] = st[i] - in; st[i] = in; }
-            rec += 12;
-        }
-        for (int i = 0; i < 12; i++) st[i] = sbox7(st[i]);
-        p2_external(st, P);
-    }
-    for (int i = 0; i < 12; i++) out[k++] = st[i] - w[lay.w_output + i];
-    return k;
-}
-
-// the unfiltered constraints of gate g in upstream order; returns how many were written
-size_t gate_constraints(const GateInfo &g, const P2GateLayout &p2_layout, const e2 *consts, const e2 *w, const u64 pih[4], std::vector<e2> &out) {
-    size_t k = 0;
-    out.assign((size_t)g.num_constraints + 8, E(0));
-    switch (g.type) {
-        case GATE_NOOP: break;
-        case GATE_CONSTANT:
-            for (u64 i = 0; i < g.param0; i++) out[k++] = consts[i] - w[i];
-            break;
-        case GATE_PUBLIC_INPUT:
-            for (int i = 0; i < 4; i++) out[k++] = w[i] - E(pih[i]);
-            break;
-        case GATE_ARITHMETIC:           // per op: multiplicand_0, multiplicand_1, addend, output
-            for (u64 i = 0; i < g.param0; i++) out[k++] = w[4 * i + 3] - ((w[4 * i] * w[4 * i + 1]) * consts[0] + w[4 * i + 2] * consts[1]);
-            break;
-        case GATE_POSEIDON:
-            poseidon_gate(w, out.data());
-            k = 123;
-            break;
-        case GATE_POSEIDON2:
-            k = poseidon2_gate(p2_layout, w, out.data());
-            break;
-        case GATE_BASE_SUM: {           // wire 0 = sum, wires 1..num_limbs = bits (little endian)
-            e2 s = E(0);
-            for (u64 i = g.param0; i-- > 0;) s = (s + s) + w[1 + i];
-            out[k++] = s - w[0];
-            for (u64 i = 0; i < g.param0; i++) out[k++] = w[1 + i] * (w[1 + i] - E(1));
-            break;
-        }
-        case GATE_ARITHMETIC_EXT:       // 8 wires per op: two multiplicands, addend, output, each an algebra element
-            for (u64 i = 0; i < g.param0; i++) {
-                const e2 *o = w + 8 * i;
-                const Alg p = alg_mul({o[0], o[1]}, {o[2], o[3]});
-                out[k++] = o[6] - (p.c0 * consts[0] + o[4] * consts[1]);
-                out[k++] = o[7] - (p.c1 * consts[0] + o[5] * consts[1]);
-            }
-            break;
-        case GATE_MUL_EXT:              // 6 wires per op
-            for (u64 i = 0; i < g.param0; i++) {
-                const e2 *o = w + 6 * i;
-                const Alg p = alg_mul({o[0], o[1]}, {o[2], o[3]});
-                out[k++] = o[4] - p.c0 * consts[0];
-                out[k++] = o[5] - p.c1 * consts[0];
-            }
-            break;
-        case GATE_REDUCING:             // output 0..2, alpha 2..4, old_acc 4..6, coefficients from 6 (base field), accumulators after
-        case GATE_REDUCING_EXT: {       // the same with extension coefficients (two wires each)
-            const bool ext = g.type == GATE_REDUCING_EXT;
-            const u64 n = g.param0, accs = 6 + (ext ? 2 * n : n);
-            const Alg alpha = {w[2], w[3]};
-            Alg acc = {w[4], w[5]};
-            for (u64 i = 0; i < n; i++) {
-                Alg t = alg_mul(acc, alpha);
-                const Alg next = i == n - 1 ? Alg{w[0], w[1]} : Alg{w[accs + 2 * i], w[accs + 2 * i + 1]};
-                if (ext) { t.c0 = t.c0 + w[6 + 2 * i]; t.c1 = t.c1 + w[7 + 2 * i]; } else t.c0 = t.c0 + w[6 + i];
-                out[k++] = t.c0 - next.c0; out[k++] = t.c1 - next.c1;
-                acc = next;
-            }
-            break;
-        }
-        case GATE_RANDOM_ACCESS: {      // per copy: access_index, claimed_element, 2^bits items; the bit wires follow the routed ones
-            const u64 bits = g.param0, copies = g.param1, extra = g.param2, vec = 1ull << bits;
-            const u64 routed = (2 + vec) * copies + extra;
-            std::vector<e2> items(vec);
-            for (u64 c = 0; c < copies; c++) {
-                const e2 *cw = w + (2 + vec) * c, *bw = w + routed + c * bits;
-                for (u64 i = 0; i < vec; i++) items[i] = cw[2 + i];
-                for (u64 i = 0; i < bits; i++) out[k++] = bw[i] * (bw[i] - E(1));
-                e2 idx = E(0);
-                for (u64 i = bits; i-- > 0;) idx = (idx + idx) + bw[i];
-                out[k++] = idx - cw[0];
-                u64 len = vec;
-                for (u64 b = 0; b < bits; b++) {
-                    for (u64 i = 0; i < len / 2; i++) items[i] = items[2 * i] + bw[b] * (items[2 * i + 1] - items[2 * i]);
-                    len >>= 1;
-                }
-                out[k++] = items[0] - cw[1];
-            }
-            for (u64 i = 0; i < extra; i++) out[k++] = consts[i] - w[(2 + vec) * copies + i];
-            break;
-        }
-        case GATE_EXPONENTIATION: {     // base 0, power bits 1..1+n (little endian), output 1+n, intermediate values after
-            const u64 n = g.param0;
-            for (u64 i = 0; i < n; i++) {
-                const e2 prev = i == 0 ? E(1) : w[2 + n + i - 1] * w[2 + n + i - 1];
-                const e2 bit = w[1 + (n - 1 - i)];
-                out[k++] = prev * (bit * w[0] + (E(1) - bit)) - w[2 + n + i];
-            }
-            out[k++] = w[1 + n] - w[2 + n + n - 1];
-            break;
-        }
-        case GATE_POSEIDON_MDS: {       // 12 algebra elements in (wires 0..24), 12 out (24..48): out - MDS * in
-            static const u64 CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-            for (int r = 0; r < 12; r++)
-                for (int comp = 0; comp < 2; comp++) {
-                    e2 s = r == 0 ? scale(w[comp], 8) : E(0);
-                    for (int i = 0; i < 12; i++) s = s + scale(w[2 * ((i + r) % 12) + comp], CIRC[i]);
-                    out[k++] = w[24 + 2 * r + comp] - s;
-                }
-            break;
-        }
-        case GATE_COSET_INTERPOLATION: {   // shift, 2^bits values (algebra), evaluation point, value, intermediates, shifted point
-            const u64 bits = g.param0, degree = g.param1, np = 1ull << bits, ni = (np - 2) / (degree - 1);
-            const u64 s_ep = 1 + 2 * np, s_ev = s_ep + 2, s_int = s_ev + 2;
-            // barycentric weights of the subgroup of order np: 1 / prod_{j != i} (x_i - x_j) = x_i / np
-            std::vector<u64> dom(np), wt(np);
-            { const u64 om = gl::root_of_unity((unsigned)bits), ninv = gl::inv(np); u64 x = 1; for (u64 i = 0; i < np; i++) { dom[i] = x; wt[i] = gl::mul(x, ninv); x = gl::mul(x, om); } }
-            const e2 shift = w[0];
-            const Alg ep = {w[s_ep], w[s_ep + 1]}, sp = {w[s_int + 4 * ni], w[s_int + 4 * ni + 1]};
-            out[k++] = ep.c0 - sp.c0 * shift; out[k++] = ep.c1 - sp.c1 * shift;
-            Alg ev = {E(0), E(0)}, pr = {E(1), E(0)};
-            u64 lo = 0, hi = degree;
-            for (u64 c = 0; c <= ni; c++) {
-                for (u64 q = lo; q < hi; q++) {      // partial_interpolate_ext_algebra
-                    Alg term = sp;
-                    term.c0 = term.c0 - E(dom[q]);
-                    const Alg t = alg_mul({w[1 + 2 * q], w[2 + 2 * q]}, pr);
-                    ev = alg_mul(ev, term);
-                    ev.c0 = ev.c0 + scale(t.c0, wt[q]); ev.c1 = ev.c1 + scale(t.c1, wt[q]);
-                    pr = alg_mul(pr, term);
-                }
-                if (c == ni) break;
-                const Alg ie = {w[s_int + 2 * c], w[s_int + 2 * c + 1]}, ip = {w[s_int + 2 * (ni + c)], w[s_int + 2 * (ni + c) + 1]};
-                out[k++] = ie.c0 - ev.c0; out[k++] = ie.c1 - ev.c1;
-                out[k++] = ip.c0 - pr.c0; out[k++] = ip.c1 - pr.c1;
-                ev = ie; pr = ip;
-                lo = 1 + (degree - 1) * (c + 1); hi = std::min<u64>(lo + degree - 1, np);
-            }
-            out[k++] = w[s_ev] - ev.c0; out[k++] = w[s_ev + 1] - ev.c1;
-            break;
-        }
-        default: break;
-    }
-    return k;
-}
+// the gate constraints and the vanishing polynomial at one point: verify_math.hpp (shared with the in-circuit verifier)
+using vmath::gate_constraints;
 
 }  // namespace
 
@@ -507,9 +257,9 @@ static int verify_impl(const qpgpu_verifier *v, const uint8_t *proof, size_t len
     const Hash H{&v->hash};
     if (len != v->proof_size) return fail(err, QPGPU_EVERIFY, "proof has %zu bytes, this circuit's proofs have %zu", len, v->proof_size);
     const unsigned d = (unsigned)c.degree_bits, rb = (unsigned)c.rate_bits, cap_h = (unsigned)c.cap_height, L = d + rb;
-    const size_t n = (size_t)1 << d, lde_n = n << rb, R = c.num_routed_wires, NW = c.num_wires, nch = c.num_challenges;
-    const size_t npp = c.num_partial_products, nchunks = npp + 1, chunk = c.quotient_degree_factor, ncs = c.num_cs_cols();
-    const size_t sig0 = c.num_selectors + c.num_constants, cap_words = ((size_t)1 << cap_h) * 4, nq = nch * c.quotient_degree_factor;
+    const size_t n = (size_t)1 << d, lde_n = n << rb, NW = c.num_wires, nch = c.num_challenges;
+    const size_t npp = c.num_partial_products, ncs = c.num_cs_cols();
+    const size_t cap_words = ((size_t)1 << cap_h) * 4, nq = nch * c.quotient_degree_factor;
     const size_t n_rounds = c.arity_bits.size();
 
     Reader b{proof, len};
@@ -569,41 +319,16 @@ static int verify_impl(const qpgpu_verifier *v, const uint8_t *proof, size_t len
         for (unsigned i = 0; i < d; i++) zeta_n = zeta_n * zeta_n;
         const e2 zh = zeta_n - E(1);
         const e2 l0 = zh * gl::e2_inv(scale(zeta - E(1), (u64)n));
-        std::vector<e2> terms;
-        terms.reserve(nch + nch * nchunks + c.num_gate_constraints);
-        for (size_t k = 0; k < nch; k++) terms.push_back(l0 * (o_zs[k] - E(1)));
-        for (size_t k = 0; k < nch; k++)
-            for (size_t cc = 0; cc < nchunks; cc++) {
-                const e2 prev = cc == 0 ? o_zs[k] : o_pp[k * npp + cc - 1];
-                const e2 next = cc == nchunks - 1 ? o_zn[k] : o_pp[k * npp + cc];
-                e2 pn = E(1), pd = E(1);
-                for (size_t j = cc * chunk; j < (cc + 1) * chunk && j < R; j++) {
-                    pn = pn * (o_w[j] + scale(zeta, gl::mul(betas[k], c.k_is[j])) + E(gammas[k]));
-                    pd = pd * (o_w[j] + scale(o_cs[sig0 + j], betas[k]) + E(gammas[k]));
-                }
-                terms.push_back(prev * pn - next * pd);
-            }
-        std::vector<e2> gate_terms(c.num_gate_constraints, E(0)), cst;
-        const e2 *consts = o_cs.data() + c.num_selectors;
-        for (size_t gi = 0; gi < c.gates.size(); gi++) {
-            const GateInfo &g = c.gates[gi];
-            if (g.num_constraints == 0) continue;
-            e2 f = E(1);          // compute_filter: prod_{j in group, j != gate} (j - s), times (UNUSED - s) with several selectors
-            const e2 s = o_cs[g.selector_index];
-            for (u64 j = g.group_start; j < g.group_end; j++) if (j != gi) f = f * (E(j) - s);
-            if (c.num_selectors > 1) f = f * (E(0xFFFFFFFFull) - s);
-            const size_t cnt = gate_constraints(g, c.p2_layout, consts, o_w.data(), pih, cst);
-            if (cnt != g.num_constraints || cnt > gate_terms.size())
-                return fail(err, QPGPU_EVERIFY, "gate %zu: the pack declares %llu constraints, the gate has %zu", gi, (unsigned long long)g.num_constraints, cnt);
-            for (size_t i = 0; i < cnt; i++) gate_terms[i] = gate_terms[i] + f * cst[i];
-        }
-        terms.insert(terms.end(), gate_terms.begin(), gate_terms.end());
+        e2 xb[4], xg[4], xa[4], xpih[4];
+        for (size_t k = 0; k < nch; k++) { xb[k] = E(betas[k]); xg[k] = E(gammas[k]); xa[k] = E(alphas[k]); }
+        for (int i = 0; i < 4; i++) xpih[i] = E(pih[i]);
+        std::vector<e2> van;
+        const std::string why = vmath::vanishing_at_zeta<e2>(c, zeta, l0, o_cs.data(), o_w.data(), o_zs.data(), o_zn.data(), o_pp.data(), xb, xg, xa, xpih, van);
+        if (!why.empty()) return fail(err, QPGPU_EVERIFY, "%s", why.c_str());
         for (size_t k = 0; k < nch; k++) {
-            e2 acc = E(0);
-            for (size_t j = terms.size(); j-- > 0;) acc = scale(acc, alphas[k]) + terms[j];
             e2 qv = E(0);
             for (size_t j = c.quotient_degree_factor; j-- > 0;) qv = qv * zeta_n + o_q[k * c.quotient_degree_factor + j];
-            if (!same(acc, zh * qv)) return fail(err, QPGPU_EVERIFY, "quotient identity fails at zeta (challenge %zu): the openings do not satisfy the circuit", k);
+            if (!same(van[k], zh * qv)) return fail(err, QPGPU_EVERIFY, "quotient identity fails at zeta (challenge %zu): the openings do not satisfy the circuit", k);
         }
     }
 

@@ -32,12 +32,30 @@
 #include "../../include/qpgpu_batch.h"
 #include "builder.hpp"
 #include "poseidon.hpp"
+#include "verify_math.hpp"
 
 using cb::BoolTarget;
 using cb::Builder;
 using cb::HashOutTarget;
 using cb::Target;
 using gl::u64;
+
+// ---- verify_math.hpp's element type over the circuit builder: an ExtensionTarget, every operation one ArithmeticExtensionGate
+// slot (a b + c or a - b forms; constants are ConstantGate targets, so all operations of a circuit share two kinds of rows) ----
+namespace cbx {
+thread_local Builder *g_b = nullptr;
+struct XT { cb::ExtTarget t; };
+inline XT K(u64 c) { return {g_b->constant_ext(c)}; }
+inline XT operator+(XT a, XT b) { return {g_b->arithmetic_ext(1, 1, g_b->one_ext(), a.t, b.t)}; }
+inline XT operator-(XT a, XT b) { return {g_b->arithmetic_ext(1, gl::P - 1, g_b->one_ext(), a.t, b.t)}; }
+inline XT operator*(XT a, XT b) { return {g_b->arithmetic_ext(1, 1, a.t, b.t, g_b->zero_ext())}; }
+inline XT madd(XT a, XT b, XT c) { return {g_b->arithmetic_ext(1, 1, a.t, b.t, c.t)}; }
+inline XT scale(XT x, u64 s) { return x * K(s); }
+inline XT sadd(XT a, u64 s, XT c) { return madd(a, K(s), c); }
+inline XT lift(Target t) { return {g_b->to_ext(t)}; }
+}  // namespace cbx
+namespace vmath { template <> inline cbx::XT konst<cbx::XT>(u64 c) { return cbx::K(c); } }
+using cbx::XT;
 
 namespace {
 
@@ -112,6 +130,7 @@ struct RecursiveChallenger {
         in.clear();
         out.assign(state.begin(), state.begin() + 8);
     }
+    cb::ExtTarget get_ext() { const Target a = get(), c = get(); return {{a, c}}; }
     Target get() {
         absorb();
         if (out.empty()) { state = b.permute_swapped(state, b._false()); out.assign(state.begin(), state.begin() + 8); }
@@ -298,6 +317,120 @@ std::vector<Target> public_batch_logic(Builder &b, const std::vector<std::vector
     return out;
 }
 
+// ---- the arithmetic half of verify_proof: the openings against the vanishing polynomial at zeta, and the FRI consistency checks ----
+struct Challenges { std::vector<Target> betas, gammas, alphas; cb::ExtTarget zeta, fri_alpha; std::vector<cb::ExtTarget> fri_betas; };
+struct FriPre { XT red0, red1, zeta, g_zeta, alpha, alpha_nch; };
+struct FriQuery { XT old_eval; Target subgroup_x, inv_x; };
+
+// verify_proof_with_challenges_circuit up to the FRI call (plonk/recursive_verifier.rs): eval_vanishing_poly_circuit at zeta — every
+// gate of the INNER circuit through verify_math.hpp's generic constraints — equals Z_H(zeta) * reduce_with_powers(quotient chunks,
+// zeta^n) for every challenge; then precompute_reduced_evals (fri/recursive_verifier.rs). p.openings is in transcript order:
+// constants/sigmas, wires, Zs, partial products, quotient chunks, Zs at g zeta.
+std::string verify_openings(Builder &b, const CircuitPack &c, const ProofTargets &p, const HashOutTarget &pih, const Challenges &ch, FriPre &fri) {
+    const size_t ncs = c.num_cs_cols(), NW = c.num_wires, nch = c.num_challenges, npp = c.num_partial_products, qdf = c.quotient_degree_factor, nq = nch * qdf;
+    if (p.openings.size() != 2 * (ncs + NW + nch + nch * npp + nq + nch)) return "opening count disagrees with the inner circuit";
+    std::vector<XT> o(p.openings.size() / 2);
+    for (size_t i = 0; i < o.size(); i++) o[i] = XT{{{p.openings[2 * i], p.openings[2 * i + 1]}}};
+    const XT *o_cs = o.data(), *o_w = o_cs + ncs, *o_zs = o_w + NW, *o_pp = o_zs + nch, *o_q = o_pp + nch * npp, *o_zn = o_q + nq;
+    const XT zeta{ch.zeta}, one = cbx::K(1);
+    XT zeta_n = zeta;
+    for (uint64_t i = 0; i < c.degree_bits; i++) zeta_n = zeta_n * zeta_n;
+    const XT zh = zeta_n - one;
+    // eval_l_0_circuit: (zeta^n - 1) / (n (zeta - 1))
+    const XT l0{b.div_ext(zh.t, scale(zeta - one, 1ull << c.degree_bits).t)};
+    std::vector<XT> betas, gammas, alphas, van;
+    for (size_t k = 0; k < nch; k++) { betas.push_back(cbx::lift(ch.betas[k])); gammas.push_back(cbx::lift(ch.gammas[k])); alphas.push_back(cbx::lift(ch.alphas[k])); }
+    XT xpih[4];
+    for (int i = 0; i < 4; i++) xpih[i] = cbx::lift(pih.elements[i]);
+    const std::string why = vmath::vanishing_at_zeta<XT>(c, zeta, l0, o_cs, o_w, o_zs, o_zn, o_pp, betas.data(), gammas.data(), alphas.data(), xpih, van);
+    if (!why.empty()) return why;
+    for (size_t k = 0; k < nch; k++) {
+        XT qv = cbx::K(0);
+        for (size_t j = qdf; j-- > 0;) qv = madd(qv, zeta_n, o_q[k * qdf + j]);
+        b.connect_ext(van[k].t, (zh * qv).t);
+    }
+    // precompute_reduced_evals: batch 0 = everything opened at zeta in oracle order, batch 1 = Zs at g zeta
+    fri.alpha = XT{ch.fri_alpha};
+    {
+        std::vector<cb::ExtTarget> at_zeta, at_g_zeta;
+        for (size_t j = 0; j < ncs + NW + nch + nch * npp + nq; j++) at_zeta.push_back(o[j].t);
+        for (size_t j = 0; j < nch; j++) at_g_zeta.push_back(o_zn[j].t);
+        fri.red0 = XT{b.reduce_ext(ch.fri_alpha, at_zeta)};
+        fri.red1 = XT{b.reduce_ext(ch.fri_alpha, at_g_zeta)};
+    }
+    fri.zeta = zeta;
+    fri.g_zeta = scale(zeta, gl::canon(gl::root_of_unity((unsigned)c.degree_bits)));
+    fri.alpha_nch = cbx::K(1);
+    for (size_t k = 0; k < nch; k++) fri.alpha_nch = fri.alpha_nch * fri.alpha;
+    return "";
+}
+
+// fri_verifier_query_round, first part: subgroup_x = g * w^rev(x_index) (and its inverse, for the coset interpolation) from the
+// index bits; fri_combine_initial: the opened rows reduced with alpha (salts are not opened), minus the reduced openings, over
+// (x - zeta) and (x - g zeta)
+FriQuery fri_query_begin(Builder &b, const CircuitPack &c, const QueryRoundTargets &r, const std::vector<BoolTarget> &bits, const Challenges &, const FriPre &fri) {
+    const unsigned L = (unsigned)bits.size();
+    const size_t nch = c.num_challenges, polys[4] = {(size_t)c.num_cs_cols(), (size_t)c.num_wires, (size_t)c.num_zs_pp_cols(), (size_t)c.num_quotient_cols()};
+    const std::vector<BoolTarget> rev(bits.rbegin(), bits.rend());               // rev(x_index), little endian
+    const u64 w = gl::canon(gl::root_of_unity(L));
+    FriQuery q;
+    q.subgroup_x = b.mul_const(gl::MULT_GEN, b.exp_from_bits_const_base(w, rev));
+    q.inv_x = b.mul_const(gl::canon(gl::inv(gl::MULT_GEN)), b.exp_from_bits_const_base(gl::canon(gl::inv(w)), rev));
+    std::vector<Target> at_zeta, at_g_zeta;
+    for (int o = 0; o < 4; o++) at_zeta.insert(at_zeta.end(), r.evals[o].begin(), r.evals[o].begin() + (long)polys[o]);
+    at_g_zeta.assign(r.evals[2].begin(), r.evals[2].begin() + (long)nch);
+    const XT e0{b.reduce_base(fri.alpha.t, at_zeta)}, e1{b.reduce_base(fri.alpha.t, at_g_zeta)};
+    const XT sx = cbx::lift(q.subgroup_x);
+    XT sum{b.div_ext((e0 - fri.red0).t, (sx - fri.zeta).t)};
+    const XT second{b.div_ext((e1 - fri.red1).t, (sx - fri.g_zeta).t)};
+    q.old_eval = madd(sum, fri.alpha_nch, second);
+    return q;
+}
+
+// one reduction step: the step's coset of evaluations holds the running evaluation at position x_index mod arity
+// (random_access_extension); compute_evaluation: the coset's interpolant at beta. With s = coset_start = subgroup_x g^(-rev(within))
+// the interpolant through (s g^i, y_i) at beta is the interpolant through the FIXED subgroup (g^i, y_i) at t = beta / s, in
+// barycentric form sum_i y_i (g^i / arity) prod_{j != i} (t - g^j); y_i = evals[rev(i)] (the coset is stored bit-reversed).
+void fri_query_fold(Builder &b, const CircuitPack &c, const QueryRoundTargets &r, size_t step, const std::vector<BoolTarget> &bits, const Challenges &ch, FriQuery &q) {
+    const unsigned ab = (unsigned)c.arity_bits[step], arity = 1u << ab;
+    const std::vector<BoolTarget> within(bits.begin(), bits.begin() + ab);
+    const std::vector<Target> &ev = r.step_evals[step];
+    std::vector<Target> c0(arity), c1(arity);
+    for (unsigned i = 0; i < arity; i++) { c0[i] = ev[2 * i]; c1[i] = ev[2 * i + 1]; }
+    const Target within_t = b.le_sum(within);
+    b.connect(b.random_access(within_t, c0), q.old_eval.t.t[0]);
+    b.connect(b.random_access(within_t, c1), q.old_eval.t.t[1]);
+    const u64 g = gl::canon(gl::root_of_unity(ab));
+    const std::vector<BoolTarget> rev_within(within.rbegin(), within.rend());
+    const Target s_inv = b.mul(q.inv_x, b.exp_from_bits_const_base(g, rev_within));
+    const XT t = XT{ch.fri_betas[step]} * cbx::lift(s_inv);
+    std::vector<XT> d(arity), pre(arity), suf(arity);
+    { u64 x = 1; for (unsigned j = 0; j < arity; j++) { d[j] = t - cbx::K(gl::canon(x)); x = gl::mul(x, g); } }
+    pre[0] = cbx::K(1); suf[arity - 1] = cbx::K(1);
+    for (unsigned j = 1; j < arity; j++) pre[j] = pre[j - 1] * d[j - 1];
+    for (unsigned j = arity - 1; j-- > 0;) suf[j] = suf[j + 1] * d[j + 1];
+    XT acc = cbx::K(0);
+    const u64 ninv = gl::inv(arity);
+    u64 x = 1;
+    for (unsigned i = 0; i < arity; i++) {
+        unsigned src = 0;
+        for (unsigned k = 0; k < ab; k++) src |= ((i >> k) & 1u) << (ab - 1 - k);
+        const XT y{{{ev[2 * src], ev[2 * src + 1]}}};
+        acc = sadd(y * (pre[i] * suf[i]), gl::canon(gl::mul(x, ninv)), acc);
+        x = gl::mul(x, g);
+    }
+    q.old_eval = acc;
+    for (unsigned k = 0; k < ab; k++) { q.subgroup_x = b.mul(q.subgroup_x, q.subgroup_x); q.inv_x = b.mul(q.inv_x, q.inv_x); }
+}
+
+// the final polynomial at the last subgroup point equals the last folded evaluation
+void fri_query_end(Builder &b, const ProofTargets &p, const FriQuery &q) {
+    const XT sx = cbx::lift(q.subgroup_x);
+    std::vector<cb::ExtTarget> coeffs;
+    for (size_t i = 0; i < p.final_poly.size() / 2; i++) coeffs.push_back({{p.final_poly[2 * i], p.final_poly[2 * i + 1]}});
+    b.connect_ext(b.reduce_ext(sx.t, coeffs), q.old_eval.t);
+}
+
 }  // namespace
 
 extern "C" {
@@ -308,11 +441,14 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
     auto fail = [&](int code, const std::string &m) { if (err) std::snprintf(err, QPGPU_BATCH_ERR_CAP, "%s", m.c_str()); return code; };
     if (err) err[0] = 0;
     if (!inner_pack || !inner_cs_cap || !pack_words || num_proofs == 0 || num_proofs > 64) return fail(QPGPU_EINVAL, "wrapper_circuit_build: null argument or proof count outside 1..64");
-    if (flags & ~(QPGPU_WRAPPER_TRANSCRIPT | QPGPU_WRAPPER_PRIVATE_BATCH | QPGPU_WRAPPER_PUBLIC_BATCH)) return fail(QPGPU_EINVAL, "wrapper_circuit_build: unknown flag");
+    if (flags & ~(QPGPU_WRAPPER_TRANSCRIPT | QPGPU_WRAPPER_PRIVATE_BATCH | QPGPU_WRAPPER_PUBLIC_BATCH | QPGPU_WRAPPER_VERIFY)) return fail(QPGPU_EINVAL, "wrapper_circuit_build: unknown flag");
     const bool transcript = (flags & QPGPU_WRAPPER_TRANSCRIPT) != 0, private_batch = (flags & QPGPU_WRAPPER_PRIVATE_BATCH) != 0, public_batch = (flags & QPGPU_WRAPPER_PUBLIC_BATCH) != 0;
+    const bool verify = (flags & QPGPU_WRAPPER_VERIFY) != 0;
+    if (verify && !transcript) return fail(QPGPU_EINVAL, "wrapper_circuit_build: QPGPU_WRAPPER_VERIFY needs the in-circuit transcript (its challenges are what the arithmetic consumes)");
     if (private_batch && public_batch) return fail(QPGPU_EINVAL, "wrapper_circuit_build: a circuit is the private-batch or the public-batch layer, not both");
     CircuitPack inner;
     { const std::string why = inner.parse(inner_pack, inner_words); if (!why.empty()) return fail(QPGPU_EINVAL, "wrapper_circuit_build: inner pack: " + why); }
+    if (verify && inner.zero_knowledge) return fail(QPGPU_EINVAL, "wrapper_circuit_build: QPGPU_WRAPPER_VERIFY over a zero-knowledge inner circuit is not built");
     if (cap_words != ((size_t)4 << inner.cap_height)) return fail(QPGPU_EINVAL, "wrapper_circuit_build: the inner constants/sigmas cap has the wrong size");
     // the shape checks of PrivateBatchCircuit::new / PublicBatchCircuit::new (circuit_logic.rs:94-104 / :74-87), with their messages
     size_t n_leaf_inner = 0;
@@ -332,6 +468,7 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
         cfg.min_degree_bits = min_degree_bits;
         cfg.inner_hasher = inner_hasher;
         Builder b(cfg);
+        cbx::g_b = &b;
         const unsigned L = (unsigned)(inner.degree_bits + inner.rate_bits), cap_h = (unsigned)inner.cap_height;
         // verifier data of the inner circuit: constants of this one (builder.constant_merkle_cap)
         std::vector<HashOutTarget> cs_cap((size_t)1 << cap_h);
@@ -349,6 +486,7 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
             const ProofTargets &p = proofs[i];
             if (!private_batch && !public_batch) for (Target t : p.public_inputs) b.register_public_input(t);                // forwarded
             const HashOutTarget pih = b.hash_n_to_hash_no_pad(p.public_inputs);         // verify_proof's public_inputs_hash
+            Challenges chal;
             if (transcript) {
                 // get_challenges (plonk/get_challenges.rs) + fri_challenges: the prover's transcript replayed in-circuit, in the order
                 // of csrc/verifier.cpp; the Plonk and FRI challenges themselves are not consumed yet (nothing in-circuit evaluates the
@@ -357,14 +495,15 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
                 for (int k = 0; k < 4; k++) ch.observe(b.constant(inner.circuit_digest[k]));
                 ch.observe(pih);
                 ch.observe_cap(p.caps[0]);
-                for (uint64_t k = 0; k < 2 * inner.num_challenges; k++) (void)ch.get();       // betas, gammas
+                for (uint64_t k = 0; k < inner.num_challenges; k++) chal.betas.push_back(ch.get());
+                for (uint64_t k = 0; k < inner.num_challenges; k++) chal.gammas.push_back(ch.get());
                 ch.observe_cap(p.caps[1]);
-                for (uint64_t k = 0; k < inner.num_challenges; k++) (void)ch.get();           // alphas
+                for (uint64_t k = 0; k < inner.num_challenges; k++) chal.alphas.push_back(ch.get());
                 ch.observe_cap(p.caps[2]);
-                (void)ch.get(); (void)ch.get();                                               // zeta
+                chal.zeta = ch.get_ext();
                 ch.observe(p.openings);
-                (void)ch.get(); (void)ch.get();                                               // FRI alpha
-                for (size_t s = 0; s < inner.arity_bits.size(); s++) { ch.observe_cap(p.commit_caps[s]); (void)ch.get(); (void)ch.get(); }   // FRI betas
+                chal.fri_alpha = ch.get_ext();
+                for (size_t s = 0; s < inner.arity_bits.size(); s++) { ch.observe_cap(p.commit_caps[s]); chal.fri_betas.push_back(ch.get_ext()); }
                 ch.observe(p.final_poly);
                 ch.observe(p.pow_witness);
                 const Target pow_response = ch.get();
@@ -372,6 +511,11 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
                 if (inner.proof_of_work_bits) b.range_check(pow_response, 64 - (unsigned)inner.proof_of_work_bits);
                 x_indices[i].resize(Q);
                 for (size_t q = 0; q < Q; q++) x_indices[i][q] = ch.get();
+            }
+            FriPre fri;
+            if (verify) {
+                const std::string why = verify_openings(b, inner, p, pih, chal, fri);
+                if (!why.empty()) return fail(QPGPU_EINVAL, "wrapper_circuit_build: " + why);
             }
             for (size_t q = 0; q < Q; q++) {
                 const QueryRoundTargets &r = p.rounds[q];
@@ -382,10 +526,14 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
                 const Target cap_index = b.le_sum(std::vector<BoolTarget>(bits.end() - cap_h, bits.end()));
                 const std::vector<HashOutTarget> *caps[4] = {&cs_cap, &p.caps[0], &p.caps[1], &p.caps[2]};
                 for (int o = 0; o < 4; o++) b.verify_merkle_proof_to_cap_with_cap_index(r.evals[o], bits, cap_index, *caps[o], r.siblings[o]);
+                FriQuery fq;
+                if (verify) fq = fri_query_begin(b, inner, r, bits, chal, fri);
                 for (size_t s = 0; s < inner.arity_bits.size(); s++) {
+                    if (verify) fri_query_fold(b, inner, r, s, bits, chal, fq);                    // (before the step's index bits are dropped)
                     bits.erase(bits.begin(), bits.begin() + (long)inner.arity_bits[s]);        // coset_index_bits
                     b.verify_merkle_proof_to_cap_with_cap_index(r.step_evals[s], bits, cap_index, p.commit_caps[s], r.step_siblings[s]);
                 }
+                if (verify) fri_query_end(b, p, fq);
             }
             rows_hash = b.num_gates();
         }

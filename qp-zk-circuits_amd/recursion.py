@@ -37,13 +37,15 @@ class WrapperCircuit:
 
     FLAGS = {None: 0, "private_batch": 2, "public_batch": 4}          # QPGPU_WRAPPER_PRIVATE_BATCH / _PUBLIC_BATCH
 
-    def __init__(self, inner_pack, verifier, num_proofs, num_routed_wires=80, min_degree_bits=0, inner_hasher=0, transcript=True, logic=None):
+    def __init__(self, inner_pack, verifier, num_proofs, num_routed_wires=80, min_degree_bits=0, inner_hasher=0, transcript=True, logic=None, verify=False):
         """transcript=True (QPGPU_WRAPPER_TRANSCRIPT): the inner proofs' Fiat-Shamir transcripts are replayed in-circuit, the query
         indices are derived there and the proof-of-work response is range-checked; False: the query indices are witness inputs.
         logic: None (inner public inputs forwarded), "private_batch" (build_private_batch_constraints over leaf proofs) or
-        "public_batch" (build_public_batch_constraints over private-batch proofs): the layer's own constraints and public inputs."""
+        "public_batch" (build_public_batch_constraints over private-batch proofs): the layer's own constraints and public inputs.
+        verify=True (QPGPU_WRAPPER_VERIFY): the arithmetic half of verify_proof in-circuit too (openings against the vanishing
+        polynomial at zeta, FRI consistency) — the wrapper then enforces everything the host verifier checks on an inner proof."""
         L = _lib()
-        self.logic = logic
+        self.logic, self.verify = logic, verify
         self.inner_pack = np.ascontiguousarray(inner_pack, dtype=np.uint64)
         self.verifier, self.num_proofs, self.transcript = verifier, num_proofs, transcript
         cap_h = int(self.inner_pack[11])
@@ -53,7 +55,7 @@ class WrapperCircuit:
         n, m = ctypes.c_size_t(), ctypes.c_size_t()
         err = ctypes.create_string_buffer(200)
         args = (self.inner_pack.ctypes.data, self.inner_pack.size, cap.ctypes.data, cap.size, num_proofs, num_routed_wires, min_degree_bits, inner_hasher,
-                (1 if transcript else 0) | self.FLAGS[logic])
+                (1 if transcript else 0) | self.FLAGS[logic] | (8 if verify else 0))
         rc = L.qpgpu_wrapper_circuit_build(*args, None, 0, ctypes.byref(n), None, 0, ctypes.byref(m), None, err)
         if rc != 0:
             raise QpGpuError(rc, err.value.decode())
