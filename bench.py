@@ -536,13 +536,16 @@ def main():
                       "root_public_inputs": parsed,
                       "checked": "the library's verifier accepts the root, a first-level proof and a leaf; the root's public inputs are the PublicBatchPublicInputs the host "
                                  "restatement of the two layers' logic computes from the 64 leaves' public inputs, and parse (96 paid exit slots, 64 nullifiers)" if ok_a else "FAILED",
-                      "note": "first level = the private-batch circuit's own constraints (dummy flags, block / asset / fee consistency, exit-account grouping, distinct real "
-                              "nullifiers, dummy nullifiers = H(H(preimage)), sorting network), second level = the public-batch circuit's, both restated on the native builder "
-                              "(circuit_logic.rs of each layer); every wrapper also checks in-circuit, for each inner proof and each of its 28 query rounds, that the four opened "
-                              "rows and every FRI step's coset of evaluations hash up their Merkle paths to the committed caps, and replays the inner proof's Fiat-Shamir "
-                              "transcript (query indices derived there, proof-of-work response range-checked); NOT in-circuit yet: the openings against the vanishing "
-                              "polynomial at zeta, the folding arithmetic, zero-knowledge blinding of the private layer. Times include commit on the host (fill_witness; "
-                              "fill_private_batch_witness per inner proof)."}
+                      "arithmetic_extension_rows": {"first_level": at.w1.info["rows_before_padding"] - at.w1.info["rows_poseidon"] - at.w1.info["rows_random_access"] - at.w1.info["rows_base_sum"] - at.w1.info["rows_arithmetic"] - at.w1.info["rows_constant"]},
+                      "note": "every wrapper is a complete recursive verifier of its inner proofs (QPGPU_WRAPPER_VERIFY): for each inner proof it hashes the public inputs, replays "
+                              "the Fiat-Shamir transcript in-circuit (challenges, proof-of-work check, query indices), checks in every one of the 28 query rounds that the four opened "
+                              "rows and every FRI step's coset hash up their Merkle paths to the committed caps, evaluates the openings against the vanishing polynomial at zeta "
+                              "(every gate of the inner circuit, permutation argument; the same generic expressions as the host verifier, csrc/verify_math.hpp) and the FRI "
+                              "consistency arithmetic (reduced openings, coset interpolation per step, final polynomial); first level + the private-batch circuit's own "
+                              "constraints (dummy flags, block / asset / fee consistency, exit-account grouping, distinct real nullifiers, dummy nullifiers = H(H(preimage)), "
+                              "sorting network), second level + the public-batch circuit's, restated on the native builder (circuit_logic.rs of each layer). Not built: "
+                              "zero-knowledge blinding of the private layer; the gate set and row order are the native builder's, not the fork's (verifier data differs). "
+                              "Times include commit on the host (fill_witness; fill_private_batch_witness per inner proof)."}
             ok = ok and ok_a
             at.close()
         except pkg.QpGpuError as e:

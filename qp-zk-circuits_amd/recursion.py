@@ -127,15 +127,16 @@ class AttestingTree:
     """BASELINE configs[4]'s shape with circuits that check something: `batches` x `per_batch` leaf proofs of the restated
     Wormhole leaf circuit (from CircuitInputs), one first-level wrapper per `per_batch` leaves, one second-level wrapper over the
     first-level proofs (wormhole/aggregator/src/aggregator.rs:187-227's two layers). Every wrapper is a WrapperCircuit: it checks
-    the Merkle half of each inner proof in-circuit (csrc/wrapper_circuit.cpp says what that leaves out: openings at zeta and the
-    folding arithmetic; the private layer's zero-knowledge blinding is not part of it either), replays the inner proofs'
-    transcripts in-circuit (query indices derived, proof of work checked) and, with batch_logic (the default), carries its
+    the Merkle half of each inner proof in-circuit, replays the inner proofs' transcripts in-circuit (query indices derived, proof
+    of work checked), with verify (the default) evaluates the openings against the vanishing polynomial and the FRI consistency
+    arithmetic in-circuit as well — everything VerifierCircuitData::verify checks; the private layer's zero-knowledge blinding
+    is the part of the reference's layers that is not built — and, with batch_logic (the default), carries its
     layer's own constraints: the first level is the private-batch circuit's logic over its leaves' public inputs, the second the
     public-batch circuit's over the first level's — the root proof's public inputs are a PublicBatchPublicInputs. The leaves
     of one tree must then be what the reference's layers accept (real spends of ONE block, dummies elsewhere). One lockstep batch
     per level and rank."""
 
-    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0, rank=0, world=1, batch_logic=True, aggregator_address=bytes(32), seed=1):
+    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0, rank=0, world=1, batch_logic=True, aggregator_address=bytes(32), seed=1, verify=True):
         """rank / world: with several ranks (one per GPU) a rank proves the leaves and the first-level wrapper of batches
         b = rank, rank + world, ..; the first-level proofs travel to rank 0, which proves the second level."""
         self.pkg, self.gpu, self.per_batch, self.batches = pkg, gpu, per_batch, batches
@@ -146,12 +147,12 @@ class AttestingTree:
         n_leaves = per_batch * max(1, len(self.my_batches))
         self.leaf_circ = pkg.Circuit(gpu, self.leaf.pack, max_batch=n_leaves)
         self.leaf_ver = pkg.Verifier(self.leaf.pack, circuit=self.leaf_circ)
-        self.batch_logic, self.aggregator_address = batch_logic, bytes(aggregator_address)
+        self.batch_logic, self.aggregator_address, self.verify = batch_logic, bytes(aggregator_address), verify
         self.seed = seed
-        self.w1 = WrapperCircuit(self.leaf.pack, self.leaf_ver, per_batch, logic="private_batch" if batch_logic else None)
+        self.w1 = WrapperCircuit(self.leaf.pack, self.leaf_ver, per_batch, logic="private_batch" if batch_logic else None, verify=verify)
         self.w1_circ = pkg.Circuit(gpu, self.w1.pack, max_batch=max(1, len(self.my_batches)))
         self.w1_ver = pkg.Verifier(self.w1.pack, circuit=self.w1_circ)
-        self.w2 = WrapperCircuit(self.w1.pack, self.w1_ver, batches, logic="public_batch" if batch_logic else None)
+        self.w2 = WrapperCircuit(self.w1.pack, self.w1_ver, batches, logic="public_batch" if batch_logic else None, verify=verify)
         self.w2_circ = pkg.Circuit(gpu, self.w2.pack)
         self.w2_ver = pkg.Verifier(self.w2.pack, circuit=self.w2_circ)
         self.words = [135 << c.info["degree_bits"] for c in (self.leaf, self.w1, self.w2)]

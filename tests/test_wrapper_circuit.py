@@ -114,3 +114,42 @@ def test_tampered_inner_proofs_are_unsatisfiable(pkg, orc, setup):
     with pytest.raises(ValueError) as e:
         w.commit([proofs[0], base[:-8]])
     assert "malformed" in str(e.value)
+
+
+def test_full_verification_in_circuit(pkg, orc, setup):
+    """QPGPU_WRAPPER_VERIFY: the arithmetic half of verify_proof in-circuit too (csrc/verify_math.hpp instantiated over the
+    builder). The case the Merkle half and the transcript cannot see: a proof made HONESTLY by the prover from a trace that does
+    not satisfy the inner circuit — its rows are committed under its caps, its transcript is its own, its proof of work is valid;
+    only the quotient identity at zeta / the FRI consistency fail. The host verifier rejects it; the wrapper without the flag has a
+    witness for it; the wrapper with the flag has none."""
+    leaf, proofs, ver, w, w0 = setup
+    L = pkg.leaf
+    wv = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, verify=True)
+    assert wv.info["degree_bits"] == 13 and wv.info["rows_poseidon"] == w.info["rows_poseidon"]
+    c = wv.commit(proofs[:2])
+    rc, wires, _ = orc.generate_witness(wv.pack, *c)
+    assert rc == orc.WIT_OK
+    ocw = ob.OracleCircuit(orc, wv.pack)
+    proof = ocw.prove(wires, c[2])
+    assert ocw.verify(proof) == 0
+    ocw.close()
+    # traces that violate the leaf circuit: a wire of a used gate slot changed (gate constraint or copy constraint broken); and one
+    # that does not: a wire no gate of that row reads
+    x = lc.real_inputs(L, depth=3)
+    cells, vals, pis = leaf.commit(x)
+    rc, lw, _ = orc.generate_witness(leaf.pack, cells, vals, pis)
+    assert rc == orc.WIT_OK
+    oc = ob.OracleCircuit(orc, leaf.pack)
+    for (col, row), valid in (((3, 0), False), ((20, 40), False), ((100, 17), True)):
+        bw = lw.copy(); bw[col, row] = (int(bw[col, row]) + 1) % pkg.P
+        forged = oc.prove(bw, pis)
+        assert bool(ver.verify(forged)) == valid, (col, row)
+        c0 = w.commit([proofs[1], forged])
+        assert orc.generate_witness(w.pack, *c0)[0] == orc.WIT_OK, (col, row)            # Merkle half + transcript: satisfied
+        cv = wv.commit([proofs[1], forged])
+        assert orc.generate_witness(wv.pack, *cv)[0] == (orc.WIT_OK if valid else orc.WIT_CONFLICT), (col, row)
+    oc.close()
+    # the flag needs the in-circuit transcript
+    with pytest.raises(pkg.QpGpuError) as e:
+        pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, transcript=False, verify=True)
+    assert "needs the in-circuit transcript" in str(e.value)

@@ -119,3 +119,48 @@ def test_two_level_tree_with_the_batch_layers_logic(pkg, gpu, orc):
         st = tree.w1_circ.generate_witness_partial_batch_dev(c[0], c[1][None], c[2][None], tree.d_wires)
         assert st == [-4] and "set twice with different values" in gpu.last_error()
     tree.close()
+
+
+def test_full_verification_on_the_device(pkg, gpu, orc):
+    """QPGPU_WRAPPER_VERIFY on the device: the wrapper's witness (ArithmeticExtension / Reducing / ReducingExtension rows and the
+    quotient hints of the in-circuit verifier next to the Poseidon / RandomAccess rows) generated by stage s1 equals the oracle's,
+    the proof equals the oracle's bytes; an inner proof the device prover made from a trace that violates the leaf circuit has a
+    witness in the wrapper WITHOUT the flag and none with it (QPGPU_EUNSAT)."""
+    L = pkg.leaf
+    leaf = L.LeafCircuit()
+    lp = L.LeafProver(pkg, gpu, leaf)
+    xs = [lc.real_inputs(L, depth=4, seed=8), lc.dummy_inputs(L)]
+    proofs = [lp.prove(x)[0] for x in xs]
+    ver = pkg.Verifier(leaf.pack, circuit=lp.circ)
+    wv = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, verify=True)
+    w0 = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2)
+    wc, w0c = pkg.Circuit(gpu, wv.pack), pkg.Circuit(gpu, w0.pack)
+    nw, n = 135, 1 << wv.info["degree_bits"]
+    assert w0.info["degree_bits"] == wv.info["degree_bits"] == 13
+    d = gpu.alloc(nw * n * 8)
+    cells, vals, pis = wv.commit(proofs)
+    wc.generate_witness_partial_dev(cells, vals, pis, d)
+    rc, want, _ = orc.generate_witness(wv.pack, cells, vals, pis)
+    assert rc == orc.WIT_OK and np.array_equal(d.download().reshape(nw, n), want)
+    wc.set_witness_check(True)
+    proof = wc.prove_dev(d, pis)
+    oc = ob.OracleCircuit(orc, wv.pack)
+    assert proof == oc.prove(want, pis) and oc.verify(proof) == 0
+    oc.close()
+    wver = pkg.Verifier(wv.pack, circuit=wc)
+    assert wver.verify(proof)
+    # a leaf proof of a trace that violates the leaf circuit, made by the device prover (its witness check is off by default)
+    pis_leaf = lp.generate_witness(xs[0])
+    trace = lp.witness().copy()
+    trace[3, 0] = (int(trace[3, 0]) + 1) % pkg.P
+    lp.d_wires.upload(trace)
+    forged = lp.circ.prove_dev(lp.d_wires, pis_leaf)
+    assert not ver.verify(forged)
+    c0 = w0.commit([proofs[1], forged])
+    w0c.generate_witness_partial_dev(c0[0], c0[1], c0[2], d)                     # Merkle half + transcript: nothing to object to
+    cv = wv.commit([proofs[1], forged])
+    with pytest.raises(pkg.QpGpuError) as e:
+        wc.generate_witness_partial_dev(cv[0], cv[1], cv[2], d)
+    assert e.value.code == -4 and "set twice with different values" in str(e.value)
+    wver.close(); wc.close(); w0c.close(); ver.close(); lp.close()
+    d.free(scrub=True)
