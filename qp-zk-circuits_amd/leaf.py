@@ -105,6 +105,25 @@ def zk_proof_from_unsorted(leaf_hash, unsorted_siblings):
     return so.raw[:96 * depth], list(po.raw[:depth]), root.raw
 
 
+def dummy_circuit_inputs():
+    """build_dummy_circuit_inputs (wormhole/aggregator/src/dummy_proof.rs:58-84,125-170): the CircuitInputs of the dummy leaf the
+    batch layers pad with, and the reference bench's input (wormhole/prover/benches/prover.rs:31-42). Zero block hash, outputs,
+    nullifier and exit accounts (the sentinel), depth-0 Merkle proof; secret / transfer count / state root / digest are the
+    reference's DEFAULT_* constants, the unspendable account is derived from the secret."""
+    x = LeafInputs()
+    secret = bytes.fromhex("4c8587bd422e01d961acdc75e7d66f6761b7af7c9b1864a492f369c9d6724f05")
+    x.asset_id, x.output_amount_1, x.output_amount_2, x.volume_fee_bps, x.block_number = 0, 0, 0, 10, 0
+    x.transfer_count, x.input_amount, x.zk_merkle_depth = 4, 100, 0
+    for name in ("nullifier", "exit_account_1", "exit_account_2", "block_hash", "parent_hash", "extrinsics_root", "zk_tree_root"):
+        x.set32(name, bytes(32))
+    x.set32("secret", secret).set32("unspendable_account", unspendable_account(secret))
+    x.set32("state_root", bytes.fromhex("ae6e4ff0dca1ef5ede9dccc84365cecfab4e431c6f3086216bc3b819cdf0a893"))
+    digest = bytes.fromhex("0806706f775f80e9b6b76b9e017313db7efd561ed0b046152db4e5093e5b040635f53430267be105706f775f0101") + bytes(61) + bytes.fromhex("124fe2")
+    assert len(digest) == 110
+    ctypes.memmove(x.digest, digest, 110)
+    return x
+
+
 class LeafCircuit:
     """WormholeCircuit::new(config) -> build_prover(): the circuit pack and the wire cell of every logical target. Host only."""
 

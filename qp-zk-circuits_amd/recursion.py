@@ -123,6 +123,124 @@ class WrapperCircuit:
         return cells[:k].copy(), vals[:k].copy(), pis
 
 
+class PrivateBatchProver:
+    """PrivateBatchProver::{new, commit, prove} (wormhole/aggregator/src/private_batch/prover/lib.rs:244-343) over the restated
+    circuits: the private-batch circuit is a WrapperCircuit over the leaf circuit with the layer's logic and the complete
+    in-circuit verifier; the dummy leaf the slots are padded with is proven here from build_dummy_circuit_inputs (generate_dummy_proof,
+    dummy_proof.rs:104-115). commit: the reference's admission checks (qpgpu_private_batch_preflight, then every supplied proof
+    against the leaf verifier), padding + uniform shuffle + one dummy-nullifier preimage per slot (qpgpu_private_batch_arrange),
+    fill_private_batch_witness. prove: stage s1 and s2..s12 on the device. The zero-knowledge blinding of the reference's
+    private layer is not built."""
+
+    def __init__(self, pkg, gpu, leaf_circuit, num_leaf_proofs, verify=True, leaf_prover=None):
+        from . import aggregation, leaf as leaf_mod
+        self.pkg, self.gpu, self.N, self.A = pkg, gpu, num_leaf_proofs, aggregation
+        self.own_leaf_prover = leaf_prover is None
+        self.leaf_prover = leaf_prover or leaf_mod.LeafProver(pkg, gpu, leaf_circuit)
+        self.leaf_verifier = pkg.Verifier(leaf_circuit.pack, circuit=self.leaf_prover.circ)
+        self.circuit = WrapperCircuit(leaf_circuit.pack, self.leaf_verifier, num_leaf_proofs, logic="private_batch", verify=verify)
+        self.circ = pkg.Circuit(gpu, self.circuit.pack)
+        self.verifier = pkg.Verifier(self.circuit.pack, circuit=self.circ)
+        self.d_wires = gpu.alloc(8 * (135 << self.circuit.info["degree_bits"]))
+        # verify_dummy_leaf_template: the sentinel, then the cryptographic check
+        self.dummy_leaf_proof = self.leaf_prover.prove(leaf_mod.dummy_circuit_inputs())[0]
+        dp = aggregation.proof_public_inputs(self.dummy_leaf_proof, 21)
+        aggregation._call(aggregation._lib().qpgpu_dummy_leaf_template_check, dp.ctypes.data, dp.size)
+        if not self.leaf_verifier.verify(self.dummy_leaf_proof):
+            raise ValueError("dummy leaf proof template failed verification")
+        self.committed, self.arrangement = None, None
+
+    def close(self):
+        self.d_wires.free(scrub=True)
+        for x in (self.verifier, self.circ, self.leaf_verifier):
+            x.close()
+        if self.own_leaf_prover:
+            self.leaf_prover.close()
+
+    def _fill(self, slot_proofs, preimages):
+        self.committed = self.circuit.commit(slot_proofs, preimages=preimages)
+        return self
+
+    def commit(self, leaf_proofs, seed=None):
+        """leaf_proofs: 1..N serialized leaf proofs. seed: 32 bytes for a reproducible arrangement (None: OS entropy).
+        ValueError with the reference's message for a batch the preflight refuses or a proof the leaf verifier rejects."""
+        A, N = self.A, self.N
+        rows = np.stack([A.proof_public_inputs(p, 21) for p in leaf_proofs]) if len(leaf_proofs) else np.zeros((0, 21), dtype=np.uint64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        A._call(A._lib().qpgpu_private_batch_preflight, rows.ctypes.data if rows.size else None, rows.shape[0], N)
+        for i, ok in enumerate(self.leaf_verifier.verify_many(list(leaf_proofs))):
+            if not ok:
+                raise ValueError("leaf proof %d failed verification against the pinned leaf verifier" % i)
+        src = np.zeros(N, dtype=np.uint32); pre = np.zeros(4 * N, dtype=np.uint64)
+        A._call(A._lib().qpgpu_private_batch_arrange, rows.shape[0], N, seed, src.ctypes.data, pre.ctypes.data)
+        self.arrangement = (src, pre.reshape(N, 4))
+        return self._fill([self.dummy_leaf_proof if k == 0xFFFFFFFF else leaf_proofs[k] for k in src.tolist()], pre.reshape(N, 4))
+
+    def prove(self):
+        if self.committed is None:
+            raise ValueError("prove() before commit()")
+        cells, vals, pis = self.committed
+        self.committed = None
+        self.circ.generate_witness_partial_dev(cells, vals, pis, self.d_wires)
+        return self.circ.prove_dev(self.d_wires, pis)
+
+    def prove_dummy_template(self):
+        """generate_dummy_private_batch_proof (private_batch/circuit/build.rs:165-193): the all-dummy private-batch proof the
+        public level pads with — built from explicit dummy leaves, never through commit (which refuses an all-dummy batch)."""
+        A, N = self.A, self.N
+        src = np.zeros(N, dtype=np.uint32); pre = np.zeros(4 * N, dtype=np.uint64)
+        A._call(A._lib().qpgpu_private_batch_arrange, 1, N, None, src.ctypes.data, pre.ctypes.data)      # only the preimages are used
+        return self._fill([self.dummy_leaf_proof] * N, pre.reshape(N, 4)).prove()
+
+
+class PublicBatchProver:
+    """PublicBatchProver::{new, commit, prove} (wormhole/aggregator/src/public_batch/prover/lib.rs:268-305): the public-batch
+    circuit is a WrapperCircuit over the private-batch circuit with the layer's logic and the complete in-circuit verifier;
+    admission checks on the supplied private-batch proofs, order-preserving padding with the all-dummy private-batch template
+    (no shuffle), the aggregator address as a witness input that becomes the first four public inputs."""
+
+    def __init__(self, pkg, gpu, private_prover, num_private_batch_proofs, verify=True):
+        from . import aggregation
+        self.pkg, self.gpu, self.M, self.N, self.A = pkg, gpu, num_private_batch_proofs, private_prover.N, aggregation
+        self.private_verifier = private_prover.verifier
+        self.inner_len = aggregation.private_batch_pi_len(self.N)
+        self.circuit = WrapperCircuit(private_prover.circuit.pack, self.private_verifier, self.M, logic="public_batch", verify=verify)
+        self.circ = pkg.Circuit(gpu, self.circuit.pack)
+        self.verifier = pkg.Verifier(self.circuit.pack, circuit=self.circ)
+        self.d_wires = gpu.alloc(8 * (135 << self.circuit.info["degree_bits"]))
+        # verify_dummy_private_batch_template: the sentinel, then the cryptographic check
+        self.dummy_private_batch_proof = private_prover.prove_dummy_template()
+        dp = aggregation.proof_public_inputs(self.dummy_private_batch_proof, self.inner_len)
+        aggregation._call(aggregation._lib().qpgpu_dummy_private_batch_template_check, dp.ctypes.data, dp.size)
+        if not self.private_verifier.verify(self.dummy_private_batch_proof):
+            raise ValueError("dummy private-batch proof template failed verification")
+        self.committed = None
+
+    def close(self):
+        self.d_wires.free(scrub=True)
+        self.verifier.close(); self.circ.close()
+
+    def commit(self, private_batch_proofs, aggregator_address=bytes(32)):
+        A = self.A
+        rows = np.stack([A.proof_public_inputs(p, self.inner_len) for p in private_batch_proofs]) if len(private_batch_proofs) else np.zeros((0, self.inner_len), dtype=np.uint64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        A._call(A._lib().qpgpu_public_batch_preflight, rows.ctypes.data if rows.size else None, rows.shape[0], self.inner_len, self.M)
+        for i, ok in enumerate(self.private_verifier.verify_many(list(private_batch_proofs))):
+            if not ok:
+                raise ValueError("private-batch proof %d failed verification against the pinned private-batch verifier" % i)
+        padded = list(private_batch_proofs) + [self.dummy_private_batch_proof] * (self.M - len(private_batch_proofs))
+        self.committed = self.circuit.commit(padded, aggregator_address=aggregator_address)
+        return self
+
+    def prove(self):
+        if self.committed is None:
+            raise ValueError("prove() before commit()")
+        cells, vals, pis = self.committed
+        self.committed = None
+        self.circ.generate_witness_partial_dev(cells, vals, pis, self.d_wires)
+        return self.circ.prove_dev(self.d_wires, pis)
+
+
 class AttestingTree:
     """BASELINE configs[4]'s shape with circuits that check something: `batches` x `per_batch` leaf proofs of the restated
     Wormhole leaf circuit (from CircuitInputs), one first-level wrapper per `per_batch` leaves, one second-level wrapper over the
