@@ -494,7 +494,7 @@ def main():
     attest = None
     if not args.no_tree:
         try:
-            at = pkg.recursion.AttestingTree(pkg, gpu, per_batch=8, batches=8, rank=rank, world=world, aggregator_address=bytes([3] * 32))
+            at = pkg.recursion.AttestingTree(pkg, gpu, per_batch=8, batches=8, rank=rank, world=world, aggregator_address=bytes([3] * 32), zero_knowledge=True)
             # the same 64 inputs on every rank: 48 real spends of ONE block (their leaves in one 4-ary tree of depth 3), every spend
             # with its own exit accounts, 6 per batch; the reference's dummy in the two other slots of a batch, at moving positions
             rng_a = np.random.default_rng(4)
@@ -530,7 +530,7 @@ def main():
                 parsed = {"total_exit_slots": hdr_["total_exit_slots"], "block_number": hdr_["block_number"], "nonzero_exit_slots": sum(1 for s_ in slots_ if s_[0]),
                           "summed_output_amount": sum(s_[0] for s_ in slots_), "nullifiers": len(nulls_)}
                 ok_a = ok_a and parsed["nonzero_exit_slots"] == 96 and parsed["summed_output_amount"] == 48 * 297 and hdr_["aggregator_address"] == bytes([3] * 32)
-            attest = {"leaves": 64, "real_spends": 48, "first_level": 8, "second_level": 1, "seconds": round(adt, 4), "levels_rank0": dict(at.times), "ranks": world,
+            attest = {"leaves": 64, "real_spends": 48, "first_level": 8, "second_level": 1, "first_level_zero_knowledge": True, "first_level_blinding_rows": at.w1.info["rows_blinding"], "seconds": round(adt, 4), "levels_rank0": dict(at.times), "ranks": world,
                       "degree_bits": {"leaf": at.leaf.info["degree_bits"], "first_level": at.w1.info["degree_bits"], "second_level": at.w2.info["degree_bits"]},
                       "poseidon_gate_rows": {"first_level": at.w1.info["rows_poseidon"], "second_level": at.w2.info["rows_poseidon"]},
                       "root_public_inputs": parsed,
@@ -543,8 +543,9 @@ def main():
                               "(every gate of the inner circuit, permutation argument; the same generic expressions as the host verifier, csrc/verify_math.hpp) and the FRI "
                               "consistency arithmetic (reduced openings, coset interpolation per step, final polynomial); first level + the private-batch circuit's own "
                               "constraints (dummy flags, block / asset / fee consistency, exit-account grouping, distinct real nullifiers, dummy nullifiers = H(H(preimage)), "
-                              "sorting network), second level + the public-batch circuit's, restated on the native builder (circuit_logic.rs of each layer). Not built: "
-                              "zero-knowledge blinding of the private layer; the gate set and row order are the native builder's, not the fork's (verifier data differs). "
+                              "sorting network) and built zero-knowledge as the reference's private layer is (60 routed wires, CircuitBuilder::blind's rows with fresh random "
+                              "wires per proof, salted Merkle leaves), second level + the public-batch circuit's, restated on the native builder (circuit_logic.rs of each "
+                              "layer). The gate set, row order and blinding counts are the native builder's / upstream plonky2's, not the fork's (verifier data differs). "
                               "Times include commit on the host (fill_witness; fill_private_batch_witness per inner proof)."}
             ok = ok and ok_a
             at.close()

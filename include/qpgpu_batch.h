@@ -180,7 +180,8 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
  * qpgpu_proof_target_count); dummy-nullifier preimage limb -> N * T + 4 i + limb (assigned by fill_private_batch_witness, unused
  * here); query index q of slot i -> N * (T + 4) + i * Q + q. num_routed_wires: 80 (public batch) or 60 (private batch),
  * 0 = 80. info_out (QPGPU_WRAPPER_CIRCUIT_INFO_WORDS, may be NULL): degree_bits, rows before padding, T, Q, PoseidonGate rows,
- * RandomAccessGate rows, BaseSumGate rows, ArithmeticGate rows, ConstantGate rows, public inputs. */
+ * RandomAccessGate rows, BaseSumGate rows, ArithmeticGate rows, ConstantGate rows, public inputs, rows of the verification part,
+ * blinding rows (zero-knowledge circuits). */
 #define QPGPU_WRAPPER_CIRCUIT_INFO_WORDS 12
 /* flags: QPGPU_WRAPPER_TRANSCRIPT — the Fiat-Shamir transcript of every inner proof is replayed IN-CIRCUIT (RecursiveChallenger on
  * PoseidonGate rows: circuit digest, public-input hash, caps, openings, FRI caps, final polynomial, proof-of-work witness, in the
@@ -206,8 +207,18 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
  * Z_H(zeta) * quotient(zeta) for every challenge; per query round the opened rows reduced with the FRI alpha and divided by
  * (x - zeta) / (x - g zeta), every reduction step's coset interpolated at its beta (and holding the previous evaluation at the
  * index's position), the final polynomial at the last point. With it the wrapper enforces everything
- * VerifierCircuitData::verify checks on an inner proof (not built for zero-knowledge inner circuits). */
+ * VerifierCircuitData::verify checks on an inner proof.
+ * QPGPU_WRAPPER_ZERO_KNOWLEDGE — the circuit is built zero-knowledge as the reference's private-batch layer is
+ * (wormhole_private_batch_circuit_config, common/src/circuit.rs:396-402; pass num_routed_wires = 60 for its wire budget):
+ * CircuitBuilder::blind's rows are added before padding (upstream plonky2's counts; the fork's "row blinding" mode is
+ * un-vendored), the pack says zero_knowledge = 1 (the prover salts the Merkle leaves of the wires / Z / quotient oracles). The
+ * wire cells that need a FRESH RANDOM value per proof follow the query-index block of the target map, as cells (no logical
+ * id); the caller assigns them with the PartialWitness — qpgpu_random_field_elements draws them. */
 #define QPGPU_WRAPPER_VERIFY 8u
+#define QPGPU_WRAPPER_ZERO_KNOWLEDGE 16u
+/* n uniform field elements from ChaCha20 keyed with seed32, or with 32 bytes of operating-system entropy when seed32 is NULL
+ * (RandomValueGenerator's F::rand(), for the blinding cells of a zero-knowledge circuit) */
+int qpgpu_random_field_elements(const uint8_t *seed32, uint64_t *out, size_t n, char *err);
 int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, const uint64_t *inner_cs_cap, size_t cap_words, unsigned num_proofs,
                                 unsigned num_routed_wires, unsigned min_degree_bits, int inner_hasher, unsigned flags, uint64_t *pack_out, size_t pack_cap_words,
                                 size_t *pack_words, uint64_t *target_map_out, size_t map_cap, size_t *map_count, uint64_t *info_out, char *err);

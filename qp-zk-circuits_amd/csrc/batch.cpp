@@ -317,6 +317,29 @@ int qpgpu_private_batch_arrange(size_t count, size_t num_leaf_proofs, const uint
     return 0;
 }
 
+int qpgpu_random_field_elements(const uint8_t *seed32, uint64_t *out, size_t n, char *err) {
+    if (!out && n) return fail(err, ERR_INVALID, "null argument");
+    uint8_t key[32];
+    if (seed32) std::memcpy(key, seed32, 32);
+    else {
+        size_t got = 0;
+        while (got < 32) {
+            const ssize_t r = getrandom(key + got, 32 - got, 0);
+            if (r <= 0) return fail(err, ERR_INVALID, "operating-system entropy source unavailable");
+            got += (size_t)r;
+        }
+    }
+    ChaCha20 rng(key);
+    volatile uint8_t *k = key;
+    for (int i = 0; i < 32; i++) k[i] = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t v;
+        do v = rng.next64(); while (v >= P);
+        out[i] = v;
+    }
+    return 0;
+}
+
 int qpgpu_private_batch_outputs(const uint64_t *leaf_pis, size_t n_leaf, const uint64_t *dummy_preimages, uint64_t *out, char *err) {
     if (!leaf_pis || !dummy_preimages || !out) return fail(err, ERR_INVALID, "null argument");
     if (int rc = qpgpu_validate_proof_count(n_leaf, "n_leaf", err)) return rc;

@@ -421,6 +421,41 @@ std::map<uint64_t, size_t> Builder::gate_counts() const {
     return m;
 }
 
+// CircuitBuilder::blind (plonk/circuit_builder.rs, upstream plonky2): blinding_counts looks for the smallest degree estimate
+// 2^k >= the gate count whose own blinding rows still fit under it; one NoopGate row of random wires per opening of a regular
+// polynomial (D at zeta + what the FRI queries reveal), and per opening of Z (2 D: zeta and g zeta) a PAIR of NoopGate rows whose
+// routed wires hold the same random values under a copy constraint (random factors of the permutation product that cancel).
+// Restated from upstream: the fork's "row blinding" mode may count differently (un-vendored).
+void Builder::blind() {
+    const size_t num_gates = rows_.size(), D = 2;
+    unsigned k = 0;
+    while ((1ull << k) < num_gates) k++;
+    size_t regular = 0, zs = 0;
+    for (;; k++) {
+        if (k > 22) throw std::length_error("blind: circuit too large");
+        const std::vector<uint64_t> arity_bits = fri_reduction_arity_bits(k, cfg_.rate_bits, cfg_.cap_height, cfg_.arity_bits, cfg_.final_poly_bits);
+        size_t folding_points = 0, reduced_bits = 0;
+        for (uint64_t ab : arity_bits) { folding_points += ((size_t)1 << ab) - 1; reduced_bits += ab; }
+        const size_t final_poly_coeffs = (size_t)1 << (k - reduced_bits);
+        const size_t fri_openings = cfg_.num_query_rounds * (1 + D * folding_points + D * final_poly_coeffs);
+        regular = D + fri_openings; zs = 2 * D + fri_openings;
+        if (num_gates + regular + 2 * zs <= (1ull << k)) break;
+    }
+    const uint32_t noop = spec_index(GATE_NOOP, 0, 0, 0);
+    for (size_t i = 0; i < regular; i++) {
+        const uint32_t row = add_gate(noop);
+        for (uint32_t w = 0; w < cfg_.num_wires; w++) blinding_cells_.push_back((u64)row * cfg_.num_wires + w);
+    }
+    for (size_t i = 0; i < zs; i++) {
+        const uint32_t g1 = add_gate(noop), g2 = add_gate(noop);
+        for (uint32_t w = 0; w < cfg_.num_routed_wires; w++) {
+            connect(wire(g1, w), wire(g2, w));
+            blinding_cells_.push_back((u64)g1 * cfg_.num_wires + w);
+        }
+    }
+    blinding_rows_ = regular + 2 * zs;
+}
+
 u64 Builder::cell_of(Target t) {
     if (!built_ || t >= parent_.size()) return NO_CELL;
     return class_cell_[find(t)];
@@ -471,7 +506,8 @@ std::string Builder::build(CircuitPack &pack) {
         }
     }
     rows_before_padding_ = rows_.size();
-    // blind_and_pad without blinding: NoopGate rows up to a power of two
+    if (cfg_.zero_knowledge) blind();
+    // blind_and_pad: NoopGate rows up to a power of two
     unsigned degree_bits = std::max<unsigned>(cfg_.min_degree_bits, 5);
     while ((1ull << degree_bits) < rows_.size()) degree_bits++;
     if (degree_bits > 20) return "build: circuit too large";

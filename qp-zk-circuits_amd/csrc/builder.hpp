@@ -155,6 +155,10 @@ public:
     // gate rows by gate type after build() (GateType -> count), for profiles like the reference's print_gate_counts
     std::map<uint64_t, size_t> gate_counts() const;
     size_t rows_before_padding() const { return rows_before_padding_; }
+    // after build() of a zero-knowledge circuit: the wire cells of the blinding rows that take a fresh random value per proof
+    // (CircuitBuilder::blind's RandomValueGenerator targets); the prover's caller assigns them with the PartialWitness
+    const std::vector<u64> &blinding_cells() const { return blinding_cells_; }
+    size_t blinding_rows() const { return blinding_rows_; }
 
 private:
     struct GateSpec { uint64_t type, p0, p1, p2, degree, ncons; std::string id; };
@@ -209,7 +213,9 @@ private:
     std::map<ExtKey, ExtTarget> ext_results_;
     std::map<std::pair<u64, u64>, std::pair<uint32_t, uint32_t>> ext_slots_;     // (c0, c1) -> (row, next free operation)
     bool built_ = false;
-    size_t rows_before_padding_ = 0;
+    size_t rows_before_padding_ = 0, blinding_rows_ = 0;
+    std::vector<u64> blinding_cells_;
+    void blind();
     std::vector<u64> class_cell_;                            // after build(): representative wire cell per class root
 };
 

@@ -441,14 +441,13 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
     auto fail = [&](int code, const std::string &m) { if (err) std::snprintf(err, QPGPU_BATCH_ERR_CAP, "%s", m.c_str()); return code; };
     if (err) err[0] = 0;
     if (!inner_pack || !inner_cs_cap || !pack_words || num_proofs == 0 || num_proofs > 64) return fail(QPGPU_EINVAL, "wrapper_circuit_build: null argument or proof count outside 1..64");
-    if (flags & ~(QPGPU_WRAPPER_TRANSCRIPT | QPGPU_WRAPPER_PRIVATE_BATCH | QPGPU_WRAPPER_PUBLIC_BATCH | QPGPU_WRAPPER_VERIFY)) return fail(QPGPU_EINVAL, "wrapper_circuit_build: unknown flag");
+    if (flags & ~(QPGPU_WRAPPER_TRANSCRIPT | QPGPU_WRAPPER_PRIVATE_BATCH | QPGPU_WRAPPER_PUBLIC_BATCH | QPGPU_WRAPPER_VERIFY | QPGPU_WRAPPER_ZERO_KNOWLEDGE)) return fail(QPGPU_EINVAL, "wrapper_circuit_build: unknown flag");
     const bool transcript = (flags & QPGPU_WRAPPER_TRANSCRIPT) != 0, private_batch = (flags & QPGPU_WRAPPER_PRIVATE_BATCH) != 0, public_batch = (flags & QPGPU_WRAPPER_PUBLIC_BATCH) != 0;
     const bool verify = (flags & QPGPU_WRAPPER_VERIFY) != 0;
     if (verify && !transcript) return fail(QPGPU_EINVAL, "wrapper_circuit_build: QPGPU_WRAPPER_VERIFY needs the in-circuit transcript (its challenges are what the arithmetic consumes)");
     if (private_batch && public_batch) return fail(QPGPU_EINVAL, "wrapper_circuit_build: a circuit is the private-batch or the public-batch layer, not both");
     CircuitPack inner;
     { const std::string why = inner.parse(inner_pack, inner_words); if (!why.empty()) return fail(QPGPU_EINVAL, "wrapper_circuit_build: inner pack: " + why); }
-    if (verify && inner.zero_knowledge) return fail(QPGPU_EINVAL, "wrapper_circuit_build: QPGPU_WRAPPER_VERIFY over a zero-knowledge inner circuit is not built");
     if (cap_words != ((size_t)4 << inner.cap_height)) return fail(QPGPU_EINVAL, "wrapper_circuit_build: the inner constants/sigmas cap has the wrong size");
     // the shape checks of PrivateBatchCircuit::new / PublicBatchCircuit::new (circuit_logic.rs:94-104 / :74-87), with their messages
     size_t n_leaf_inner = 0;
@@ -461,12 +460,12 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
     }
     const size_t T = qpgpu_proof_target_count(inner_pack, inner_words), Q = inner.num_query_rounds;
     const size_t total = (size_t)num_proofs * (T + 4 + Q);
-    if (map_count) *map_count = total;
     try {
         cb::Config cfg;
         cfg.num_routed_wires = num_routed_wires ? num_routed_wires : 80;
         cfg.min_degree_bits = min_degree_bits;
         cfg.inner_hasher = inner_hasher;
+        cfg.zero_knowledge = (flags & QPGPU_WRAPPER_ZERO_KNOWLEDGE) != 0;
         Builder b(cfg);
         cbx::g_b = &b;
         const unsigned L = (unsigned)(inner.degree_bits + inner.rate_bits), cap_h = (unsigned)inner.cap_height;
@@ -553,8 +552,11 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
             if (pack_cap_words < words.size()) return fail(QPGPU_EBUFSIZE, "wrapper_circuit_build: pack buffer too small");
             std::memcpy(pack_out, words.data(), words.size() * 8);
         }
+        const std::vector<u64> &blind = b.blinding_cells();
+        if (map_count) *map_count = total + blind.size();
         if (target_map_out) {
-            if (map_cap < total) return fail(QPGPU_EBUFSIZE, "wrapper_circuit_build: target map buffer too small");
+            if (map_cap < total + blind.size()) return fail(QPGPU_EBUFSIZE, "wrapper_circuit_build: target map buffer too small");
+            std::memcpy(target_map_out + total, blind.data(), blind.size() * 8);             // the blinding rows' random wires: cells as they are
             auto cell = [&](Target t) { const u64 c = b.cell_of(t); return c == cb::NO_CELL ? UINT64_MAX : c; };
             size_t k = 0;
             for (unsigned i = 0; i < num_proofs; i++) for (Target t : proofs[i].all) target_map_out[k++] = cell(t);
@@ -565,7 +567,7 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
             const std::map<uint64_t, size_t> gc = b.gate_counts();
             auto cnt = [&](uint64_t t) { auto it = gc.find(t); return it == gc.end() ? (uint64_t)0 : (uint64_t)it->second; };
             const uint64_t info[QPGPU_WRAPPER_CIRCUIT_INFO_WORDS] = {pack.degree_bits, b.rows_before_padding(), (uint64_t)T, (uint64_t)Q, cnt(GATE_POSEIDON), cnt(GATE_RANDOM_ACCESS),
-                                                                    cnt(GATE_BASE_SUM), cnt(GATE_ARITHMETIC), cnt(GATE_CONSTANT), pack.num_public_inputs, (uint64_t)rows_hash, 0};
+                                                                    cnt(GATE_BASE_SUM), cnt(GATE_ARITHMETIC), cnt(GATE_CONSTANT), pack.num_public_inputs, (uint64_t)rows_hash, (uint64_t)b.blinding_rows()};
             std::memcpy(info_out, info, sizeof info);
         }
     } catch (const std::exception &e) {

@@ -9,7 +9,7 @@ import numpy as np
 from .binding import QpGpuError, load_library
 
 INFO_FIELDS = ("degree_bits", "rows_before_padding", "targets_per_proof", "query_rounds", "rows_poseidon", "rows_random_access", "rows_base_sum",
-               "rows_arithmetic", "rows_constant", "public_inputs", "rows_verification", "_")
+               "rows_arithmetic", "rows_constant", "public_inputs", "rows_verification", "rows_blinding")
 NO_CELL = 0xFFFFFFFFFFFFFFFF
 
 
@@ -24,6 +24,7 @@ def _lib():
         L.qpgpu_proof_target_count.argtypes = [vp, sz]; L.qpgpu_proof_target_count.restype = sz
         L.qpgpu_verifier_query_indices.restype = c.c_int
         L.qpgpu_verifier_query_indices.argtypes = [vp, cp, sz, vp, sz, cp]
+        L.qpgpu_random_field_elements.argtypes = [cp, vp, sz, cp]
         L.qpgpu_leaf_map_targets.restype = sz
         L.qpgpu_leaf_map_targets.argtypes = [vp, vp, sz, vp, sz, vp, vp]
         L._rec_sigs = True
@@ -37,15 +38,18 @@ class WrapperCircuit:
 
     FLAGS = {None: 0, "private_batch": 2, "public_batch": 4}          # QPGPU_WRAPPER_PRIVATE_BATCH / _PUBLIC_BATCH
 
-    def __init__(self, inner_pack, verifier, num_proofs, num_routed_wires=80, min_degree_bits=0, inner_hasher=0, transcript=True, logic=None, verify=False):
+    def __init__(self, inner_pack, verifier, num_proofs, num_routed_wires=80, min_degree_bits=0, inner_hasher=0, transcript=True, logic=None, verify=False, zero_knowledge=False):
         """transcript=True (QPGPU_WRAPPER_TRANSCRIPT): the inner proofs' Fiat-Shamir transcripts are replayed in-circuit, the query
         indices are derived there and the proof-of-work response is range-checked; False: the query indices are witness inputs.
         logic: None (inner public inputs forwarded), "private_batch" (build_private_batch_constraints over leaf proofs) or
         "public_batch" (build_public_batch_constraints over private-batch proofs): the layer's own constraints and public inputs.
         verify=True (QPGPU_WRAPPER_VERIFY): the arithmetic half of verify_proof in-circuit too (openings against the vanishing
-        polynomial at zeta, FRI consistency) — the wrapper then enforces everything the host verifier checks on an inner proof."""
+        polynomial at zeta, FRI consistency) — the wrapper then enforces everything the host verifier checks on an inner proof.
+        zero_knowledge=True (QPGPU_WRAPPER_ZERO_KNOWLEDGE): the circuit is built with CircuitBuilder::blind's rows and proven with
+        salted Merkle leaves; commit draws the blinding rows' random wires (blinding_seed: 32 bytes for reproducible tests, None:
+        operating-system entropy)."""
         L = _lib()
-        self.logic, self.verify = logic, verify
+        self.logic, self.verify, self.zero_knowledge = logic, verify, zero_knowledge
         self.inner_pack = np.ascontiguousarray(inner_pack, dtype=np.uint64)
         self.verifier, self.num_proofs, self.transcript = verifier, num_proofs, transcript
         cap_h = int(self.inner_pack[11])
@@ -55,7 +59,7 @@ class WrapperCircuit:
         n, m = ctypes.c_size_t(), ctypes.c_size_t()
         err = ctypes.create_string_buffer(200)
         args = (self.inner_pack.ctypes.data, self.inner_pack.size, cap.ctypes.data, cap.size, num_proofs, num_routed_wires, min_degree_bits, inner_hasher,
-                (1 if transcript else 0) | self.FLAGS[logic] | (8 if verify else 0))
+                (1 if transcript else 0) | self.FLAGS[logic] | (8 if verify else 0) | (16 if zero_knowledge else 0))
         rc = L.qpgpu_wrapper_circuit_build(*args, None, 0, ctypes.byref(n), None, 0, ctypes.byref(m), None, err)
         if rc != 0:
             raise QpGpuError(rc, err.value.decode())
@@ -68,6 +72,8 @@ class WrapperCircuit:
             raise QpGpuError(rc, err.value.decode())
         self.info = {k: int(v) for k, v in zip(INFO_FIELDS, info) if k != "_"}
         self.T, self.Q = self.info["targets_per_proof"], self.info["query_rounds"]
+        self.blinding_cells = self.target_map[num_proofs * (self.T + 4 + self.Q):].copy()       # cells, not logical ids
+        self.target_map = self.target_map[:num_proofs * (self.T + 4 + self.Q)]
 
     def query_indices(self, proof):
         out = np.empty(self.Q, dtype=np.uint64)
@@ -77,7 +83,7 @@ class WrapperCircuit:
             raise ValueError(err.value.decode())
         return out
 
-    def commit(self, proofs, preimages=None, query_indices=None, aggregator_address=None, public_inputs=None):
+    def commit(self, proofs, preimages=None, query_indices=None, aggregator_address=None, public_inputs=None, blinding_seed=None):
         """fill_private_batch_witness / fill_public_batch_witness + the query indices: (cells, values, public_inputs) of the
         wrapper's PartialWitness. Raises ValueError with the reference's message for a malformed proof. preimages: the dummy-nullifier
         preimages (private batch, N x 4 felts); aggregator_address: 32 bytes (public batch). With a batch logic the public inputs
@@ -120,7 +126,13 @@ class WrapperCircuit:
         elif self.logic == "public_batch":
             from . import aggregation
             pis = aggregation.public_batch_outputs(pis.reshape(N, npis), (npis - 8) // 21, addr)
-        return cells[:k].copy(), vals[:k].copy(), pis
+        cells, vals = cells[:k].copy(), vals[:k].copy()
+        if self.blinding_cells.size:          # RandomValueGenerator: one fresh field element per blinding wire, per proof
+            rnd = np.empty(self.blinding_cells.size, dtype=np.uint64)
+            if L.qpgpu_random_field_elements(blinding_seed, rnd.ctypes.data, rnd.size, err) != 0:
+                raise QpGpuError(-1, err.value.decode())
+            cells, vals = np.concatenate([cells, self.blinding_cells]), np.concatenate([vals, rnd])
+        return cells, vals, pis
 
 
 class PrivateBatchProver:
@@ -129,16 +141,19 @@ class PrivateBatchProver:
     in-circuit verifier; the dummy leaf the slots are padded with is proven here from build_dummy_circuit_inputs (generate_dummy_proof,
     dummy_proof.rs:104-115). commit: the reference's admission checks (qpgpu_private_batch_preflight, then every supplied proof
     against the leaf verifier), padding + uniform shuffle + one dummy-nullifier preimage per slot (qpgpu_private_batch_arrange),
-    fill_private_batch_witness. prove: stage s1 and s2..s12 on the device. The zero-knowledge blinding of the reference's
-    private layer is not built."""
+    fill_private_batch_witness (+ the blinding rows' random wires of the zero-knowledge circuit). prove: stage s1 and s2..s12 on
+    the device (Merkle leaves salted)."""
 
-    def __init__(self, pkg, gpu, leaf_circuit, num_leaf_proofs, verify=True, leaf_prover=None):
+    def __init__(self, pkg, gpu, leaf_circuit, num_leaf_proofs, verify=True, leaf_prover=None, zero_knowledge=True, num_routed_wires=60):
+        """zero_knowledge / num_routed_wires: wormhole_private_batch_circuit_config (common/src/circuit.rs:396-402) — the one
+        zero-knowledge layer of the stack, 60 routed wires."""
         from . import aggregation, leaf as leaf_mod
         self.pkg, self.gpu, self.N, self.A = pkg, gpu, num_leaf_proofs, aggregation
         self.own_leaf_prover = leaf_prover is None
         self.leaf_prover = leaf_prover or leaf_mod.LeafProver(pkg, gpu, leaf_circuit)
         self.leaf_verifier = pkg.Verifier(leaf_circuit.pack, circuit=self.leaf_prover.circ)
-        self.circuit = WrapperCircuit(leaf_circuit.pack, self.leaf_verifier, num_leaf_proofs, logic="private_batch", verify=verify)
+        self.circuit = WrapperCircuit(leaf_circuit.pack, self.leaf_verifier, num_leaf_proofs, num_routed_wires=num_routed_wires, logic="private_batch", verify=verify,
+                                      zero_knowledge=zero_knowledge)
         self.circ = pkg.Circuit(gpu, self.circuit.pack)
         self.verifier = pkg.Verifier(self.circuit.pack, circuit=self.circ)
         self.d_wires = gpu.alloc(8 * (135 << self.circuit.info["degree_bits"]))
@@ -157,12 +172,12 @@ class PrivateBatchProver:
         if self.own_leaf_prover:
             self.leaf_prover.close()
 
-    def _fill(self, slot_proofs, preimages):
-        self.committed = self.circuit.commit(slot_proofs, preimages=preimages)
+    def _fill(self, slot_proofs, preimages, blinding_seed=None):
+        self.committed = self.circuit.commit(slot_proofs, preimages=preimages, blinding_seed=blinding_seed)
         return self
 
     def commit(self, leaf_proofs, seed=None):
-        """leaf_proofs: 1..N serialized leaf proofs. seed: 32 bytes for a reproducible arrangement (None: OS entropy).
+        """leaf_proofs: 1..N serialized leaf proofs. seed: 32 bytes for a reproducible arrangement and blinding (None: OS entropy).
         ValueError with the reference's message for a batch the preflight refuses or a proof the leaf verifier rejects."""
         A, N = self.A, self.N
         rows = np.stack([A.proof_public_inputs(p, 21) for p in leaf_proofs]) if len(leaf_proofs) else np.zeros((0, 21), dtype=np.uint64)
@@ -174,7 +189,8 @@ class PrivateBatchProver:
         src = np.zeros(N, dtype=np.uint32); pre = np.zeros(4 * N, dtype=np.uint64)
         A._call(A._lib().qpgpu_private_batch_arrange, rows.shape[0], N, seed, src.ctypes.data, pre.ctypes.data)
         self.arrangement = (src, pre.reshape(N, 4))
-        return self._fill([self.dummy_leaf_proof if k == 0xFFFFFFFF else leaf_proofs[k] for k in src.tolist()], pre.reshape(N, 4))
+        return self._fill([self.dummy_leaf_proof if k == 0xFFFFFFFF else leaf_proofs[k] for k in src.tolist()], pre.reshape(N, 4),
+                          None if seed is None else bytes(b ^ 0x5A for b in seed))
 
     def prove(self):
         if self.committed is None:
@@ -247,14 +263,13 @@ class AttestingTree:
     first-level proofs (wormhole/aggregator/src/aggregator.rs:187-227's two layers). Every wrapper is a WrapperCircuit: it checks
     the Merkle half of each inner proof in-circuit, replays the inner proofs' transcripts in-circuit (query indices derived, proof
     of work checked), with verify (the default) evaluates the openings against the vanishing polynomial and the FRI consistency
-    arithmetic in-circuit as well — everything VerifierCircuitData::verify checks; the private layer's zero-knowledge blinding
-    is the part of the reference's layers that is not built — and, with batch_logic (the default), carries its
+    arithmetic in-circuit as well — everything VerifierCircuitData::verify checks — and, with batch_logic (the default), carries its
     layer's own constraints: the first level is the private-batch circuit's logic over its leaves' public inputs, the second the
     public-batch circuit's over the first level's — the root proof's public inputs are a PublicBatchPublicInputs. The leaves
     of one tree must then be what the reference's layers accept (real spends of ONE block, dummies elsewhere). One lockstep batch
     per level and rank."""
 
-    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0, rank=0, world=1, batch_logic=True, aggregator_address=bytes(32), seed=1, verify=True):
+    def __init__(self, pkg, gpu, per_batch=8, batches=8, leaf_min_degree_bits=0, rank=0, world=1, batch_logic=True, aggregator_address=bytes(32), seed=1, verify=True, zero_knowledge=False):
         """rank / world: with several ranks (one per GPU) a rank proves the leaves and the first-level wrapper of batches
         b = rank, rank + world, ..; the first-level proofs travel to rank 0, which proves the second level."""
         self.pkg, self.gpu, self.per_batch, self.batches = pkg, gpu, per_batch, batches
@@ -267,7 +282,10 @@ class AttestingTree:
         self.leaf_ver = pkg.Verifier(self.leaf.pack, circuit=self.leaf_circ)
         self.batch_logic, self.aggregator_address, self.verify = batch_logic, bytes(aggregator_address), verify
         self.seed = seed
-        self.w1 = WrapperCircuit(self.leaf.pack, self.leaf_ver, per_batch, logic="private_batch" if batch_logic else None, verify=verify)
+        # zero_knowledge: the first level as the reference configures its private layer (blinding rows, salted leaves, 60 routed wires)
+        self.zero_knowledge = zero_knowledge
+        self.w1 = WrapperCircuit(self.leaf.pack, self.leaf_ver, per_batch, num_routed_wires=60 if zero_knowledge else 80, logic="private_batch" if batch_logic else None,
+                                 verify=verify, zero_knowledge=zero_knowledge)
         self.w1_circ = pkg.Circuit(gpu, self.w1.pack, max_batch=max(1, len(self.my_batches)))
         self.w1_ver = pkg.Verifier(self.w1.pack, circuit=self.w1_circ)
         self.w2 = WrapperCircuit(self.w1.pack, self.w1_ver, batches, logic="public_batch" if batch_logic else None, verify=verify)

@@ -150,3 +150,45 @@ def test_shape_checks(pkg, setup):
         R.WrapperCircuit(w.pack, v1, 2, logic="private_batch")
     assert "leaf_common.num_public_inputs (71) != expected wormhole leaf PI len (21)" in str(e.value)
     v1.close()
+
+
+def test_zero_knowledge_private_layer(pkg, orc, setup):
+    """The private layer as the reference configures it (wormhole_private_batch_circuit_config, common/src/circuit.rs:396-402:
+    zero-knowledge, 60 routed wires): CircuitBuilder::blind's rows (upstream's counts: per opening of a regular polynomial one
+    NoopGate row of random wires, per opening of Z a copy-constrained pair), fresh random wires per proof, salted Merkle leaves
+    in the proof; the public layer verifies such a proof completely in-circuit (the salts are hashed, not opened)."""
+    leaf, xs, proofs, ver, w = setup
+    real0, real1, real2, other, dummy = proofs
+    wz = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, num_routed_wires=60, logic="private_batch", verify=True, zero_knowledge=True)
+    h = pkg.pack_header(wz.pack)
+    assert h["zero_knowledge"] == 1 and h["num_routed_wires"] == 60 and h["degree_bits"] == 15
+    # blinding_counts at the degree estimate 2^15 (three arity-16 reductions, final polynomial of 8 coefficients, 28 queries, D = 2)
+    fri_openings = 28 * (1 + 2 * 3 * 15 + 2 * 8)
+    assert wz.info["rows_blinding"] == (2 + fri_openings) + 2 * (4 + fri_openings)
+    assert wz.blinding_cells.size == (2 + fri_openings) * 135 + (4 + fri_openings) * 60
+    p = pre(9, 2)
+    ca = wz.commit([real0, dummy], preimages=p, blinding_seed=bytes([1] * 32))
+    cb = wz.commit([real0, dummy], preimages=p, blinding_seed=bytes([2] * 32))
+    cc = wz.commit([real0, dummy], preimages=p)                                     # operating-system entropy
+    assert np.array_equal(ca[0], cb[0]) and ca[2].tolist() == cb[2].tolist()
+    nb = wz.blinding_cells.size
+    assert not np.array_equal(ca[1][-nb:], cb[1][-nb:]) and not np.array_equal(ca[1][-nb:], cc[1][-nb:]) and np.array_equal(ca[1][:-nb], cb[1][:-nb])
+    assert int(ca[1][-nb:].max()) < pkg.P
+    rc, wires, _ = orc.generate_witness(wz.pack, *ca)
+    assert rc == orc.WIT_OK
+    # the pair rows of the Z blinding carry the same values
+    first_pair = (wz.info["rows_before_padding"] + 2 + fri_openings)
+    assert np.array_equal(wires[:60, first_pair], wires[:60, first_pair + 1]) and not np.array_equal(wires[:60, first_pair], wires[:60, first_pair + 2])
+    oc = ob.OracleCircuit(orc, wz.pack)
+    proof = oc.prove(wires, ca[2])
+    assert oc.verify(proof) == 0
+    oc.close()
+    vz = pkg.Verifier(wz.pack)
+    assert vz.verify(proof)
+    w2 = pkg.recursion.WrapperCircuit(wz.pack, vz, 1, logic="public_batch", verify=True)
+    c2 = w2.commit([proof], aggregator_address=bytes(32))
+    assert orc.generate_witness(w2.pack, *c2)[0] == orc.WIT_OK
+    bad = bytearray(proof); bad[len(bad) // 3] ^= 1
+    c2 = w2.commit([bytes(bad)], aggregator_address=bytes(32), public_inputs=c2[2])
+    assert orc.generate_witness(w2.pack, *c2)[0] == orc.WIT_CONFLICT
+    vz.close()

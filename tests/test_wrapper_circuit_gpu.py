@@ -86,7 +86,8 @@ def test_two_level_tree_with_the_batch_layers_logic(pkg, gpu, orc):
     L = pkg.leaf
     A = pkg.aggregation
     addr = bytes([5] * 32)
-    tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=2, aggregator_address=addr)
+    tree = pkg.recursion.AttestingTree(pkg, gpu, per_batch=2, batches=2, aggregator_address=addr, zero_knowledge=True)     # first level as the reference's private layer
+    assert tree.w1.info["rows_blinding"] > 0 and pkg.pack_header(tree.w1.pack)["zero_knowledge"] == 1
     e1, e2 = bytes([4] * 32), bytes([7] * 32)
     sp = lc.shared_tree_inputs(L, 3, exits=[(e1, e2), (e1, e1), (e2, e1)], outputs=[(200, 97), (1, 2), (30, 40)])
     xs = [sp[0], lc.dummy_inputs(L), sp[1], sp[2]]
