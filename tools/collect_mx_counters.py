@@ -25,7 +25,16 @@ def derive(k, perms):
     return d
 
 
-m = derive([v for k, v in mx.items() if "mx::leaf_hash_kernel<mx::PoseidonV1>" in k or k == "mx::leaf_hash_kernel"][0], PERMS)
+# only the launches of the probe's tree (2^21 threads): the device self-test at context set-up launches the same kernel on a small
+# input since round 4, and an average over all dispatches of the name would mix it in
+mk = {}
+for sub in ("p1", "p2"):
+    for path in glob.glob(os.path.join(O, sub, "**", "*.db"), recursive=True):
+        db = sqlite3.connect(path)
+        for cname, val, dur in db.execute("select counter_name, avg(value), avg(duration) from counters_collection where kernel_name like "
+                                          "'%mx::leaf_hash_kernel<mx::PoseidonV1>%' and grid_size = 2097152 group by counter_name"):
+            mk[cname] = val; mk["duration_ns_under_pmc"] = dur
+m = derive(mk, PERMS)
 # the throughput build's kernel names collapse in pmc_db_summary.py (template arguments in anonymous namespaces): read its pass directly
 tk = {}
 for path in glob.glob(os.path.join(O, "p3", "**", "*.db"), recursive=True):
