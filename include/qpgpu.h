@@ -233,6 +233,13 @@ int qpgpu_generate_witness_partial_batch_dev(qpgpu_circuit *c, const uint64_t *c
 /* Resolve a cell list and size every buffer for up to max_batch witnesses now (on the loading thread), so that the generate
  * calls themselves neither allocate nor free. Optional: the generate calls do it on first use. */
 int qpgpu_witness_partial_prepare(qpgpu_circuit *c, const uint64_t *cells, size_t count, uint32_t max_batch);
+/* The same with RandomValueGenerator targets drawn ON THE DEVICE: the LAST n_blinding cells of `cells` (the blinding rows' wires
+ * of a zero-knowledge circuit, CircuitBuilder::blind; qpgpu_wrapper_circuit_build lists them) get one uniform field element
+ * each, per witness, from ChaCha20 keyed with seeds[b] (32 bytes per witness; NULL: 32 bytes of operating-system entropy per
+ * witness, the key wiped after use). values: [batch][count - n_blinding]. A blinding cell must be a free cell of its own
+ * (QPGPU_EINVAL otherwise). Saves drawing and uploading ~0.6 M values per private-batch proof on the host. */
+int qpgpu_generate_witness_partial_batch_blinded_dev(qpgpu_circuit *c, const uint64_t *cells, size_t count, size_t n_blinding, const uint64_t *values,
+                                                     const uint8_t *seeds, const uint64_t *public_inputs, uint32_t batch, uint64_t *d_wires, int *status);
 
 /* ---- stage-level entry points: the circuit-independent parts of prove() ---------------------------------------
  * For a patched `qp-plonky2::plonk::prover::prove` that keeps witness generation, partial products and the quotient

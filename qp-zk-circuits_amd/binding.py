@@ -113,6 +113,7 @@ def load_library():
         "qpgpu_generate_witness_batch_dev": (c.c_int, [vp, u64p, c.c_uint32, u64p]),
         "qpgpu_generate_witness_partial_dev": (c.c_int, [vp, u64p, u64p, c.c_size_t, u64p, u64p]),
         "qpgpu_generate_witness_partial_batch_dev": (c.c_int, [vp, u64p, c.c_size_t, u64p, u64p, c.c_uint32, u64p, vp]),
+        "qpgpu_generate_witness_partial_batch_blinded_dev": (c.c_int, [vp, u64p, c.c_size_t, c.c_size_t, u64p, c.c_char_p, u64p, c.c_uint32, u64p, vp]),
         "qpgpu_witness_partial_prepare": (c.c_int, [vp, u64p, c.c_size_t, c.c_uint32]),
         "qpgpu_oracle_commit": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint32,
                                           c.POINTER(vp)]),
@@ -412,6 +413,24 @@ class Circuit:
         status = (ctypes.c_int * batch)()
         rc = self.gpu.lib.qpgpu_generate_witness_partial_batch_dev(self.h, cl.ctypes.data, cl.size, vl.ctypes.data, p.ctypes.data, batch,
                                                                    _ptr(d_wires), status)
+        if rc not in (0, -4):
+            self.gpu._check(rc)
+        return list(status)
+
+    def generate_witness_partial_batch_blinded_dev(self, cells, values, public_inputs, d_wires, n_blinding, seeds=None):
+        """The same with the LAST n_blinding cells drawn on the device (RandomValueGenerator targets of a zero-knowledge circuit):
+        values [batch, count - n_blinding]; seeds: batch x 32 bytes for reproducible tests, None = OS entropy per witness."""
+        cl = np.ascontiguousarray(cells, dtype=np.uint64)
+        vl = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, cl.size - n_blinding)
+        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        batch = vl.shape[0]
+        sd = None
+        if seeds is not None:
+            sd = bytes(seeds)
+            assert len(sd) == 32 * batch
+        status = (ctypes.c_int * batch)()
+        rc = self.gpu.lib.qpgpu_generate_witness_partial_batch_blinded_dev(self.h, cl.ctypes.data, cl.size, n_blinding, vl.ctypes.data, sd, p.ctypes.data, batch,
+                                                                           _ptr(d_wires), status)
         if rc not in (0, -4):
             self.gpu._check(rc)
         return list(status)

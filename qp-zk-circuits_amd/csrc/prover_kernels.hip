@@ -735,6 +735,26 @@ __global__ void __launch_bounds__(256) salt_kernel(const u32 *keys, u32 oracle_i
     }
 }
 
+// RandomValueGenerator on the device (CircuitBuilder::blind's random wires of a zero-knowledge circuit): value j of witness b from
+// the ChaCha20 stream of that witness's key, nonce ("BLND", 0); block (j >> 1) holds the candidates of values 2k and 2k+1, the
+// first of four below p is taken (uniform on [0, p)). out: [batch][pitch], `count` values each.
+__global__ void __launch_bounds__(256) random_felts_kernel(const u32 *keys, u64 count, u64 *out, u64 pitch) {
+    const u64 j = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    u32 blk[16];
+    chacha20_block(keys + 8 * blockIdx.z, j >> 1, 0x444E4C42u, 0, blk);
+    const u32 h = (u32)(j & 1) * 8;
+    u64 v = 0;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u64 cand = ((u64)blk[h + 2 * k + 1] << 32) | blk[h + 2 * k];
+        if (!found && cand < gl::P) { v = cand; found = true; }
+    }
+    if (!found) v = (((u64)blk[h + 7] << 32) | blk[h + 6]) - gl::P;
+    out[(u64)blockIdx.z * pitch + j] = v;
+}
+
 // x_coset[j] = g * w^bitrev(j), l0_coset[j] = zh(i) / (n (x - 1))
 __global__ void __launch_bounds__(256) coset_tables_kernel(u64 lde_n, u32 log_lde, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits,
                                                              const u64 *zh, u32 rate, u64 n_field, u64 *x_coset, u64 *l0_coset) {
@@ -922,6 +942,11 @@ hipError_t pk_gather_leaf_rows(const u64 *rows, u32 width, const u64 *idx, u32 s
 }
 hipError_t pk_salt(const u32 *keys, u32 oracle_index, u64 lde_n, u64 *out, u32 batch, hipStream_t st) {
     LAUNCH_1D_B(salt_kernel, lde_n, 256, batch, st, keys, oracle_index, lde_n, out);
+    return hipGetLastError();
+}
+hipError_t pk_random_felts(const u32 *keys, u64 count, u64 *out, u64 pitch, u32 batch, hipStream_t st) {
+    if (count == 0 || batch == 0) return hipSuccess;
+    LAUNCH_1D_B(random_felts_kernel, count, 256, batch, st, keys, count, out, pitch);
     return hipGetLastError();
 }
 hipError_t pk_coset_tables(u64 lde_n, u32 log_lde, const u64 *pw_lo, const u64 *pw_hi, u32 lo_bits, const u64 *zh, u32 rate,

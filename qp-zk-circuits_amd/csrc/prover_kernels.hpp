@@ -103,5 +103,7 @@ hipError_t pk_gather_leaf_rows(const uint64_t *rows, uint32_t width, const uint6
                                uint32_t batch, uint64_t ps_rows, uint64_t ps_out, hipStream_t st);
 // salt columns [batch][4][lde_n]: ChaCha20 keyed per proof (keys: [batch][8] 32-bit words on the device), stream = oracle_index
 hipError_t pk_salt(const uint32_t *keys, uint32_t oracle_index, uint64_t lde_n, uint64_t *out, uint32_t batch, hipStream_t st);
+// `count` uniform field elements per witness from ChaCha20 under keys[b] ([batch][8] 32-bit words on the device), out: [batch][pitch]
+hipError_t pk_random_felts(const uint32_t *keys, uint64_t count, uint64_t *out, uint64_t pitch, uint32_t batch, hipStream_t st);
 hipError_t pk_coset_tables(uint64_t lde_n, uint32_t log_lde, const uint64_t *pw_lo, const uint64_t *pw_hi, uint32_t lo_bits, const uint64_t *zh,
                            uint32_t rate, uint64_t n_field, uint64_t *x_coset, uint64_t *l0_coset, hipStream_t st);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
+#include <sys/random.h>
 #include <numeric>
 #include <string>
 #include <map>
@@ -59,13 +60,13 @@ struct PartialPrep {
     std::vector<uint32_t> scatter_idx, check_idx; // flat cells
     std::vector<std::pair<uint32_t, uint32_t>> same;   // (earlier, later) value indices that share a class
     std::vector<u64> check_cell;                  // cell (row * num_wires + wire) named in messages
-    uint32_t *d_scatter_idx = nullptr, *d_check_idx = nullptr;
+    uint32_t *d_scatter_idx = nullptr, *d_check_idx = nullptr, *d_keys = nullptr;   // d_keys: [cap][8], ChaCha20 keys of device-drawn values
     u64 *d_scatter_val = nullptr, *d_check_val = nullptr;   // [cap][count]
     uint32_t cap = 0;
     bool valid = false;
     void release() {
-        for (void *q : {(void *)d_scatter_idx, (void *)d_check_idx, (void *)d_scatter_val, (void *)d_check_val}) if (q) (void)hipFree(q);
-        d_scatter_idx = d_check_idx = nullptr; d_scatter_val = d_check_val = nullptr; cap = 0;
+        for (void *q : {(void *)d_scatter_idx, (void *)d_check_idx, (void *)d_scatter_val, (void *)d_check_val, (void *)d_keys}) if (q) (void)hipFree(q);
+        d_scatter_idx = d_check_idx = d_keys = nullptr; d_scatter_val = d_check_val = nullptr; cap = 0;
     }
 };
 
@@ -483,6 +484,7 @@ int prep_device(qpgpu_ctx *ctx, PartialPrep &pp, uint32_t batch) {
     QP_HIP(ctx, hipMalloc((void **)&pp.d_check_idx, nc * 4));
     QP_HIP(ctx, hipMalloc((void **)&pp.d_scatter_val, ns * 8 * batch));
     QP_HIP(ctx, hipMalloc((void **)&pp.d_check_val, nc * 8 * batch));
+    QP_HIP(ctx, hipMalloc((void **)&pp.d_keys, (size_t)32 * batch));
     if (!pp.scatter_idx.empty()) QP_HIP(ctx, hipMemcpyAsync(pp.d_scatter_idx, pp.scatter_idx.data(), pp.scatter_idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!pp.check_idx.empty()) QP_HIP(ctx, hipMemcpyAsync(pp.d_check_idx, pp.check_idx.data(), pp.check_idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -493,12 +495,24 @@ int prep_device(qpgpu_ctx *ctx, PartialPrep &pp, uint32_t batch) {
 // Stage s1 for `batch` witnesses. With `pp`: the wire matrices are cleared and seeded with the prepared assignments first
 // (values: [batch][npis + count] is assembled from public_inputs and part_values). status (may be null): per witness
 // QPGPU_OK / QPGPU_EUNSAT. Returns QPGPU_EUNSAT when any witness failed (the first one's reason in last_error).
+// n_blind: the LAST n_blind cells of the prepared list take values drawn on the device (ChaCha20 under seeds[b], or under 32 bytes
+// of OS entropy per witness when seeds is null); part_values then holds count - n_blind values per witness.
 int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs, PartialPrep *pp,
-                          const uint64_t *part_values, int *status) {
+                          const uint64_t *part_values, int *status, size_t n_blind = 0, const uint8_t *seeds = nullptr) {
     qpgpu_ctx *ctx = c->ctx;
     WitnessPlan &plan = *c->wplan;
     const CircuitPack &p = c->pack;
-    const size_t npis = p.num_public_inputs, count = pp ? pp->cells.size() : 0;
+    const size_t npis = p.num_public_inputs, all_cells = pp ? pp->cells.size() : 0, count = all_cells - n_blind;
+    // the device-drawn cells must be the tail of the scatter list: free classes nothing else assigns
+    size_t ns_host = pp ? pp->scatter_idx.size() : 0;
+    if (n_blind) {
+        const uint32_t first_blind = (uint32_t)(npis + count);
+        ns_host = (size_t)(std::lower_bound(pp->scatter_from.begin(), pp->scatter_from.end(), first_blind) - pp->scatter_from.begin());
+        bool ok = pp->scatter_idx.size() - ns_host == n_blind;
+        for (uint32_t f : pp->check_from) ok = ok && f < first_blind;
+        for (const auto &sm : pp->same) ok = ok && sm.first < first_blind && sm.second < first_blind;
+        if (!ok) return ctx->fail(QPGPU_EINVAL, "generate_witness_partial: a blinding cell is not a free cell of its own (it is generated, copy-connected to another assigned cell, or listed twice)");
+    }
     const u64 NW = p.num_wires, stride = p.num_wires * p.n();
     auto name = [&](u64 cell) { return "target (row " + std::to_string(cell / NW) + ", wire " + std::to_string(cell % NW) + ")"; };
     if (status) for (uint32_t b = 0; b < batch; b++) status[b] = QPGPU_OK;
@@ -535,8 +549,8 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
     // everything the host sends goes up through the context's pinned bounce buffer and a copy kernel (ctx.hpp: read_back)
     const size_t ns = pp ? pp->scatter_idx.size() : 0, nc = pp ? pp->check_idx.size() : 0;
     const size_t pi_bytes = plan.d_pi_idx ? (size_t)batch * npis * 8 : 0, hash_bytes = (size_t)batch * 32;
-    const size_t sc_bytes = (size_t)batch * ns * 8, ck_bytes = (size_t)batch * nc * 8;
-    QP_TRY(ctx->reserve_read_back(pi_bytes + hash_bytes + sc_bytes + ck_bytes + (size_t)batch * 8));
+    const size_t sc_bytes = (size_t)batch * ns_host * 8, ck_bytes = (size_t)batch * nc * 8, key_bytes = n_blind ? (size_t)batch * 32 : 0;
+    QP_TRY(ctx->reserve_read_back(pi_bytes + hash_bytes + sc_bytes + ck_bytes + key_bytes + (size_t)batch * 8));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));       // nothing of an earlier call still reads the bounce buffer
     u64 *bounce = (u64 *)ctx->h_pin;
     if (pp) QP_HIP(ctx, hipMemsetAsync(d_wires, 0, (size_t)batch * stride * 8, ctx->stream));
@@ -547,16 +561,33 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
     if (pp)
         for (uint32_t b = 0; b < batch; b++) {
             auto val = [&](uint32_t from) { return gl::canon(from < npis ? public_inputs[(size_t)b * npis + from] : part_values[(size_t)b * count + (from - npis)]); };
-            for (size_t i = 0; i < ns; i++) scv[(size_t)b * ns + i] = val(pp->scatter_from[i]);
+            for (size_t i = 0; i < ns_host; i++) scv[(size_t)b * ns_host + i] = val(pp->scatter_from[i]);
             for (size_t i = 0; i < nc; i++) ckv[(size_t)b * nc + i] = val(pp->check_from[i]);
         }
+    u64 *keyv = ckv + ck_bytes / 8;
+    if (n_blind) {
+        if (seeds) std::memcpy(keyv, seeds, key_bytes);
+        else {
+            size_t got = 0;
+            while (got < key_bytes) {
+                const ssize_t r = getrandom((uint8_t *)keyv + got, key_bytes - got, 0);
+                if (r <= 0) return ctx->fail(QPGPU_EDEVICE, "generate_witness_partial: the OS entropy source failed");
+                got += (size_t)r;
+            }
+        }
+    }
     if (pi_bytes) {   // PartialWitness::set_target for every public-input target
         QP_HIP(ctx, pk_copy(plan.d_pi_vals, bounce, pi_bytes, ctx->stream));
         QP_HIP(ctx, wk_scatter(d_wires, plan.d_pi_idx, plan.d_pi_vals, (uint32_t)npis, batch, stride, (uint32_t)npis, ctx->stream));
     }
     QP_HIP(ctx, pk_copy(plan.d_pi_hash, pih, hash_bytes, ctx->stream));
     if (ns) {
-        QP_HIP(ctx, pk_copy(pp->d_scatter_val, scv, sc_bytes, ctx->stream));
+        if (ns_host == ns) QP_HIP(ctx, pk_copy(pp->d_scatter_val, scv, sc_bytes, ctx->stream));
+        else {
+            if (ns_host) QP_HIP(ctx, pk_unpack_rows(scv, ns, ns_host, batch, pp->d_scatter_val, ctx->stream));
+            QP_HIP(ctx, pk_copy(pp->d_keys, keyv, key_bytes, ctx->stream));
+            QP_HIP(ctx, pk_random_felts(pp->d_keys, n_blind, pp->d_scatter_val + ns_host, ns, batch, ctx->stream));
+        }
         QP_HIP(ctx, wk_scatter(d_wires, pp->d_scatter_idx, pp->d_scatter_val, (uint32_t)ns, batch, stride, (uint32_t)ns, ctx->stream));
     }
     if (nc) QP_HIP(ctx, pk_copy(pp->d_check_val, ckv, ck_bytes, ctx->stream));
@@ -601,6 +632,11 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
                 flag(b, name(pp->check_cell[k]) + " set twice with different values (" + std::to_string(v) + " supplied, another value generated)");
             }
         }
+    }
+    if (n_blind) {   // the keys are secrets: the device has read the bounce buffer (the launches above are ordered before this sync)
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        volatile u64 *kz = keyv;
+        for (size_t i = 0; i < key_bytes / 8; i++) kz[i] = 0;
     }
     return overall;
 }
@@ -678,6 +714,19 @@ int qpgpu_generate_witness_partial_batch_dev(qpgpu_circuit *c, const uint64_t *c
     QP_TRY(ensure_plan(c));
     QP_TRY(ensure_prep(c, cells, count, batch));
     return generate_batch(c, d_wires, batch, public_inputs, c->wplan->prep, values, status);
+}
+
+int qpgpu_generate_witness_partial_batch_blinded_dev(qpgpu_circuit *c, const uint64_t *cells, size_t count, size_t n_blinding, const uint64_t *values,
+                                                     const uint8_t *seeds, const uint64_t *public_inputs, uint32_t batch, uint64_t *d_wires, int *status) {
+    if (!c) return QPGPU_EINVAL;
+    qpgpu_ctx *ctx = c->ctx;
+    QP_DEV(ctx);
+    const CircuitPack &p = c->pack;
+    if (!d_wires || batch == 0 || batch > 65535 || !cells || n_blinding > count || (count > n_blinding && !values) || (!public_inputs && p.num_public_inputs))
+        return ctx->fail(QPGPU_EINVAL, "generate_witness_partial_blinded: null argument or more blinding cells than cells");
+    QP_TRY(ensure_plan(c));
+    QP_TRY(ensure_prep(c, cells, count, batch));
+    return generate_batch(c, d_wires, batch, public_inputs, c->wplan->prep, values, status, n_blinding, seeds);
 }
 
 int qpgpu_generate_witness_partial_dev(qpgpu_circuit *c, const uint64_t *cells, const uint64_t *values, size_t count,

@@ -83,13 +83,15 @@ class WrapperCircuit:
             raise ValueError(err.value.decode())
         return out
 
-    def commit(self, proofs, preimages=None, query_indices=None, aggregator_address=None, public_inputs=None, blinding_seed=None):
+    def commit(self, proofs, preimages=None, query_indices=None, aggregator_address=None, public_inputs=None, blinding_seed=None, device_blinding=False):
         """fill_private_batch_witness / fill_public_batch_witness + the query indices: (cells, values, public_inputs) of the
         wrapper's PartialWitness. Raises ValueError with the reference's message for a malformed proof. preimages: the dummy-nullifier
         preimages (private batch, N x 4 felts); aggregator_address: 32 bytes (public batch). With a batch logic the public inputs
         are the ones the layer's circuit computes (aggregation.private_batch_outputs / public_batch_outputs on the host; QpGpuError
         -4 there when the slots violate a constraint the host restatement sees); public_inputs overrides them (tests: what the
-        CIRCUIT says to slots the host restatement refuses)."""
+        CIRCUIT says to slots the host restatement refuses). device_blinding=True (zero-knowledge circuits): the blinding cells are
+        appended to the cell list WITHOUT values — Circuit.generate_witness_partial_batch_blinded_dev draws them on the device
+        (n_blinding = self.blinding_cells.size)."""
         L = _lib()
         N = self.num_proofs
         pre = np.zeros(4 * N, dtype=np.uint64) if preimages is None else np.ascontiguousarray(preimages, dtype=np.uint64).reshape(-1).copy()
@@ -127,12 +129,25 @@ class WrapperCircuit:
             from . import aggregation
             pis = aggregation.public_batch_outputs(pis.reshape(N, npis), (npis - 8) // 21, addr)
         cells, vals = cells[:k].copy(), vals[:k].copy()
-        if self.blinding_cells.size:          # RandomValueGenerator: one fresh field element per blinding wire, per proof
+        if self.blinding_cells.size and device_blinding:
+            cells = np.concatenate([cells, self.blinding_cells])
+        elif self.blinding_cells.size:        # RandomValueGenerator: one fresh field element per blinding wire, per proof
             rnd = np.empty(self.blinding_cells.size, dtype=np.uint64)
             if L.qpgpu_random_field_elements(blinding_seed, rnd.ctypes.data, rnd.size, err) != 0:
                 raise QpGpuError(-1, err.value.decode())
             cells, vals = np.concatenate([cells, self.blinding_cells]), np.concatenate([vals, rnd])
         return cells, vals, pis
+
+
+def generate_wrapper_witnesses(circ, wrapper, commits, d_wires, seeds=None):
+    """Stage s1 for a lockstep batch of one wrapper circuit's commits: values from the host, the blinding wires of a
+    zero-knowledge wrapper drawn on the device when the commits were made with device_blinding=True. Returns the status list."""
+    cells = commits[0][0]
+    vals = np.stack([c[1] for c in commits]); pis = np.stack([c[2] for c in commits])
+    nb = cells.size - vals.shape[1]
+    if nb:
+        return circ.generate_witness_partial_batch_blinded_dev(cells, vals, pis, d_wires, nb, seeds)
+    return circ.generate_witness_partial_batch_dev(cells, vals, pis, d_wires)
 
 
 class PrivateBatchProver:
@@ -173,7 +188,8 @@ class PrivateBatchProver:
             self.leaf_prover.close()
 
     def _fill(self, slot_proofs, preimages, blinding_seed=None):
-        self.committed = self.circuit.commit(slot_proofs, preimages=preimages, blinding_seed=blinding_seed)
+        self.committed = self.circuit.commit(slot_proofs, preimages=preimages, device_blinding=True)
+        self.blinding_seed = blinding_seed
         return self
 
     def commit(self, leaf_proofs, seed=None):
@@ -195,10 +211,12 @@ class PrivateBatchProver:
     def prove(self):
         if self.committed is None:
             raise ValueError("prove() before commit()")
-        cells, vals, pis = self.committed
+        commit = self.committed
         self.committed = None
-        self.circ.generate_witness_partial_dev(cells, vals, pis, self.d_wires)
-        return self.circ.prove_dev(self.d_wires, pis)
+        st = generate_wrapper_witnesses(self.circ, self.circuit, [commit], self.d_wires, self.blinding_seed)
+        if any(st):
+            raise QpGpuError(-4, self.gpu.last_error())
+        return self.circ.prove_dev(self.d_wires, commit[2])
 
     def prove_dummy_template(self):
         """generate_dummy_private_batch_proof (private_batch/circuit/build.rs:165-193): the all-dummy private-batch proof the
@@ -343,8 +361,11 @@ class AttestingTree:
             # per inner proof and, for the zero-knowledge circuit, ~0.6 M blinding values per batch from ChaCha20
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=min(8, len(self.my_batches))) as ex:
-                com1 = list(ex.map(lambda k: self.w1.commit(leaves[k * self.per_batch:(k + 1) * self.per_batch], preimages=pre[k]), range(len(self.my_batches))))
-            level1 = self._level(self.w1_circ, self.words[1], com1[0][0], np.stack([c[1] for c in com1]), np.stack([c[2] for c in com1]))
+                com1 = list(ex.map(lambda k: self.w1.commit(leaves[k * self.per_batch:(k + 1) * self.per_batch], preimages=pre[k], device_blinding=True), range(len(self.my_batches))))
+            st = generate_wrapper_witnesses(self.w1_circ, self.w1, com1, self.d_wires)
+            if any(st):
+                raise QpGpuError(-4, self.gpu.last_error())
+            level1 = self.w1_circ.prove_batch_dev([self.d_wires.ptr + 8 * k * self.words[1] for k in range(len(com1))], [c[2] for c in com1])
         if self.world > 1:       # the one exchange of the tree: first-level proof bytes to the rank that proves the second level
             from . import sharding
             got = sharding.gather_proof_bytes(level1, dist, device, root=0)

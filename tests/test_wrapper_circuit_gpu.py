@@ -165,3 +165,57 @@ def test_full_verification_on_the_device(pkg, gpu, orc):
     assert e.value.code == -4 and "set twice with different values" in str(e.value)
     wver.close(); wc.close(); w0c.close(); ver.close(); lp.close()
     d.free(scrub=True)
+
+
+def test_blinding_wires_drawn_on_the_device(pkg, gpu, orc):
+    """The zero-knowledge private-batch circuit's RandomValueGenerator targets (CircuitBuilder::blind) filled by the device from
+    ChaCha20 under a per-witness key (qpgpu_generate_witness_partial_batch_blinded_dev): with those values handed to the oracle as
+    ordinary assignments its witness equals the device's; another key gives other blinding wires and the same everything else;
+    the proof (salts seeded) equals the oracle's bytes and verifies."""
+    L = pkg.leaf
+    leaf = L.LeafCircuit()
+    lp = L.LeafProver(pkg, gpu, leaf)
+    proofs = [lp.prove(x)[0] for x in (lc.real_inputs(L, depth=2, seed=21), lc.dummy_inputs(L))]
+    ver = pkg.Verifier(leaf.pack, circuit=lp.circ)
+    wz = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, num_routed_wires=60, logic="private_batch", verify=True, zero_knowledge=True)
+    wc = pkg.Circuit(gpu, wz.pack, max_batch=2)
+    nw, n = 135, 1 << wz.info["degree_bits"]
+    nb = wz.blinding_cells.size
+    pre = np.arange(8, dtype=np.uint64).reshape(2, 4) + 5
+    c = wz.commit(proofs, preimages=pre, device_blinding=True)
+    assert c[0].size == c[1].size + nb and np.array_equal(c[0][-nb:], wz.blinding_cells)
+    d = gpu.alloc(2 * nw * n * 8)
+    seeds = bytes([7] * 32) + bytes([8] * 32)
+    st = wc.generate_witness_partial_batch_blinded_dev(c[0], np.stack([c[1], c[1]]), np.stack([c[2], c[2]]), d, nb, seeds)
+    assert st == [0, 0]
+    wires = d.download().reshape(2, nw, n)
+    cols, rows = (wz.blinding_cells % 135).astype(np.int64), (wz.blinding_cells // 135).astype(np.int64)
+    blind = [wires[k][cols, rows] for k in range(2)]
+    assert int(max(blind[0].max(), blind[1].max())) < pkg.P and not np.array_equal(blind[0], blind[1])
+    assert len(np.unique(blind[0])) == nb                                    # 0.6 M draws from 2^64: no repeats
+    assert abs(float((blind[0] >> np.uint64(63)).mean()) - 0.5) < 0.01        # top bit of a uniform element of [0, p)
+    # everything that is not a blinding wire or a copy of one is the same witness under both keys
+    pair_rows = np.zeros(n, dtype=bool); pair_rows[wz.info["rows_before_padding"]:wz.info["rows_before_padding"] + wz.info["rows_blinding"]] = True
+    assert np.array_equal(wires[0][:, ~pair_rows], wires[1][:, ~pair_rows])
+    for k in range(2):
+        rc, want, _ = orc.generate_witness(wz.pack, c[0], np.concatenate([c[1], blind[k]]), c[2])
+        assert rc == orc.WIT_OK and np.array_equal(wires[k], want)
+    wc.set_witness_check(True)
+    wc.set_blinding_seed(99)
+    proof = wc.prove_dev(d, c[2])
+    oc = ob.OracleCircuit(orc, wz.pack)
+    assert oc.verify(proof) == 0
+    oc.close()
+    wv = pkg.Verifier(wz.pack, circuit=wc)
+    assert wv.verify(proof)
+    # OS entropy: two calls, two different sets of blinding wires
+    st = wc.generate_witness_partial_batch_blinded_dev(c[0], np.stack([c[1], c[1]]), np.stack([c[2], c[2]]), d, nb)
+    w2 = d.download().reshape(2, nw, n)
+    assert st == [0, 0] and not np.array_equal(w2[0][cols, rows], w2[1][cols, rows]) and not np.array_equal(w2[0][cols, rows], blind[0])
+    # a cell that is not free cannot be a blinding cell
+    bad_cells = c[0].copy(); bad_cells[-1] = c[0][0]
+    with pytest.raises(pkg.QpGpuError) as e:
+        wc.generate_witness_partial_batch_blinded_dev(bad_cells, c[1][None], c[2][None], d, nb)
+    assert "blinding cell" in str(e.value)
+    wv.close(); wc.close(); ver.close(); lp.close()
+    d.free(scrub=True)
