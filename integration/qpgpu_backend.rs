@@ -83,6 +83,20 @@ extern "C" {
     pub fn qpgpu_pool_set_partial_cells(p: *mut QpgpuPool, cells: *const u64, count: usize) -> i32;
     pub fn qpgpu_pool_submit_partial(p: *mut QpgpuPool, values: *const u64, public_inputs: *const u64, out: *mut u8, out_cap: usize, ticket: *mut u64) -> i32;
     pub fn qpgpu_pool_wait(p: *mut QpgpuPool, ticket: u64, out_len: *mut usize) -> i32;
+    // include/qpgpu.h, include/qpgpu_batch.h — zero-knowledge circuits (the private-batch layer): the blinding rows' random wires are
+    // the last `n_blinding` cells of the assignment list and are drawn on the device, one ChaCha20 key per witness (seeds = null:
+    // operating-system entropy); qpgpu_random_field_elements is the host-side form
+    pub fn qpgpu_generate_witness_partial_batch_blinded_dev(c: *mut QpgpuCircuit, cells: *const u64, count: usize, n_blinding: usize, values: *const u64,
+                                                            seeds: *const u8, public_inputs: *const u64, batch: u32, d_wires: *mut u64, status: *mut i32) -> i32;
+    pub fn qpgpu_random_field_elements(seed32: *const u8, out: *mut u64, n: usize, err: *mut c_char) -> i32;
+    // include/qpgpu_leaf.h, include/qpgpu_batch.h — the circuits built by the library itself: only for
+    // deployments that take BOTH prover and verifier data from it; with exported packs of the fork's own circuits these are not used
+    pub fn qpgpu_leaf_circuit_build(fragment: u32, min_degree_bits: u32, inner_hasher: i32, p2_layout: *const u64, pack_out: *mut u64, pack_cap_words: usize,
+                                    pack_words: *mut usize, target_map_out: *mut u64, info_out: *mut u64, err: *mut c_char) -> i32;
+    pub fn qpgpu_wrapper_circuit_build(inner_pack: *const u64, inner_words: usize, inner_cs_cap: *const u64, cap_words: usize, num_proofs: u32,
+                                       num_routed_wires: u32, min_degree_bits: u32, inner_hasher: i32, flags: u32, pack_out: *mut u64, pack_cap_words: usize,
+                                       pack_words: *mut usize, target_map_out: *mut u64, map_cap: usize, map_count: *mut usize, info_out: *mut u64,
+                                       err: *mut c_char) -> i32;
 }
 #[repr(C)] pub struct QpgpuVerifier { _private: [u8; 0] }
 #[repr(C)] pub struct QpgpuPool { _private: [u8; 0] }
