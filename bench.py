@@ -534,6 +534,10 @@ def main():
                       "degree_bits": {"leaf": at.leaf.info["degree_bits"], "first_level": at.w1.info["degree_bits"], "second_level": at.w2.info["degree_bits"]},
                       "poseidon_gate_rows": {"first_level": at.w1.info["rows_poseidon"], "second_level": at.w2.info["rows_poseidon"]},
                       "root_public_inputs": parsed,
+                      "per_proof_ms": {"private_batch_N8_zero_knowledge_lockstep8": round(1e3 * at.times["first_level_s"] / max(1, len(at.my_batches)), 2),
+                                       "public_batch_M8": round(1e3 * at.times["second_level_s"], 2)},
+                      "reference_published": {"private_batch_N8_s": 5.39, "public_batch_M8_s": 3.84, "tree_64_leaves_sequential_s": 48, "hw": "Apple M2 Max 12c",
+                                              "source": "paper/main.tex:466-470,488-492; BASELINE.md section 1 (the fork's own circuits, whose sizes are 2^16 for both layers)"},
                       "checked": "the library's verifier accepts the root, a first-level proof and a leaf; the root's public inputs are the PublicBatchPublicInputs the host "
                                  "restatement of the two layers' logic computes from the 64 leaves' public inputs, and parse (96 paid exit slots, 64 nullifiers)" if ok_a else "FAILED",
                       "arithmetic_extension_rows": {"first_level": at.w1.info["rows_before_padding"] - at.w1.info["rows_poseidon"] - at.w1.info["rows_random_access"] - at.w1.info["rows_base_sum"] - at.w1.info["rows_arithmetic"] - at.w1.info["rows_constant"]},
