@@ -205,6 +205,9 @@ int qpgpu_leaf_check_constraints(const qpgpu_leaf_inputs *in, char *err);
 #define QPGPU_LEAF_FRAGMENT_BLOCK_HEADER 1u
 #define QPGPU_LEAF_FRAGMENT_UNSPENDABLE_ACCOUNT 2u
 #define QPGPU_LEAF_FRAGMENT_NULLIFIER 3u
+/* build_fake_leaf_circuit (wormhole/tests/test-helpers/src/fake_leaf.rs): 21 free public inputs in the leaf layout + the three 32-bit
+ * range checks; no logical targets (the public inputs are the whole witness) — for tests of the batch layers on arbitrary leaf values */
+#define QPGPU_LEAF_FRAGMENT_FAKE_LEAF 4u
 int qpgpu_leaf_circuit_build(unsigned fragment, unsigned min_degree_bits, int inner_hasher, const uint64_t *p2_layout, uint64_t *pack_out, size_t pack_cap_words,
                              size_t *pack_words, uint64_t *target_map_out, uint64_t *info_out, char *err);
 /* WormholeProver::commit (wormhole/prover/src/lib.rs:156-163) against such a circuit: qpgpu_leaf_fill_witness followed by

@@ -30,7 +30,7 @@ typedef struct {
     size_t n, nw, r;
     uint32_t *cls;          /* [nw * n] flat cell (col * n + row) -> slot */
     gl_t *val; uint8_t *set; /* per slot */
-    int conflict; uint64_t conflict_cell;
+    int conflict; uint64_t conflict_cell; int derive_pis;
 } pw_t;
 
 static inline size_t flat(const pw_t *p, size_t row, size_t col) { return col * p->n + row; }
@@ -223,7 +223,7 @@ static int run_gate(pw_t *p, const gen_t *g, const gl_t pih[4]) {
     gl_t in[64];
     switch (gt->type) {
     case OG_CONSTANT: pw_set(p, row, g->op, consts[(size_t)g->op * n]); return 1;
-    case OG_PUBLIC_INPUT: for (int i = 0; i < 4; i++) pw_set(p, row, i, pih[i]); return 1;
+    case OG_PUBLIC_INPUT: if (!p->derive_pis) for (int i = 0; i < 4; i++) pw_set(p, row, i, pih[i]); return 1;
     case OG_ARITHMETIC: {
         const size_t b = 4 * (size_t)g->op;
         for (int i = 0; i < 3; i++) if (!pw_get(p, row, b + i, &in[i])) return 0;
@@ -400,8 +400,12 @@ int orc_witness_generate(const orc_witness_plan *w, const uint64_t *cells, const
     p.val = (gl_t *)calloc(NW * n, sizeof(gl_t));
     p.set = (uint8_t *)calloc(NW * n, 1);
     gl_t pih[4] = {0, 0, 0, 0};
-    if (c->num_pis) orc_hash_no_pad(public_inputs, c->num_pis, pih);
-    for (size_t i = 0; i < w->n_pi && i < c->num_pis; i++) pw_set(&p, w->pi_cells[i] / NW, w->pi_cells[i] % NW, public_inputs[i]);
+    /* public_inputs == NULL: plonky2's own order of things — the public inputs are whatever the generators make of the
+     * public-input targets; the PublicInputGate's wires get the hash through their copy constraints (tests read the public
+     * inputs back from the trace) */
+    p.derive_pis = public_inputs == NULL;
+    if (c->num_pis && public_inputs) orc_hash_no_pad(public_inputs, c->num_pis, pih);
+    for (size_t i = 0; public_inputs && i < w->n_pi && i < c->num_pis; i++) pw_set(&p, w->pi_cells[i] / NW, w->pi_cells[i] % NW, public_inputs[i]);
     for (size_t i = 0; i < count; i++) {
         if (cells[i] >= NW * n) { rc = ORC_WIT_BAD_PACK; break; }
         pw_set(&p, cells[i] / NW, cells[i] % NW, values[i]);

@@ -370,6 +370,12 @@ int qpgpu_leaf_circuit_build(unsigned fragment, unsigned min_degree_bits, int in
             b.connect_hashes(t.hash, computed_nullifier(t, b));
             for (int i = 0; i < 4; i++) { lt[QPGPU_LT_NULLIFIER_HASH + i] = t.hash.elements[i]; lt[QPGPU_LT_NULLIFIER_SECRET + i] = t.secret.elements[i]; }
             for (int i = 0; i < 2; i++) lt[QPGPU_LT_NULLIFIER_TRANSFER_COUNT + i] = t.transfer_count[i];
+        } else if (fragment == QPGPU_LEAF_FRAGMENT_FAKE_LEAF) {
+            // build_fake_leaf_circuit (wormhole/tests/test-helpers/src/fake_leaf.rs:20-39): 21 free public inputs in the leaf's layout,
+            // the three 32-bit range checks — the reference's way of testing the aggregation layers on arbitrary leaf public inputs
+            const std::vector<Target> pis = b.add_virtual_targets(21);
+            b.range_check(pis[1], 32); b.range_check(pis[2], 32); b.range_check(pis[3], 32);
+            for (Target t : pis) b.register_public_input(t);
         } else return fail(QPGPU_EINVAL, "leaf_circuit_build: unknown fragment");
         CircuitPack pack;
         const std::string why = b.build(pack);

@@ -14,7 +14,7 @@ import numpy as np
 from .binding import QpGpuError, load_library
 
 MAX_DEPTH, DIGEST_LEN, LT_COUNT, PUBLIC_INPUTS = 16, 110, 299, 21
-FRAGMENT_FULL, FRAGMENT_BLOCK_HEADER, FRAGMENT_UNSPENDABLE_ACCOUNT, FRAGMENT_NULLIFIER = 0, 1, 2, 3
+FRAGMENT_FULL, FRAGMENT_BLOCK_HEADER, FRAGMENT_UNSPENDABLE_ACCOUNT, FRAGMENT_NULLIFIER, FRAGMENT_FAKE_LEAF = 0, 1, 2, 3, 4
 NO_CELL = 0xFFFFFFFFFFFFFFFF
 INFO_FIELDS = ("degree_bits", "rows_before_padding", "gates_after_targets", "gates_unspendable_account", "gates_zk_merkle_proof",
                "gates_block_number_range_check", "gates_connect_shared_targets", "rows_arithmetic", "rows_base_sum", "rows_poseidon2",

@@ -122,9 +122,9 @@ class Oracle:
         pw = np.ascontiguousarray(pack_words, dtype=np.uint64)
         nw, n = int(pw[2]), 1 << int(pw[1])
         c = np.ascontiguousarray(cells, dtype=np.uint64); v = np.ascontiguousarray(values, dtype=np.uint64)
-        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        p = None if public_inputs is None else np.ascontiguousarray(public_inputs, dtype=np.uint64)     # None: derived (read them from the trace)
         wires = np.zeros((nw, n), dtype=np.uint64); bad = ctypes.c_uint64()
-        rc = self.lib.orc_generate_witness(_vp(pw), pw.size, _vp(c), _vp(v), c.size, _vp(p), _vp(wires), ctypes.byref(bad))
+        rc = self.lib.orc_generate_witness(_vp(pw), pw.size, _vp(c), _vp(v), c.size, None if p is None else _vp(p), _vp(wires), ctypes.byref(bad))
         return rc, wires, bad.value
 
     # ---- field ----

@@ -24,4 +24,7 @@ c2 = tree.w2.commit(l1, aggregator_address=bytes(32))
 t=time.perf_counter(); tree.w2_circ.generate_witness_partial_batch_dev(c2[0], c2[1][None], c2[2][None], tree.d_wires); gpu.sync(); t4=time.perf_counter()-t
 t=time.perf_counter(); tree.w2_circ.prove_batch_dev([tree.d_wires.ptr], [c2[2]]); t5=time.perf_counter()-t
 print("second level: s1 %.4f prove %.4f" % (t4, t5))
-print(tree.w1_circ.witness_plan_info() if hasattr(tree.w1_circ, "witness_plan_info") else "")
+
+for name, circ in (("leaf", tree.leaf_circ), ("first level", tree.w1_circ), ("second level", tree.w2_circ)):
+    gens, levels, free = circ.witness_info()
+    print("%s: %d generator instances in %d dependency levels, %d free cells" % (name, gens, levels, free))
