@@ -590,6 +590,17 @@ def main():
                                       "note": "qpgpu_circuit_set_witness_check: filtered gate constraints on every trace row + permutation "
                                               "product closure before the quotient stage; returns QPGPU_EUNSAT naming the row"}
             extra["single_proof_latency_ms"] = round(sum(stages.values()), 4)
+            # the same region as the headline for ONE proof alone on the device: commit (host) + stage s1 + stages s2..s12 + bytes back
+            def _one(i_):
+                c_, v_, p_ = leaf.commit(inputs_all[i_])
+                circ.generate_witness_partial_dev(c_, v_, p_, w_t)
+                return circ.prove_dev(w_t, p_, outs[0])
+            _one(1); _one(2)
+            t1_ = time.perf_counter()
+            for i_ in range(10):
+                _one(1 + i_ % (S - 1))
+            extra["single_proof_commit_prove_ms"] = round((time.perf_counter() - t1_) / 10 * 1e3, 3)
+            _one(0)                                      # (w_t holds input 0's witness again)
             extra["proof_stage_ms"] = stages
             extra["merkle_leaf_hash_avg_ms"] = round(leaf_ms / max(leaf_n, 1), 4)
             # the kernel that dominates a proof is integer-ALU-bound, not HBM-bound: its rate next to the bytes it moves
