@@ -218,6 +218,10 @@ class PrivateBatchProver:
             raise QpGpuError(-4, self.gpu.last_error())
         return self.circ.prove_dev(self.d_wires, commit[2])
 
+    def aggregate(self, leaf_proofs, seed=None):
+        """PrivateBatchProver::aggregate (private_batch/prover/lib.rs:336-343): commit + prove."""
+        return self.commit(leaf_proofs, seed=seed).prove()
+
     def prove_dummy_template(self):
         """generate_dummy_private_batch_proof (private_batch/circuit/build.rs:165-193): the all-dummy private-batch proof the
         public level pads with — built from explicit dummy leaves, never through commit (which refuses an all-dummy batch)."""
@@ -273,6 +277,32 @@ class PublicBatchProver:
         self.committed = None
         self.circ.generate_witness_partial_dev(cells, vals, pis, self.d_wires)
         return self.circ.prove_dev(self.d_wires, pis)
+
+
+class ProvingContext:
+    """ProvingContext (wormhole/aggregator/src/aggregator.rs:158-248): what a miner's proving worker holds — the public-batch
+    prover pinned at construction and the aggregator's address. prove_batch: admission checks, order-preserving padding, proof,
+    then the proof is checked against the pinned verifier AND its exposed aggregator address before it is handed back."""
+
+    def __init__(self, public_prover, aggregator_address):
+        self.prover, self.aggregator_address = public_prover, bytes(aggregator_address)
+
+    def prove_batch(self, private_batch_proofs):
+        proof = self.prover.commit(list(private_batch_proofs), aggregator_address=self.aggregator_address).prove()
+        self.verify(proof)
+        return proof
+
+    def verify(self, proof):
+        from . import aggregation
+        n = aggregation.public_batch_pi_len(self.prover.M, self.prover.N)
+        if len(proof) < 8 * n:
+            raise ValueError("public-batch proof: shorter than its public inputs")
+        pis = aggregation.proof_public_inputs(proof, n)
+        got = pis[:4].astype("<u8").tobytes()
+        if got != self.aggregator_address:
+            raise ValueError("public-batch proof aggregator address %s does not match configured aggregator address %s" % (got.hex(), self.aggregator_address.hex()))
+        if not self.prover.verifier.verify(proof):
+            raise ValueError("public-batch aggregated proof verification failed: " + getattr(self.prover.verifier, "reason", ""))
 
 
 class AttestingTree:

@@ -70,6 +70,13 @@ def test_two_layers_from_circuit_inputs(pkg, gpu, orc):
     h2, s2, n2 = A.parse_public_batch_public_inputs(rp, 2, 4)
     assert h2["aggregator_address"] == addr and h2["block_hash"] == hdr["block_hash"] and h2["total_exit_slots"] == 16
     assert s2[:8] == slots and s2[8:] == [(0, bytes(32))] * 8 and n2[:4] == nulls and n2[4:] == [bytes(32)] * 4
+    # ProvingContext::prove_batch / verify (aggregator.rs:187-248): the proof is bound to the configured aggregator address
+    ctx = R.ProvingContext(pub, addr)
+    root2 = ctx.prove_batch([priv.aggregate(proofs[:2], seed=bytes([9] * 32))])
+    ctx.verify(root2); ctx.verify(root)
+    with pytest.raises(ValueError) as e:
+        R.ProvingContext(pub, bytes([4] * 32)).verify(root)
+    assert "does not match configured aggregator address" in str(e.value)
     with pytest.raises(ValueError):
         pub.commit([])
     bad = bytearray(pb); bad[100] ^= 1
