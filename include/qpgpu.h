@@ -240,6 +240,12 @@ int qpgpu_witness_partial_prepare(qpgpu_circuit *c, const uint64_t *cells, size_
  * (QPGPU_EINVAL otherwise). Saves drawing and uploading ~0.6 M values per private-batch proof on the host. */
 int qpgpu_generate_witness_partial_batch_blinded_dev(qpgpu_circuit *c, const uint64_t *cells, size_t count, size_t n_blinding, const uint64_t *values,
                                                      const uint8_t *seeds, const uint64_t *public_inputs, uint32_t batch, uint64_t *d_wires, int *status);
+/* ProverCircuitData::prove takes its public inputs OUT of the generated witness (`get_targets(&prover_data.public_inputs)`). The
+ * same here: pass public_inputs = NULL to the two functions above (allowed when the circuit's PublicInputGate wires are
+ * copy-connected to the in-circuit hash of the public-input targets, as CircuitBuilder::build wires them: exported circuits and
+ * the library's own builder; QPGPU_EINVAL otherwise) — the public-input targets are then whatever the caller's assignments and the
+ * generators make of them — and read them back with this call ([batch][num_public_inputs]) for qpgpu_prove*_dev. */
+int qpgpu_witness_public_inputs_dev(qpgpu_circuit *c, const uint64_t *d_wires, uint32_t batch, uint64_t *public_inputs_out);
 
 /* ---- stage-level entry points: the circuit-independent parts of prove() ---------------------------------------
  * For a patched `qp-plonky2::plonk::prover::prove` that keeps witness generation, partial products and the quotient

@@ -114,6 +114,7 @@ def load_library():
         "qpgpu_generate_witness_partial_dev": (c.c_int, [vp, u64p, u64p, c.c_size_t, u64p, u64p]),
         "qpgpu_generate_witness_partial_batch_dev": (c.c_int, [vp, u64p, c.c_size_t, u64p, u64p, c.c_uint32, u64p, vp]),
         "qpgpu_generate_witness_partial_batch_blinded_dev": (c.c_int, [vp, u64p, c.c_size_t, c.c_size_t, u64p, c.c_char_p, u64p, c.c_uint32, u64p, vp]),
+        "qpgpu_witness_public_inputs_dev": (c.c_int, [vp, u64p, c.c_uint32, u64p]),
         "qpgpu_witness_partial_prepare": (c.c_int, [vp, u64p, c.c_size_t, c.c_uint32]),
         "qpgpu_oracle_commit": (c.c_int, [vp, u64p, c.c_uint32, c.c_uint, c.c_uint, c.c_uint, c.c_uint, c.c_uint64, c.c_uint32,
                                           c.POINTER(vp)]),
@@ -331,6 +332,7 @@ class Circuit:
         gpu._check(gpu.lib.qpgpu_circuit_load_batch(gpu.ctx, pw.ctypes.data, pw.size, max_batch, ctypes.byref(h)))
         self.h = h
         self.max_batch = max_batch
+        self.num_public_inputs = int(pw[9])
 
     def scrub(self):
         """Overwrite every witness-derived device region of the workspace now."""
@@ -408,10 +410,10 @@ class Circuit:
         """`batch` PartialWitnesses over one cell list: values [batch, count], public_inputs [batch, num_pis], d_wires batch
         matrices back to back. Returns the per-witness status list (0 or -4); never raises for an unsatisfied witness."""
         cl = np.ascontiguousarray(cells, dtype=np.uint64); vl = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, cl.size)
-        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        p = None if public_inputs is None else np.ascontiguousarray(public_inputs, dtype=np.uint64)     # None: derived (witness_public_inputs_dev reads them)
         batch = vl.shape[0]
         status = (ctypes.c_int * batch)()
-        rc = self.gpu.lib.qpgpu_generate_witness_partial_batch_dev(self.h, cl.ctypes.data, cl.size, vl.ctypes.data, p.ctypes.data, batch,
+        rc = self.gpu.lib.qpgpu_generate_witness_partial_batch_dev(self.h, cl.ctypes.data, cl.size, vl.ctypes.data, None if p is None else p.ctypes.data, batch,
                                                                    _ptr(d_wires), status)
         if rc not in (0, -4):
             self.gpu._check(rc)
@@ -422,18 +424,25 @@ class Circuit:
         values [batch, count - n_blinding]; seeds: batch x 32 bytes for reproducible tests, None = OS entropy per witness."""
         cl = np.ascontiguousarray(cells, dtype=np.uint64)
         vl = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, cl.size - n_blinding)
-        p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        p = None if public_inputs is None else np.ascontiguousarray(public_inputs, dtype=np.uint64)
         batch = vl.shape[0]
         sd = None
         if seeds is not None:
             sd = bytes(seeds)
             assert len(sd) == 32 * batch
         status = (ctypes.c_int * batch)()
-        rc = self.gpu.lib.qpgpu_generate_witness_partial_batch_blinded_dev(self.h, cl.ctypes.data, cl.size, n_blinding, vl.ctypes.data, sd, p.ctypes.data, batch,
-                                                                           _ptr(d_wires), status)
+        rc = self.gpu.lib.qpgpu_generate_witness_partial_batch_blinded_dev(self.h, cl.ctypes.data, cl.size, n_blinding, vl.ctypes.data, sd,
+                                                                           None if p is None else p.ctypes.data, batch, _ptr(d_wires), status)
         if rc not in (0, -4):
             self.gpu._check(rc)
         return list(status)
+
+    def witness_public_inputs_dev(self, d_wires, batch=1):
+        """The public inputs of `batch` resident witnesses, [batch, num_public_inputs] (what plonky2's prove() reads out of the
+        partition witness)."""
+        out = np.empty((batch, self.num_public_inputs), dtype=np.uint64)
+        self.gpu._check(self.gpu.lib.qpgpu_witness_public_inputs_dev(self.h, _ptr(d_wires), batch, out.ctypes.data))
+        return out
 
     def witness_partial_prepare(self, cells, max_batch):
         cl = np.ascontiguousarray(cells, dtype=np.uint64)

@@ -26,6 +26,7 @@ struct WitnessPlan {
     std::vector<uint32_t> level_start;       // level l = insts[level_start[l] .. level_start[l+1])
     std::vector<uint32_t> level_poseidon;    // first PoseidonGate instance of level l (they come last in their level)
     std::vector<std::pair<uint32_t, uint32_t>> segments;   // launches: [l0, l1) — one wide level, or a run of narrow ones
+    bool pi_gate_from_hash = true;           // every PublicInputGate row takes its wires from a hash output through the copy pass
     uint32_t *d_level_start = nullptr, *d_level_poseidon = nullptr;
     std::vector<uint8_t> free_mask;          // [num_wires][n]: 1 = supplied by the caller
     uint64_t num_free = 0;
@@ -63,7 +64,7 @@ struct PartialPrep {
     uint32_t *d_scatter_idx = nullptr, *d_check_idx = nullptr, *d_keys = nullptr;   // d_keys: [cap][8], ChaCha20 keys of device-drawn values
     u64 *d_scatter_val = nullptr, *d_check_val = nullptr;   // [cap][count]
     uint32_t cap = 0;
-    bool valid = false;
+    bool valid = false, with_pis = true;          // with_pis: the public-input cells are assignments too (values supplied by the caller)
     void release() {
         for (void *q : {(void *)d_scatter_idx, (void *)d_check_idx, (void *)d_scatter_val, (void *)d_check_val, (void *)d_keys}) if (q) (void)hipFree(q);
         d_scatter_idx = d_check_idx = d_keys = nullptr; d_scatter_val = d_check_val = nullptr; cap = 0;
@@ -239,6 +240,7 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
                 size_t taken = 0;
                 for (const Cell &oc : io.out) if (oc.col < R && !producers[find((uint32_t)((u64)oc.row * R + oc.col))].empty()) taken++;
                 if (taken == io.out.size()) { dropped[id] = 1; continue; }
+                plan.pi_gate_from_hash = false;
                 if (taken) return "witness plan: PublicInputGate wires are only partly connected to a hash output (row " + std::to_string(insts[id].row) + ")";
             }
             for (const Cell &oc : io.out) {
@@ -453,7 +455,7 @@ int qpgpu_witness_free_mask(qpgpu_circuit *c, uint8_t *mask, size_t mask_len) {
 
 namespace {
 // Resolve an assignment list against the plan (see PartialPrep). Public inputs come first in the combined value vector.
-std::string prepare_partial(const CircuitPack &p, const WitnessPlan &plan, const uint64_t *cells, size_t count, PartialPrep &pp) {
+std::string prepare_partial(const CircuitPack &p, const WitnessPlan &plan, const uint64_t *cells, size_t count, PartialPrep &pp, bool with_pis) {
     const u64 n = p.n(), NW = p.num_wires, R = p.num_routed_wires;
     const uint32_t npis = (uint32_t)p.num_public_inputs;
     pp.cells.assign(cells, cells + count);
@@ -471,7 +473,8 @@ std::string prepare_partial(const CircuitPack &p, const WitnessPlan &plan, const
         else { pp.scatter_idx.push_back(key); pp.scatter_from.push_back(from); }   // a free class is read through its source cell
         return "";
     };
-    for (size_t i = 0; i < p.pi_cells.size(); i++) { const std::string e = assign(p.pi_cells[i], (uint32_t)i); if (!e.empty()) return e; }
+    pp.with_pis = with_pis;
+    for (size_t i = 0; with_pis && i < p.pi_cells.size(); i++) { const std::string e = assign(p.pi_cells[i], (uint32_t)i); if (!e.empty()) return e; }
     for (size_t i = 0; i < count; i++) { const std::string e = assign(cells[i], npis + (uint32_t)i); if (!e.empty()) return e; }
     return "";
 }
@@ -548,7 +551,7 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
     if (pp) QP_TRY(prep_device(ctx, *pp, batch));
     // everything the host sends goes up through the context's pinned bounce buffer and a copy kernel (ctx.hpp: read_back)
     const size_t ns = pp ? pp->scatter_idx.size() : 0, nc = pp ? pp->check_idx.size() : 0;
-    const size_t pi_bytes = plan.d_pi_idx ? (size_t)batch * npis * 8 : 0, hash_bytes = (size_t)batch * 32;
+    const size_t pi_bytes = plan.d_pi_idx && public_inputs ? (size_t)batch * npis * 8 : 0, hash_bytes = (size_t)batch * 32;
     const size_t sc_bytes = (size_t)batch * ns_host * 8, ck_bytes = (size_t)batch * nc * 8, key_bytes = n_blind ? (size_t)batch * 32 : 0;
     QP_TRY(ctx->reserve_read_back(pi_bytes + hash_bytes + sc_bytes + ck_bytes + key_bytes + (size_t)batch * 8));
     QP_HIP(ctx, hipStreamSynchronize(ctx->stream));       // nothing of an earlier call still reads the bounce buffer
@@ -556,7 +559,10 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
     if (pp) QP_HIP(ctx, hipMemsetAsync(d_wires, 0, (size_t)batch * stride * 8, ctx->stream));
     if (pi_bytes) std::memcpy(bounce, public_inputs, pi_bytes);
     u64 *pih = bounce + pi_bytes / 8;
-    for (uint32_t b = 0; b < batch; b++) host_pi_hash(ctx->hasher, public_inputs + (size_t)b * npis, npis, pih + 4 * b);
+    for (uint32_t b = 0; b < batch; b++) {
+        if (public_inputs) host_pi_hash(ctx->hasher, public_inputs + (size_t)b * npis, npis, pih + 4 * b);
+        else std::memset(pih + 4 * b, 0, 32);        // derived public inputs: no PublicInputGate generator reads it (pi_gate_from_hash)
+    }
     u64 *scv = pih + hash_bytes / 8, *ckv = scv + sc_bytes / 8;
     if (pp)
         for (uint32_t b = 0; b < batch; b++) {
@@ -642,15 +648,15 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
 }
 
 // the plan's prepared assignment list for `cells` (rebuilt when the caller's list changes)
-int ensure_prep(qpgpu_circuit *c, const uint64_t *cells, size_t count, uint32_t batch) {
+int ensure_prep(qpgpu_circuit *c, const uint64_t *cells, size_t count, uint32_t batch, bool with_pis = true) {
     qpgpu_ctx *ctx = c->ctx;
     WitnessPlan &plan = *c->wplan;
     if (!plan.prep) plan.prep = new PartialPrep();
     PartialPrep &pp = *plan.prep;
-    if (!pp.valid || pp.cells.size() != count || (count && std::memcmp(pp.cells.data(), cells, count * 8) != 0)) {
+    if (!pp.valid || pp.with_pis != with_pis || pp.cells.size() != count || (count && std::memcmp(pp.cells.data(), cells, count * 8) != 0)) {
         QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         pp.release();
-        const std::string err = prepare_partial(c->pack, plan, cells, count, pp);
+        const std::string err = prepare_partial(c->pack, plan, cells, count, pp, with_pis);
         if (!err.empty()) { pp.valid = false; return ctx->fail(QPGPU_EINVAL, err); }
         pp.valid = true;
     }
@@ -709,10 +715,12 @@ int qpgpu_generate_witness_partial_batch_dev(qpgpu_circuit *c, const uint64_t *c
     qpgpu_ctx *ctx = c->ctx;
     QP_DEV(ctx);
     const CircuitPack &p = c->pack;
-    if (!d_wires || batch == 0 || batch > 65535 || (count && (!cells || !values)) || (!public_inputs && p.num_public_inputs))
+    if (!d_wires || batch == 0 || batch > 65535 || (count && (!cells || !values)))
         return ctx->fail(QPGPU_EINVAL, "generate_witness_partial: null argument");
     QP_TRY(ensure_plan(c));
-    QP_TRY(ensure_prep(c, cells, count, batch));
+    if (!public_inputs && p.num_public_inputs && !c->wplan->pi_gate_from_hash)
+        return ctx->fail(QPGPU_EINVAL, "generate_witness_partial: public inputs can only be derived in a circuit whose PublicInputGate wires are copy-connected to the in-circuit hash of the public-input targets");
+    QP_TRY(ensure_prep(c, cells, count, batch, public_inputs != nullptr));
     return generate_batch(c, d_wires, batch, public_inputs, c->wplan->prep, values, status);
 }
 
@@ -722,16 +730,45 @@ int qpgpu_generate_witness_partial_batch_blinded_dev(qpgpu_circuit *c, const uin
     qpgpu_ctx *ctx = c->ctx;
     QP_DEV(ctx);
     const CircuitPack &p = c->pack;
-    if (!d_wires || batch == 0 || batch > 65535 || !cells || n_blinding > count || (count > n_blinding && !values) || (!public_inputs && p.num_public_inputs))
+    if (!d_wires || batch == 0 || batch > 65535 || !cells || n_blinding > count || (count > n_blinding && !values))
         return ctx->fail(QPGPU_EINVAL, "generate_witness_partial_blinded: null argument or more blinding cells than cells");
     QP_TRY(ensure_plan(c));
-    QP_TRY(ensure_prep(c, cells, count, batch));
+    if (!public_inputs && p.num_public_inputs && !c->wplan->pi_gate_from_hash)
+        return ctx->fail(QPGPU_EINVAL, "generate_witness_partial_blinded: public inputs can only be derived in a circuit whose PublicInputGate wires are copy-connected to the in-circuit hash of the public-input targets");
+    QP_TRY(ensure_prep(c, cells, count, batch, public_inputs != nullptr));
     return generate_batch(c, d_wires, batch, public_inputs, c->wplan->prep, values, status, n_blinding, seeds);
 }
 
 int qpgpu_generate_witness_partial_dev(qpgpu_circuit *c, const uint64_t *cells, const uint64_t *values, size_t count,
                                        const uint64_t *public_inputs, uint64_t *d_wires) {
     return qpgpu_generate_witness_partial_batch_dev(c, cells, count, values, public_inputs, 1, d_wires, nullptr);
+}
+
+// ProverCircuitData::prove reads the public inputs out of the partition witness (`get_targets(&prover_data.public_inputs)`): the
+// values at the public-input targets' cells of `batch` resident witnesses, [batch][num_public_inputs]
+int qpgpu_witness_public_inputs_dev(qpgpu_circuit *c, const uint64_t *d_wires, uint32_t batch, uint64_t *public_inputs_out) {
+    if (!c) return QPGPU_EINVAL;
+    qpgpu_ctx *ctx = c->ctx;
+    QP_DEV(ctx);
+    const CircuitPack &p = c->pack;
+    const size_t npis = p.num_public_inputs;
+    if (!d_wires || batch == 0 || batch > 65535 || (npis && !public_inputs_out)) return ctx->fail(QPGPU_EINVAL, "witness_public_inputs: bad argument");
+    if (npis == 0) return QPGPU_OK;
+    if (p.pi_cells.size() != npis) return ctx->fail(QPGPU_EINVAL, "witness_public_inputs: the circuit pack carries no public-input cell trailer");
+    QP_TRY(ensure_plan(c));
+    WitnessPlan &plan = *c->wplan;
+    if (plan.pi_cap < batch) {
+        QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (plan.d_pi_vals) { (void)hipFree(plan.d_pi_vals); plan.d_pi_vals = nullptr; }
+        if (plan.d_pi_hash) { (void)hipFree(plan.d_pi_hash); plan.d_pi_hash = nullptr; }
+        plan.pi_cap = 0;
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_hash, (size_t)batch * 32));
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_vals, (size_t)batch * npis * 8));
+        plan.pi_cap = batch;
+    }
+    const u64 stride = p.num_wires * p.n();
+    for (uint32_t b = 0; b < batch; b++) QP_HIP(ctx, wk_gather(d_wires + (size_t)b * stride, plan.d_pi_idx, plan.d_pi_vals + (size_t)b * npis, (uint32_t)npis, ctx->stream));
+    return ctx->read_back(public_inputs_out, plan.d_pi_vals, (size_t)batch * npis * 8);
 }
 
 int qpgpu_generate_witness(qpgpu_circuit *c, uint64_t *wires, const uint64_t *public_inputs) {

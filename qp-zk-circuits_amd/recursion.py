@@ -83,7 +83,7 @@ class WrapperCircuit:
             raise ValueError(err.value.decode())
         return out
 
-    def commit(self, proofs, preimages=None, query_indices=None, aggregator_address=None, public_inputs=None, blinding_seed=None, device_blinding=False):
+    def commit(self, proofs, preimages=None, query_indices=None, aggregator_address=None, public_inputs=None, blinding_seed=None, device_blinding=False, derive_public_inputs=False):
         """fill_private_batch_witness / fill_public_batch_witness + the query indices: (cells, values, public_inputs) of the
         wrapper's PartialWitness. Raises ValueError with the reference's message for a malformed proof. preimages: the dummy-nullifier
         preimages (private batch, N x 4 felts); aggregator_address: 32 bytes (public batch). With a batch logic the public inputs
@@ -91,7 +91,8 @@ class WrapperCircuit:
         -4 there when the slots violate a constraint the host restatement sees); public_inputs overrides them (tests: what the
         CIRCUIT says to slots the host restatement refuses). device_blinding=True (zero-knowledge circuits): the blinding cells are
         appended to the cell list WITHOUT values — Circuit.generate_witness_partial_batch_blinded_dev draws them on the device
-        (n_blinding = self.blinding_cells.size)."""
+        (n_blinding = self.blinding_cells.size). derive_public_inputs=True: the third element is None — the public inputs are
+        what the circuit computes (generate_wrapper_witnesses reads them back from the device witness), as in plonky2's prove()."""
         L = _lib()
         N = self.num_proofs
         pre = np.zeros(4 * N, dtype=np.uint64) if preimages is None else np.ascontiguousarray(preimages, dtype=np.uint64).reshape(-1).copy()
@@ -120,7 +121,9 @@ class WrapperCircuit:
         k = L.qpgpu_leaf_map_targets(t.ctypes.data, v.ctypes.data, t.size, self.target_map.ctypes.data, self.target_map.size, cells.ctypes.data, vals.ctypes.data)
         npis = int(self.inner_pack[9])
         pis = np.concatenate([np.frombuffer(p[-8 * npis:], dtype=np.uint64) if npis else np.zeros(0, dtype=np.uint64) for p in proofs])
-        if public_inputs is not None:
+        if derive_public_inputs:
+            pis = None
+        elif public_inputs is not None:
             pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         elif self.logic == "private_batch":
             from . import aggregation
@@ -143,7 +146,8 @@ def generate_wrapper_witnesses(circ, wrapper, commits, d_wires, seeds=None):
     """Stage s1 for a lockstep batch of one wrapper circuit's commits: values from the host, the blinding wires of a
     zero-knowledge wrapper drawn on the device when the commits were made with device_blinding=True. Returns the status list."""
     cells = commits[0][0]
-    vals = np.stack([c[1] for c in commits]); pis = np.stack([c[2] for c in commits])
+    vals = np.stack([c[1] for c in commits])
+    pis = None if commits[0][2] is None else np.stack([c[2] for c in commits])
     nb = cells.size - vals.shape[1]
     if nb:
         return circ.generate_witness_partial_batch_blinded_dev(cells, vals, pis, d_wires, nb, seeds)
@@ -188,7 +192,7 @@ class PrivateBatchProver:
             self.leaf_prover.close()
 
     def _fill(self, slot_proofs, preimages, blinding_seed=None):
-        self.committed = self.circuit.commit(slot_proofs, preimages=preimages, device_blinding=True)
+        self.committed = self.circuit.commit(slot_proofs, preimages=preimages, device_blinding=True, derive_public_inputs=True)
         self.blinding_seed = blinding_seed
         return self
 
@@ -216,7 +220,8 @@ class PrivateBatchProver:
         st = generate_wrapper_witnesses(self.circ, self.circuit, [commit], self.d_wires, self.blinding_seed)
         if any(st):
             raise QpGpuError(-4, self.gpu.last_error())
-        return self.circ.prove_dev(self.d_wires, commit[2])
+        # the public inputs are the circuit's: read out of the witness, as ProverCircuitData::prove does
+        return self.circ.prove_dev(self.d_wires, self.circ.witness_public_inputs_dev(self.d_wires)[0])
 
     def aggregate(self, leaf_proofs, seed=None):
         """PrivateBatchProver::aggregate (private_batch/prover/lib.rs:336-343): commit + prove."""
@@ -267,16 +272,18 @@ class PublicBatchProver:
             if not ok:
                 raise ValueError("private-batch proof %d failed verification against the pinned private-batch verifier" % i)
         padded = list(private_batch_proofs) + [self.dummy_private_batch_proof] * (self.M - len(private_batch_proofs))
-        self.committed = self.circuit.commit(padded, aggregator_address=aggregator_address)
+        self.committed = self.circuit.commit(padded, aggregator_address=aggregator_address, derive_public_inputs=True)
         return self
 
     def prove(self):
         if self.committed is None:
             raise ValueError("prove() before commit()")
-        cells, vals, pis = self.committed
+        commit = self.committed
         self.committed = None
-        self.circ.generate_witness_partial_dev(cells, vals, pis, self.d_wires)
-        return self.circ.prove_dev(self.d_wires, pis)
+        st = generate_wrapper_witnesses(self.circ, self.circuit, [commit], self.d_wires)
+        if any(st):
+            raise QpGpuError(-4, self.gpu.last_error())
+        return self.circ.prove_dev(self.d_wires, self.circ.witness_public_inputs_dev(self.d_wires)[0])
 
 
 class ProvingContext:
@@ -391,11 +398,12 @@ class AttestingTree:
             # per inner proof and, for the zero-knowledge circuit, ~0.6 M blinding values per batch from ChaCha20
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=min(8, len(self.my_batches))) as ex:
-                com1 = list(ex.map(lambda k: self.w1.commit(leaves[k * self.per_batch:(k + 1) * self.per_batch], preimages=pre[k], device_blinding=True), range(len(self.my_batches))))
+                com1 = list(ex.map(lambda k: self.w1.commit(leaves[k * self.per_batch:(k + 1) * self.per_batch], preimages=pre[k], device_blinding=True, derive_public_inputs=True), range(len(self.my_batches))))
             st = generate_wrapper_witnesses(self.w1_circ, self.w1, com1, self.d_wires)
             if any(st):
                 raise QpGpuError(-4, self.gpu.last_error())
-            level1 = self.w1_circ.prove_batch_dev([self.d_wires.ptr + 8 * k * self.words[1] for k in range(len(com1))], [c[2] for c in com1])
+            pis1 = self.w1_circ.witness_public_inputs_dev(self.d_wires, len(com1))        # the circuit's own outputs, as prove() reads them
+            level1 = self.w1_circ.prove_batch_dev([self.d_wires.ptr + 8 * k * self.words[1] for k in range(len(com1))], list(pis1))
         if self.world > 1:       # the one exchange of the tree: first-level proof bytes to the rank that proves the second level
             from . import sharding
             got = sharding.gather_proof_bytes(level1, dist, device, root=0)
@@ -407,8 +415,11 @@ class AttestingTree:
         t2 = time.perf_counter()
         root = None
         if self.rank == 0:
-            c2 = self.w2.commit(level1, aggregator_address=self.aggregator_address)
-            root = self._level(self.w2_circ, self.words[2], c2[0], c2[1][None], c2[2][None])[0]
+            c2 = self.w2.commit(level1, aggregator_address=self.aggregator_address, derive_public_inputs=True)
+            st = generate_wrapper_witnesses(self.w2_circ, self.w2, [c2], self.d_wires)
+            if any(st):
+                raise QpGpuError(-4, self.gpu.last_error())
+            root = self.w2_circ.prove_dev(self.d_wires, self.w2_circ.witness_public_inputs_dev(self.d_wires)[0])
         t3 = time.perf_counter()
         self.times = {"leaf_level_s": round(t1 - t0, 4), "first_level_s": round(t2 - t1, 4), "second_level_s": round(t3 - t2, 4)}
         return leaves, level1, root

@@ -191,3 +191,41 @@ def test_leaf_circuit_under_the_poseidon2_hasher(pkg, orc, L):
         pr.close(); g2.close()
     finally:
         pkg.set_hasher_poseidon(); orc.select_poseidon()
+
+
+def test_public_inputs_read_out_of_the_witness(pkg, gpu, orc, L, full, prover):
+    """plonky2's prove() does not take public inputs, it reads them out of the generated witness
+    (`partition_witness.get_targets(&prover_data.public_inputs)`). The same through the C ABI: stage s1 with public_inputs = NULL —
+    the public-input targets are then just what fill_witness assigns and the generators compute — and
+    qpgpu_witness_public_inputs_dev afterwards. Same witness, same public inputs, same proof as with the public inputs handed in;
+    a synthetic pack whose PublicInputGate takes a host-computed hash cannot derive them (QPGPU_EINVAL)."""
+    xs = [lc.real_inputs(L, depth=6, seed=77), lc.dummy_inputs(L), lc.test_inputs(L, 1)]
+    com = [full.commit(x) for x in xs]
+    cells = com[0][0]; vals = np.stack([c[1] for c in com]); pis = np.stack([c[2] for c in com])
+    nw, n = prover.shape
+    d = gpu.alloc(3 * nw * n * 8)
+    circ = pkg.Circuit(gpu, full.pack, max_batch=3)
+    assert circ.generate_witness_partial_batch_dev(cells, vals, pis, d) == [0, 0, 0]
+    want = d.download().copy()
+    assert circ.generate_witness_partial_batch_dev(cells, vals, None, d) == [0, 0, 0]
+    assert np.array_equal(d.download(), want)
+    got = circ.witness_public_inputs_dev(d, 3)
+    assert got.tolist() == pis.tolist()
+    proofs = circ.prove_batch_dev([d.ptr + 8 * k * nw * n for k in range(3)], list(got))
+    for k, x in enumerate(xs):
+        assert proofs[k] == prover.prove(x)[0]
+    # an input the circuit has no witness for is still named (the block hash the header does not hash to)
+    bad = xs[0].copy(); bad.block_hash[3] ^= 1
+    c_ = full.commit(bad)
+    st = circ.generate_witness_partial_batch_dev(c_[0], c_[1][None], None, d)
+    assert st == [-4] and "set twice with different values" in gpu.last_error()
+    circ.close(); d.free(scrub=True)
+    # a pack whose PublicInputGate wires are NOT fed by an in-circuit hash (the synthetic test circuits)
+    sp, wires, spis = pkg.synth_circuit(degree_bits=6, num_public_inputs=3, seed=2) if hasattr(pkg, "synth_circuit") else (None, None, None)
+    if sp is not None:
+        sc = pkg.Circuit(gpu, sp)
+        ds = gpu.alloc(wires.size * 8)
+        with pytest.raises(pkg.QpGpuError) as e:
+            sc.generate_witness_partial_batch_dev(np.zeros(1, dtype=np.uint64), wires[:1, :1], None, ds)
+        assert "can only be derived" in str(e.value)
+        sc.close(); ds.free()
