@@ -89,6 +89,9 @@ extern "C" {
     pub fn qpgpu_generate_witness_partial_batch_blinded_dev(c: *mut QpgpuCircuit, cells: *const u64, count: usize, n_blinding: usize, values: *const u64,
                                                             seeds: *const u8, public_inputs: *const u64, batch: u32, d_wires: *mut u64, status: *mut i32) -> i32;
     pub fn qpgpu_random_field_elements(seed32: *const u8, out: *mut u64, n: usize, err: *mut c_char) -> i32;
+    // with stage s1 on the device the public inputs are read out of the device witness, the way `prove` reads them out of the
+    // partition witness: pass public_inputs = null to the generate_witness_partial* calls, then this, then qpgpu_prove*_dev
+    pub fn qpgpu_witness_public_inputs_dev(c: *mut QpgpuCircuit, d_wires: *const u64, batch: u32, public_inputs_out: *mut u64) -> i32;
     // include/qpgpu_leaf.h, include/qpgpu_batch.h — the circuits built by the library itself: only for
     // deployments that take BOTH prover and verifier data from it; with exported packs of the fork's own circuits these are not used
     pub fn qpgpu_leaf_circuit_build(fragment: u32, min_degree_bits: u32, inner_hasher: i32, p2_layout: *const u64, pack_out: *mut u64, pack_cap_words: usize,
