@@ -358,6 +358,12 @@ int qpgpu_pool_submit_host(qpgpu_pool *p, const uint64_t *wires, const uint64_t 
  * from the committed assignments on. `values` (as many words as the cell list) are copied at submit and wiped after use; an
  * unsatisfiable witness fails its own ticket with QPGPU_EUNSAT and the target's name, the rest of its batch is proven. */
 int qpgpu_pool_set_partial_cells(qpgpu_pool *p, const uint64_t *cells, size_t count);
+/* The same for a zero-knowledge circuit: the LAST n_blinding cells are the blinding rows' random wires, drawn on the device for
+ * every proof (qpgpu_generate_witness_partial_batch_blinded_dev, operating-system entropy); a job's `values` then has
+ * count - n_blinding words. public_inputs may be NULL in qpgpu_pool_submit_partial: the job is proven with the public inputs its
+ * witness holds (they are the last num_public_inputs words of the proof) — the batch layers, whose public inputs the circuit
+ * computes; public inputs that ARE handed in are compared with the witness's (QPGPU_EUNSAT when they differ). */
+int qpgpu_pool_set_partial_cells_blinded(qpgpu_pool *p, const uint64_t *cells, size_t count, size_t n_blinding);
 int qpgpu_pool_submit_partial(qpgpu_pool *p, const uint64_t *values, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, uint64_t *ticket);
 int qpgpu_pool_wait(qpgpu_pool *p, uint64_t ticket, size_t *out_len);
 

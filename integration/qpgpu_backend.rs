@@ -81,6 +81,7 @@ extern "C" {
     pub fn qpgpu_pool_last_error(p: *const QpgpuPool) -> *const c_char;
     pub fn qpgpu_pool_submit_host(p: *mut QpgpuPool, wires: *const u64, public_inputs: *const u64, out: *mut u8, out_cap: usize, ticket: *mut u64) -> i32;
     pub fn qpgpu_pool_set_partial_cells(p: *mut QpgpuPool, cells: *const u64, count: usize) -> i32;
+    pub fn qpgpu_pool_set_partial_cells_blinded(p: *mut QpgpuPool, cells: *const u64, count: usize, n_blinding: usize) -> i32;
     pub fn qpgpu_pool_submit_partial(p: *mut QpgpuPool, values: *const u64, public_inputs: *const u64, out: *mut u8, out_cap: usize, ticket: *mut u64) -> i32;
     pub fn qpgpu_pool_wait(p: *mut QpgpuPool, ticket: u64, out_len: *mut usize) -> i32;
     // include/qpgpu.h, include/qpgpu_batch.h — zero-knowledge circuits (the private-batch layer): the blinding rows' random wires are

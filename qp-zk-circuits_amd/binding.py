@@ -101,6 +101,7 @@ def load_library():
         "qpgpu_pool_devices": (c.c_uint, [vp]),
         "qpgpu_pool_serialized": (c.c_int, [vp]),
         "qpgpu_pool_set_partial_cells": (c.c_int, [vp, u64p, c.c_size_t]),
+        "qpgpu_pool_set_partial_cells_blinded": (c.c_int, [vp, u64p, c.c_size_t, c.c_size_t]),
         "qpgpu_pool_submit_on": (c.c_int, [vp, c.c_uint, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
         "qpgpu_pool_submit_host": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
         "qpgpu_pool_submit_partial": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_uint64)]),
@@ -718,20 +719,23 @@ class ProvingPool:
         rc = self.lib.qpgpu_pool_submit_host(self.h, w.ctypes.data, p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(t))
         return self._submitted(rc, t, (p, out, w))
 
-    def set_partial_cells(self, cells):
+    def set_partial_cells(self, cells, n_blinding=0):
+        """n_blinding: the last n_blinding cells are the blinding wires of a zero-knowledge circuit, drawn on the device per proof."""
         cl = np.ascontiguousarray(cells, dtype=np.uint64)
-        rc = self.lib.qpgpu_pool_set_partial_cells(self.h, cl.ctypes.data, cl.size)
+        rc = self.lib.qpgpu_pool_set_partial_cells_blinded(self.h, cl.ctypes.data, cl.size, n_blinding)
         if rc != 0:
             raise QpGpuError(rc, self.lib.qpgpu_pool_last_error(self.h).decode())
-        self._ncells = cl.size
+        self._ncells = cl.size - n_blinding
 
     def submit_partial(self, values, public_inputs, out=None):
-        """A PartialWitness over the pool's cell list: stage s1 on the device, then the proof."""
-        v = np.ascontiguousarray(values, dtype=np.uint64); p = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        """A PartialWitness over the pool's cell list: stage s1 on the device, then the proof. public_inputs=None: the proof carries
+        the public inputs its witness holds (circuits that compute them)."""
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        p = None if public_inputs is None else np.ascontiguousarray(public_inputs, dtype=np.uint64)
         assert v.size == self._ncells
         out = np.empty(self.proof_size(), dtype=np.uint8) if out is None else out
         t = ctypes.c_uint64()
-        rc = self.lib.qpgpu_pool_submit_partial(self.h, v.ctypes.data, p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(t))
+        rc = self.lib.qpgpu_pool_submit_partial(self.h, v.ctypes.data, None if p is None else p.ctypes.data, out.ctypes.data, out.size, ctypes.byref(t))
         return self._submitted(rc, t, (p, out, None))
 
     def wait(self, ticket, copy=True):

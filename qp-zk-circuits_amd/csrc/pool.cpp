@@ -56,6 +56,7 @@ struct qpgpu_pool {
     unsigned max_batch = 1;          // proofs a worker takes from the queue at once and proves in lockstep
     size_t wit_words = 0, num_pis = 0;    // words of one wire matrix; public inputs per proof
     std::vector<uint64_t> cells;     // the prepared PartialWitness cell list (qpgpu_pool_set_partial_cells)
+    size_t n_blinding = 0;           // its last n_blinding cells are drawn on the device per proof (qpgpu_pool_set_partial_cells_blinded)
     bool host_witness = false;       // workers own a witness workspace of max_batch matrices
     // Under a profiler that intercepts the HSA queues (rocprofv3) the workers take turns on the device: one thread submits at a
     // time. rocprofiler-sdk's queue-write interceptor has faulted (a read one AQL packet slot past a mapping) in multi-worker
@@ -116,6 +117,7 @@ void worker(qpgpu_pool *p, size_t wi) {
         std::vector<std::string> errs(nb);
         std::vector<size_t> lens(nb, 0);
         std::vector<const uint64_t *> wires(nb), pis(nb);
+        std::vector<uint64_t> derived_pis;           // JOB_PARTIAL: the public inputs the batch is proven with (supplied or read out of the witnesses)
         std::vector<uint8_t *> outs(nb);
         for (uint32_t i = 0; i < nb; i++) { wires[i] = js[i].wires; pis[i] = js[i].public_inputs; outs[i] = js[i].out; }
         if (js[0].kind == JOB_HOST) {
@@ -128,17 +130,39 @@ void worker(qpgpu_pool *p, size_t wi) {
             if (e == hipSuccess) e = hipStreamSynchronize(w.ctx->stream);
             if (e != hipSuccess) { for (uint32_t i = 0; i < nb; i++) { rcs[i] = QPGPU_EDEVICE; errs[i] = std::string("pool: witness upload: ") + hipGetErrorString(e); } finish(p, js, rcs, lens, errs); continue; }
         } else if (js[0].kind == JOB_PARTIAL) {
-            // stage s1 for the whole batch: WormholeProver::commit's assignments -> generate_partial_witness on the device
-            const size_t count = p->cells.size();
+            // stage s1 for the whole batch: WormholeProver::commit's assignments -> generate_partial_witness on the device. The
+            // last n_blinding cells of the list are drawn on the device; a job submitted without public inputs takes them out
+            // of its witness afterwards (then the whole batch is generated that way and supplied ones are compared)
+            const size_t all_cells = p->cells.size(), count = all_cells - p->n_blinding;
+            bool derive = false;
+            for (uint32_t i = 0; i < nb; i++) derive = derive || (p->num_pis && !js[i].public_inputs);
             std::vector<uint64_t> vals((size_t)nb * count), pv((size_t)nb * p->num_pis);
             for (uint32_t i = 0; i < nb; i++) {
                 std::memcpy(vals.data() + (size_t)i * count, js[i].values.data(), count * 8);
-                if (p->num_pis) std::memcpy(pv.data() + (size_t)i * p->num_pis, js[i].public_inputs, p->num_pis * 8);
+                if (p->num_pis && js[i].public_inputs) std::memcpy(pv.data() + (size_t)i * p->num_pis, js[i].public_inputs, p->num_pis * 8);
                 wipe(js[i].values);
                 wires[i] = w.d_wit + (size_t)i * p->wit_words;
             }
             std::vector<int> st(nb, QPGPU_OK);
-            int rc = qpgpu_generate_witness_partial_batch_dev(w.circ, p->cells.data(), count, vals.data(), pv.data(), nb, w.d_wit, st.data());
+            auto generate = [&](const uint64_t *v, const uint64_t *pi, uint32_t batch, uint64_t *dst, int *status) {
+                return p->n_blinding ? qpgpu_generate_witness_partial_batch_blinded_dev(w.circ, p->cells.data(), all_cells, p->n_blinding, v, nullptr, pi, batch, dst, status)
+                                     : qpgpu_generate_witness_partial_batch_dev(w.circ, p->cells.data(), all_cells, v, pi, batch, dst, status);
+            };
+            int rc = generate(vals.data(), derive ? nullptr : pv.data(), nb, w.d_wit, st.data());
+            if ((rc == QPGPU_OK || rc == QPGPU_EUNSAT) && derive) {
+                std::vector<uint64_t> got((size_t)nb * p->num_pis);
+                const int rr = qpgpu_witness_public_inputs_dev(w.circ, w.d_wit, nb, got.data());
+                if (rr != QPGPU_OK) rc = rr;
+                else
+                    for (uint32_t i = 0; i < nb; i++) {
+                        if (js[i].public_inputs && st[i] == QPGPU_OK && std::memcmp(got.data() + (size_t)i * p->num_pis, pv.data() + (size_t)i * p->num_pis, p->num_pis * 8) != 0) {
+                            st[i] = QPGPU_EUNSAT; rc = QPGPU_EUNSAT;
+                        }
+                        std::memcpy(pv.data() + (size_t)i * p->num_pis, got.data() + (size_t)i * p->num_pis, p->num_pis * 8);
+                    }
+            }
+            derived_pis.swap(pv);
+            for (uint32_t i = 0; i < nb; i++) pis[i] = derived_pis.data() + (size_t)i * p->num_pis;
             if (rc != QPGPU_OK && rc != QPGPU_EUNSAT) {
                 for (uint32_t i = 0; i < nb; i++) { rcs[i] = rc; errs[i] = qpgpu_last_error(w.ctx); }
                 wipe(vals);
@@ -155,8 +179,8 @@ void worker(qpgpu_pool *p, size_t wi) {
                     bool slot_free = true;
                     for (uint32_t k = 0; k < nb; k++) if (st[k] == QPGPU_OK && wires[k] == scratch) slot_free = false;
                     if (slot_free && nb > 1) {
-                        (void)qpgpu_generate_witness_partial_batch_dev(w.circ, p->cells.data(), count, vals.data() + (size_t)i * count, pv.data() + (size_t)i * p->num_pis, 1, scratch, nullptr);
-                        errs[i] = qpgpu_last_error(w.ctx);
+                        const int r1 = generate(vals.data() + (size_t)i * count, js[i].public_inputs ? js[i].public_inputs : nullptr, 1, scratch, nullptr);
+                        errs[i] = r1 == QPGPU_OK ? "witness generation: the public inputs handed in are not the ones the circuit computes" : std::string(qpgpu_last_error(w.ctx));
                     } else errs[i] = nb > 1 ? "witness generation: a target was set twice with different values" : std::string(qpgpu_last_error(w.ctx));
                 }
             }
@@ -211,10 +235,10 @@ int submit(qpgpu_pool *p, Job &&j, uint64_t *ticket) {
     return QPGPU_OK;
 }
 // a job is checked on its own at submit, so that a bad one cannot reach a lockstep batch of other callers' proofs
-int check_job(qpgpu_pool *p, const void *witness, const uint64_t *public_inputs, const uint8_t *out, size_t out_cap, uint64_t *ticket) {
+int check_job(qpgpu_pool *p, const void *witness, const uint64_t *public_inputs, const uint8_t *out, size_t out_cap, uint64_t *ticket, bool pis_optional = false) {
     if (!p || !ticket) return QPGPU_EINVAL;
     const size_t need = qpgpu_pool_proof_size(p);
-    if (!witness || !out || (p->num_pis && !public_inputs) || out_cap < need) {
+    if (!witness || !out || (p->num_pis && !public_inputs && !pis_optional) || out_cap < need) {
         std::lock_guard<std::mutex> lk(p->mu);
         const bool small = out_cap < need && witness && out;
         p->err = small ? "pool_submit: output buffer smaller than the proof (" + std::to_string(out_cap) + " < " + std::to_string(need) + " bytes)" : "pool_submit: null argument";
@@ -298,8 +322,9 @@ int qpgpu_pool_set_witness_check(qpgpu_pool *p, int on) {
     return QPGPU_OK;
 }
 
-int qpgpu_pool_set_partial_cells(qpgpu_pool *p, const uint64_t *cells, size_t count) {
-    if (!p || (count && !cells)) return QPGPU_EINVAL;
+int qpgpu_pool_set_partial_cells(qpgpu_pool *p, const uint64_t *cells, size_t count) { return qpgpu_pool_set_partial_cells_blinded(p, cells, count, 0); }
+int qpgpu_pool_set_partial_cells_blinded(qpgpu_pool *p, const uint64_t *cells, size_t count, size_t n_blinding) {
+    if (!p || (count && !cells) || n_blinding > count) return QPGPU_EINVAL;
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->queue.empty() || p->next_ticket != p->oldest_live) { p->err = "pool_set_partial_cells: jobs in flight"; return QPGPU_EINVAL; }
     if (ensure_workspace(p) != QPGPU_OK) return QPGPU_EDEVICE;
@@ -308,6 +333,7 @@ int qpgpu_pool_set_partial_cells(qpgpu_pool *p, const uint64_t *cells, size_t co
         if (rc != QPGPU_OK) { p->err = qpgpu_last_error(w.ctx); return rc; }
     }
     p->cells.assign(cells, cells + count);
+    p->n_blinding = n_blinding;
     return QPGPU_OK;
 }
 
@@ -327,10 +353,10 @@ int qpgpu_pool_submit_host(qpgpu_pool *p, const uint64_t *wires, const uint64_t 
     return submit(p, Job{0, JOB_HOST, -1, wires, public_inputs, out, out_cap, {}}, ticket);
 }
 int qpgpu_pool_submit_partial(qpgpu_pool *p, const uint64_t *values, const uint64_t *public_inputs, uint8_t *out, size_t out_cap, uint64_t *ticket) {
-    const int rc = check_job(p, values, public_inputs, out, out_cap, ticket);
+    const int rc = check_job(p, values, public_inputs, out, out_cap, ticket, true);
     if (rc != QPGPU_OK) return rc;
     if (p->cells.empty()) { std::lock_guard<std::mutex> lk(p->mu); p->err = "pool_submit_partial: no cell list (qpgpu_pool_set_partial_cells)"; return QPGPU_EINVAL; }
-    Job j{0, JOB_PARTIAL, -1, nullptr, public_inputs, out, out_cap, std::vector<uint64_t>(values, values + p->cells.size())};
+    Job j{0, JOB_PARTIAL, -1, nullptr, public_inputs, out, out_cap, std::vector<uint64_t>(values, values + (p->cells.size() - p->n_blinding))};
     return submit(p, std::move(j), ticket);
 }
 

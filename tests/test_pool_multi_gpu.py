@@ -91,3 +91,48 @@ def test_leaf_c_example_runs(pkg):
     res = subprocess.run([out, "0", "0,0", "2", "4", "2"], capture_output=True, text=True, timeout=180)
     assert res.returncode == 0, res.stderr + res.stdout
     assert "ok devices=2 workers=2 lockstep=4" in res.stdout and "unsatisfiable job alone" in res.stdout
+
+
+def test_private_batches_through_the_pool(pkg, gpu, orc):
+    """The private layer through the multi-device pool (two worker sets on the one GPU): a zero-knowledge private-batch circuit
+    over two leaf proofs, jobs = fill_private_batch_witness's values only — the blinding wires are drawn on the device
+    (qpgpu_pool_set_partial_cells_blinded), the public inputs are read out of each job's witness (public_inputs = NULL) — and every
+    proof verifies and carries the public inputs the host restatement predicts; a job that hands in OTHER public inputs, or inner
+    proofs the layer does not accept, fails alone."""
+    import leaf_cases as lc
+    import oracle_binding as ob
+    L, R, A = pkg.leaf, pkg.recursion, pkg.aggregation
+    leaf = L.LeafCircuit()
+    lp = L.LeafProver(pkg, gpu, leaf)
+    sp = lc.shared_tree_inputs(L, 3, seed=31)
+    proofs = [lp.prove(x)[0] for x in sp] + [lp.prove(lc.dummy_inputs(L))[0]]
+    other = lp.prove(lc.real_inputs(L, depth=2))[0]
+    ver = pkg.Verifier(leaf.pack, circuit=lp.circ)
+    w = R.WrapperCircuit(leaf.pack, ver, 2, num_routed_wires=60, logic="private_batch", verify=True, zero_knowledge=True)
+    pool = pkg.ProvingPool(w.pack, workers=1, devices=[0, 0], max_batch=2)
+    pre = [np.arange(8, dtype=np.uint64).reshape(2, 4) + 10 * k for k in range(4)]
+    slots = [[proofs[0], proofs[1]], [proofs[3], proofs[2]], [proofs[1], proofs[3]], [proofs[2], proofs[0]]]
+    com = [w.commit(s, preimages=pre[k], device_blinding=True) for k, s in enumerate(slots)]
+    pool.set_partial_cells(com[0][0], n_blinding=w.blinding_cells.size)
+    tickets = [pool.submit_partial(c[1], None) for c in com]
+    # the same slots with the host restatement's public inputs handed in (compared with the witness's), with wrong ones, and slots
+    # of two blocks
+    t_given = pool.submit_partial(com[0][1], com[0][2])
+    wrong = com[0][2].copy(); wrong[8] += 1
+    t_wrong = pool.submit_partial(com[0][1], wrong)
+    bad = w.commit([proofs[0], other], preimages=pre[0], device_blinding=True, public_inputs=com[0][2])
+    t_bad = pool.submit_partial(bad[1], None)
+    wv = pkg.Verifier(w.pack)
+    npis = A.private_batch_pi_len(2)
+    for k, t in enumerate(tickets + [t_given]):
+        proof = pool.wait(t)
+        assert wv.verify(proof), k
+        assert A.proof_public_inputs(proof, npis).tolist() == com[k % 4][2].tolist(), k
+    for t in (t_wrong, t_bad):
+        with pytest.raises(pkg.QpGpuError) as e:
+            pool.wait(t)
+        assert e.value.code == -4
+    oc = ob.OracleCircuit(orc, w.pack)
+    assert oc.verify(pool.wait(pool.submit_partial(com[1][1], None))) == 0
+    oc.close()
+    pool.close(); wv.close(); ver.close(); lp.close()
