@@ -413,3 +413,21 @@ def test_public_batch_preflight_and_dummy_template():
     assert "non-zero exit account at slot 0" in call(L.qpgpu_dummy_private_batch_template_check, marked.ctypes.data, marked.size)[1]
     paying = inner_dummy.copy(); paying[13] = 3
     assert "non-zero payout at slot 1 (3)" in call(L.qpgpu_dummy_private_batch_template_check, paying.ctypes.data, paying.size)[1]
+
+
+def test_random_field_elements():
+    """qpgpu_random_field_elements (RandomValueGenerator's F::rand() for the blinding wires of a zero-knowledge circuit): canonical,
+    reproducible under a seed, fresh without one."""
+    L.qpgpu_random_field_elements.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p]
+    L.qpgpu_random_field_elements.restype = ctypes.c_int
+    err = ctypes.create_string_buffer(200)
+    def draw(seed, n=4096):
+        out = np.empty(n, dtype=np.uint64)
+        assert L.qpgpu_random_field_elements(seed, out.ctypes.data, n, err) == 0
+        return out
+    a, b, c, d = draw(bytes(32)), draw(bytes(32)), draw(bytes([1] * 32)), draw(None)
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, d) and not np.array_equal(d, draw(None))
+    for v in (a, c, d):
+        assert int(v.max()) < 0xFFFFFFFF00000001 and len(np.unique(v)) == v.size
+    assert abs(float((d >> np.uint64(63)).mean()) - 0.5) < 0.05
+    assert L.qpgpu_random_field_elements(None, None, 4, err) != 0
