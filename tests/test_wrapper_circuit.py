@@ -153,3 +153,41 @@ def test_full_verification_in_circuit(pkg, orc, setup):
     with pytest.raises(pkg.QpGpuError) as e:
         pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, transcript=False, verify=True)
     assert "needs the in-circuit transcript" in str(e.value)
+
+
+def test_recursion_under_the_poseidon2_hasher(pkg, orc):
+    """Were the fork's proof-system hasher Poseidon2, every hash of the recursive verifier — public-input
+    hash, transcript, Merkle paths — would be rows of the Poseidon2 gate (with its swap wire) instead of PoseidonGate rows, and the
+    inner circuit's own Poseidon2 rows are what the vanishing polynomial evaluates. The same builder code under inner_hasher = 1,
+    proof system (oracle and host verifier) switched to Poseidon2 with qp-poseidon-core's parameters."""
+    L = pkg.leaf
+    qp = pkg.poseidon2_qp_params()
+    pkg.set_hasher_poseidon2(*qp); orc.select_poseidon2(*qp)
+    try:
+        leaf = L.LeafCircuit(inner_hasher=1)
+        xs = lc.shared_tree_inputs(L, 2) + [lc.dummy_inputs(L)]
+        com = [leaf.commit(x) for x in xs]
+        op = ob.OracleProver(orc, leaf.pack)
+        proofs = op.commit_prove_many(com[0][0], np.stack([c[1] for c in com]), np.stack([c[2] for c in com]))
+        op.close()
+        ver = pkg.Verifier(leaf.pack, hasher=1)
+        assert all(ver.verify(p) for p in proofs)
+        w = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, inner_hasher=1, logic="private_batch", verify=True)
+        assert w.info["rows_poseidon"] == 0 and w.info["degree_bits"] == 13
+        pre = np.arange(8, dtype=np.uint64).reshape(2, 4)
+        c = w.commit([proofs[0], proofs[2]], preimages=pre)
+        rc, wires, _ = orc.generate_witness(w.pack, *c)
+        assert rc == orc.WIT_OK
+        oc = ob.OracleCircuit(orc, w.pack)
+        proof = oc.prove(wires, c[2])
+        assert oc.verify(proof) == 0
+        oc.close()
+        wv = pkg.Verifier(w.pack, hasher=1)
+        assert wv.verify(proof)
+        wv.close()
+        bad = bytearray(proofs[0]); bad[len(bad) // 2] ^= 1
+        c = w.commit([bytes(bad), proofs[2]], preimages=pre, public_inputs=c[2])
+        assert orc.generate_witness(w.pack, *c)[0] == orc.WIT_CONFLICT
+        ver.close()
+    finally:
+        pkg.set_hasher_poseidon(); orc.select_poseidon()
