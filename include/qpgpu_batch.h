@@ -164,18 +164,18 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
                                    size_t num_proof_targets, const uint64_t *dummy_nullifier_preimages, size_t num_preimages, size_t num_preimage_targets,
                                    const char *label, uint32_t *targets_out, uint64_t *values_out, size_t cap, size_t *count, char *err);
 
-/* ---- a wrapper circuit that checks the Merkle half of its inner proofs (csrc/wrapper_circuit.cpp) ------------------------
- * add_recursive_verifiers (wormhole/aggregator/src/common/recursive.rs:74-102) restated on the library's native builder as far
- * as the commitments go: `num_proofs` proof targets of the circuit `inner_pack` (logical targets in the order above), and for
- * every proof and every query round the in-circuit Merkle verification of its four opened rows and of every FRI step's coset of
- * evaluations (hash the row with PoseidonGate rows, one permute_swapped per path level, RandomAccessGate look-up of the cap entry)
- * against the inner circuit's constants/sigmas cap (`inner_cs_cap`, 4 << cap_height words: qpgpu_circuit_constants_sigmas_cap of the
- * loaded inner circuit; it becomes constants of the wrapper) and against the caps the proof carries. The inner public inputs are
- * the wrapper's public inputs (proof 0's first); their hash is computed as verify_proof does.
- * NOT verified in-circuit (csrc/wrapper_circuit.cpp says so at length): the transcript — the query indices are therefore inputs
- * (logical targets below; take them from qpgpu_verifier_query_indices) —, the openings at zeta, the folding arithmetic, the proof
- * of work. A flipped byte in an opened row, an evaluation or a sibling of an inner proof makes the wrapper's witness
- * unsatisfiable (QPGPU_EUNSAT at witness generation, naming the target).
+/* ---- the recursive verifier and the two batch circuits (csrc/wrapper_circuit.cpp) -------------------------------------------
+ * add_recursive_verifiers (wormhole/aggregator/src/common/recursive.rs:74-102) restated on the library's native builder:
+ * `num_proofs` proof targets of the circuit `inner_pack` (logical targets in the order above) and verify_proof on each. Without
+ * flags: the commitment half — for every proof and every query round the in-circuit Merkle verification of its four opened rows
+ * and of every FRI step's coset of evaluations (hash the row with PoseidonGate rows, one permute_swapped per path level,
+ * RandomAccessGate look-up of the cap entry) against the inner circuit's constants/sigmas cap (`inner_cs_cap`, 4 << cap_height
+ * words: qpgpu_circuit_constants_sigmas_cap of the loaded inner circuit; it becomes constants of the wrapper) and against the caps
+ * the proof carries, the query indices being inputs (qpgpu_verifier_query_indices); the inner public inputs are forwarded. The
+ * flags below add the transcript, the arithmetic half (with both: everything VerifierCircuitData::verify checks), the two batch
+ * layers' own constraints and the private layer's zero-knowledge configuration. A flipped byte of an inner proof makes the
+ * wrapper's witness unsatisfiable (QPGPU_EUNSAT at witness generation, naming the target). examples/batch_prove_example.c drives
+ * both layers from C.
  * Logical targets of the wrapper, target_map_out[...] = wire cell or UINT64_MAX: proof slot i target j -> i * T + j (T =
  * qpgpu_proof_target_count); dummy-nullifier preimage limb -> N * T + 4 i + limb (assigned by fill_private_batch_witness, unused
  * here); query index q of slot i -> N * (T + 4) + i * Q + q. num_routed_wires: 80 (public batch) or 60 (private batch),
@@ -187,8 +187,7 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
  * PoseidonGate rows: circuit digest, public-input hash, caps, openings, FRI caps, final polynomial, proof-of-work witness, in the
  * prover's order), the proof-of-work response is range-checked (fri_verify_proof_of_work) and the 28 query indices are the low
  * bits of the transcript's challenges instead of inputs: the query-index logical targets then map to UINT64_MAX and need no
- * assignment. Still not in-circuit with this flag: the openings against the vanishing polynomial at zeta and the folding
- * arithmetic (the Plonk / FRI challenges are derived but not yet consumed). */
+ * assignment. The Plonk / FRI challenges are derived too; QPGPU_WRAPPER_VERIFY consumes them. */
 #define QPGPU_WRAPPER_TRANSCRIPT 1u
 /* QPGPU_WRAPPER_PRIVATE_BATCH — the private-batch layer's own logic on top (build_private_batch_constraints,
  * wormhole/aggregator/src/private_batch/circuit/circuit_logic.rs:171-477): the inner circuit must have the leaf's 21 public inputs;

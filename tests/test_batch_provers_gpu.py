@@ -84,3 +84,19 @@ def test_two_layers_from_circuit_inputs(pkg, gpu, orc):
         pub.commit([bytes(bad)])
     assert "private-batch proof 0 failed verification" in str(e.value)
     pub.close(); priv.close()
+
+
+def test_batch_c_example_runs(pkg):
+    """examples/batch_prove_example.c: both aggregation layers from plain C — CircuitInputs -> leaf proofs -> zero-knowledge private
+    batch -> public batch, circuits built by the library, blinding wires and public inputs on the device, every proof verified."""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tempfile.gettempdir(), "qpgpu_batch_prove_example_gpu")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "batch_prove_example.c"),
+                           "-L", os.path.join(root, "qp-zk-circuits_amd"), "-lqpgpu", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(root, "qp-zk-circuits_amd"), "-o", out])
+    res = subprocess.run([out], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr + res.stdout
+    assert "ok leaves=2 private_batch_pis=50 public_batch_pis=40" in res.stdout and "tampered leaf proof:" in res.stdout and "2 paid exit slots, 297 paid out" in res.stdout
