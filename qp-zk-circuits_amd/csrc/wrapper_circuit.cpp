@@ -556,7 +556,7 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
         if (map_count) *map_count = total + blind.size();
         if (target_map_out) {
             if (map_cap < total + blind.size()) return fail(QPGPU_EBUFSIZE, "wrapper_circuit_build: target map buffer too small");
-            std::memcpy(target_map_out + total, blind.data(), blind.size() * 8);             // the blinding rows' random wires: cells as they are
+            if (!blind.empty()) std::memcpy(target_map_out + total, blind.data(), blind.size() * 8);             // the blinding rows' random wires: cells as they are
             auto cell = [&](Target t) { const u64 c = b.cell_of(t); return c == cb::NO_CELL ? UINT64_MAX : c; };
             size_t k = 0;
             for (unsigned i = 0; i < num_proofs; i++) for (Target t : proofs[i].all) target_map_out[k++] = cell(t);

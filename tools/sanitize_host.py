@@ -28,5 +28,23 @@ cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-s
 subprocess.check_call(cmd)
 env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
 rc = subprocess.call([exe, os.path.join(work, "pack.bin"), os.path.join(work, "proof.bin"), iters], env=env)
-print("sanitizer pass", "clean" if rc == 0 else f"FAILED (exit {rc})")
+print("sanitizer pass (parsers, verifier, batch host side)", "clean" if rc == 0 else f"FAILED (exit {rc})")
+if rc:
+    sys.exit(rc)
+# second driver: the circuit builder and the circuits restated on it (builder.cpp, leaf_circuit.cpp, wrapper_circuit.cpp)
+fake = pkg.leaf.LeafCircuit(fragment=pkg.leaf.FRAGMENT_FAKE_LEAF)
+none = np.zeros(0, dtype=np.uint64)
+fpis = np.arange(21, dtype=np.uint64) + 5
+rcw, fw, _ = orc.generate_witness(fake.pack, none, none, fpis)
+assert rcw == orc.WIT_OK
+foc = oracle_binding.OracleCircuit(orc, fake.pack)
+open(os.path.join(work, "fake_proof.bin"), "wb").write(foc.prove(fw, fpis))
+foc.close()
+srcs2 = [os.path.join(csrc, f) for f in ("builder.cpp", "leaf_circuit.cpp", "wrapper_circuit.cpp", "batch.cpp", "proof_targets.cpp", "wire.cpp", "leaf_witness.cpp", "verifier.cpp",
+                                          "circuit.cpp", "poseidon_constants.cpp")]
+exe2 = os.path.join(work, "builder_driver")
+subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-pthread",
+                       "-I", csrc, os.path.join(ROOT, "tools", "sanitize", "builder_driver.cpp")] + srcs2 + ["-o", exe2])
+rc = subprocess.call([exe2, os.path.join(work, "fake_proof.bin"), str(max(10, int(iters) // 5))], env=env)
+print("sanitizer pass (circuit builder, leaf / wrapper circuits)", "clean" if rc == 0 else f"FAILED (exit {rc})")
 sys.exit(rc)
