@@ -219,3 +219,40 @@ def test_blinding_wires_drawn_on_the_device(pkg, gpu, orc):
     assert "blinding cell" in str(e.value)
     wv.close(); wc.close(); ver.close(); lp.close()
     d.free(scrub=True)
+
+
+def test_recursion_under_the_poseidon2_hasher_on_the_device(pkg, orc):
+    """tests/test_wrapper_circuit.py::test_recursion_under_the_poseidon2_hasher through the device: with Poseidon2 as the proof-system
+    hasher the wrapper's hashing is Poseidon2-gate rows whose swap wire is a Merkle index bit; stage s1 (the lane-cooperative
+    Poseidon2 row generator) and the prover reproduce the oracle's witness and proof bytes."""
+    L = pkg.leaf
+    qp = pkg.poseidon2_qp_params()
+    pkg.set_hasher_poseidon2(*qp); orc.select_poseidon2(*qp)
+    try:
+        g2 = pkg.QpGpu(0, hasher=qp)
+        leaf = L.LeafCircuit(inner_hasher=1)
+        lp = L.LeafProver(pkg, g2, leaf)
+        proofs = [lp.prove(x)[0] for x in (lc.real_inputs(L, depth=2, seed=9), lc.dummy_inputs(L))]
+        ver = pkg.Verifier(leaf.pack, circuit=lp.circ, hasher=1)
+        assert all(ver.verify(p) for p in proofs)
+        w = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, inner_hasher=1, logic="private_batch", verify=True)
+        assert w.info["rows_poseidon"] == 0
+        wc = pkg.Circuit(g2, w.pack)
+        nw, n = 135, 1 << w.info["degree_bits"]
+        d = g2.alloc(nw * n * 8)
+        c = w.commit(proofs, preimages=np.arange(8, dtype=np.uint64).reshape(2, 4))
+        wc.generate_witness_partial_dev(c[0], c[1], c[2], d)
+        rc, want, _ = orc.generate_witness(w.pack, *c)
+        assert rc == orc.WIT_OK and np.array_equal(d.download().reshape(nw, n), want)
+        proof = wc.prove_dev(d, c[2])
+        oc = ob.OracleCircuit(orc, w.pack)
+        assert proof == oc.prove(want, c[2]) and oc.verify(proof) == 0
+        oc.close()
+        bad = bytearray(proofs[0]); bad[len(bad) // 2] ^= 1
+        cb = w.commit([bytes(bad), proofs[1]], preimages=np.arange(8, dtype=np.uint64).reshape(2, 4), public_inputs=c[2])
+        with pytest.raises(pkg.QpGpuError) as e:
+            wc.generate_witness_partial_dev(cb[0], cb[1], cb[2], d)
+        assert e.value.code == -4
+        d.free(scrub=True); wc.close(); ver.close(); lp.close(); g2.close()
+    finally:
+        pkg.set_hasher_poseidon(); orc.select_poseidon()
