@@ -295,6 +295,36 @@ static int run_gate(pw_t *p, const gen_t *g, const gl_t pih[4]) {
         }
         return 1;
     }
+    case OG_COSET_INTERP: {
+        /* InterpolationGenerator (gates/coset_interpolation.rs): shifted point = point / shift; barycentric interpolation over the subgroup
+         * of order 2^bits in chunks of `degree` points, the running evaluation and product written at every chunk boundary */
+        const size_t bits = gt->param0, deg = gt->param1, np = (size_t)1 << bits, ni = (np - 2) / (deg - 1);
+        const size_t s_ep = 1 + 2 * np, s_ev = s_ep + 2, s_int = s_ev + 2;
+        gl_t shift, e[2], v[64];
+        if (!pw_get(p, row, 0, &shift) || !pw_get(p, row, s_ep, &e[0]) || !pw_get(p, row, s_ep + 1, &e[1])) return 0;
+        for (size_t i = 0; i < 2 * np; i++) if (!pw_get(p, row, 1 + i, &v[i])) return 0;
+        const gl2_t sp = gl2_scale(gl2_make(e[0], e[1]), gl_inv(shift));
+        pw_set(p, row, s_int + 4 * ni, sp.c[0]); pw_set(p, row, s_int + 4 * ni + 1, sp.c[1]);
+        const gl_t omega = gl_root_of_unity((unsigned)bits), inv_n = gl_inv((gl_t)np);
+        gl2_t ev = gl2_make(0, 0), pr = gl2_make(1, 0);
+        gl_t x = 1;
+        size_t lo = 0, hi = deg;
+        for (size_t cidx = 0; cidx <= ni; cidx++) {
+            for (size_t q = lo; q < hi; q++) {
+                const gl2_t term = gl2_make(gl_sub(sp.c[0], x), sp.c[1]);
+                const gl2_t t = gl2_scale(gl2_mul(gl2_make(v[2 * q], v[2 * q + 1]), pr), gl_mul(x, inv_n));
+                ev = gl2_add(gl2_mul(ev, term), t);
+                pr = gl2_mul(pr, term);
+                x = gl_mul(x, omega);
+            }
+            if (cidx == ni) break;
+            pw_set(p, row, s_int + 2 * cidx, ev.c[0]); pw_set(p, row, s_int + 2 * cidx + 1, ev.c[1]);
+            pw_set(p, row, s_int + 2 * (ni + cidx), pr.c[0]); pw_set(p, row, s_int + 2 * (ni + cidx) + 1, pr.c[1]);
+            lo = 1 + (deg - 1) * (cidx + 1); hi = lo + deg - 1 < np ? lo + deg - 1 : np;
+        }
+        pw_set(p, row, s_ev, ev.c[0]); pw_set(p, row, s_ev + 1, ev.c[1]);
+        return 1;
+    }
     case OG_POSEIDON_MDS: {
         for (int i = 0; i < 24; i++) if (!pw_get(p, row, i, &in[i])) return 0;
         for (int comp = 0; comp < 2; comp++) {
@@ -356,7 +386,7 @@ orc_witness_plan *orc_witness_plan_create(const uint64_t *words_in, size_t n_wor
     }
     for (size_t i = 0; i < c->n_gates; i++) {
         const uint64_t t = c->gates[i].type;
-        if (t == OG_EXPONENTIATION || t == OG_COSET_INTERP) rc = ORC_WIT_UNSUPPORTED;
+        if (t == OG_EXPONENTIATION) rc = ORC_WIT_UNSUPPORTED;
     }
     pw_t p;
     memset(&p, 0, sizeof p);

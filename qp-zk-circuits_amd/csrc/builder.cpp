@@ -92,6 +92,9 @@ uint32_t Builder::spec_index(uint64_t type, uint64_t p0, uint64_t p1, uint64_t p
     case GATE_ARITHMETIC_EXT: s.degree = 3; s.ncons = 2 * p0; s.id = "ArithmeticExtensionGate { num_ops: " + std::to_string(p0) + " }"; break;
     case GATE_REDUCING: s.degree = 2; s.ncons = 2 * p0; s.id = "ReducingGate { num_coeffs: " + std::to_string(p0) + " }"; break;
     case GATE_REDUCING_EXT: s.degree = 2; s.ncons = 2 * p0; s.id = "ReducingExtensionGate { num_coeffs: " + std::to_string(p0) + " }"; break;
+    case GATE_COSET_INTERPOLATION: { const uint64_t np = 1ull << p0; s.degree = p1; s.ncons = 2 * (2 + 2 * ((np - 2) / (p1 - 1)));
+                                     s.id = "CosetInterpolationGate { subgroup_bits: " + std::to_string(p0) + ", degree: " + std::to_string(p1) + " }"; break; }
+    case GATE_POSEIDON_MDS: s.degree = 1; s.ncons = 24; s.id = "PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"; break;
     case GATE_BASE_SUM: s.degree = 2; s.ncons = p0 + 1; s.id = "BaseSumGate { num_limbs: " + std::to_string(p0) + " } + Base: 2"; break;
     case GATE_POSEIDON: s.degree = 7; s.ncons = 123; s.id = "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"; break;
     case GATE_RANDOM_ACCESS: s.degree = p0 + 1; s.ncons = p1 * (p0 + 2) + p2; s.id = "RandomAccessGate { bits: " + std::to_string(p0) + ", num_copies: " + std::to_string(p1) + " }"; break;
@@ -217,6 +220,26 @@ ExtTarget Builder::reduce_ext(ExtTarget alpha, const std::vector<ExtTarget> &ter
         acc = {{wire(row, 0), wire(row, 1)}};
     }
     return acc;
+}
+
+ExtTarget Builder::interpolate_coset(unsigned bits, Target shift, const std::vector<ExtTarget> &values, ExtTarget point) {
+    const uint64_t np = 1ull << bits, max_degree = cfg_.max_quotient_degree_factor;
+    if (values.size() != np || bits < 2 || bits > 5) throw std::logic_error("interpolate_coset: 2^subgroup_bits values, 2..5 bits");
+    // CosetInterpolationGate::with_max_degree: as few intermediates as the degree bound allows, then the smallest degree with that many
+    const uint64_t n_int = (np - 2) / (max_degree - 1), degree = (np - 2) / (n_int + 1) + 2;
+    const uint32_t s_ep = 1 + 2 * (uint32_t)np, row = add_gate(spec_index(GATE_COSET_INTERPOLATION, bits, degree, 0));
+    if (s_ep + 4 > cfg_.num_routed_wires) throw std::logic_error("interpolate_coset: too few routed wires");
+    connect(shift, wire(row, 0));
+    for (uint32_t i = 0; i < np; i++) for (uint32_t e = 0; e < 2; e++) connect(values[i].t[e], wire(row, 1 + 2 * i + e));
+    for (uint32_t e = 0; e < 2; e++) connect(point.t[e], wire(row, s_ep + e));
+    return {{wire(row, s_ep + 2), wire(row, s_ep + 3)}};
+}
+std::array<ExtTarget, 12> Builder::poseidon_mds_ext(const std::array<ExtTarget, 12> &in) {
+    if (cfg_.num_routed_wires < 48) throw std::logic_error("poseidon_mds_ext: too few routed wires");
+    const uint32_t row = add_gate(spec_index(GATE_POSEIDON_MDS, 0, 0, 0));
+    std::array<ExtTarget, 12> out;
+    for (uint32_t i = 0; i < 12; i++) for (uint32_t e = 0; e < 2; e++) { connect(in[i].t[e], wire(row, 2 * i + e)); out[i].t[e] = wire(row, 24 + 2 * i + e); }
+    return out;
 }
 
 ExtTarget Builder::div_ext(ExtTarget x, ExtTarget y) {

@@ -139,6 +139,11 @@ public:
     // rows of max_coeffs_len coefficients each (highest power first, zero-padded at the front, rows chained through old_acc)
     ExtTarget reduce_base(ExtTarget alpha, const std::vector<Target> &terms);
     ExtTarget reduce_ext(ExtTarget alpha, const std::vector<ExtTarget> &terms);
+    // interpolate_coset (gadgets/interpolation.rs): the interpolant through (shift * w^i, values[i]), w the generator of the subgroup of
+    // order 2^subgroup_bits, evaluated at `point`: one CosetInterpolationGate row (with_max_degree(subgroup_bits, max_quotient_degree_factor))
+    ExtTarget interpolate_coset(unsigned subgroup_bits, Target shift, const std::vector<ExtTarget> &values, ExtTarget point);
+    // PoseidonMdsGate (gates/poseidon_mds.rs): the Poseidon MDS layer on twelve extension elements, one row
+    std::array<ExtTarget, 12> poseidon_mds_ext(const std::array<ExtTarget, 12> &in);
     // base^(sum bits[i] 2^i) for a CONSTANT base, as a product of select(bit, base^(2^i), 1) factors (exp_from_bits_const_base)
     Target exp_from_bits_const_base(u64 base, const std::vector<BoolTarget> &exponent_bits);
 

@@ -54,7 +54,16 @@ inline XT scale(XT x, u64 s) { return x * K(s); }
 inline XT sadd(XT a, u64 s, XT c) { return madd(a, K(s), c); }
 inline XT lift(Target t) { return {g_b->to_ext(t)}; }
 }  // namespace cbx
-namespace vmath { template <> inline cbx::XT konst<cbx::XT>(u64 c) { return cbx::K(c); } }
+namespace vmath {
+template <> inline cbx::XT konst<cbx::XT>(u64 c) { return cbx::K(c); }
+// the PoseidonGate's MDS layer at zeta: one PoseidonMdsGate row instead of 144 multiply-adds (what eval_unfiltered_circuit does upstream)
+inline void mds_ext(cbx::XT (&s)[12]) {
+    std::array<cb::ExtTarget, 12> in;
+    for (int i = 0; i < 12; i++) in[i] = s[i].t;
+    const std::array<cb::ExtTarget, 12> out = cbx::g_b->poseidon_mds_ext(in);
+    for (int i = 0; i < 12; i++) s[i].t = out[i];
+}
+}  // namespace vmath
 using cbx::XT;
 
 namespace {
@@ -320,7 +329,7 @@ std::vector<Target> public_batch_logic(Builder &b, const std::vector<std::vector
 // ---- the arithmetic half of verify_proof: the openings against the vanishing polynomial at zeta, and the FRI consistency checks ----
 struct Challenges { std::vector<Target> betas, gammas, alphas; cb::ExtTarget zeta, fri_alpha; std::vector<cb::ExtTarget> fri_betas; };
 struct FriPre { XT red0, red1, zeta, g_zeta, alpha, alpha_nch; };
-struct FriQuery { XT old_eval; Target subgroup_x, inv_x; };
+struct FriQuery { XT old_eval; Target subgroup_x; };
 
 // verify_proof_with_challenges_circuit up to the FRI call (plonk/recursive_verifier.rs): eval_vanishing_poly_circuit at zeta — every
 // gate of the INNER circuit through verify_math.hpp's generic constraints — equals Z_H(zeta) * reduce_with_powers(quotient chunks,
@@ -375,7 +384,6 @@ FriQuery fri_query_begin(Builder &b, const CircuitPack &c, const QueryRoundTarge
     const u64 w = gl::canon(gl::root_of_unity(L));
     FriQuery q;
     q.subgroup_x = b.mul_const(gl::MULT_GEN, b.exp_from_bits_const_base(w, rev));
-    q.inv_x = b.mul_const(gl::canon(gl::inv(gl::MULT_GEN)), b.exp_from_bits_const_base(gl::canon(gl::inv(w)), rev));
     std::vector<Target> at_zeta, at_g_zeta;
     for (int o = 0; o < 4; o++) at_zeta.insert(at_zeta.end(), r.evals[o].begin(), r.evals[o].begin() + (long)polys[o]);
     at_g_zeta.assign(r.evals[2].begin(), r.evals[2].begin() + (long)nch);
@@ -388,9 +396,8 @@ FriQuery fri_query_begin(Builder &b, const CircuitPack &c, const QueryRoundTarge
 }
 
 // one reduction step: the step's coset of evaluations holds the running evaluation at position x_index mod arity
-// (random_access_extension); compute_evaluation: the coset's interpolant at beta. With s = coset_start = subgroup_x g^(-rev(within))
-// the interpolant through (s g^i, y_i) at beta is the interpolant through the FIXED subgroup (g^i, y_i) at t = beta / s, in
-// barycentric form sum_i y_i (g^i / arity) prod_{j != i} (t - g^j); y_i = evals[rev(i)] (the coset is stored bit-reversed).
+// (random_access_extension); compute_evaluation: the coset's interpolant at beta, one CosetInterpolationGate row
+// (builder.interpolate_coset: the points are coset_start g^i, the values evals[rev(i)] — the coset is stored bit-reversed).
 void fri_query_fold(Builder &b, const CircuitPack &c, const QueryRoundTargets &r, size_t step, const std::vector<BoolTarget> &bits, const Challenges &ch, FriQuery &q) {
     const unsigned ab = (unsigned)c.arity_bits[step], arity = 1u << ab;
     const std::vector<BoolTarget> within(bits.begin(), bits.begin() + ab);
@@ -400,27 +407,18 @@ void fri_query_fold(Builder &b, const CircuitPack &c, const QueryRoundTargets &r
     const Target within_t = b.le_sum(within);
     b.connect(b.random_access(within_t, c0), q.old_eval.t.t[0]);
     b.connect(b.random_access(within_t, c1), q.old_eval.t.t[1]);
-    const u64 g = gl::canon(gl::root_of_unity(ab));
+    // coset_start = subgroup_x * g^(-rev(within)); the coset's values in natural order of its points are evals[rev(i)]
+    const u64 g_inv = gl::canon(gl::inv(gl::root_of_unity(ab)));
     const std::vector<BoolTarget> rev_within(within.rbegin(), within.rend());
-    const Target s_inv = b.mul(q.inv_x, b.exp_from_bits_const_base(g, rev_within));
-    const XT t = XT{ch.fri_betas[step]} * cbx::lift(s_inv);
-    std::vector<XT> d(arity), pre(arity), suf(arity);
-    { u64 x = 1; for (unsigned j = 0; j < arity; j++) { d[j] = t - cbx::K(gl::canon(x)); x = gl::mul(x, g); } }
-    pre[0] = cbx::K(1); suf[arity - 1] = cbx::K(1);
-    for (unsigned j = 1; j < arity; j++) pre[j] = pre[j - 1] * d[j - 1];
-    for (unsigned j = arity - 1; j-- > 0;) suf[j] = suf[j + 1] * d[j + 1];
-    XT acc = cbx::K(0);
-    const u64 ninv = gl::inv(arity);
-    u64 x = 1;
+    const Target coset_start = b.mul(q.subgroup_x, b.exp_from_bits_const_base(g_inv, rev_within));
+    std::vector<cb::ExtTarget> ys(arity);
     for (unsigned i = 0; i < arity; i++) {
         unsigned src = 0;
         for (unsigned k = 0; k < ab; k++) src |= ((i >> k) & 1u) << (ab - 1 - k);
-        const XT y{{{ev[2 * src], ev[2 * src + 1]}}};
-        acc = sadd(y * (pre[i] * suf[i]), gl::canon(gl::mul(x, ninv)), acc);
-        x = gl::mul(x, g);
+        ys[i] = {{ev[2 * src], ev[2 * src + 1]}};
     }
-    q.old_eval = acc;
-    for (unsigned k = 0; k < ab; k++) { q.subgroup_x = b.mul(q.subgroup_x, q.subgroup_x); q.inv_x = b.mul(q.inv_x, q.inv_x); }
+    q.old_eval = XT{b.interpolate_coset(ab, coset_start, ys, ch.fri_betas[step])};
+    for (unsigned k = 0; k < ab; k++) q.subgroup_x = b.mul(q.subgroup_x, q.subgroup_x);
 }
 
 // the final polynomial at the last subgroup point equals the last folded evaluation

@@ -161,11 +161,22 @@ def test_zero_knowledge_private_layer(pkg, orc, setup):
     real0, real1, real2, other, dummy = proofs
     wz = pkg.recursion.WrapperCircuit(leaf.pack, ver, 2, num_routed_wires=60, logic="private_batch", verify=True, zero_knowledge=True)
     h = pkg.pack_header(wz.pack)
-    assert h["zero_knowledge"] == 1 and h["num_routed_wires"] == 60 and h["degree_bits"] == 15
-    # blinding_counts at the degree estimate 2^15 (three arity-16 reductions, final polynomial of 8 coefficients, 28 queries, D = 2)
-    fri_openings = 28 * (1 + 2 * 3 * 15 + 2 * 8)
-    assert wz.info["rows_blinding"] == (2 + fri_openings) + 2 * (4 + fri_openings)
-    assert wz.blinding_cells.size == (2 + fri_openings) * 135 + (4 + fri_openings) * 60
+    assert h["zero_knowledge"] == 1 and h["num_routed_wires"] == 60
+    # CircuitBuilder::blinding_counts, restated: the smallest degree estimate 2^k >= the gate count that also holds its own blinding rows;
+    # per estimate: arity-16 reductions while more than 2^5 coefficients remain, 28 queries, D = 2
+    gates = wz.info["rows_before_padding"]
+    k = max(5, (gates - 1).bit_length())
+    while True:
+        rounds, d = 0, k
+        while d > 5:
+            rounds, d = rounds + 1, d - 4
+        fri_openings = 28 * (1 + 2 * rounds * 15 + 2 * (1 << d))
+        regular, zs = 2 + fri_openings, 4 + fri_openings
+        if gates + regular + 2 * zs <= 1 << k:
+            break
+        k += 1
+    assert wz.info["rows_blinding"] == regular + 2 * zs and h["degree_bits"] == (gates + regular + 2 * zs - 1).bit_length()
+    assert wz.blinding_cells.size == regular * 135 + zs * 60
     p = pre(9, 2)
     ca = wz.commit([real0, dummy], preimages=p, blinding_seed=bytes([1] * 32))
     cb = wz.commit([real0, dummy], preimages=p, blinding_seed=bytes([2] * 32))
@@ -177,7 +188,7 @@ def test_zero_knowledge_private_layer(pkg, orc, setup):
     rc, wires, _ = orc.generate_witness(wz.pack, *ca)
     assert rc == orc.WIT_OK
     # the pair rows of the Z blinding carry the same values
-    first_pair = (wz.info["rows_before_padding"] + 2 + fri_openings)
+    first_pair = wz.info["rows_before_padding"] + regular
     assert np.array_equal(wires[:60, first_pair], wires[:60, first_pair + 1]) and not np.array_equal(wires[:60, first_pair], wires[:60, first_pair + 2])
     oc = ob.OracleCircuit(orc, wz.pack)
     proof = oc.prove(wires, ca[2])
