@@ -1,29 +1,28 @@
-// wrapper_circuit.cpp — a recursive wrapper circuit that really checks part of its inner proofs:
-// the Merkle half of plonky2's in-circuit verifier, restated on the native builder (builder.hpp).
+// wrapper_circuit.cpp — plonky2's recursive verifier and the reference's two batch circuits, restated on the native builder
+// (builder.hpp): SURVEY.md §8 rows a3 / a4 / a6.
 //
 //   add_recursive_verifiers                      wormhole/aggregator/src/common/recursive.rs:74-102
 //     builder.add_virtual_proof_with_pis(common)   one virtual target per field element of an inner proof (proof_targets.cpp's order)
 //     builder.verify_proof::<C>(proof, vd, common) qp-plonky2 1.5.5, un-vendored; restated from upstream plonky2:
 //       public_inputs_hash = hash_n_to_hash_no_pad(public_inputs)                               plonk/recursive_verifier.rs
+//       get_challenges on a RecursiveChallenger, fri_verify_proof_of_work                       plonk/get_challenges.rs, iop/challenger.rs
+//       eval_vanishing_poly_circuit at zeta == Z_H(zeta) * reduce(quotient chunks)             plonk/vanishing_poly.rs  (verify_math.hpp)
 //       fri_verifier_query_round: x_index bits, cap_index = le_sum(high bits),                  fri/recursive_verifier.rs
 //         fri_verify_initial_proof: verify_merkle_proof_to_cap_with_cap_index per oracle        hash/merkle_proofs.rs
-//         per reduction step: verify_merkle_proof_to_cap_with_cap_index(flatten(evals), coset_index_bits, ..)
+//         fri_combine_initial (ReducingGate rows), per reduction step: random_access_extension of the previous evaluation,
+//         compute_evaluation (CosetInterpolationGate), verify_merkle_proof_to_cap_with_cap_index(flatten(evals), ..), final polynomial
+//   build_private_batch_constraints              wormhole/aggregator/src/private_batch/circuit/circuit_logic.rs:171-477
+//   build_public_batch_constraints               wormhole/aggregator/src/public_batch/circuit/circuit_logic.rs:167-317
+//   the gadgets both use (bytes_digest_eq, u32_lt, split_canonical_u32_halves, halves8_lt, sort_digests4)   common/src/gadgets.rs:144-334
 //
-// WHAT IS VERIFIED: for every inner proof and every one of its query rounds, the four opened rows (constants/sigmas, wires,
-// Z / partial products, quotient) and every FRI step's coset of evaluations are hashed in-circuit (PoseidonGate rows) and
-// walked up their Merkle paths (one PoseidonGate row per level, swap = the index bit) to the cap entry the index selects
-// (RandomAccessGate rows): against the inner CIRCUIT's constants/sigmas cap (verifier data, constants of this circuit) and
-// against the caps the proof itself carries. With QPGPU_WRAPPER_TRANSCRIPT the Fiat-Shamir transcript is replayed in-circuit
-// too (RecursiveChallenger: circuit digest, public-input hash, caps, all openings, FRI caps, final polynomial, proof-of-work
-// witness), the proof-of-work response is range-checked and the 28 query indices are the low bits of the transcript's
-// challenges — so the indices cannot be chosen, and everything the transcript absorbs is bound to the rows that are opened.
-// The inner public inputs are forwarded as this circuit's public inputs. A byte flipped anywhere in an inner proof except in
-// places only the missing arithmetic looks at makes the witness unsatisfiable ("set twice with different values").
-// WHAT IS NOT: the openings against the vanishing polynomial at zeta (gate constraints, permutation argument) and the
-// reduced-opening / folding arithmetic that ties the opened rows to the FRI evaluations and to the final polynomial — the
-// Plonk and FRI challenges are derived in-circuit but not consumed yet. A wrapper proof therefore attests "a proof-shaped
-// object with a valid proof of work whose transcript-chosen rows and cosets are committed under its caps", not yet "the inner
-// proofs verify". The wrapper-specific logic of the private / public batch (circuit_logic.rs) is not part of it either.
+// The flags of qpgpu_wrapper_circuit_build (include/qpgpu_batch.h) choose how much of this a circuit carries: none = the commitment
+// half (Merkle paths of every opened row and FRI coset; query indices are inputs), TRANSCRIPT = the Fiat-Shamir replay (indices and
+// proof of work in-circuit), VERIFY = the arithmetic half — with both, everything VerifierCircuitData::verify checks —,
+// PRIVATE_BATCH / PUBLIC_BATCH = the layer's own constraints and public inputs, ZERO_KNOWLEDGE = CircuitBuilder::blind's rows.
+// The inner circuit's verifier data (constants/sigmas cap, circuit digest) are CONSTANTS of the wrapper, which is what makes a proof
+// of another circuit of the same shape unusable (private_batch_rejects_malicious_circuit_proofs). A byte flipped anywhere in an
+// inner proof, or an inner proof made honestly from a trace that violates the inner circuit, leaves the wrapper without a witness
+// ("set twice with different values"); tests/test_wrapper_circuit*.py, test_batch_circuits*.py, tools/fuzz_wrapper_tamper.py.
 #include <array>
 #include <cstdio>
 #include <cstring>
