@@ -8,16 +8,18 @@ Reference flow:
 A batch proof's public inputs are a function of its inner proofs' public inputs, and its witness is regenerated
 from them; the proof bytes of level k are the input of level k+1.
 
-The recursive wrapper circuits themselves need the Rust CircuitBuilder (circuit-pack exporter), so the
-circuit proven here is the synthetic stand-in of the level's size and gate mix ("shape-equivalent"). What is
-real: inner proofs are parsed from their bytes; the reference's admission checks run on them (include/qpgpu_batch.h:
+THIS module is round 3's form of the two levels: the circuit proven is a SYNTHETIC stand-in of the level's size and gate mix
+("shape-equivalent") — kept for the bench's `aggregation_tree` leg and as the home of the host-side helpers
+(public-input layouts, parsers, outputs). The levels with circuits that verify their inner proofs (recursive verifier + the
+layer's own constraints, restated on the library's builder) are in recursion.py: PrivateBatchProver / PublicBatchProver /
+ProvingContext / AttestingTree. What is real here: inner proofs are parsed from their bytes; the reference's admission checks run on them (include/qpgpu_batch.h:
 counts, asset / block / fee consistency, duplicate nullifiers, all-dummy, the padding templates' sentinels; the
 cryptographic half through the caller's verifier); short batches are padded with the dummy template, private batches
 shuffled uniformly and given one dummy-nullifier preimage per slot; the batch's public inputs are exactly what the
 wrapper circuit would emit (layout 21 N + 8 / 12 + 14 M N: references from the first non-dummy slot, exit accounts
 merged, dummy nullifiers hashed, the nullifier region sorted); the witness is generated on the device from a
 PartialWitness (stage s1); and the proof is produced by the same qpgpu_prove path as every other proof.
-What is not: the inner proofs are not verified in-circuit (no recursive verifier gates are wired to them).
+What is not, in the stand-ins of this module: the inner proofs are not verified in-circuit (recursion.py's circuits do that).
 """
 import numpy as np
 

@@ -1,7 +1,9 @@
-"""Host-side harness of the wrapper circuit that checks the Merkle half of its inner proofs (include/qpgpu_batch.h,
-qpgpu_wrapper_circuit_build; csrc/wrapper_circuit.cpp) — ctypes only. Mirrors, as far as it goes, the reference's
-add_recursive_verifiers + fill_private_batch_witness (wormhole/aggregator/src/common/recursive.rs:74-102,
-private_batch/prover/witness.rs:15-77)."""
+"""The recursive circuits and their provers over the C ABI (include/qpgpu_batch.h: qpgpu_wrapper_circuit_build; csrc/wrapper_circuit.cpp)
+— ctypes only. WrapperCircuit = add_recursive_verifiers (wormhole/aggregator/src/common/recursive.rs:74-102) with the flags' parts
+(in-circuit transcript, the arithmetic half of verify_proof, the private- / public-batch logic, zero-knowledge blinding) and
+fill_private_batch_witness (private_batch/prover/witness.rs:15-77) as its commit(); PrivateBatchProver / PublicBatchProver /
+ProvingContext carry the reference's new / commit / prove / aggregate / prove_batch (private_batch/prover/lib.rs:244-343,
+public_batch/prover/lib.rs:268-305, aggregator.rs:158-248); AttestingTree is BASELINE configs[4] on them."""
 import ctypes
 
 import numpy as np
