@@ -4,8 +4,11 @@
 // and this image has no Rust toolchain to run either. What is restated here is the builder's *observable* behaviour as
 // upstream plonky2 has it — virtual targets, copy constraints as a union-find over targets, `arithmetic` with its special
 // cases and memoised operations, operations packed into ArithmeticGate rows per constant pair, `split_le` on BaseSumGate<2>
-// rows, `is_equal` with its EqualityGenerator, constants gathered into ConstantGate rows at build time, the public-input
-// hash wired into a PublicInputGate, Noop padding to a power of two, gates sorted by (degree, id) into selector groups —
+// rows, `is_equal` with its EqualityGenerator, random access, sponges and Merkle verification, extension-field arithmetic on
+// ArithmeticExtensionGate rows with its QuotientGeneratorExtension, Reducing / ReducingExtension / CosetInterpolation / PoseidonMds
+// gate gadgets (what the recursive verifier consists of), constants gathered into ConstantGate rows at build time, the public-input
+// hash wired into a PublicInputGate, `blind()` for zero-knowledge circuits, Noop padding to a power of two, gates sorted by
+// (degree, id) into selector groups —
 // and its output is a circuit pack (circuit.hpp) plus the wire cell every target ended up in.
 //
 // Not byte-reproducible against the fork (row order of gates, the fork's Poseidon2 sponge wiring and its `circuit_digest`
