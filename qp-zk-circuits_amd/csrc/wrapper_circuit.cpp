@@ -53,16 +53,17 @@ inline XT scale(XT x, u64 s) { return x * K(s); }
 inline XT sadd(XT a, u64 s, XT c) { return madd(a, K(s), c); }
 inline XT lift(Target t) { return {g_b->to_ext(t)}; }
 }  // namespace cbx
-namespace vmath {
-template <> inline cbx::XT konst<cbx::XT>(u64 c) { return cbx::K(c); }
-// the PoseidonGate's MDS layer at zeta: one PoseidonMdsGate row instead of 144 multiply-adds (what eval_unfiltered_circuit does upstream)
-inline void mds_ext(cbx::XT (&s)[12]) {
+namespace vmath { template <> inline cbx::XT konst<cbx::XT>(u64 c) { return cbx::K(c); } }
+namespace cbx {
+// the PoseidonGate's MDS layer at zeta: one PoseidonMdsGate row instead of 144 multiply-adds (what eval_unfiltered_circuit does
+// upstream). Found by argument-dependent lookup from verify_math.hpp's poseidon_gate<XT> (a better match than the generic template).
+inline void mds_ext(XT (&s)[12]) {
     std::array<cb::ExtTarget, 12> in;
     for (int i = 0; i < 12; i++) in[i] = s[i].t;
-    const std::array<cb::ExtTarget, 12> out = cbx::g_b->poseidon_mds_ext(in);
+    const std::array<cb::ExtTarget, 12> out = g_b->poseidon_mds_ext(in);
     for (int i = 0; i < 12; i++) s[i].t = out[i];
 }
-}  // namespace vmath
+}  // namespace cbx
 using cbx::XT;
 
 namespace {

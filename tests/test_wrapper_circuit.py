@@ -191,3 +191,19 @@ def test_recursion_under_the_poseidon2_hasher(pkg, orc):
         ver.close()
     finally:
         pkg.set_hasher_poseidon(); orc.select_poseidon()
+
+
+def test_wire_budget_of_the_wrapper(pkg):
+    """The config policy of the wrapper builder (the reference's new_rejects_pathological_circuit_configs, circuit_logic.rs:2015-2040,
+    as far as the ABI exposes the config): a routed-wire count the gates of the recursive verifier cannot live in is refused with
+    the reason, before any expensive construction."""
+    L = pkg.leaf
+    fake = L.LeafCircuit(fragment=L.FRAGMENT_FAKE_LEAF)
+    ver = pkg.Verifier(fake.pack)
+    for routed, needle in ((8, "num_routed_wires outside"), (136, "num_routed_wires outside"), (40, "poseidon_mds_ext: too few routed wires")):
+        with pytest.raises(pkg.QpGpuError) as e:
+            pkg.recursion.WrapperCircuit(fake.pack, ver, 1, num_routed_wires=routed, verify=True)
+        assert needle in str(e.value), routed
+    for routed in (48, 60, 80):
+        assert pkg.recursion.WrapperCircuit(fake.pack, ver, 1, num_routed_wires=routed, verify=True).info["degree_bits"] == 12
+    ver.close()
