@@ -1,0 +1,31 @@
+"""Short runs of the three fuzz tools as part of the GPU suite (the long runs are recorded in profiles/r04_soak.txt): random and
+mutated CircuitInputs through the leaf path (host constraint check, device s1 and oracle agree; witnesses equal), single-bit flips
+of a leaf proof through the complete in-circuit verifier (verdict equals the host verifier's), random private batches over fake
+leaves (a witness exists iff the host restatement accepts, and the public inputs read out of the witness equal the host's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tool,args,keys", [
+    ("fuzz_leaf_inputs.py", ["384", "21"], {"inputs": 384}),
+    ("fuzz_wrapper_tamper.py", ["96", "22"], {"flips": 96, "accepted_by_both": 0}),
+    ("fuzz_private_batch.py", ["192", "23"], {"batches": 192}),
+])
+def test_fuzz_tool(tool, args, keys):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    stats = json.loads(res.stdout.strip().splitlines()[-1])
+    assert stats["mismatches"] == 0
+    for k, v in keys.items():
+        assert stats[k] == v
+    if tool == "fuzz_private_batch.py":
+        assert stats["satisfiable"] > 50 and stats["unsatisfiable"] > 20
+    if tool == "fuzz_leaf_inputs.py":
+        assert stats["satisfiable"] > 150 and stats["unsatisfiable"] > 50 and stats["witnesses_compared"] == stats["satisfiable"]
