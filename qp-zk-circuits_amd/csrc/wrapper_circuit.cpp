@@ -465,7 +465,7 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
         cfg.inner_hasher = inner_hasher;
         cfg.zero_knowledge = (flags & QPGPU_WRAPPER_ZERO_KNOWLEDGE) != 0;
         Builder b(cfg);
-        cbx::g_b = &b;
+        struct Bind { explicit Bind(Builder *p) { cbx::g_b = p; } ~Bind() { cbx::g_b = nullptr; } } bind(&b);     // XT's operations build into `b` while it lives
         const unsigned L = (unsigned)(inner.degree_bits + inner.rate_bits), cap_h = (unsigned)inner.cap_height;
         // verifier data of the inner circuit: constants of this one (builder.constant_merkle_cap)
         std::vector<HashOutTarget> cs_cap((size_t)1 << cap_h);
