@@ -138,6 +138,26 @@ impl GpuProvingPool {
         Ok(len)
     }
     pub fn proof_size(&self) -> usize { self.proof_size }
+
+    /// A circuit whose witness is a PartialWitness (stage s1 on the device too): `cells` is the assignment list resolved once —
+    /// for an exported circuit the wire cells of the targets `fill_witness` / `fill_private_batch_witness` set, in their order;
+    /// the last `n_blinding` of them are the `RandomValueGenerator` targets of a zero-knowledge circuit (`CircuitBuilder::blind`),
+    /// which the device draws per proof.
+    pub fn set_partial_cells(&self, cells: &[u64], n_blinding: usize) -> Result<()> {
+        let rc = unsafe { qpgpu_pool_set_partial_cells_blinded(self.pool, cells.as_ptr(), cells.len(), n_blinding) };
+        if rc != 0 { bail!("qpgpu_pool_set_partial_cells: {}", unsafe { std::ffi::CStr::from_ptr(qpgpu_pool_last_error(self.pool)).to_string_lossy() }) }
+        Ok(())
+    }
+    /// `values`: one per cell of the list, without the blinding ones. `public_inputs = None`: what `ProverCircuitData::prove` does —
+    /// they are read out of the generated witness (the batch layers, whose public inputs the circuit computes) and come back as the
+    /// last `num_public_inputs` words of the proof.
+    pub fn submit_partial(&self, values: &[u64], public_inputs: Option<&[u64]>, out: &mut [u8]) -> Result<u64> {
+        let mut ticket = 0u64;
+        let pis = public_inputs.map_or(std::ptr::null(), |p| p.as_ptr());
+        let rc = unsafe { qpgpu_pool_submit_partial(self.pool, values.as_ptr(), pis, out.as_mut_ptr(), out.len(), &mut ticket) };
+        if rc != 0 { bail!("qpgpu_pool_submit_partial: {}", unsafe { std::ffi::CStr::from_ptr(qpgpu_pool_last_error(self.pool)).to_string_lossy() }) }
+        Ok(ticket)
+    }
 }
 impl Drop for GpuProvingPool { fn drop(&mut self) { unsafe { qpgpu_pool_destroy(self.pool) } } }
 
