@@ -845,7 +845,7 @@ def main():
                        "circuit": {"degree_bits": d, "gate_rows_before_padding": leaf.info["rows_before_padding"], "rows": {k[5:]: v for k, v in leaf.info.items() if k.startswith("rows_")},
                                    "caveats": "the circuit proves the reference's statement over the reference's gate set, built by this repository's restatement of plonky2's builder: "
                                               "row order, the Poseidon2 gate's wire layout (pack table, LAYOUT UNPINNED) and the circuit digest cannot be matched to the fork offline; padded with "
-                                              "NoopGate rows from 2^%d to 2^%d because the reference states its circuits are >= 2^12 rows" % (max(5, (leaf.info["rows_before_padding"] - 1).bit_length()), d)},
+                                              "NoopGate rows from 2^%d to 2^%d because the reference states its circuits are >= 2^12 rows (common/src/circuit.rs:464-467) and profiles its leaf at degree 13 (wormhole/circuit/src/profile.rs:121)" % (max(5, (leaf.info["rows_before_padding"] - 1).bit_length()), d)},
                        "degree_bits": d, "gates": "PublicInput, Constant, BaseSum<2>(63 limbs), Arithmetic(20 ops), Poseidon(123 constraints; public-input hash), Poseidon2 gate (123 constraints; the leaf's 61 application-hash permutations), Noop; 2 selector groups", "num_wires": 135, "num_routed_wires": 80, "rate_bits": 3, "cap_height": 4,
                        "num_query_rounds": 28, "proof_of_work_bits": 16, "fri_arity_bits": 4, "proof_bytes": proof_len, "proofs_in_flight_per_gpu": S, "proofs_per_step_per_gpu": S, "workers": WORKERS, "lockstep_batch": LOCKSTEP,
                        "multi_gpu": ("independent proofs per rank + one %s of each step's proof bytes (%s)" % ("all_gather" if args.all_gather else "gather to rank 0", "RCCL" if backend == "nccl" else backend + " rehearsal, ranks share the visible GPUs")) if world > 1 else "single GPU"},
