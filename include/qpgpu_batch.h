@@ -218,6 +218,20 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
 /* n uniform field elements from ChaCha20 keyed with seed32, or with 32 bytes of operating-system entropy when seed32 is NULL
  * (RandomValueGenerator's F::rand(), for the blinding cells of a zero-knowledge circuit) */
 int qpgpu_random_field_elements(const uint8_t *seed32, uint64_t *out, size_t n, char *err);
+
+/* ---- gadget circuits: the builder's gadgets one at a time, for tests (csrc/wrapper_circuit.cpp) ---------------------------------
+ * A small circuit that applies ONE family of gadgets of the native builder to free inputs: pack_out is its circuit pack,
+ * cells_out its input cells followed by its output cells (row * num_wires + wire), n_inputs / n_outputs their counts. A test
+ * assigns the inputs, lets a witness generator run and compares the outputs with the gadget's definition computed independently
+ * (tests/test_builder_gadgets.py). kind:
+ *   0  extension arithmetic     in: a, b, c (2 each)                     out: a b, a b + c, a - b, a / b
+ *   1  reducing                 in: alpha (2), 100 base terms, 40 extension terms     out: sum t_i alpha^i for both lists
+ *   2  coset interpolation      in: shift, 16 extension values, point (2)            out: the interpolant through (shift w^i, v_i) at point
+ *   3  bits                     in: x (< 2^10), y (any)                   out: 7^x (exp_from_bits_const_base), le_sum(split_le(x, 10)), the 64 bits of y
+ *   4  selection                in: index (< 16), 16 values, b (0/1), u, v            out: values[index], select(b, u, v), is_equal(u, v)
+ *   5  digest order             in: 5 digests (4 each)                    out: the digests sorted (sort_digests4), digest_eq(d0, d1) */
+int qpgpu_builder_gadget_circuit(unsigned kind, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words, uint64_t *cells_out, size_t cells_cap,
+                                 size_t *n_inputs, size_t *n_outputs, char *err);
 int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, const uint64_t *inner_cs_cap, size_t cap_words, unsigned num_proofs,
                                 unsigned num_routed_wires, unsigned min_degree_bits, int inner_hasher, unsigned flags, uint64_t *pack_out, size_t pack_cap_words,
                                 size_t *pack_words, uint64_t *target_map_out, size_t map_cap, size_t *map_count, uint64_t *info_out, char *err);

@@ -574,4 +574,75 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
     return QPGPU_OK;
 }
 
+int qpgpu_builder_gadget_circuit(unsigned kind, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words, uint64_t *cells_out, size_t cells_cap,
+                                 size_t *n_inputs, size_t *n_outputs, char *err) {
+    auto fail = [&](int code, const std::string &m) { if (err) std::snprintf(err, QPGPU_BATCH_ERR_CAP, "%s", m.c_str()); return code; };
+    if (err) err[0] = 0;
+    if (!pack_words || !n_inputs || !n_outputs) return fail(QPGPU_EINVAL, "builder_gadget_circuit: null argument");
+    try {
+        cb::Config cfg;
+        Builder b(cfg);
+        std::vector<Target> in, out;
+        auto input = [&]() { const Target t = b.add_virtual_target(); in.push_back(t); return t; };
+        auto input_ext = [&]() { cb::ExtTarget e; e.t[0] = input(); e.t[1] = input(); return e; };
+        auto output_ext = [&](cb::ExtTarget e) { out.push_back(e.t[0]); out.push_back(e.t[1]); };
+        if (kind == 0) {
+            const cb::ExtTarget x = input_ext(), y = input_ext(), z = input_ext();
+            output_ext(b.mul_ext(x, y)); output_ext(b.mul_add_ext(x, y, z)); output_ext(b.sub_ext(x, y)); output_ext(b.div_ext(x, y));
+        } else if (kind == 1) {
+            const cb::ExtTarget alpha = input_ext();
+            std::vector<Target> base; std::vector<cb::ExtTarget> ext;
+            for (int i = 0; i < 100; i++) base.push_back(input());
+            for (int i = 0; i < 40; i++) ext.push_back(input_ext());
+            output_ext(b.reduce_base(alpha, base)); output_ext(b.reduce_ext(alpha, ext));
+        } else if (kind == 2) {
+            const Target shift = input();
+            std::vector<cb::ExtTarget> v;
+            for (int i = 0; i < 16; i++) v.push_back(input_ext());
+            const cb::ExtTarget pt = input_ext();
+            output_ext(b.interpolate_coset(4, shift, v, pt));
+        } else if (kind == 3) {
+            const Target x = input(), y = input();
+            const std::vector<BoolTarget> xb = b.split_le(x, 10);
+            out.push_back(b.exp_from_bits_const_base(7, xb));
+            out.push_back(b.le_sum(xb));
+            for (const BoolTarget &bit : b.split_le(y, 64)) out.push_back(bit.target);
+        } else if (kind == 4) {
+            const Target idx = input();
+            std::vector<Target> v;
+            for (int i = 0; i < 16; i++) v.push_back(input());
+            const Target sel = input(), u = input(), w = input();
+            b.assert_bool({sel});
+            out.push_back(b.random_access(idx, v));
+            out.push_back(b.select({sel}, u, w));
+            out.push_back(b.is_equal(u, w).target);
+        } else if (kind == 5) {
+            std::vector<Digest> ds(5);
+            for (Digest &d : ds) for (Target &t : d) t = input();
+            for (const Digest &d : sort_digests4(b, ds)) for (Target t : d) out.push_back(t);
+            out.push_back(digest_eq(b, ds[0], ds[1]).target);
+        } else return fail(QPGPU_EINVAL, "builder_gadget_circuit: unknown kind");
+        // the outputs are public inputs (so that each sits in a gate and has a cell); every input is consumed by its gadget
+        for (Target t : out) b.register_public_input(t);
+        CircuitPack pack;
+        const std::string why = b.build(pack);
+        if (!why.empty()) return fail(QPGPU_EINVAL, "builder_gadget_circuit: " + why);
+        const std::vector<uint64_t> words = pack.serialize();
+        *pack_words = words.size(); *n_inputs = in.size(); *n_outputs = out.size();
+        if (pack_out) {
+            if (pack_cap_words < words.size()) return fail(QPGPU_EBUFSIZE, "builder_gadget_circuit: pack buffer too small");
+            std::memcpy(pack_out, words.data(), words.size() * 8);
+        }
+        if (cells_out) {
+            if (cells_cap < in.size() + out.size()) return fail(QPGPU_EBUFSIZE, "builder_gadget_circuit: cell buffer too small");
+            size_t k = 0;
+            for (Target t : in) { const u64 c = b.cell_of(t); if (c == cb::NO_CELL) return fail(QPGPU_EINVAL, "builder_gadget_circuit: an input touches no gate"); cells_out[k++] = c; }
+            for (Target t : out) { const u64 c = b.cell_of(t); if (c == cb::NO_CELL) return fail(QPGPU_EINVAL, "builder_gadget_circuit: an output touches no gate"); cells_out[k++] = c; }
+        }
+    } catch (const std::exception &e) {
+        return fail(QPGPU_EINVAL, std::string("builder_gadget_circuit: ") + e.what());
+    }
+    return QPGPU_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,141 @@
+"""The native circuit builder's gadgets one at a time (csrc/builder.cpp through qpgpu_builder_gadget_circuit): a small circuit per
+gadget family, random inputs assigned, the ORACLE's witness generator run on the pack, and the outputs compared with the gadget's
+definition computed here with Python integers — extension-field arithmetic and division (ArithmeticExtensionGate rows +
+QuotientGeneratorExtension), ReducingGate / ReducingExtensionGate chains, the CosetInterpolationGate against plain Lagrange
+interpolation, exp_from_bits_const_base / le_sum / the 64-bit split_le on two BaseSum rows, random access / select / is_equal, the
+sorting network of common/src/gadgets.rs and digest equality. The recursive verifier is these gadgets wired together; the host
+verifier agreeing with it on honest and forged proofs (tests/test_wrapper_circuit.py) checks the wiring, this file the parts."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+P = 0xFFFFFFFF00000001
+W = 7                                                                    # F[x] / (x^2 - 7)
+
+
+def emul(a, b): return ((a[0] * b[0] + W * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+def eadd(a, b): return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+def esub(a, b): return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+def einv(a):
+    n = pow((a[0] * a[0] - W * a[1] * a[1]) % P, P - 2, P)
+    return (a[0] * n % P, (-a[1]) * n % P)
+
+
+@pytest.fixture(scope="module")
+def gadget(pkg, orc):
+    L = pkg.load_library()
+    c = ctypes
+    L.qpgpu_builder_gadget_circuit.restype = c.c_int
+    L.qpgpu_builder_gadget_circuit.argtypes = [c.c_uint, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t), c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t), c.POINTER(c.c_size_t), c.c_char_p]
+    cache = {}
+
+    def run(kind, inputs, expect_rc=None, want_trace=False):
+        if kind not in cache:
+            n, ni, no = c.c_size_t(), c.c_size_t(), c.c_size_t()
+            err = c.create_string_buffer(400)
+            assert L.qpgpu_builder_gadget_circuit(kind, None, 0, c.byref(n), None, 0, c.byref(ni), c.byref(no), err) == 0, err.value
+            pack = np.empty(n.value, dtype=np.uint64); cells = np.empty(ni.value + no.value, dtype=np.uint64)
+            assert L.qpgpu_builder_gadget_circuit(kind, pack.ctypes.data, pack.size, c.byref(n), cells.ctypes.data, cells.size, c.byref(ni), c.byref(no), err) == 0, err.value
+            cache[kind] = (pack, cells[:ni.value].copy(), cells[ni.value:].copy())
+        pack, cin, cout = cache[kind]
+        assert len(inputs) == cin.size
+        rc, wires, _ = orc.generate_witness(pack, cin, np.array(inputs, dtype=np.uint64), None)
+        if expect_rc is not None:
+            assert rc == expect_rc
+            return None
+        assert rc == orc.WIT_OK
+        outs = [int(wires[int(cell) % 135, int(cell) // 135]) for cell in cout]
+        if want_trace:
+            return pack, wires, np.array(outs, dtype=np.uint64)          # the outputs are the circuit's public inputs, in order
+        return outs
+    return run
+
+
+def rnd(rng, n):
+    return [int(v) for v in rng.integers(0, P, n, dtype=np.uint64)]
+
+
+def test_extension_arithmetic(gadget):
+    rng = np.random.default_rng(1)
+    for _ in range(8):
+        v = rnd(rng, 6)
+        a, b, c = (v[0], v[1]), (v[2], v[3]), (v[4], v[5])
+        got = gadget(0, v)
+        want = [*emul(a, b), *eadd(emul(a, b), c), *esub(a, b), *emul(a, einv(b))]
+        assert got == want
+    # edge values: zero, one, p - 1, pure-imaginary elements
+    for v in ([0, 0, 5, 9, 1, 2], [1, 0, P - 1, P - 1, 0, 0], [0, 1, 0, 1, P - 1, 0]):
+        a, b, c = (v[0], v[1]), (v[2], v[3]), (v[4], v[5])
+        assert gadget(0, v) == [*emul(a, b), *eadd(emul(a, b), c), *esub(a, b), *emul(a, einv(b))]
+
+
+def test_reducing_gates(gadget):
+    rng = np.random.default_rng(2)
+    for _ in range(4):
+        v = rnd(rng, 2 + 100 + 80)
+        alpha, base, ext = (v[0], v[1]), v[2:102], [(v[102 + 2 * i], v[103 + 2 * i]) for i in range(40)]
+        acc_b, acc_e, pw = (0, 0), (0, 0), (1, 0)
+        for i in range(100):
+            acc_b = eadd(acc_b, emul(pw, (base[i], 0)))
+            if i < 40:
+                acc_e = eadd(acc_e, emul(pw, ext[i]))
+            pw = emul(pw, alpha)
+        assert gadget(1, v) == [*acc_b, *acc_e]
+
+
+def test_coset_interpolation_gate_is_lagrange_interpolation(gadget, orc):
+    rng = np.random.default_rng(3)
+    w = orc.root(4)
+    for _ in range(4):
+        v = rnd(rng, 1 + 32 + 2)
+        shift, vals, pt = v[0] or 1, [(v[1 + 2 * i], v[2 + 2 * i]) for i in range(16)], (v[33], v[34])
+        v[0] = shift
+        xs = [shift * pow(w, i, P) % P for i in range(16)]
+        acc = (0, 0)
+        for i in range(16):
+            num, den = (1, 0), 1
+            for j in range(16):
+                if j != i:
+                    num = emul(num, esub(pt, (xs[j], 0)))
+                    den = den * (xs[i] - xs[j]) % P
+            acc = eadd(acc, emul(emul(vals[i], num), (pow(den, P - 2, P), 0)))
+        assert gadget(2, v) == list(acc)
+
+
+def test_bits(gadget, orc):
+    rng = np.random.default_rng(4)
+    for x, y in [(0, 0), (1023, P - 1), (1, 1 << 63), (513, 0xFFFFFFFF), *[(int(rng.integers(0, 1024)), int(rng.integers(0, P, dtype=np.uint64))) for _ in range(6)]]:
+        got = gadget(3, [x, y])
+        assert got[0] == pow(7, x, P) and got[1] == x and got[2:] == [(y >> i) & 1 for i in range(64)]
+    gadget(3, [1024, 5], expect_rc=orc.WIT_CONFLICT)                    # x is range-checked to 10 bits by its split
+
+
+def test_selection(gadget, orc):
+    rng = np.random.default_rng(5)
+    for _ in range(8):
+        vals = rnd(rng, 16)
+        idx, sel = int(rng.integers(0, 16)), int(rng.integers(0, 2))
+        u = int(rng.integers(0, P, dtype=np.uint64)); v = u if rng.integers(0, 2) else int(rng.integers(0, P, dtype=np.uint64))
+        assert gadget(4, [idx] + vals + [sel, u, v]) == [vals[idx], u if sel else v, 1 if u == v else 0]
+    gadget(4, [3] + [0] * 16 + [2, 1, 2], expect_rc=orc.WIT_CONFLICT)    # a selector that is not a bit: the assert_bool product is wired to zero
+    # an index outside the list: the generators run (the gate's own constraint, index = sum of its bits, is not a copy constraint),
+    # but the trace does not satisfy the gate and the proof made from it does not verify
+    pack, wires, pis = gadget(4, [16] + list(range(16)) + [0, 1, 2], want_trace=True)
+    oc = ob.OracleCircuit(orc, pack)
+    assert oc.verify(oc.prove(wires, pis)) != 0
+    pack, wires, pis = gadget(4, [5] + list(range(16)) + [0, 1, 2], want_trace=True)
+    assert oc.verify(oc.prove(wires, pis)) == 0
+    oc.close()
+
+
+def test_digest_order(gadget):
+    rng = np.random.default_rng(6)
+    cases = [[tuple(rnd(rng, 4)) for _ in range(5)] for _ in range(4)]
+    cases.append([(P - 1, 0, 0, 0), (P - 1, 0, 0, 0), (0, P - 1, 1, 2), (0, 0xFFFFFFFF, 0xFFFFFFFF00000000, 3), (0, 0xFFFFFFFF, 0xFFFFFFFF00000000, 2)])   # equal digests, limbs next to p and 2^32
+    cases.append([(5, 5, 5, 5)] * 5)
+    for ds in cases:
+        got = gadget(5, [x for d in ds for x in d])
+        assert [tuple(got[4 * i:4 * i + 4]) for i in range(5)] == sorted(ds) and got[20] == (1 if ds[0] == ds[1] else 0)
