@@ -27,6 +27,12 @@ struct WitnessPlan {
     std::vector<uint32_t> level_poseidon;    // first PoseidonGate instance of level l (they come last in their level)
     std::vector<std::pair<uint32_t, uint32_t>> segments;   // launches: [l0, l1) — one wide level, or a run of narrow ones
     bool pi_gate_from_hash = true;           // every PublicInputGate row takes its wires from a hash output through the copy pass
+    // A plan built WITH the caller's assignment list (only when the plan without it is cyclic: a generator that needs a target the
+    // caller sets, whose only other producer depends on that generator — split_low_high / div_extension of an input): the classes
+    // the caller assigns are known from the start, as a PartialWitness's values are in plonky2; their producers are checked.
+    bool assigned_aware = false;
+    std::vector<u64> assigned_cells;         // the list (incl. the public-input cells when they are supplied) the plan was built for
+    std::vector<uint8_t> assigned_checked;   // [num_wires][n]: 1 = a caller-assigned class that generators produce too (scatter AND check)
     uint32_t *d_level_start = nullptr, *d_level_poseidon = nullptr;
     std::vector<uint8_t> free_mask;          // [num_wires][n]: 1 = supplied by the caller
     uint64_t num_free = 0;
@@ -174,7 +180,7 @@ void describe_any(const CircuitPack &p, const WitnessInst &w, IO &tmp, CellIO &i
     }
 }
 
-std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
+std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan, const std::vector<u64> *assigned = nullptr) {
     const CircuitPack &p = c->pack;
     const u64 n = p.n(), R = p.num_routed_wires, NW = p.num_wires;
     const size_t sig0 = p.num_selectors + p.num_constants;
@@ -258,6 +264,15 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
         insts.swap(kept);
     }
 
+    // the caller's assignments (assignment-aware plans only): class root -> the cell the caller names first
+    std::unordered_map<uint32_t, uint32_t> assigned_root;
+    if (assigned)
+        for (u64 cell : *assigned) {
+            if (cell >= NW * n) continue;
+            const u64 row = cell / NW, col = cell % NW;
+            if (col >= R) continue;
+            assigned_root.emplace(find((uint32_t)(row * R + col)), (uint32_t)(row * R + col));
+        }
     // ---- levels, the way generate_partial_witness gets there: a generator runs once every target it watches is set, a
     // partition is set by the first of its producers to run. Level of an instance = 1 + the latest level at which one of its
     // input classes becomes known; a class becomes known at the level of its earliest producer (level 0 = caller-supplied).
@@ -271,7 +286,7 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
             if (c_.col >= R) continue;
             const uint32_t root = find((uint32_t)((u64)c_.row * R + c_.col));
             const auto &pl = producers[root];
-            if (pl.empty() || (pl.size() == 1 && pl[0] == id)) continue;      // free, or produced by this very instance
+            if (pl.empty() || (pl.size() == 1 && pl[0] == id) || assigned_root.count(root)) continue;      // free, produced by this very instance, or set by the caller
             ic.push_back(root);
         }
         std::sort(ic.begin(), ic.end());
@@ -282,6 +297,7 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     std::vector<int32_t> primary(n * R, -1);            // class root -> the producer that is its source
     std::vector<uint32_t> source(n * R);                // class root -> source cell (row * R + col)
     for (uint32_t i = 0; i < n * R; i++) source[i] = i;
+    for (const auto &ar : assigned_root) { class_level[ar.first] = 0; source[ar.first] = ar.second; }
     {
         std::vector<uint32_t> waiting(insts.size());
         std::vector<std::vector<uint32_t>> bucket(2);   // bucket[l] = instances that run at level l (levels are reached in order)
@@ -328,9 +344,17 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     plan.num_free = 0;
     for (uint8_t m : plan.free_mask) plan.num_free += m;
     plan.generated.assign(NW * n, 0);
+    plan.assigned_checked.assign(assigned ? NW * n : 0, 0);
     for (u64 col = 0; col < NW; col++)
-        for (u64 r = 0; r < n; r++)
-            plan.generated[col * n + r] = col < R ? !producers[find((uint32_t)(r * R + col))].empty() : (plan.free_mask[col * n + r] == 0);
+        for (u64 r = 0; r < n; r++) {
+            if (col >= R) { plan.generated[col * n + r] = plan.free_mask[col * n + r] == 0; continue; }
+            const uint32_t root = find((uint32_t)(r * R + col));
+            const bool produced = !producers[root].empty(), by_caller = assigned_root.count(root) != 0;
+            plan.generated[col * n + r] = produced && !by_caller;
+            if (produced && by_caller) plan.assigned_checked[col * n + r] = 1;
+        }
+    plan.assigned_aware = assigned != nullptr;
+    if (assigned) plan.assigned_cells = *assigned;
     plan.h_src_of = src_of;
 
     int32_t max_level = 0;
@@ -409,10 +433,19 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan) {
     return "";
 }
 
-int ensure_plan(qpgpu_circuit *c) {
-    if (c->wplan) return QPGPU_OK;
+// The plan of a circuit. Without an assignment list: the plan every entry point shares. With one (the PartialWitness entries): the same
+// plan, unless the circuit's generators form a cycle that only the caller's values break — then a plan built for that list (rebuilt
+// when the list changes).
+int ensure_plan(qpgpu_circuit *c, const std::vector<u64> *assigned = nullptr) {
+    if (c->wplan && (!assigned || !c->wplan->assigned_aware || c->wplan->assigned_cells == *assigned)) return QPGPU_OK;
+    if (c->wplan) { QP_HIP(c->ctx, hipStreamSynchronize(c->ctx->stream)); witness_plan_free(c->wplan); c->wplan = nullptr; }
     WitnessPlan *plan = new WitnessPlan();
-    const std::string err = build_plan(c, *plan);
+    std::string err = build_plan(c, *plan);
+    if (!err.empty() && assigned && err.find("cyclic generator dependency") != std::string::npos) {
+        witness_plan_free(plan);
+        plan = new WitnessPlan();
+        err = build_plan(c, *plan, assigned);
+    }
     if (!err.empty()) { witness_plan_free(plan); return c->ctx->fail(QPGPU_EINVAL, err); }
     c->wplan = plan;
     return QPGPU_OK;
@@ -471,6 +504,9 @@ std::string prepare_partial(const CircuitPack &p, const WitnessPlan &plan, const
         first.emplace(key, from);
         if (plan.generated[own]) { pp.check_idx.push_back(key); pp.check_from.push_back(from); pp.check_cell.push_back(cell); }
         else { pp.scatter_idx.push_back(key); pp.scatter_from.push_back(from); }   // a free class is read through its source cell
+        if (!plan.assigned_checked.empty() && plan.assigned_checked[own]) {       // set by the caller AND produced: what the generators leave there must be the caller's value
+            pp.check_idx.push_back(key); pp.check_from.push_back(from); pp.check_cell.push_back(cell);
+        }
         return "";
     };
     pp.with_pis = with_pis;
@@ -663,6 +699,16 @@ int ensure_prep(qpgpu_circuit *c, const uint64_t *cells, size_t count, uint32_t 
     return prep_device(ctx, pp, batch);
 }
 
+// the PartialWitness entries: the shared plan, or — for a circuit whose generators only the caller's values untangle — one built for
+// this assignment list (the public-input cells belong to it when the public inputs are supplied)
+int ensure_plan_for(qpgpu_circuit *c, const uint64_t *cells, size_t count, bool with_pis) {
+    if (c->wplan && !c->wplan->assigned_aware) return QPGPU_OK;
+    std::vector<u64> assigned;
+    if (with_pis) assigned.assign(c->pack.pi_cells.begin(), c->pack.pi_cells.end());
+    assigned.insert(assigned.end(), cells, cells + count);
+    return ensure_plan(c, &assigned);
+}
+
 }  // namespace
 
 extern "C" {
@@ -690,7 +736,7 @@ int qpgpu_witness_partial_prepare(qpgpu_circuit *c, const uint64_t *cells, size_
     qpgpu_ctx *ctx = c->ctx;
     QP_DEV(ctx);
     if ((count && !cells) || max_batch == 0 || max_batch > 65535) return ctx->fail(QPGPU_EINVAL, "witness_partial_prepare: bad argument");
-    QP_TRY(ensure_plan(c));
+    QP_TRY(ensure_plan_for(c, cells, count, true));
     QP_TRY(ensure_prep(c, cells, count, max_batch));
     WitnessPlan &plan = *c->wplan;
     // size what generation will need, so that the calls themselves neither allocate nor free
@@ -717,7 +763,7 @@ int qpgpu_generate_witness_partial_batch_dev(qpgpu_circuit *c, const uint64_t *c
     const CircuitPack &p = c->pack;
     if (!d_wires || batch == 0 || batch > 65535 || (count && (!cells || !values)))
         return ctx->fail(QPGPU_EINVAL, "generate_witness_partial: null argument");
-    QP_TRY(ensure_plan(c));
+    QP_TRY(ensure_plan_for(c, cells, count, public_inputs != nullptr));
     if (!public_inputs && p.num_public_inputs && !c->wplan->pi_gate_from_hash)
         return ctx->fail(QPGPU_EINVAL, "generate_witness_partial: public inputs can only be derived in a circuit whose PublicInputGate wires are copy-connected to the in-circuit hash of the public-input targets");
     QP_TRY(ensure_prep(c, cells, count, batch, public_inputs != nullptr));
@@ -732,7 +778,7 @@ int qpgpu_generate_witness_partial_batch_blinded_dev(qpgpu_circuit *c, const uin
     const CircuitPack &p = c->pack;
     if (!d_wires || batch == 0 || batch > 65535 || !cells || n_blinding > count || (count > n_blinding && !values))
         return ctx->fail(QPGPU_EINVAL, "generate_witness_partial_blinded: null argument or more blinding cells than cells");
-    QP_TRY(ensure_plan(c));
+    QP_TRY(ensure_plan_for(c, cells, count, public_inputs != nullptr));
     if (!public_inputs && p.num_public_inputs && !c->wplan->pi_gate_from_hash)
         return ctx->fail(QPGPU_EINVAL, "generate_witness_partial_blinded: public inputs can only be derived in a circuit whose PublicInputGate wires are copy-connected to the in-circuit hash of the public-input targets");
     QP_TRY(ensure_prep(c, cells, count, batch, public_inputs != nullptr));

@@ -1,0 +1,47 @@
+"""tests/test_builder_gadgets.py's gadget circuits through stage s1 on the device: for every gadget family the device's wire matrix
+(public inputs read out of the witness) equals the oracle's on random inputs, batched."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.mark.parametrize("kind", range(6))
+def test_gadget_circuit_on_the_device(pkg, gpu, orc, kind):
+    L = pkg.load_library()
+    c = ctypes
+    L.qpgpu_builder_gadget_circuit.restype = c.c_int
+    L.qpgpu_builder_gadget_circuit.argtypes = [c.c_uint, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t), c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t), c.POINTER(c.c_size_t), c.c_char_p]
+    n, ni, no = c.c_size_t(), c.c_size_t(), c.c_size_t()
+    err = c.create_string_buffer(400)
+    assert L.qpgpu_builder_gadget_circuit(kind, None, 0, c.byref(n), None, 0, c.byref(ni), c.byref(no), err) == 0
+    pack = np.empty(n.value, dtype=np.uint64); cells = np.empty(ni.value + no.value, dtype=np.uint64)
+    assert L.qpgpu_builder_gadget_circuit(kind, pack.ctypes.data, pack.size, c.byref(n), cells.ctypes.data, cells.size, c.byref(ni), c.byref(no), err) == 0
+    cin = cells[:ni.value]
+    rng = np.random.default_rng(40 + kind)
+    B = 4
+    vals = rng.integers(0, P, (B, cin.size), dtype=np.uint64)
+    if kind == 2:
+        vals[:, 0] |= np.uint64(1)                         # a non-zero shift
+    if kind == 3:
+        vals[:, 0] %= np.uint64(1024)
+    if kind == 4:
+        vals[:, 0] %= np.uint64(16); vals[:, 17] %= np.uint64(2); vals[1, 19] = vals[1, 18]
+    circ = pkg.Circuit(gpu, pack, max_batch=B)
+    nw, rows = 135, 1 << int(pack[1])
+    d = gpu.alloc(B * nw * rows * 8)
+    assert circ.generate_witness_partial_batch_dev(cin, vals, None, d) == [0] * B
+    got = d.download().reshape(B, nw, rows)
+    pis = circ.witness_public_inputs_dev(d, B)
+    for b in range(B):
+        rc, want, _ = orc.generate_witness(pack, cin, vals[b], None)
+        assert rc == orc.WIT_OK and np.array_equal(got[b], want), (kind, b)
+        cout = cells[ni.value:]
+        assert pis[b].tolist() == [int(want[int(x) % 135, int(x) // 135]) for x in cout]
+    proof = circ.prove_dev(d, pis[0])
+    ver = pkg.Verifier(pack, circuit=circ)
+    assert ver.verify(proof)
+    ver.close(); circ.close(); d.free(scrub=True)
