@@ -216,7 +216,10 @@ int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32
  * generators run. A target set twice with different values — two assignments inside one copy class, or an assignment that
  * disagrees with the value a generator or the public-input argument gives that target — returns QPGPU_EUNSAT and names
  * the target in qpgpu_last_error: plonky2's "set twice with different values" panic, which six reference tests expect
- * (wormhole/tests/src/circuit/block_header_tests.rs:34-95, nullifier_tests.rs:53-58). Unassigned free cells stay zero. */
+ * (wormhole/tests/src/circuit/block_header_tests.rs:34-95, nullifier_tests.rs:53-58). Unassigned free cells stay zero.
+ * A generator that divides by zero — QuotientGeneratorExtension's denominator, InterpolationGenerator's coset shift; plonky2's
+ * Field::inverse panics with "Tried to invert zero" — returns QPGPU_EUNSAT too and names the zero target (every witness entry
+ * point; it is reported before a "set twice" the value written in its place may have caused). */
 int qpgpu_generate_witness_partial_dev(qpgpu_circuit *c, const uint64_t *cells, const uint64_t *values, size_t count,
                                        const uint64_t *public_inputs, uint64_t *d_wires);
 /* `batch` PartialWitnesses over the SAME cell list at once (every proof of one circuit assigns the same targets: the 299 of

@@ -229,7 +229,8 @@ int qpgpu_random_field_elements(const uint8_t *seed32, uint64_t *out, size_t n, 
  *   2  coset interpolation      in: shift, 16 extension values, point (2)            out: the interpolant through (shift w^i, v_i) at point
  *   3  bits                     in: x (< 2^10), y (any)                   out: 7^x (exp_from_bits_const_base), le_sum(split_le(x, 10)), the 64 bits of y
  *   4  selection                in: index (< 16), 16 values, b (0/1), u, v            out: values[index], select(b, u, v), is_equal(u, v)
- *   5  digest order             in: 5 digests (4 each)                    out: the digests sorted (sort_digests4), digest_eq(d0, d1) */
+ *   5  digest order             in: 5 digests (4 each)                    out: the digests sorted (sort_digests4), digest_eq(d0, d1)
+ *   1000 + seed: a random program of 40-80 gadget applications over 6 inputs (differential tests of builder, stage s1 and prover) */
 int qpgpu_builder_gadget_circuit(unsigned kind, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words, uint64_t *cells_out, size_t cells_cap,
                                  size_t *n_inputs, size_t *n_outputs, char *err);
 int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, const uint64_t *inner_cs_cap, size_t cap_words, unsigned num_proofs,

@@ -20,7 +20,8 @@
 #include "plonk.h"
 #include "poseidon2.h"
 
-enum { ORC_WIT_OK = 0, ORC_WIT_CONFLICT = 1, ORC_WIT_INCOMPLETE = 2, ORC_WIT_UNSUPPORTED = 3, ORC_WIT_BAD_PACK = 4 };
+enum { ORC_WIT_OK = 0, ORC_WIT_CONFLICT = 1, ORC_WIT_INCOMPLETE = 2, ORC_WIT_UNSUPPORTED = 3, ORC_WIT_BAD_PACK = 4,
+       ORC_WIT_ZERO_INVERSE = 5 /* a generator divided by zero (plonky2's Field::inverse panics: "Tried to invert zero") */ };
 
 void orc_poseidon_round_constants(gl_t *out);
 int orc_prove_many_entry(const orc_circuit *c, const gl_t *wires, const gl_t *public_inputs, uint8_t *out, size_t cap, size_t *len);   /* prove.c: orc_prove without the stage trace */
@@ -31,6 +32,7 @@ typedef struct {
     uint32_t *cls;          /* [nw * n] flat cell (col * n + row) -> slot */
     gl_t *val; uint8_t *set; /* per slot */
     int conflict; uint64_t conflict_cell; int derive_pis;
+    int zero_inverse; uint64_t zero_cell;      /* the first generator that inverted zero, named by the cell it read */
 } pw_t;
 
 static inline size_t flat(const pw_t *p, size_t row, size_t col) { return col * p->n + row; }
@@ -202,6 +204,7 @@ static int run_hint(pw_t *p, const uint64_t *h) {
     case 3: if (!pw_get(p, HR(h[1]), HC(h[1]), &a)) return 0; pw_set(p, HR(h[2]), HC(h[2]), (a >> h[3]) & ((1ULL << h[4]) - 1)); return 1;
     case 4: {
         if (!pw_get(p, HR(h[1]), HC(h[1]), &a) || !pw_get(p, HR(h[2]), HC(h[2]), &b) || !pw_get(p, HR(h[3]), HC(h[3]), &c2) || !pw_get(p, HR(h[4]), HC(h[4]), &d)) return 0;
+        if (c2 == 0 && d == 0 && !p->zero_inverse) { p->zero_inverse = 1; p->zero_cell = h[3]; }
         const gl2_t q = gl2_mul(gl2_make(a, b), gl2_inv(gl2_make(c2, d)));
         pw_set(p, HR(h[5]), HC(h[5]), q.c[0]); pw_set(p, HR(h[6]), HC(h[6]), q.c[1]);
         return 1;
@@ -303,6 +306,7 @@ static int run_gate(pw_t *p, const gen_t *g, const gl_t pih[4]) {
         gl_t shift, e[2], v[64];
         if (!pw_get(p, row, 0, &shift) || !pw_get(p, row, s_ep, &e[0]) || !pw_get(p, row, s_ep + 1, &e[1])) return 0;
         for (size_t i = 0; i < 2 * np; i++) if (!pw_get(p, row, 1 + i, &v[i])) return 0;
+        if (shift == 0 && !p->zero_inverse) { p->zero_inverse = 1; p->zero_cell = row * p->nw; }
         const gl2_t sp = gl2_scale(gl2_make(e[0], e[1]), gl_inv(shift));
         pw_set(p, row, s_int + 4 * ni, sp.c[0]); pw_set(p, row, s_int + 4 * ni + 1, sp.c[1]);
         const gl_t omega = gl_root_of_unity((unsigned)bits), inv_n = gl_inv((gl_t)np);
@@ -454,11 +458,12 @@ int orc_witness_generate(const orc_witness_plan *w, const uint64_t *cells, const
             if (kept == np || kept == 0) { np = kept; break; }
             np = kept;
         }
-        if (p.conflict) rc = ORC_WIT_CONFLICT;
+        if (p.zero_inverse) rc = ORC_WIT_ZERO_INVERSE;     /* first: the value such a generator writes (inverse taken as 0) is what later conflicts come from */
+        else if (p.conflict) rc = ORC_WIT_CONFLICT;
         else if (np) rc = ORC_WIT_INCOMPLETE;    /* generators left waiting: plonky2 would fail on the first unset target */
         free(pending);
     }
-    if (conflict_cell_out) *conflict_cell_out = p.conflict ? p.conflict_cell : ~0ULL;
+    if (conflict_cell_out) *conflict_cell_out = p.zero_inverse ? p.zero_cell : p.conflict ? p.conflict_cell : ~0ULL;
     if (wires_out) for (size_t i = 0; i < NW * n; i++) { const uint32_t s = p.cls[i]; wires_out[i] = p.set[s] ? p.val[s] : 0; }
     /* the slots held the spend secret */
     memset(p.val, 0, NW * n * sizeof(gl_t));

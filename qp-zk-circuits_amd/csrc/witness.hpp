@@ -41,5 +41,6 @@ hipError_t wk_scatter(uint64_t *wires, const uint32_t *idx, const uint64_t *vals
 hipError_t wk_gather(const uint64_t *wires, const uint32_t *idx, uint64_t *out, uint32_t count, hipStream_t st);
 // a partition set twice: err[2 * b + slot] = min over failing comparisons of (index), 0xFFFFFFFF = none (the caller presets it).
 // pairs: wires[own[i]] against wires[src[i]]; vals: wires[idx[i]] against vals[b * val_stride + i] (flat cells, canonical compare)
+hipError_t wk_check_nonzero(const uint64_t *wires, const uint32_t *a, const uint32_t *b, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t *err, uint32_t slot, hipStream_t st);
 hipError_t wk_check_pairs(const uint64_t *wires, const uint32_t *own, const uint32_t *src, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t *err, uint32_t slot, hipStream_t st);
 hipError_t wk_check_vals(const uint64_t *wires, const uint32_t *idx, const uint64_t *vals, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t val_stride, uint32_t *err, uint32_t slot, hipStream_t st);

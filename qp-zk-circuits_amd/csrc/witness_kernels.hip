@@ -395,16 +395,28 @@ __global__ void __launch_bounds__(256) witness_check_pairs_kernel(const u64 *wir
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const u64 *w = wires + (u64)blockIdx.y * batch_stride;
-    if (gl::canon(w[own[i]]) != gl::canon(w[src[i]])) atomicMin(&err[2 * blockIdx.y + slot], i);
+    if (gl::canon(w[own[i]]) != gl::canon(w[src[i]])) atomicMin(&err[4 * blockIdx.y + slot], i);
+}
+// a generator's divisor that is zero (see WitnessPlan::h_nz_a)
+__global__ void __launch_bounds__(256) witness_check_nonzero_kernel(const u64 *wires, const u32 *a, const u32 *b, u32 count, u64 batch_stride, u32 *err, u32 slot) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64 *w = wires + (u64)blockIdx.y * batch_stride;
+    if (gl::canon(w[a[i]]) == 0 && gl::canon(w[b[i]]) == 0) atomicMin(&err[4 * blockIdx.y + slot], i);
 }
 __global__ void __launch_bounds__(256) witness_check_vals_kernel(const u64 *wires, const u32 *idx, const u64 *vals, u32 count, u64 batch_stride, u32 val_stride, u32 *err, u32 slot) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    if (gl::canon(wires[(u64)blockIdx.y * batch_stride + idx[i]]) != gl::canon(vals[(u64)blockIdx.y * val_stride + i])) atomicMin(&err[2 * blockIdx.y + slot], i);
+    if (gl::canon(wires[(u64)blockIdx.y * batch_stride + idx[i]]) != gl::canon(vals[(u64)blockIdx.y * val_stride + i])) atomicMin(&err[4 * blockIdx.y + slot], i);
 }
 
 }  // namespace
 
+hipError_t wk_check_nonzero(const uint64_t *wires, const uint32_t *a, const uint32_t *b, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t *err, uint32_t slot, hipStream_t st) {
+    if (!count || !batch) return hipSuccess;
+    hipLaunchKernelGGL(witness_check_nonzero_kernel, dim3((count + 255) / 256, batch), dim3(256), 0, st, wires, a, b, count, batch_stride, err, slot);
+    return hipGetLastError();
+}
 hipError_t wk_check_pairs(const uint64_t *wires, const uint32_t *own, const uint32_t *src, uint32_t count, uint32_t batch, uint64_t batch_stride, uint32_t *err, uint32_t slot, hipStream_t st) {
     if (count == 0 || batch == 0) return hipSuccess;
     hipLaunchKernelGGL(witness_check_pairs_kernel, dim3((count + 255) / 256, batch), dim3(256), 0, st, wires, own, src, count, batch_stride, err, slot);

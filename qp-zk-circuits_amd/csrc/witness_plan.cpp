@@ -53,7 +53,14 @@ struct WitnessPlan {
     // write are compared with the source before the copy pass overwrites them (check_own[i] vs check_src[i], flat cells).
     std::vector<uint32_t> h_check_own, h_check_src;
     uint32_t *d_check_own = nullptr, *d_check_src = nullptr;
-    uint32_t *d_err = nullptr; uint32_t err_cap = 0;     // [err_cap][2]: first failing pair + 1 (secondary producers; assignments)
+    // generators that invert one of their inputs (QuotientGeneratorExtension's denominator, InterpolationGenerator's coset shift):
+    // plonky2's Field::inverse panics on zero ("Tried to invert zero"), so a witness where one of them is zero is an error, not a
+    // witness. nz_a[i] / nz_b[i]: the flat source cells of the two limbs (the same cell twice for a base-field value); nz_cell[i]: the
+    // cell (row * num_wires + wire) named in the message
+    std::vector<uint32_t> h_nz_a, h_nz_b;
+    std::vector<u64> h_nz_cell;
+    uint32_t *d_nz_a = nullptr, *d_nz_b = nullptr;
+    uint32_t *d_err = nullptr; uint32_t err_cap = 0;     // [err_cap][4]: first failing index per check (secondary producers; assignments; zero inverses)
     // a prepared PartialWitness shape (the cells a caller assigns are the same for every proof of a circuit): see PartialPrep
     struct PartialPrep *prep = nullptr;
 };
@@ -91,6 +98,8 @@ void witness_plan_free(WitnessPlan *p) {
     if (p->d_pair_val) (void)hipFree(p->d_pair_val);
     if (p->d_check_own) (void)hipFree(p->d_check_own);
     if (p->d_check_src) (void)hipFree(p->d_check_src);
+    if (p->d_nz_a) (void)hipFree(p->d_nz_a);
+    if (p->d_nz_b) (void)hipFree(p->d_nz_b);
     if (p->d_err) (void)hipFree(p->d_err);
     if (p->prep) { p->prep->release(); delete p->prep; }
     delete p;
@@ -356,6 +365,19 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan, const std::vector<u6
     plan.assigned_aware = assigned != nullptr;
     if (assigned) plan.assigned_cells = *assigned;
     plan.h_src_of = src_of;
+    for (const WitnessInst &w : insts) {
+        if (w.gate == WITNESS_HINT) {
+            const HintOp &h = p.hints[w.row];
+            if (h.w[0] != 4) continue;
+            plan.h_nz_a.push_back(src_of[(h.w[3] / NW) * R + h.w[3] % NW]);
+            plan.h_nz_b.push_back(src_of[(h.w[4] / NW) * R + h.w[4] % NW]);
+            plan.h_nz_cell.push_back(h.w[3]);
+        } else if (p.gates[w.gate].type == GATE_COSET_INTERPOLATION) {
+            plan.h_nz_a.push_back(src_of[(u64)w.row * R]);
+            plan.h_nz_b.push_back(src_of[(u64)w.row * R]);
+            plan.h_nz_cell.push_back((u64)w.row * NW);
+        }
+    }
 
     int32_t max_level = 0;
     for (int32_t l : level) max_level = std::max(max_level, l);
@@ -429,6 +451,10 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan, const std::vector<u6
     if (!plan.h_check_own.empty()) {
         if (!up(plan.h_check_own.data(), plan.h_check_own.size() * 4, (void **)&plan.d_check_own)) return "witness plan: device allocation failed";
         if (!up(plan.h_check_src.data(), plan.h_check_src.size() * 4, (void **)&plan.d_check_src)) return "witness plan: device allocation failed";
+    }
+    if (!plan.h_nz_a.empty()) {
+        if (!up(plan.h_nz_a.data(), plan.h_nz_a.size() * 4, (void **)&plan.d_nz_a)) return "witness plan: device allocation failed";
+        if (!up(plan.h_nz_b.data(), plan.h_nz_b.size() * 4, (void **)&plan.d_nz_b)) return "witness plan: device allocation failed";
     }
     return "";
 }
@@ -572,7 +598,7 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
                     break;
                 }
         }
-    const bool pair_checks = !plan.h_check_own.empty(), val_checks = pp && !pp->check_idx.empty();
+    const bool pair_checks = !plan.h_check_own.empty(), val_checks = pp && !pp->check_idx.empty(), nz_checks = !plan.h_nz_a.empty();
     if (plan.pi_cap < batch || (plan.err_cap < batch)) {
         QP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (plan.d_pi_hash) { (void)hipFree(plan.d_pi_hash); plan.d_pi_hash = nullptr; }
@@ -581,7 +607,7 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
         plan.pi_cap = 0; plan.err_cap = 0;
         QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_hash, (size_t)batch * 32));
         QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_vals, std::max<size_t>((size_t)batch * npis * 8, 8)));
-        QP_HIP(ctx, hipMalloc((void **)&plan.d_err, (size_t)batch * 8));
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_err, (size_t)batch * 16));
         plan.pi_cap = batch; plan.err_cap = batch;
     }
     if (pp) QP_TRY(prep_device(ctx, *pp, batch));
@@ -633,7 +659,7 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
         QP_HIP(ctx, wk_scatter(d_wires, pp->d_scatter_idx, pp->d_scatter_val, (uint32_t)ns, batch, stride, (uint32_t)ns, ctx->stream));
     }
     if (nc) QP_HIP(ctx, pk_copy(pp->d_check_val, ckv, ck_bytes, ctx->stream));
-    if (pair_checks || val_checks) QP_HIP(ctx, hipMemsetAsync(plan.d_err, 0xFF, (size_t)batch * 8, ctx->stream));
+    if (pair_checks || val_checks || nz_checks) QP_HIP(ctx, hipMemsetAsync(plan.d_err, 0xFF, (size_t)batch * 16, ctx->stream));
     WitnessArgs a{};
     a.wires = d_wires; a.src_of = plan.d_src_of; a.insts = plan.d_insts; a.gates = c->d_gates; a.cs = c->d_cs_values;
     a.poseidon_rc = c->d_poseidon_rc; a.poseidon_fast = c->d_poseidon_fast; a.pi_hash = plan.d_pi_hash;
@@ -658,18 +684,21 @@ int generate_batch(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const ui
     // generated classes, against the value the class's source holds (before the copy pass makes them equal)
     if (pair_checks) QP_HIP(ctx, wk_check_pairs(d_wires, plan.d_check_own, plan.d_check_src, (uint32_t)plan.h_check_own.size(), batch, stride, plan.d_err, 0, ctx->stream));
     if (val_checks) QP_HIP(ctx, wk_check_vals(d_wires, pp->d_check_idx, pp->d_check_val, (uint32_t)nc, batch, stride, (uint32_t)nc, plan.d_err, 1, ctx->stream));
+    if (nz_checks) QP_HIP(ctx, wk_check_nonzero(d_wires, plan.d_nz_a, plan.d_nz_b, (uint32_t)plan.h_nz_a.size(), batch, stride, plan.d_err, 2, ctx->stream));
     QP_HIP(ctx, wk_fill_copies(a, batch, ctx->stream));
     ctx->prof_end();
-    if (pair_checks || val_checks) {
-        std::vector<uint32_t> err((size_t)batch * 2);
+    if (pair_checks || val_checks || nz_checks) {
+        std::vector<uint32_t> err((size_t)batch * 4);
         QP_TRY(ctx->read_back(err.data(), plan.d_err, err.size() * 4));
         const u64 n = p.n();
         for (uint32_t b = 0; b < batch; b++) {
-            if (pair_checks && err[2 * b] != 0xFFFFFFFFu) {
-                const uint32_t own = plan.h_check_own[err[2 * b]];
+            if (nz_checks && err[4 * b + 2] != 0xFFFFFFFFu) {      // first: the value such a generator wrote is what the other two checks would trip over
+                flag(b, "a generator inverts " + name(plan.h_nz_cell[err[4 * b + 2]]) + ", which is zero (a quotient's denominator or an interpolation's coset shift)");
+            } else if (pair_checks && err[4 * b] != 0xFFFFFFFFu) {
+                const uint32_t own = plan.h_check_own[err[4 * b]];
                 flag(b, name((u64)(own % n) * NW + own / n) + " set twice with different values (two generators of one copy class disagree)");
-            } else if (val_checks && err[2 * b + 1] != 0xFFFFFFFFu) {
-                const uint32_t k = err[2 * b + 1], from = pp->check_from[k];
+            } else if (val_checks && err[4 * b + 1] != 0xFFFFFFFFu) {
+                const uint32_t k = err[4 * b + 1], from = pp->check_from[k];
                 const u64 v = gl::canon(from < npis ? public_inputs[(size_t)b * npis + from] : part_values[(size_t)b * count + (from - npis)]);
                 flag(b, name(pp->check_cell[k]) + " set twice with different values (" + std::to_string(v) + " supplied, another value generated)");
             }
@@ -748,7 +777,7 @@ int qpgpu_witness_partial_prepare(qpgpu_circuit *c, const uint64_t *cells, size_
         plan.pi_cap = 0; plan.err_cap = 0;
         QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_hash, (size_t)max_batch * 32));
         QP_HIP(ctx, hipMalloc((void **)&plan.d_pi_vals, std::max<size_t>((size_t)max_batch * c->pack.num_public_inputs * 8, 8)));
-        QP_HIP(ctx, hipMalloc((void **)&plan.d_err, (size_t)max_batch * 8));
+        QP_HIP(ctx, hipMalloc((void **)&plan.d_err, (size_t)max_batch * 16));
         plan.pi_cap = max_batch; plan.err_cap = max_batch;
     }
     const PartialPrep &pp = *plan.prep;

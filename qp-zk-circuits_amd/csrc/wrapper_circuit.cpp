@@ -621,6 +621,48 @@ int qpgpu_builder_gadget_circuit(unsigned kind, uint64_t *pack_out, size_t pack_
             for (Digest &d : ds) for (Target &t : d) t = input();
             for (const Digest &d : sort_digests4(b, ds)) for (Target t : d) out.push_back(t);
             out.push_back(digest_eq(b, ds[0], ds[1]).target);
+        } else if (kind >= 1000) {
+            // a random program over the builder's gadgets (seed = kind - 1000): 6 inputs, ~60 operations drawn from the base and
+            // extension arithmetic, bits, selection, hashing and the recursion gadgets, each consuming earlier values; every sixth value
+            // an output. For differential tests of builder + stage s1 + prover on circuits nobody wrote by hand.
+            uint64_t st = 0x9E3779B97F4A7C15ull * (kind - 999);
+            auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+            std::vector<Target> vals;
+            for (int i = 0; i < 6; i++) vals.push_back(input());
+            for (int i = 0; i < 6; i++) vals.push_back(b.mul_add(vals[i], vals[(i + 1) % 6], vals[(i + 2) % 6]));      // every input sits in a gate
+            auto pick = [&]() { return vals[next() % vals.size()]; };
+            auto pick_ext = [&]() { cb::ExtTarget e; e.t[0] = pick(); e.t[1] = pick(); return e; };
+            const int ops = 40 + (int)(next() % 40);
+            for (int i = 0; i < ops; i++) {
+                const unsigned op = (unsigned)(next() % 14);
+                switch (op) {
+                case 0: vals.push_back(b.mul(pick(), pick())); break;
+                case 1: vals.push_back(b.add(pick(), pick())); break;
+                case 2: vals.push_back(b.sub(pick(), pick())); break;
+                case 3: vals.push_back(b.mul_const_add(next() % gl::P, pick(), pick())); break;
+                case 4: { const BoolTarget e = b.is_equal(pick(), pick()); vals.push_back(b.select(e, pick(), pick())); vals.push_back(e.target); break; }
+                case 5: { const cb::ExtTarget r = b.mul_add_ext(pick_ext(), pick_ext(), pick_ext()); vals.push_back(r.t[0]); vals.push_back(r.t[1]); break; }
+                case 6: { cb::ExtTarget d = pick_ext(); d.t[0] = b.add_const(b.mul(d.t[0], d.t[0]), 1);          // a denominator that is not zero: (x^2 + 1, y) has norm x^4 + 2 x^2 + 1 - 7 y^2
+                          const cb::ExtTarget r = b.div_ext(pick_ext(), d); vals.push_back(r.t[0]); vals.push_back(r.t[1]); break; }
+                case 7: { Target lo, hi; b.split_low_high(pick(), 32, 64, lo, hi); vals.push_back(lo); vals.push_back(hi); break; }
+                case 8: { const std::vector<BoolTarget> bits = b.split_le(pick(), 64); vals.push_back(b.le_sum(std::vector<BoolTarget>(bits.begin(), bits.begin() + 5)));
+                          vals.push_back(b.exp_from_bits_const_base(3 + next() % 100, std::vector<BoolTarget>(bits.begin() + 5, bits.begin() + 12))); break; }
+                case 9: { std::vector<Target> h; const int cnt = 1 + (int)(next() % 11); for (int k = 0; k < cnt; k++) h.push_back(pick());
+                          const HashOutTarget d = (next() & 1) ? b.hash_n_to_hash_no_pad(h) : b.hash_n_to_hash_no_pad_p2(h); for (Target t : d.elements) vals.push_back(t); break; }
+                case 10: { const std::vector<BoolTarget> bits = b.split_le(pick(), 64); std::vector<Target> list; for (int k = 0; k < 8; k++) list.push_back(pick());
+                           vals.push_back(b.random_access(b.le_sum(std::vector<BoolTarget>(bits.begin(), bits.begin() + 3)), list)); break; }
+                case 11: { std::vector<Target> t; const int cnt = 1 + (int)(next() % 60); for (int k = 0; k < cnt; k++) t.push_back(pick());
+                           const cb::ExtTarget r = b.reduce_base(pick_ext(), t); vals.push_back(r.t[0]); vals.push_back(r.t[1]); break; }
+                case 12: { std::vector<cb::ExtTarget> v; for (int k = 0; k < 16; k++) v.push_back(pick_ext());
+                           const Target sq = pick(); const Target shift = b.add_const(b.mul(sq, sq), 1);     // never zero for the tests' inputs: the pool holds zeros (x - x, a false
+                                                                                                                    // is_equal), and a zero shift has no interpolant (upstream's generator panics on it)
+                           const cb::ExtTarget r = b.interpolate_coset(4, shift, v, pick_ext()); vals.push_back(r.t[0]); vals.push_back(r.t[1]); break; }
+                default: { std::vector<Digest> ds(3); for (Digest &d : ds) for (Target &t : d) t = pick();
+                           for (const Digest &d : sort_digests4(b, ds)) vals.push_back(d[0]); break; }
+                }
+            }
+            for (size_t i = 6; i < vals.size(); i += 6) out.push_back(vals[i]);
+            out.push_back(vals.back());
         } else return fail(QPGPU_EINVAL, "builder_gadget_circuit: unknown kind");
         // the outputs are public inputs (so that each sits in a gate and has a cell); every input is consumed by its gadget
         for (Target t : out) b.register_public_input(t);

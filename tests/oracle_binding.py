@@ -115,7 +115,7 @@ class Oracle:
     def max_threads(self): return int(self.lib.orc_max_threads())
 
     # ---- stage s1: generate_partial_witness over a pack (oracle/witness.c) ----
-    WIT_OK, WIT_CONFLICT, WIT_INCOMPLETE, WIT_UNSUPPORTED, WIT_BAD_PACK = 0, 1, 2, 3, 4
+    WIT_OK, WIT_CONFLICT, WIT_INCOMPLETE, WIT_UNSUPPORTED, WIT_BAD_PACK, WIT_ZERO_INVERSE = 0, 1, 2, 3, 4, 5
     def generate_witness(self, pack_words, cells, values, public_inputs):
         """(rc, wires[num_wires, n], conflict_cell): rc 0 = every generator ran, 1 = a target was set twice with different values
         (conflict_cell = row * num_wires + wire), 2 = generators left waiting for unset targets."""

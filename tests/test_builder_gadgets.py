@@ -139,3 +139,34 @@ def test_digest_order(gadget):
     for ds in cases:
         got = gadget(5, [x for d in ds for x in d])
         assert [tuple(got[4 * i:4 * i + 4]) for i in range(5)] == sorted(ds) and got[20] == (1 if ds[0] == ds[1] else 0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_gadget_programs(pkg, orc, gadget, seed):
+    """qpgpu_builder_gadget_circuit(1000 + seed): a random program of 40-80 gadget applications. The oracle generates the witness
+    (public inputs derived), proves; the oracle's verifier and the library's host verifier accept; a changed output does not verify."""
+    rng = np.random.default_rng(500 + seed)
+    inputs = [int(v) | 1 for v in rng.integers(1, P, 6, dtype=np.uint64)]
+    inputs = [v if v < P else v - 2 for v in inputs]
+    pack, wires, pis = gadget(1000 + seed, inputs, want_trace=True)
+    oc = ob.OracleCircuit(orc, pack)
+    proof = oc.prove(wires, pis)
+    assert oc.verify(proof) == 0
+    ver = pkg.Verifier(pack)
+    assert ver.verify(proof)
+    bad = bytearray(proof); bad[-8] ^= 1                                     # the last public input
+    assert not ver.verify(bytes(bad)) and oc.verify(bytes(bad)) != 0
+    ver.close(); oc.close()
+
+
+def test_a_generator_that_inverts_zero_is_an_error(gadget, orc):
+    """plonky2's Field::inverse panics on zero ("Tried to invert zero"): a quotient whose denominator is zero, an interpolation
+    whose coset shift is zero, end witness generation with an error instead of a witness that cannot be proven (found by the random
+    programs above: a zero in the value pool reached interpolate_coset's shift and the proof did not verify)."""
+    rng = np.random.default_rng(77)
+    v = rnd(rng, 6); v[2] = v[3] = 0                                         # a / b with b = 0
+    gadget(0, v, expect_rc=orc.WIT_ZERO_INVERSE)
+    v[3] = 1
+    assert len(gadget(0, v)) == 8                                            # (0, 1) is invertible
+    w = rnd(rng, 1 + 32 + 2); w[0] = 0
+    gadget(2, w, expect_rc=orc.WIT_ZERO_INVERSE)
