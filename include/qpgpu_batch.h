@@ -230,7 +230,15 @@ int qpgpu_random_field_elements(const uint8_t *seed32, uint64_t *out, size_t n, 
  *   3  bits                     in: x (< 2^10), y (any)                   out: 7^x (exp_from_bits_const_base), le_sum(split_le(x, 10)), the 64 bits of y
  *   4  selection                in: index (< 16), 16 values, b (0/1), u, v            out: values[index], select(b, u, v), is_equal(u, v)
  *   5  digest order             in: 5 digests (4 each)                    out: the digests sorted (sort_digests4), digest_eq(d0, d1)
+ *   6  constant comparisons     in: r8 (< 2^8), r1 (< 2), x (any)          out: 3 < r8 (width 8), 0 < r1 (width 1), 0 < x, 1 < x, p - 2 < x, p - 1 < x
+ *                                                                           (width 64: is_const_less_than's canonical-half path, gadgets.rs:40-97)
+ *   7  0 < x forced true        in: x                                      out: x          (x = 0 has no witness: gadgets.rs:393-412)
+ *   8  a comparison 65 bits wide: refused when the circuit is built ("exceeds 64 bits", gadgets.rs:414-421)
  *   1000 + seed: a random program of 40-80 gadget applications over 6 inputs (differential tests of builder, stage s1 and prover) */
+/* gates sort_digests4 adds over n virtual digests in a builder with num_routed_wires routed wires — the reference pins this cost
+ * (common/src/gadgets.rs:423-458: 900 gates for n = 8, 57 000 for n = 64 under the private-batch config's 60 routed wires, "measured
+ * cost + 15 %"), which makes it a check of the native builder's slot packing against plonky2's */
+int qpgpu_builder_sort_gate_cost(unsigned n, unsigned num_routed_wires, size_t *gates, char *err);
 int qpgpu_builder_gadget_circuit(unsigned kind, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words, uint64_t *cells_out, size_t cells_cap,
                                  size_t *n_inputs, size_t *n_outputs, char *err);
 int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, const uint64_t *inner_cs_cap, size_t cap_words, unsigned num_proofs,

@@ -27,6 +27,7 @@
 #include "../../include/qpgpu.h"
 #include "../../include/qpgpu_leaf.h"
 #include "builder.hpp"
+#include "gadgets.hpp"
 #include "poseidon.hpp"
 
 using cb::BoolTarget;
@@ -103,35 +104,8 @@ CircuitTargets circuit_targets(Builder &b) {
     return t;
 }
 
-// ---- common/src/gadgets.rs ----
-BoolTarget gadget_xor(Builder &b, BoolTarget x, BoolTarget y) {
-    const Target ab = b.mul(x.target, y.target);
-    const Target two_ab = b.mul_const(2, ab);
-    const Target a_plus_b = b.add(x.target, y.target);
-    return {b.sub(a_plus_b, two_ab)};
-}
-// left < right for a constant left; range-constrains right to n_log bits (n_log < 64 here)
-BoolTarget is_const_less_than(Builder &b, unsigned left, Target right, unsigned n_log) {
-    if (n_log == 0 || n_log >= 64 || (left >> n_log) != 0) throw std::logic_error("is_const_less_than: bad comparison width");
-    const std::vector<BoolTarget> right_bits = b.split_le(right, n_log);
-    BoolTarget lt = b._false(), eq = b._true();
-    for (int i = (int)n_log - 1; i >= 0; i--) {
-        const BoolTarget a = b.constant_bool((left >> i) & 1);
-        const BoolTarget bb = right_bits[i];
-        const BoolTarget not_a = b.not_(a);
-        const BoolTarget not_a_and_b = b.and_(not_a, bb);
-        const BoolTarget this_lt = b.and_(not_a_and_b, eq);
-        lt = b.or_(lt, this_lt);
-        const BoolTarget a_xor_b = gadget_xor(b, a, bb);
-        const BoolTarget not_xor = b.not_(a_xor_b);
-        eq = b.and_(eq, not_xor);
-    }
-    return lt;
-}
-void enforce_target_less_than_const(Builder &b, Target target, unsigned upper_bound_exclusive, unsigned n_log) {
-    const BoolTarget overflow = is_const_less_than(b, upper_bound_exclusive - 1, target, n_log);
-    b.connect(overflow.target, b.zero());
-}
+using gadgets::enforce_target_less_than_const;
+using gadgets::is_const_less_than;
 
 // ---- fragments ----
 void unspendable_account_circuit(const UnspendableAccountTargets &t, Builder &b) {

@@ -30,6 +30,7 @@
 #include "../../include/qpgpu.h"
 #include "../../include/qpgpu_batch.h"
 #include "builder.hpp"
+#include "gadgets.hpp"
 #include "poseidon.hpp"
 #include "verify_math.hpp"
 
@@ -150,61 +151,12 @@ struct RecursiveChallenger {
 };
 
 // ---- the wrapper-specific logic of the two batch layers, over the inner proofs' public-input targets -------------------------
-using Digest = std::array<Target, 4>;
-
-// bytes_digest_eq (common/src/gadgets.rs:144-157): limb-wise is_equal, and-ed pairwise
-BoolTarget digest_eq(Builder &b, const Digest &a, const Digest &c) {
-    const BoolTarget e0 = b.is_equal(a[0], c[0]), e1 = b.is_equal(a[1], c[1]), e2 = b.is_equal(a[2], c[2]), e3 = b.is_equal(a[3], c[3]);
-    const BoolTarget e01 = b.and_(e0, e1), e23 = b.and_(e2, e3);
-    return b.and_(e01, e23);
-}
+using gadgets::Digest;
+using gadgets::digest_eq;
+using gadgets::sort_digests4;
+using gadgets::split_canonical_u32_halves;
+using gadgets::u32_lt;
 Digest digest_at(const std::vector<Target> &pis, size_t off) { return {pis[off], pis[off + 1], pis[off + 2], pis[off + 3]}; }
-
-// u32_lt (gadgets.rs:187-199): x < y for range-checked 32-bit values; bit 32 of x + 2^32 - y is x >= y
-BoolTarget u32_lt(Builder &b, Target x, Target y) {
-    const Target t = b.sub(b.add(x, b.constant(1ull << 32)), y);
-    Target low, ge;
-    b.split_low_high(t, 32, 33, low, ge);
-    return b.not_({ge});
-}
-// split_canonical_u32_halves (gadgets.rs:211-226): (lo, hi) of the CANONICAL representative — the region hi == 2^32 - 1 && lo >= 1
-// (the integers >= p) is excluded
-void split_canonical_u32_halves(Builder &b, Target x, Target &lo, Target &hi) {
-    b.split_low_high(x, 32, 64, lo, hi);
-    const BoolTarget hi_is_max = b.is_equal(hi, b.constant((1ull << 32) - 1));
-    const Target zero = b.zero();
-    const BoolTarget lo_is_zero = b.is_equal(lo, zero);
-    const BoolTarget in_wraparound = b.and_(hi_is_max, b.not_(lo_is_zero));
-    b.connect(in_wraparound.target, zero);
-}
-// halves8_lt (gadgets.rs:239-254): lexicographic lhs < rhs over 8 half-limbs, most significant first
-BoolTarget halves8_lt(Builder &b, const std::array<Target, 8> &lhs, const std::array<Target, 8> &rhs) {
-    BoolTarget lt = b._false();
-    for (int i = 7; i >= 0; i--) {
-        const BoolTarget lt_i = u32_lt(b, lhs[i], rhs[i]);
-        const BoolTarget eq_i = b.is_equal(lhs[i], rhs[i]);
-        const BoolTarget carry = b.and_(eq_i, lt);
-        lt = b.or_(lt_i, carry);
-    }
-    return lt;
-}
-// sort_digests4 (gadgets.rs:285-334): odd-even transposition network over digests split once into canonical 32-bit halves
-std::vector<Digest> sort_digests4(Builder &b, const std::vector<Digest> &values) {
-    const size_t n = values.size();
-    if (n <= 1) return values;
-    std::vector<std::array<Target, 8>> v(n);
-    for (size_t i = 0; i < n; i++)
-        for (int j = 0; j < 4; j++) { Target lo, hi; split_canonical_u32_halves(b, values[i][j], lo, hi); v[i][2 * j] = hi; v[i][2 * j + 1] = lo; }
-    for (size_t round = 0; round < n; round++)
-        for (size_t i = round % 2; i + 1 < n; i += 2) {
-            const std::array<Target, 8> lhs = v[i], rhs = v[i + 1];
-            const BoolTarget lhs_lt = halves8_lt(b, lhs, rhs);
-            for (int j = 0; j < 8; j++) { v[i][j] = b.select(lhs_lt, lhs[j], rhs[j]); v[i + 1][j] = b.select(lhs_lt, rhs[j], lhs[j]); }
-        }
-    std::vector<Digest> out(n);
-    for (size_t i = 0; i < n; i++) for (int j = 0; j < 4; j++) out[i][j] = b.mul_const_add(1ull << 32, v[i][2 * j], v[i][2 * j + 1]);
-    return out;
-}
 
 // leaf public inputs (wormhole/inputs: asset_id, output_amount_1, output_amount_2, volume_fee_bps, nullifier(4), exit_account_1(4),
 // exit_account_2(4), block_hash(4), block_number)
@@ -574,6 +526,25 @@ int qpgpu_wrapper_circuit_build(const uint64_t *inner_pack, size_t inner_words, 
     return QPGPU_OK;
 }
 
+int qpgpu_builder_sort_gate_cost(unsigned n, unsigned num_routed_wires, size_t *gates, char *err) {
+    if (err) err[0] = 0;
+    if (!gates || n > 4096) { if (err) std::snprintf(err, QPGPU_BATCH_ERR_CAP, "builder_sort_gate_cost: bad argument"); return QPGPU_EINVAL; }
+    try {
+        cb::Config cfg;
+        cfg.num_routed_wires = num_routed_wires;
+        Builder b(cfg);
+        std::vector<Digest> values(n);
+        for (Digest &d : values) for (Target &t : d) t = b.add_virtual_target();
+        const size_t before = b.num_gates();
+        (void)sort_digests4(b, values);
+        *gates = b.num_gates() - before;
+    } catch (const std::exception &e) {
+        if (err) std::snprintf(err, QPGPU_BATCH_ERR_CAP, "builder_sort_gate_cost: %s", e.what());
+        return QPGPU_EINVAL;
+    }
+    return QPGPU_OK;
+}
+
 int qpgpu_builder_gadget_circuit(unsigned kind, uint64_t *pack_out, size_t pack_cap_words, size_t *pack_words, uint64_t *cells_out, size_t cells_cap,
                                  size_t *n_inputs, size_t *n_outputs, char *err) {
     auto fail = [&](int code, const std::string &m) { if (err) std::snprintf(err, QPGPU_BATCH_ERR_CAP, "%s", m.c_str()); return code; };
@@ -621,6 +592,22 @@ int qpgpu_builder_gadget_circuit(unsigned kind, uint64_t *pack_out, size_t pack_
             for (Digest &d : ds) for (Target &t : d) t = input();
             for (const Digest &d : sort_digests4(b, ds)) for (Target t : d) out.push_back(t);
             out.push_back(digest_eq(b, ds[0], ds[1]).target);
+        } else if (kind == 6) {
+            // common/src/gadgets.rs:343-391: is_const_less_than at widths 8, 1 and 64 (the canonical-half path), as public booleans
+            const Target r8 = input(), r1 = input(), x = input();
+            out.push_back(gadgets::is_const_less_than(b, 3, r8, 8).target);
+            out.push_back(gadgets::is_const_less_than(b, 0, r1, 1).target);
+            for (u64 left : {(u64)0, (u64)1, (u64)(gl::P - 2), (u64)(gl::P - 1)}) out.push_back(gadgets::is_const_less_than(b, left, x, 64).target);
+        } else if (kind == 7) {
+            // gadgets.rs:393-412: 0 < right FORCED true at width 64 — unsatisfiable for right = 0 (no 64-bit alias of zero is admitted)
+            const Target right = input();
+            const BoolTarget lt = gadgets::is_const_less_than(b, 0, right, 64);
+            b.connect(lt.target, b._true().target);
+            out.push_back(b.add_const(right, 0));
+        } else if (kind == 8) {
+            // gadgets.rs:414-421: a comparison width above 64 is refused when the circuit is built
+            const Target right = input();
+            out.push_back(gadgets::is_const_less_than(b, 0, right, 65).target);
         } else if (kind >= 1000) {
             // a random program over the builder's gadgets (seed = kind - 1000): 6 inputs, ~60 operations drawn from the base and
             // extension arithmetic, bits, selection, hashing and the recursion gadgets, each consuming earlier values; every sixth value

@@ -22,7 +22,7 @@ def gadget_circuit(pkg, kind):
     return pack, cells, ni, no
 
 
-@pytest.mark.parametrize("kind", range(6))
+@pytest.mark.parametrize("kind", range(7))
 def test_gadget_circuit_on_the_device(pkg, gpu, orc, kind):
     pack, cells, ni, no = gadget_circuit(pkg, kind)
     cin = cells[:ni.value]
@@ -35,6 +35,8 @@ def test_gadget_circuit_on_the_device(pkg, gpu, orc, kind):
         vals[:, 0] %= np.uint64(1024)
     if kind == 4:
         vals[:, 0] %= np.uint64(16); vals[:, 17] %= np.uint64(2); vals[1, 19] = vals[1, 18]
+    if kind == 6:
+        vals[:, 0] %= np.uint64(256); vals[:, 1] %= np.uint64(2); vals[0, 2] = 0; vals[1, 2] = P - 1
     circ = pkg.Circuit(gpu, pack, max_batch=B)
     nw, rows = 135, 1 << int(pack[1])
     d = gpu.alloc(B * nw * rows * 8)
