@@ -5,7 +5,7 @@ random secrets, amounts under the fee rule, Merkle paths of 0..16 levels at rand
   * stage s1 on the device in lockstep batches (qpgpu_generate_witness_partial_batch_dev): status per witness,
   * oracle/witness.c on the same assignments,
 must agree (satisfiable / "set twice with different values"), and for satisfiable inputs the device's wire matrix must equal the
-oracle's cell for cell; every 16th satisfiable input is also proven and verified. usage: python tools/fuzz_leaf_inputs.py [count] [seed]"""
+oracle's cell for cell; every 16th satisfiable input is also proven and verified. usage: python tests/soak/fuzz_leaf_inputs.py [count] [seed]"""
 import ctypes, json, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")

@@ -2,9 +2,9 @@
 """AddressSanitizer + UndefinedBehaviorSanitizer pass over the host-only sources of the library (CPU build with g++; GPU
 sanitizers are not available on the pool): builds tools/sanitize/driver.cpp with csrc/{batch,proof_targets,wire,leaf_witness,verifier,circuit,
 poseidon_constants}.cpp, lets the CPU oracle make one valid proof, and runs the driver on it (mutated / truncated / random
-proofs and packs, random public-input rows, random config text). usage: python tools/sanitize_host.py [iterations]"""
+proofs and packs, random public-input rows, random config text). usage: python tests/soak/sanitize_host.py [iterations]"""
 import os, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as ge

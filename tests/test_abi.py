@@ -35,6 +35,15 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in text and "oracle/" not in text and "oracle_binding" not in text, f
+    # nor do the tools, examples and the Rust-side binding: drivers that check against the oracle live under tests/soak/
+    for sub in ("tools", "examples", "integration", "include"):
+        for dp, _, fs in os.walk(os.path.join(root, sub)):
+            if "scratch_bin" in dp or "__pycache__" in dp:
+                continue
+            for f in fs:
+                if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".c", ".sh", ".rs")):
+                    text = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "liboracle" not in text and "oracle_binding" not in text and "load_oracle" not in text, os.path.join(dp, f)
 
 
 def test_c_example_compiles_against_the_header():

@@ -14,18 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("tool,args,keys", [
-    ("fuzz_leaf_inputs.py", ["384", "21"], {"inputs": 384}),
-    ("fuzz_wrapper_tamper.py", ["96", "22"], {"flips": 96, "accepted_by_both": 0}),
-    ("fuzz_private_batch.py", ["192", "23"], {"batches": 192}),
+    ("tests/soak/fuzz_leaf_inputs.py", ["384", "21"], {"inputs": 384}),              # (checks against the oracle: lives under tests/)
+    ("tools/fuzz_wrapper_tamper.py", ["96", "22"], {"flips": 96, "accepted_by_both": 0}),
+    ("tools/fuzz_private_batch.py", ["192", "23"], {"batches": 192}),
 ])
 def test_fuzz_tool(tool, args, keys):
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, tool)] + args, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     stats = json.loads(res.stdout.strip().splitlines()[-1])
     assert stats["mismatches"] == 0
     for k, v in keys.items():
         assert stats[k] == v
-    if tool == "fuzz_private_batch.py":
+    if tool.endswith("fuzz_private_batch.py"):
         assert stats["satisfiable"] > 50 and stats["unsatisfiable"] > 20
-    if tool == "fuzz_leaf_inputs.py":
+    if tool.endswith("fuzz_leaf_inputs.py"):
         assert stats["satisfiable"] > 150 and stats["unsatisfiable"] > 50 and stats["witnesses_compared"] == stats["satisfiable"]

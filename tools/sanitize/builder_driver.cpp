@@ -1,4 +1,4 @@
-// Sanitizer driver for the circuit builder and the circuits restated on it (built by tools/sanitize_host.py with
+// Sanitizer driver for the circuit builder and the circuits restated on it (built by tests/soak/sanitize_host.py with
 // g++ -fsanitize=address,undefined): builds every leaf fragment and the fake leaf, commits inputs, builds wrapper circuits with
 // every flag combination over a valid inner pack, fills their proof targets from a valid proof and from mutated ones, and hands
 // the wrapper builder mutated / truncated / random inner packs and caps. The functions must only ever return error codes.

@@ -1,4 +1,4 @@
-// Sanitizer driver for the host-only part of the library (built by tools/sanitize_host.py with g++ -fsanitize=address,undefined):
+// Sanitizer driver for the host-only part of the library (built by tests/soak/sanitize_host.py with g++ -fsanitize=address,undefined):
 // feeds the parsers and the verifier valid, mutated, truncated and random inputs. Any out-of-bounds access, overflow or
 // leak aborts the run; the functions themselves must only ever return error codes.
 // usage: driver <pack.bin> <proof.bin> [iterations]
