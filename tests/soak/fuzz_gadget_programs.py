@@ -39,13 +39,16 @@ def main():
         L.qpgpu_builder_gadget_circuit(kind, pack.ctypes.data, pack.size, c.byref(n), cells.ctypes.data, cells.size, c.byref(ni), c.byref(no), err)
         cin, cout = cells[:ni.value], cells[ni.value:]
         rng = np.random.default_rng(100000 + seed)
-        vals = rng.integers(0, P, (2, cin.size), dtype=np.uint64)
+        NB = 4
+        vals = rng.integers(0, P, (NB, cin.size), dtype=np.uint64)
         vals[1, rng.integers(0, cin.size)] = 0                               # an input that is zero
+        vals[2, :] = 0                                                       # every input zero (equalities hold, selectors pick the other way)
+        vals[3, :] = np.uint64(P - 1)                                        # every input p - 1
         db = int(pack[1]); rows[db] = rows.get(db, 0) + 1
         oc = ob.OracleCircuit(orc, pack)
         ver = pkg.Verifier(pack)
         want = []
-        for b in range(2):
+        for b in range(NB):
             rc, wires, _ = orc.generate_witness(pack, cin, vals[b], None)
             if rc == orc.WIT_ZERO_INVERSE:
                 zero_inv += 1; want.append(None); continue
@@ -57,11 +60,11 @@ def main():
                 bad.append((seed, "honest proof rejected (input set %d): %s" % (b, ver.reason)))
             want.append((wires, pis, proof))
         if on_gpu:
-            circ = pkg.Circuit(gpu, pack, max_batch=2)
-            d = gpu.alloc(2 * 135 * (1 << db) * 8)
+            circ = pkg.Circuit(gpu, pack, max_batch=NB)
+            d = gpu.alloc(NB * 135 * (1 << db) * 8)
             st = circ.generate_witness_partial_batch_dev(cin, vals, None, d)
-            got = d.download().reshape(2, 135, 1 << db)
-            for b in range(2):
+            got = d.download().reshape(NB, 135, 1 << db)
+            for b in range(NB):
                 if want[b] is None:
                     if st[b] == 0:
                         bad.append((seed, "device accepted what the oracle refused (input set %d)" % b))
