@@ -234,6 +234,7 @@ int qpgpu_random_field_elements(const uint8_t *seed32, uint64_t *out, size_t n, 
  *                                                                           (width 64: is_const_less_than's canonical-half path, gadgets.rs:40-97)
  *   7  0 < x forced true        in: x                                      out: x          (x = 0 has no witness: gadgets.rs:393-412)
  *   8  a comparison 65 bits wide: refused when the circuit is built ("exceeds 64 bits", gadgets.rs:414-421)
+ *   3000 + K: K unconstrained public inputs (a stand-in inner circuit for the batch layers' logic tests; in = out = the K values)
  *   1000 + seed: a random program of 40-80 gadget applications over 6 inputs (differential tests of builder, stage s1 and prover) */
 /* gates sort_digests4 adds over n virtual digests in a builder with num_routed_wires routed wires — the reference pins this cost
  * (common/src/gadgets.rs:423-458: 900 gates for n = 8, 57 000 for n = 64 under the private-batch config's 60 routed wires, "measured

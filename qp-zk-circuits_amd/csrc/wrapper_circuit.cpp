@@ -608,6 +608,10 @@ int qpgpu_builder_gadget_circuit(unsigned kind, uint64_t *pack_out, size_t pack_
             // gadgets.rs:414-421: a comparison width above 64 is refused when the circuit is built
             const Target right = input();
             out.push_back(gadgets::is_const_less_than(b, 0, right, 65).target);
+        } else if (kind >= 3000 && kind < 3000 + 4096) {
+            // a stand-in inner circuit of kind - 3000 unconstrained public inputs (the role test-helpers' build_fake_leaf_circuit plays for
+            // the leaf, wormhole/tests/test-helpers/src/lib.rs:281-340, at any public-input length): proofs of it carry whatever a test puts in
+            for (unsigned i = 0; i < kind - 3000; i++) out.push_back(input());
         } else if (kind >= 1000) {
             // a random program over the builder's gadgets (seed = kind - 1000): 6 inputs, ~60 operations drawn from the base and
             // extension arithmetic, bits, selection, hashing and the recursion gadgets, each consuming earlier values; every sixth value

@@ -1,7 +1,8 @@
-"""Short runs of the three fuzz tools as part of the GPU suite (the long runs are recorded in profiles/r04_soak.txt): random and
+"""Short runs of the four fuzz tools as part of the GPU suite (the long runs are recorded in profiles/r04_soak.txt): random and
 mutated CircuitInputs through the leaf path (host constraint check, device s1 and oracle agree; witnesses equal), single-bit flips
 of a leaf proof through the complete in-circuit verifier (verdict equals the host verifier's), random private batches over fake
-leaves (a witness exists iff the host restatement accepts, and the public inputs read out of the witness equal the host's)."""
+leaves (a witness exists iff the host restatement accepts, and the public inputs read out of the witness equal the host's), and the same for
+random public batches over stand-in private-batch proofs."""
 import json
 import os
 import subprocess
@@ -17,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("tests/soak/fuzz_leaf_inputs.py", ["384", "21"], {"inputs": 384}),              # (checks against the oracle: lives under tests/)
     ("tools/fuzz_wrapper_tamper.py", ["96", "22"], {"flips": 96, "accepted_by_both": 0}),
     ("tools/fuzz_private_batch.py", ["192", "23"], {"batches": 192}),
+    ("tools/fuzz_public_batch.py", ["192", "24"], {"batches": 192}),
 ])
 def test_fuzz_tool(tool, args, keys):
     res = subprocess.run([sys.executable, os.path.join(ROOT, tool)] + args, capture_output=True, text=True, timeout=600)
@@ -25,7 +27,7 @@ def test_fuzz_tool(tool, args, keys):
     assert stats["mismatches"] == 0
     for k, v in keys.items():
         assert stats[k] == v
-    if tool.endswith("fuzz_private_batch.py"):
+    if tool.endswith(("fuzz_private_batch.py", "fuzz_public_batch.py")):
         assert stats["satisfiable"] > 50 and stats["unsatisfiable"] > 20
     if tool.endswith("fuzz_leaf_inputs.py"):
         assert stats["satisfiable"] > 150 and stats["unsatisfiable"] > 50 and stats["witnesses_compared"] == stats["satisfiable"]
