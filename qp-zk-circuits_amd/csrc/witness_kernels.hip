@@ -240,14 +240,18 @@ __device__ __forceinline__ void witness_poseidon2_row(WitnessArgs a, const Witne
         if (g < 4) { const u64 delta = swap ? gl::canon(gl::sub(partner, s)) : 0; WR(lay.w_delta + g, delta); s = gl::add(s, delta); }
         else if (g < 8) { const u64 delta = swap ? gl::canon(gl::sub(s, partner)) : 0; s = gl::sub(s, delta); }
     }
-    const int lane = threadIdx.x & 63, col = g & 3, nxt = (lane & ~3) | ((col + 1) & 3);
+    // cross-lane moves inside a 16-lane group as DPP operands of the vector ALU (quad permutes, rotations of a row of 16) instead of
+    // ds_bpermute round trips through the LDS crossbar: a row generator is one dependent chain, and a crossbar shuffle puts ~100 cycles
+    // of latency into it where a DPP move costs an instruction slot. Lanes 12..15 of a group hold zero throughout.
+    constexpr int XOR1 = 0xB1, XOR2 = 0x4E, NEXT_IN_QUAD = 0x39, ROR4 = 0x124, ROR8 = 0x128, ROR12 = 0x12C;
+#define P2_DPP64(v, ctrl) (((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)((v) >> 32), ctrl, 0xF, 0xF, false) << 32) | (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v), ctrl, 0xF, 0xF, false))
     // external layer with qp-poseidon-core's block circ(2, 3, 1, 1): row `col` of a block is (sum of the four) + own + 2 * next
     auto ext = [&](u64 v) -> u64 {
-        u64 sum = gl::add(v, shfl64(v, lane ^ 1));
-        sum = gl::add(sum, shfl64(sum, lane ^ 2));
-        const u64 nx = shfl64(v, nxt);
+        u64 sum = gl::add(v, P2_DPP64(v, XOR1));
+        sum = gl::add(sum, P2_DPP64(sum, XOR2));
+        const u64 nx = P2_DPP64(v, NEXT_IN_QUAD);
         const u64 t = gl::add(gl::add(sum, v), gl::add(nx, nx));
-        const u64 cs = gl::add(gl::add(shfl64(t, lane_base + col), shfl64(t, lane_base + 4 + col)), shfl64(t, lane_base + 8 + col));
+        const u64 cs = gl::add(gl::add(t, P2_DPP64(t, ROR4)), gl::add(P2_DPP64(t, ROR8), P2_DPP64(t, ROR12)));   // column sum over the three blocks (+ the idle block's zero)
         return act ? gl::add(t, cs) : 0;
     };
     s = ext(s);
@@ -262,9 +266,10 @@ __device__ __forceinline__ void witness_poseidon2_row(WitnessArgs a, const Witne
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
         if (g == 0) { s = gl::canon(gl::add(s, rc_int[r])); WR(lay.w_partial + r, s); s = poseidon::sbox7(s); }
-        u64 sum = s;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) sum = gl::add(sum, shfl64(sum, (threadIdx.x & 63) ^ off));
+        u64 sum = gl::add(s, P2_DPP64(s, XOR1));
+        sum = gl::add(sum, P2_DPP64(sum, XOR2));
+        sum = gl::add(sum, P2_DPP64(sum, ROR4));
+        sum = gl::add(sum, P2_DPP64(sum, ROR8));
         s = act ? gl::add(gl::mul(s, dg), sum) : 0;
     }
 #pragma unroll 1
@@ -274,6 +279,7 @@ __device__ __forceinline__ void witness_poseidon2_row(WitnessArgs a, const Witne
         s = ext(poseidon::sbox7(s));
     }
     if (act) WR(lay.w_output + g, s);
+#undef P2_DPP64
 }
 __device__ __forceinline__ void witness_poseidon_body(WitnessArgs a, u32 first, u32 count, const u32 tid, const u64 *rc) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
