@@ -31,3 +31,12 @@ def test_fuzz_tool(tool, args, keys):
         assert stats["satisfiable"] > 50 and stats["unsatisfiable"] > 20
     if tool.endswith("fuzz_leaf_inputs.py"):
         assert stats["satisfiable"] > 150 and stats["unsatisfiable"] > 50 and stats["witnesses_compared"] == stats["satisfiable"]
+
+
+def test_no_dead_witness_cells():
+    """tools/dead_cell_lint.py, a short pass: every advice cell a generator writes — in a synthetic circuit with all 15 gate types, the
+    leaf circuit, the gadget circuits, two random gadget programs and a private-batch wrapper — changes the verdict of the witness
+    check when it is changed: no gate here constrains less than its generator assumes."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dead_cell_lint.py"), "500"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.strip().splitlines()[-1] == "undetected total: 0"
