@@ -1,3 +1,5 @@
+"""Per-launch durations of the hashing kernels in a `rocprofv3 --kernel-trace --output-format csv -d gpurun_out/hp -- python3
+tools/hash_probe.py` trace: the last tree build, level by level (kernel, microseconds, grid size)."""
 import csv, glob, sys
 f = glob.glob('gpurun_out/hp/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
