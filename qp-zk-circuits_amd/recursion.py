@@ -156,6 +156,17 @@ def generate_wrapper_witnesses(circ, wrapper, commits, d_wires, seeds=None):
     return circ.generate_witness_partial_batch_dev(cells, vals, pis, d_wires)
 
 
+def _ensure_proof_public_input_len(proofs, proof_bytes, expected_len, label):
+    """ensure_proof_public_input_len (wormhole/aggregator/src/common/utils.rs:540-556) at the API boundary, for EVERY proof of a batch (a
+    full batch too: aggregator_tests.rs:395-412). A serialized proof of a circuit has one length; the public inputs are its tail, so a
+    proof whose public-input list is short or long is a proof of another length."""
+    for p in proofs:
+        if len(p) != proof_bytes:
+            got = expected_len + (len(p) - proof_bytes) // 8 if (len(p) - proof_bytes) % 8 == 0 else -1
+            raise ValueError("%s public input length mismatch: expected %d, got %s (%d bytes where the circuit's proofs have %d)"
+                             % (label, expected_len, got if got >= 0 else "a ragged tail", len(p), proof_bytes))
+
+
 class PrivateBatchProver:
     """PrivateBatchProver::{new, commit, prove} (wormhole/aggregator/src/private_batch/prover/lib.rs:244-343) over the restated
     circuits: the private-batch circuit is a WrapperCircuit over the leaf circuit with the layer's logic and the complete
@@ -202,6 +213,7 @@ class PrivateBatchProver:
         """leaf_proofs: 1..N serialized leaf proofs. seed: 32 bytes for a reproducible arrangement and blinding (None: OS entropy).
         ValueError with the reference's message for a batch the preflight refuses or a proof the leaf verifier rejects."""
         A, N = self.A, self.N
+        _ensure_proof_public_input_len(leaf_proofs, len(self.dummy_leaf_proof), 21, "leaf proof")
         rows = np.stack([A.proof_public_inputs(p, 21) for p in leaf_proofs]) if len(leaf_proofs) else np.zeros((0, 21), dtype=np.uint64)
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         A._call(A._lib().qpgpu_private_batch_preflight, rows.ctypes.data if rows.size else None, rows.shape[0], N)
@@ -267,6 +279,7 @@ class PublicBatchProver:
 
     def commit(self, private_batch_proofs, aggregator_address=bytes(32)):
         A = self.A
+        _ensure_proof_public_input_len(private_batch_proofs, len(self.dummy_private_batch_proof), self.inner_len, "private-batch proof")
         rows = np.stack([A.proof_public_inputs(p, self.inner_len) for p in private_batch_proofs]) if len(private_batch_proofs) else np.zeros((0, self.inner_len), dtype=np.uint64)
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         A._call(A._lib().qpgpu_public_batch_preflight, rows.ctypes.data if rows.size else None, rows.shape[0], self.inner_len, self.M)

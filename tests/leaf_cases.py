@@ -123,11 +123,12 @@ def proof_public_inputs(proof, n):
     return np.frombuffer(proof[-8 * n:], dtype=np.uint64) if n else np.zeros(0, dtype=np.uint64)
 
 
-def shared_tree_inputs(L, count, depth=2, seed=11, exits=None, outputs=None):
+def shared_tree_inputs(L, count, depth=2, seed=11, exits=None, outputs=None, asset_id=0):
     """`count` real spends of ONE block: different random secrets, their leaves in one 4-ary tree of `depth` levels (the other
     leaves random), one header committing to that tree's root — what a private batch aggregates (every real slot carries the
     same block hash, distinct nullifiers). exits: per spend (exit_account_1, exit_account_2) as 32 bytes each; outputs: per spend
-    (output_amount_1, output_amount_2) under the fee rule for an input of 300."""
+    (output_amount_1, output_amount_2) under the fee rule for an input of 300. asset_id: one value or one per spend (the asset is part of
+    the leaf hash, so leaves of different assets can share a tree)."""
     rng = np.random.default_rng(seed)
     assert 1 <= count <= 4 ** depth
 
@@ -135,12 +136,13 @@ def shared_tree_inputs(L, count, depth=2, seed=11, exits=None, outputs=None):
         b = rng.integers(0, 256, 32, dtype=np.uint8); b[7::8] &= 0x7F
         return b.tobytes()
 
+    assets = [asset_id] * count if isinstance(asset_id, int) else list(asset_id)
     spends = []
     for i in range(count):
         secret = canon32()
         tc = int(rng.integers(1, 1000))
         unsp = L.unspendable_account(secret)
-        spends.append((secret, tc, unsp, L.zk_leaf_hash(unsp, tc, 0, 300)))
+        spends.append((secret, tc, unsp, L.zk_leaf_hash(unsp, tc, assets[i], 300)))
     level = [s[3] for s in spends] + [canon32() for _ in range(4 ** depth - count)]
     levels = [level]
     for _ in range(depth):
@@ -152,7 +154,7 @@ def shared_tree_inputs(L, count, depth=2, seed=11, exits=None, outputs=None):
     out = []
     for i, (secret, tc, unsp, leaf) in enumerate(spends):
         x = L.LeafInputs()
-        x.asset_id, x.volume_fee_bps, x.transfer_count, x.input_amount = 0, DEFAULT_VOLUME_FEE_BPS, tc, 300
+        x.asset_id, x.volume_fee_bps, x.transfer_count, x.input_amount = assets[i], DEFAULT_VOLUME_FEE_BPS, tc, 300
         x.output_amount_1, x.output_amount_2 = outputs[i] if outputs else (200, 97)
         x.set32("secret", secret).set32("unspendable_account", unsp).set32("nullifier", L.nullifier(secret, tc))
         e1, e2 = exits[i] if exits else (bytes([4] * 32), bytes([7] * 32))

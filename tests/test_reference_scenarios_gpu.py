@@ -212,3 +212,31 @@ def test_aggregate_proofs_from_separate_prover_instances_hex_serialized(pkg, gpu
     hdr, slots, nulls = A.parse_private_batch_public_inputs(A.proof_public_inputs(agg, A.private_batch_pi_len(2)))
     assert set(nulls) == {bytes(x1.nullifier), bytes(x2.nullifier)} and hdr["block_hash"] == bytes(x1.block_hash)
     priv.close()
+
+
+# ---- wormhole/tests/src/aggregator/aggregator_tests.rs: the private-batch prover's preflights -------------------------------------
+
+def test_private_batch_preflights_and_a_full_batch_of_a_non_native_asset(pkg, gpu, L, full, orc):
+    """aggregator_tests.rs:289-352, 395-412 with a two-slot private-batch prover: a non-native-asset leaf that would need dummy padding,
+    an empty batch, two assets in one batch and a proof with a public input popped are refused at commit, each with the reference's
+    reason; a FULL batch of one non-native asset aggregates and verifies."""
+    priv = pkg.recursion.PrivateBatchProver(pkg, gpu, full, 2)
+    lp = priv.leaf_prover
+    a5 = [lp.prove(x)[0] for x in lc.shared_tree_inputs(L, 2, depth=1, seed=5, asset_id=5)]
+    mixed = [lp.prove(x)[0] for x in lc.shared_tree_inputs(L, 2, depth=1, seed=6, asset_id=[0, 5])]
+    for batch, needle in (([a5[0]], "dummy proofs use asset_id=0"),                    # commit_rejects_nonzero_asset_id_when_dummy_padding_is_needed
+                          ([], "no leaf proofs"),                                      # aggregate_rejects_empty_batch
+                          (mixed, "asset"),                                            # commit_rejects_batch_incompatible_proofs
+                          ([a5[0][:-8], a5[1]], "leaf proof public input length mismatch")):   # private_batch_commit_rejects_malformed_full_batch_at_api_boundary
+        with pytest.raises(ValueError) as e:
+            priv.commit(batch)
+        assert needle in str(e.value), str(e.value)
+    agg = priv.aggregate(a5, seed=bytes([8] * 32))                                    # full_batch_of_same_nonzero_asset_aggregates
+    assert priv.verifier.verify(agg)
+    oc = ob.OracleCircuit(orc, priv.circuit.pack)
+    assert oc.verify(agg) == 0
+    oc.close()
+    A = pkg.aggregation
+    hdr, _, _ = A.parse_private_batch_public_inputs(A.proof_public_inputs(agg, A.private_batch_pi_len(2)))
+    assert hdr["asset_id"] == 5
+    priv.close()
