@@ -95,17 +95,21 @@ size_t qpgpu_felts_to_bytes(const uint64_t *in, size_t n, uint8_t *out, size_t o
 }
 
 void qpgpu_bytes_to_digest(const uint8_t in[32], uint64_t out[4]) {
+    if (!in || !out) return;                       // (every entry point of the ABI takes NULL without faulting: tools/null_arg_sweep.py)
     for (int i = 0; i < 4; i++) out[i] = gl::canon(load_le64(in + 8 * i));   // from_noncanonical_u64, serialised canonical
 }
 void qpgpu_digest_to_bytes(const uint64_t in[4], uint8_t out[32]) {
+    if (!in || !out) return;
     for (int i = 0; i < 4; i++) store_le64(gl::canon(in[i]), out + 8 * i);
 }
 int qpgpu_bytes_digest_is_canonical(const uint8_t in[32]) {
+    if (!in) return 0;
     for (int i = 0; i < 4; i++) if (load_le64(in + 8 * i) >= gl::P) return 0;
     return 1;
 }
-void qpgpu_u64_to_felts(uint64_t v, uint64_t out[2]) { out[0] = v >> 32; out[1] = v & 0xFFFFFFFFull; }
+void qpgpu_u64_to_felts(uint64_t v, uint64_t out[2]) { if (!out) return; out[0] = v >> 32; out[1] = v & 0xFFFFFFFFull; }
 void qpgpu_u128_to_felts(uint64_t hi, uint64_t lo, uint64_t out[4]) {
+    if (!out) return;
     out[0] = hi >> 32; out[1] = hi & 0xFFFFFFFFull; out[2] = lo >> 32; out[3] = lo & 0xFFFFFFFFull;
 }
 

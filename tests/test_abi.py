@@ -93,3 +93,13 @@ def test_crash_trace_leaves_a_native_backtrace(pkg, tmp_path):
     env.pop("QPGPU_CRASH_TRACE")
     r = subprocess.run([sys.executable, "-c", code, "0"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == -11
+
+
+def test_every_entry_point_takes_null_arguments_without_faulting():
+    """tools/null_arg_sweep.py: each of the exported qpgpu_* functions, called with NULL / 0 for every argument in a child process of its
+    own, returns; none of them faults (a NULL context, handle or buffer is an error code, not a crash)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "null_arg_sweep.py")], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
+    assert ", 0 crashed, 0 without a prototype" in res.stdout
