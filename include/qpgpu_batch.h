@@ -219,7 +219,7 @@ int qpgpu_batch_fill_proof_targets(const uint64_t *inner_pack, size_t n_words, c
  * (RandomValueGenerator's F::rand(), for the blinding cells of a zero-knowledge circuit) */
 int qpgpu_random_field_elements(const uint8_t *seed32, uint64_t *out, size_t n, char *err);
 
-/* ---- gadget circuits: the builder's gadgets one at a time, for tests (csrc/wrapper_circuit.cpp) ---------------------------------
+/* ---- gadget circuits: the builder's gadgets one at a time, for tests (csrc/gadget_circuits.cpp) ---------------------------------
  * A small circuit that applies ONE family of gadgets of the native builder to free inputs: pack_out is its circuit pack,
  * cells_out its input cells followed by its output cells (row * num_wires + wire), n_inputs / n_outputs their counts. A test
  * assigns the inputs, lets a witness generator run and compares the outputs with the gadget's definition computed independently

@@ -40,7 +40,7 @@ assert rcw == orc.WIT_OK
 foc = oracle_binding.OracleCircuit(orc, fake.pack)
 open(os.path.join(work, "fake_proof.bin"), "wb").write(foc.prove(fw, fpis))
 foc.close()
-srcs2 = [os.path.join(csrc, f) for f in ("builder.cpp", "leaf_circuit.cpp", "wrapper_circuit.cpp", "batch.cpp", "proof_targets.cpp", "wire.cpp", "leaf_witness.cpp", "verifier.cpp",
+srcs2 = [os.path.join(csrc, f) for f in ("builder.cpp", "leaf_circuit.cpp", "wrapper_circuit.cpp", "gadget_circuits.cpp", "batch.cpp", "proof_targets.cpp", "wire.cpp", "leaf_witness.cpp", "verifier.cpp",
                                           "circuit.cpp", "poseidon_constants.cpp")]
 exe2 = os.path.join(work, "builder_driver")
 subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-pthread",
