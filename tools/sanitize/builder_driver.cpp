@@ -127,6 +127,25 @@ int main(int argc, char **argv) {
         if (i % 7 == 0) c2.resize(rng() % 100);
         if (build_wrapper(q, c2, 1 + (unsigned)(rng() % 3), 0, 1 | 8 | (i % 2 ? 2 : 0), w, wmap, err) == 0) built++; else refused++;
     }
+    // ---- the gadget circuits and random programs over the builder's gadgets (csrc/gadget_circuits.cpp), incl. kinds that do not exist ----
+    for (unsigned kind : {0u, 1u, 2u, 3u, 4u, 5u, 6u, 7u, 8u, 9u, 999u, 3000u, 3050u, 7096u, 7097u}) {
+        size_t nw = 0, ni = 0, no = 0;
+        if (qpgpu_builder_gadget_circuit(kind, nullptr, 0, &nw, nullptr, 0, &ni, &no, err) != 0) { refused++; continue; }
+        std::vector<uint64_t> gp(nw), cells(ni + no);
+        if (qpgpu_builder_gadget_circuit(kind, gp.data(), gp.size(), &nw, cells.data(), cells.size(), &ni, &no, err) != 0) { fprintf(stderr, "gadget circuit %u: %s\n", kind, err); return 1; }
+        if (qpgpu_pack_validate(gp.data(), gp.size(), err)) { fprintf(stderr, "gadget circuit %u does not validate: %s\n", kind, err); return 1; }
+        if (qpgpu_builder_gadget_circuit(kind, gp.data(), gp.size() / 2, &nw, cells.data(), cells.size(), &ni, &no, err) == 0) { fprintf(stderr, "short pack buffer accepted\n"); return 1; }
+        built++;
+    }
+    for (int i = 0; i < std::max(iters / 2, 8); i++) {
+        size_t nw = 0, ni = 0, no = 0;
+        const unsigned kind = 1000 + (unsigned)(rng() % 1900);
+        if (qpgpu_builder_gadget_circuit(kind, nullptr, 0, &nw, nullptr, 0, &ni, &no, err) != 0) { fprintf(stderr, "random program %u: %s\n", kind, err); return 1; }
+        std::vector<uint64_t> gp(nw), cells(ni + no);
+        if (qpgpu_builder_gadget_circuit(kind, gp.data(), gp.size(), &nw, cells.data(), cells.size(), &ni, &no, err) != 0 || qpgpu_pack_validate(gp.data(), gp.size(), err)) { fprintf(stderr, "random program %u: %s\n", kind, err); return 1; }
+        built++;
+    }
+    { size_t g = 0; if (qpgpu_builder_sort_gate_cost(8, 60, &g, err) != 0 || g == 0 || qpgpu_builder_sort_gate_cost(5000, 60, &g, err) == 0) { fprintf(stderr, "sort gate cost\n"); return 1; } }
     printf("builder driver: %ld circuits built, %ld refused, %ld proof-target fills, %ld refused fills\n", built, refused, filled, fill_refused);
     return 0;
 }
