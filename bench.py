@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--batch-degree-bits", type=int, default=16, help="rows of the private / public batch circuits of the tree leg")
     ap.add_argument("--streams", type=int, default=6, help="proving workers per GPU (one HIP stream + host transcript thread each)")
     ap.add_argument("--batch", type=int, default=32, help="proofs a worker proves in lockstep (qpgpu_prove_batch_dev)")
+    ap.add_argument("--hash-hints", type=int, default=0, help="1: commit also hands in the leaf circuit's hash-chain states computed on the host (qpgpu_leaf_hash_hints): "
+                                                               "stage s1 then runs the 61 hash rows side by side and checks them (14 dependency levels instead of 120)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the per-stage, witness-generation and end-to-end legs (profiling the timed region)")
@@ -291,13 +293,15 @@ def main():
     # WORKERS lockstep batches of LOCKSTEP proofs in flight: streams, circuit workspaces and transcript threads live inside
     # the library (qpgpu_pool_create_multi); the cell list of WormholeProver::commit is resolved once per worker
     prover_pool = pkg.ProvingPool(pack, workers=WORKERS, devices=[local_rank], max_batch=LOCKSTEP)
+    HINTS = bool(args.hash_hints)
     cells0, values0, pis0 = leaf.commit(inputs_all[0])
-    prover_pool.set_partial_cells(cells0)
-    commit_buf = (np.empty(L.LT_COUNT, dtype=np.uint64), np.empty(L.LT_COUNT, dtype=np.uint64))
+    prover_pool.set_partial_cells(leaf.commit(inputs_all[0], hash_hints=True)[0] if HINTS else cells0)
+    commit_buf = (np.empty(L.LT_COUNT + L.HASH_HINTS, dtype=np.uint64), np.empty(L.LT_COUNT + L.HASH_HINTS, dtype=np.uint64))
+    hints_fn = L._lib().qpgpu_leaf_hash_hints
     pis_all = [np.empty(21, dtype=np.uint64) for _ in range(S)]
     commit_fn = L._lib().qpgpu_leaf_commit
     import ctypes as _ct
-    commit_n, commit_err = _ct.c_size_t(), _ct.create_string_buffer(160)
+    commit_n, hint_n, commit_err = _ct.c_size_t(), _ct.c_size_t(), _ct.create_string_buffer(160)
     tm_ptr, cb_ptr, vb_ptr = leaf.target_map.ctypes.data, commit_buf[0].ctypes.data, commit_buf[1].ctypes.data
 
     def commit_and_submit(i, out):
@@ -305,7 +309,11 @@ def main():
         (the values are copied at submit)."""
         if commit_fn(_ct.byref(inputs_all[i]), tm_ptr, cb_ptr, vb_ptr, L.LT_COUNT, _ct.byref(commit_n), pis_all[i].ctypes.data, commit_err) != 0:
             raise SystemExit("bench.py: commit failed: " + commit_err.value.decode())
-        return prover_pool.submit_partial(commit_buf[1], pis_all[i], out)
+        if HINTS:     # the hash call sites' sponge states behind the 299 assignments (qpgpu_leaf.h "hash hints"): same witness, 14 levels instead of 120
+            if hints_fn(_ct.byref(inputs_all[i]), vb_ptr + 8 * commit_n.value, L.HASH_HINTS, _ct.byref(hint_n), commit_err) != 0:
+                raise SystemExit("bench.py: hash hints failed: " + commit_err.value.decode())
+            return prover_pool.submit_partial(commit_buf[1][:commit_n.value + hint_n.value], pis_all[i], out)
+        return prover_pool.submit_partial(commit_buf[1][:commit_n.value], pis_all[i], out)
 
     def run_steps(k, resident=None):
         """k steps = k*S proofs through the library's proving pool. All jobs are queued ahead and the workers free-run; the main
@@ -600,6 +608,19 @@ def main():
             for i_ in range(10):
                 _one(1 + i_ % (S - 1))
             extra["single_proof_commit_prove_ms"] = round((time.perf_counter() - t1_) / 10 * 1e3, 3)
+            # the same with the front-end's hash hints (include/qpgpu_leaf.h): the hash chains' states computed on the host ride along as
+            # extra assignments, stage s1 runs the 61 hash rows side by side and checks them — 14 dependency levels instead of 120
+            def _one_hinted(i_):
+                c_, v_, p_ = leaf.commit(inputs_all[i_], hash_hints=True)
+                circ.generate_witness_partial_dev(c_, v_, p_, w_t)
+                return circ.prove_dev(w_t, p_, outs[0])
+            same_ = _one_hinted(1) == _one(1); _one_hinted(2)
+            t1_ = time.perf_counter()
+            for i_ in range(10):
+                _one_hinted(1 + i_ % (S - 1))
+            extra["single_proof_commit_prove_ms_hash_hints"] = {"ms": round((time.perf_counter() - t1_) / 10 * 1e3, 3), "same_proof_bytes": bool(same_),
+                                                                "dependency_levels": circ.witness_info()[1]}
+            ok = ok and same_
             _one(0)                                      # (w_t holds input 0's witness again)
             extra["proof_stage_ms"] = stages
             extra["merkle_leaf_hash_avg_ms"] = round(leaf_ms / max(leaf_n, 1), 4)

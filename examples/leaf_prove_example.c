@@ -47,6 +47,7 @@ int main(int argc, char **argv) {
     int devices[16]; unsigned n_devices = 0;
     { char buf[128]; snprintf(buf, sizeof buf, "%s", argc > 2 ? argv[2] : "0,0"); for (char *t = strtok(buf, ","); t && n_devices < 16; t = strtok(NULL, ",")) devices[n_devices++] = atoi(t); }
     const unsigned workers = argc > 3 ? (unsigned)atoi(argv[3]) : 2, lockstep = argc > 4 ? (unsigned)atoi(argv[4]) : 4, steps = argc > 5 ? (unsigned)atoi(argv[5]) : 2;
+    const int hints = argc > 6 ? atoi(argv[6]) : 0;      /* 1: the front-end's hash hints ride along with commit's assignments (qpgpu_leaf.h) */
     char err[QPGPU_LEAF_ERR_CAP];
 
     /* WormholeCircuit::new(config).build_prover(): host only */
@@ -75,9 +76,15 @@ int main(int argc, char **argv) {
     if (qpgpu_leaf_check_constraints(&in, err)) { fprintf(stderr, "inputs: %s\n", err); return 1; }
 
     /* WormholeProver::commit */
-    uint64_t cells[QPGPU_LT_COUNT], values[QPGPU_LT_COUNT], pis[QPGPU_LEAF_PUBLIC_INPUTS];
-    size_t count = 0;
+    enum { MAX_ASSIGNMENTS = QPGPU_LT_COUNT + QPGPU_LEAF_HASH_HINTS };
+    uint64_t cells[MAX_ASSIGNMENTS], values[MAX_ASSIGNMENTS], pis[QPGPU_LEAF_PUBLIC_INPUTS];
+    size_t count = 0, n_hints = 0;
     if (qpgpu_leaf_commit(&in, target_map, cells, values, QPGPU_LT_COUNT, &count, pis, err)) { fprintf(stderr, "commit: %s\n", err); return 1; }
+    if (hints) {    /* the hash chains' states, computed here on the host: stage s1 runs the 61 hash rows side by side and checks them */
+        if (qpgpu_leaf_circuit_hash_hint_cells(min_degree_bits, 0, NULL, cells + count, QPGPU_LEAF_HASH_HINTS, &n_hints, err) ||
+            qpgpu_leaf_hash_hints(&in, values + count, QPGPU_LEAF_HASH_HINTS, &n_hints, err)) { fprintf(stderr, "hash hints: %s\n", err); return 1; }
+        count += n_hints;
+    }
 
     /* one pool over all the devices; every worker resolves the cell list once */
     qpgpu_pool *pool = NULL;
@@ -106,10 +113,11 @@ int main(int argc, char **argv) {
     /* a flipped secret byte: that job alone fails, naming the target; its neighbours are proven */
     {
         qpgpu_leaf_inputs bad = in;
-        uint64_t bc[QPGPU_LT_COUNT], bv[QPGPU_LT_COUNT], bp[QPGPU_LEAF_PUBLIC_INPUTS], t_bad, t_good[2];
+        uint64_t bc[QPGPU_LT_COUNT], bv[MAX_ASSIGNMENTS], bp[QPGPU_LEAF_PUBLIC_INPUTS], t_bad, t_good[2];
         size_t bn = 0, len = 0;
         bad.secret[3] ^= 1;
         if (qpgpu_leaf_commit(&bad, target_map, bc, bv, QPGPU_LT_COUNT, &bn, bp, err)) return 7;
+        if (hints && qpgpu_leaf_hash_hints(&bad, bv + bn, QPGPU_LEAF_HASH_HINTS, &n_hints, err)) return 7;      /* honest hints of dishonest inputs */
         if (qpgpu_pool_submit_partial(pool, values, pis, outs, cap, &t_good[0]) || qpgpu_pool_submit_partial(pool, bv, bp, outs + cap, cap, &t_bad) ||
             qpgpu_pool_submit_partial(pool, values, pis, outs + 2 * cap, cap, &t_good[1])) return 7;
         if (qpgpu_pool_wait(pool, t_good[0], &len) || len != cap) { fprintf(stderr, "neighbour failed: %s\n", qpgpu_pool_last_error(pool)); return 7; }
@@ -129,8 +137,8 @@ int main(int argc, char **argv) {
     qpgpu_pool_destroy(pool);          /* drains every device's workers */
     uint64_t h = 1469598103934665603ull;
     for (size_t i = 0; i < cap; i++) h = (h ^ outs[i]) * 1099511628211ull;
-    printf("ok devices=%u workers=%u lockstep=%u steps=%u proofs=%u proof_bytes=%zu fnv1a=%016llx commit+prove %.1f proofs/s\n", n_devices, workers, lockstep, steps,
-           steps * per_step, cap, (unsigned long long)h, steps ? steps * per_step / dt : 0.0);
+    printf("ok devices=%u workers=%u lockstep=%u steps=%u proofs=%u proof_bytes=%zu fnv1a=%016llx commit+prove %.1f proofs/s%s\n", n_devices, workers, lockstep, steps,
+           steps * per_step, cap, (unsigned long long)h, steps ? steps * per_step / dt : 0.0, hints ? " (hash hints)" : "");
     free(pack); free(outs); free(tickets);
     return 0;
 }

@@ -216,6 +216,34 @@ int qpgpu_leaf_circuit_build(unsigned fragment, unsigned min_degree_bits, int in
 int qpgpu_leaf_commit(const qpgpu_leaf_inputs *in, const uint64_t *target_map, uint64_t *cells_out, uint64_t *values_out, size_t cap,
                       size_t *count, uint64_t public_inputs_out[QPGPU_LEAF_PUBLIC_INPUTS], char *err);
 
+/* ---- hash hints: the serial part of the leaf witness, handed in by the front-end ------------------------------------------------
+ * The leaf circuit hashes in chains: 61 Poseidon2 gate rows at 8 call sites, every Merkle level waiting for the one below it. On the
+ * device a row's generator is one dependent chain (about 19 us with its launch), 45 levels deep; a host core computes the same
+ * permutation in under a microsecond. So the front-end, which knows every preimage, may hand the rows' outputs in as EXTRA assignments:
+ * a PartialWitness may set targets that generators also produce (plonky2 checks them: "set twice with different values"), stage s1 then
+ * builds its plan for that assignment list, runs all 61 rows in one level and CHECKS each against its hint — 120 dependency levels
+ * become a few dozen. Optional: a caller that does not append the hints gets the same witness, later.
+ * Call sites in the order of their tags (the order of the cells and of the values): */
+enum qpgpu_leaf_hash_site {
+    QPGPU_LEAF_HASH_UNSPENDABLE_INNER = 0,   /* H(salt "wormhole" || secret)            1 row   unspendable_account.rs:229-231 */
+    QPGPU_LEAF_HASH_UNSPENDABLE_OUTER = 1,   /* H(inner)                                1 row */
+    QPGPU_LEAF_HASH_ZK_LEAF = 2,             /* H(to, transfer_count, asset, amount)    2 rows  zk_merkle_proof.rs:482 */
+    QPGPU_LEAF_HASH_MERKLE_LEVEL_0 = 3,      /* .. + 15: H(four children)               3 rows each  zk_merkle_proof.rs:504-606 */
+    QPGPU_LEAF_HASH_NULLIFIER_INNER = 19,    /* H(salt "~nullif~" || secret || count)   2 rows  nullifier.rs:298-299 */
+    QPGPU_LEAF_HASH_NULLIFIER_OUTER = 20,    /* H(inner)                                1 row */
+    QPGPU_LEAF_HASH_BLOCK_HEADER = 21        /* H(header, 45 elements)                  6 rows  block_header/header.rs */
+};
+#define QPGPU_LEAF_HASH_ROWS 61
+/* the whole 12-element state after every permutation, then the Merkle walk's running hash (4 elements) after each of its 16 levels */
+#define QPGPU_LEAF_HASH_HINTS (12 * QPGPU_LEAF_HASH_ROWS + 4 * 16)
+/* the cells (row * num_wires + wire) of those 796 values in the FULL leaf circuit built with the same arguments as
+ * qpgpu_leaf_circuit_build (cells_out may be NULL to ask for the count) */
+int qpgpu_leaf_circuit_hash_hint_cells(unsigned min_degree_bits, int inner_hasher, const uint64_t *p2_layout, uint64_t *cells_out, size_t cap, size_t *count, char *err);
+/* the 796 values for one set of inputs, computed on the host exactly as the rows' generators would from the same assignments (field
+ * arithmetic on the inputs as given: inconsistent inputs give hints that disagree with nothing but the targets the circuit itself
+ * would refuse). values_out: room for QPGPU_LEAF_HASH_HINTS. Returns 0, or -1 with a message (inputs qpgpu_leaf_fill_witness refuses). */
+int qpgpu_leaf_hash_hints(const qpgpu_leaf_inputs *in, uint64_t *values_out, size_t cap, size_t *count, char *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,11 @@ extern "C" {
     // deployments that take BOTH prover and verifier data from it; with exported packs of the fork's own circuits these are not used
     pub fn qpgpu_leaf_circuit_build(fragment: u32, min_degree_bits: u32, inner_hasher: i32, p2_layout: *const u64, pack_out: *mut u64, pack_cap_words: usize,
                                     pack_words: *mut usize, target_map_out: *mut u64, info_out: *mut u64, err: *mut c_char) -> i32;
+    // optional: the leaf circuit's hash-chain states as extra assignments (796 cells / values appended to qpgpu_leaf_commit's) — the
+    // same witness in 14 dependency levels instead of 120 (one proof 4.6 -> 3.7 ms); a hint that disagrees is QPGPU_EUNSAT
+    pub fn qpgpu_leaf_circuit_hash_hint_cells(min_degree_bits: u32, inner_hasher: i32, p2_layout: *const u64, cells_out: *mut u64, cap: usize,
+                                              count: *mut usize, err: *mut c_char) -> i32;
+    pub fn qpgpu_leaf_hash_hints(inputs: *const c_void, values_out: *mut u64, cap: usize, count: *mut usize, err: *mut c_char) -> i32;
     pub fn qpgpu_wrapper_circuit_build(inner_pack: *const u64, inner_words: usize, inner_cs_cap: *const u64, cap_words: usize, num_proofs: u32,
                                        num_routed_wires: u32, min_degree_bits: u32, inner_hasher: i32, flags: u32, pack_out: *mut u64, pack_cap_words: usize,
                                        pack_words: *mut usize, target_map_out: *mut u64, map_cap: usize, map_count: *mut usize, info_out: *mut u64,

@@ -327,6 +327,7 @@ Builder::State Builder::permute_poseidon(const State &in, BoolTarget swap) {
 Builder::State Builder::permute_poseidon2(const State &in) {
     const P2GateLayout &l = cfg_.p2_layout;
     const uint32_t row = add_gate(spec_index(GATE_POSEIDON2, 0, 0, 0));
+    p2_rows_.push_back({hash_tag_, row});
     if (l.has_swap()) connect(zero(), wire(row, l.w_swap));
     for (uint32_t i = 0; i < 12; i++) connect(in[i], wire(row, l.w_input + i));
     State out;

@@ -103,6 +103,14 @@ public:
     // ---- hashing ----
     using State = std::array<Target, 12>;
     State permute_poseidon(const State &in, BoolTarget swap);     // one PoseidonGate row (upstream Poseidon, permute_swapped)
+    // every Poseidon2 gate row records the tag current when it was made (a circuit names its hash call sites with it) and its row:
+    // the circuit can then tell a witness front-end which cells hold each site's sponge states (see qpgpu_leaf_circuit_hash_hint_cells)
+    void set_hash_tag(int tag) { hash_tag_ = tag; }
+    const std::vector<std::pair<int, uint32_t>> &poseidon2_rows() const { return p2_rows_; }
+    u64 poseidon2_output_cell(uint32_t row, uint32_t i) { return cell_of(wire(row, cfg_.p2_layout.w_output + i)); }
+    // further targets a circuit offers a front-end for hinting (values on a serial path that the front-end knows), in the order added
+    void add_hint_target(Target t) { hint_targets_.push_back(t); }
+    const std::vector<Target> &hint_targets() const { return hint_targets_; }
     State permute_poseidon2(const State &in);                     // one row of the fork's Poseidon2 gate, swap wire (if any) = 0
     // hash_n_to_hash_no_pad::<PoseidonHash>: overwrite-mode sponge, no padding (hashing.rs)
     HashOutTarget hash_n_to_hash_no_pad(const std::vector<Target> &inputs);
@@ -222,6 +230,9 @@ private:
     std::map<std::pair<u64, u64>, std::pair<uint32_t, uint32_t>> ext_slots_;     // (c0, c1) -> (row, next free operation)
     bool built_ = false;
     size_t rows_before_padding_ = 0, blinding_rows_ = 0;
+    int hash_tag_ = -1;
+    std::vector<std::pair<int, uint32_t>> p2_rows_;
+    std::vector<Target> hint_targets_;
     std::vector<u64> blinding_cells_;
     void blind();
     std::vector<u64> class_cell_;                            // after build(): representative wire cell per class root

@@ -21,6 +21,7 @@
 //   CircuitInputs -> qpgpu_leaf_fill_witness -> cells -> stage s1 on the device -> s2..s12
 // proves the reference's statement: the proof's 21 public inputs are the reference's, its block-hash, nullifier and
 // unspendable-account digests are computed by Poseidon2 gate rows, its Merkle walk by selects over the position hints.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -111,7 +112,9 @@ using gadgets::is_const_less_than;
 void unspendable_account_circuit(const UnspendableAccountTargets &t, Builder &b) {
     std::vector<Target> preimage = salt_constants(b, "wormhole");
     for (Target e : t.secret.elements) preimage.push_back(e);
+    b.set_hash_tag(QPGPU_LEAF_HASH_UNSPENDABLE_INNER);
     const HashOutTarget inner = b.hash_n_to_hash_no_pad_p2(preimage);
+    b.set_hash_tag(QPGPU_LEAF_HASH_UNSPENDABLE_OUTER);
     const HashOutTarget outer = b.hash_n_to_hash_no_pad_p2({inner.elements[0], inner.elements[1], inner.elements[2], inner.elements[3]});
     for (int i = 0; i < 4; i++) b.connect(outer.elements[i], t.account_id.elements[i]);
 }
@@ -135,6 +138,7 @@ void zk_merkle_proof_circuit(const ZkMerkleProofTargets &t, Builder &b) {
     std::vector<Target> leaf_felts(t.leaf.to_account, t.leaf.to_account + 4);
     leaf_felts.push_back(t.leaf.transfer_count[0]); leaf_felts.push_back(t.leaf.transfer_count[1]);
     leaf_felts.push_back(t.leaf.asset_id); leaf_felts.push_back(t.leaf.input_amount);
+    b.set_hash_tag(QPGPU_LEAF_HASH_ZK_LEAF);
     const HashOutTarget leaf_hash = b.hash_n_to_hash_no_pad_p2(leaf_felts);
     // depth <= MAX_DEPTH
     unsigned n_log = 0;
@@ -173,10 +177,12 @@ void zk_merkle_proof_circuit(const ZkMerkleProofTargets &t, Builder &b) {
                 }
                 parent_preimage.push_back(child);
             }
+        b.set_hash_tag(QPGPU_LEAF_HASH_MERKLE_LEVEL_0 + (int)level);
         const HashOutTarget parent_hash = b.hash_n_to_hash_no_pad_p2(parent_preimage);
         HashOutTarget next;
         for (int i = 0; i < 4; i++) next.elements[i] = b.select(is_active_level, parent_hash.elements[i], current_hash.elements[i]);
         current_hash = next;
+        for (int i = 0; i < 4; i++) b.add_hint_target(next.elements[i]);      // the running hash after this level: the walk's serial path
     }
     // the computed root equals the expected one unless the proof is a dummy
     for (int i = 0; i < 4; i++) {
@@ -190,7 +196,9 @@ HashOutTarget computed_nullifier(const NullifierTargets &t, Builder &b) {
     std::vector<Target> preimage = salt_constants(b, "~nullif~");
     for (Target e : t.secret.elements) preimage.push_back(e);
     for (Target e : t.transfer_count) preimage.push_back(e);
+    b.set_hash_tag(QPGPU_LEAF_HASH_NULLIFIER_INNER);
     const HashOutTarget inner = b.hash_n_to_hash_no_pad_p2(preimage);
+    b.set_hash_tag(QPGPU_LEAF_HASH_NULLIFIER_OUTER);
     return b.hash_n_to_hash_no_pad_p2({inner.elements[0], inner.elements[1], inner.elements[2], inner.elements[3]});
 }
 void conditional_binding(Builder &b, const HashOutTarget &claimed, const HashOutTarget &computed, Target is_not_dummy) {
@@ -209,6 +217,7 @@ HashOutTarget computed_block_hash(const BlockHeaderTargets &t, Builder &b) {
     pre.insert(pre.end(), h.extrinsics_root, h.extrinsics_root + 4);
     pre.insert(pre.end(), h.zk_tree_root, h.zk_tree_root + 4);
     pre.insert(pre.end(), h.digest, h.digest + QPGPU_LEAF_DIGEST_LOGS_FELTS);
+    b.set_hash_tag(QPGPU_LEAF_HASH_BLOCK_HEADER);
     return b.hash_n_to_hash_no_pad_p2(pre);
 }
 
@@ -273,8 +282,8 @@ void logical_targets(const CircuitTargets &t, Target (&lt)[QPGPU_LT_COUNT]) {
 
 extern "C" {
 
-int qpgpu_leaf_circuit_build(unsigned fragment, unsigned min_degree_bits, int inner_hasher, const uint64_t *p2_layout, uint64_t *pack_out, size_t pack_cap_words,
-                             size_t *pack_words, uint64_t *target_map_out, uint64_t *info_out, char *err) {
+static int leaf_circuit_build_impl(unsigned fragment, unsigned min_degree_bits, int inner_hasher, const uint64_t *p2_layout, uint64_t *pack_out, size_t pack_cap_words,
+                                   size_t *pack_words, uint64_t *target_map_out, uint64_t *info_out, std::vector<uint64_t> *hint_cells, char *err) {
     auto fail = [&](int code, const std::string &m) { if (err) std::snprintf(err, QPGPU_LEAF_ERR_CAP, "%s", m.c_str()); return code; };
     if (err) err[0] = 0;
     if (!pack_words) return fail(QPGPU_EINVAL, "leaf_circuit_build: null argument");
@@ -363,6 +372,17 @@ int qpgpu_leaf_circuit_build(unsigned fragment, unsigned min_degree_bits, int in
         if (target_map_out) {
             for (unsigned i = 0; i < QPGPU_LT_COUNT; i++) { const u64 c = lt[i] == cb::NO_TARGET ? cb::NO_CELL : b.cell_of(lt[i]); target_map_out[i] = c == cb::NO_CELL ? UINT64_MAX : c; }
         }
+        if (hint_cells) {
+            // the 12 output cells of every Poseidon2 row, hash call sites in the order of their tags, rows of a site in sponge order
+            std::vector<std::pair<int, uint32_t>> rows = b.poseidon2_rows();
+            std::stable_sort(rows.begin(), rows.end(), [](const std::pair<int, uint32_t> &x, const std::pair<int, uint32_t> &y) { return x.first < y.first; });
+            hint_cells->clear();
+            for (const auto &r : rows) {
+                if (r.first < 0) continue;                     // (the public-input hash of a Poseidon2-hashed circuit: not a call site of the leaf)
+                for (uint32_t i = 0; i < 12; i++) hint_cells->push_back(b.poseidon2_output_cell(r.second, i));
+            }
+            for (Target t : b.hint_targets()) hint_cells->push_back(b.cell_of(t));      // then the running hash of the Merkle walk after every level
+        }
         if (info_out) {
             // the figures the reference's GateProfiler prints (wormhole/circuit/src/profile.rs): gates per fragment, rows per gate type
             const std::map<uint64_t, size_t> gc = b.gate_counts();
@@ -374,6 +394,27 @@ int qpgpu_leaf_circuit_build(unsigned fragment, unsigned min_degree_bits, int in
         }
     } catch (const std::exception &e) {
         return fail(QPGPU_EINVAL, std::string("leaf_circuit_build: ") + e.what());
+    }
+    return QPGPU_OK;
+}
+
+int qpgpu_leaf_circuit_build(unsigned fragment, unsigned min_degree_bits, int inner_hasher, const uint64_t *p2_layout, uint64_t *pack_out, size_t pack_cap_words,
+                             size_t *pack_words, uint64_t *target_map_out, uint64_t *info_out, char *err) {
+    return leaf_circuit_build_impl(fragment, min_degree_bits, inner_hasher, p2_layout, pack_out, pack_cap_words, pack_words, target_map_out, info_out, nullptr, err);
+}
+
+int qpgpu_leaf_circuit_hash_hint_cells(unsigned min_degree_bits, int inner_hasher, const uint64_t *p2_layout, uint64_t *cells_out, size_t cap, size_t *count, char *err) {
+    if (err) err[0] = 0;
+    if (!count) { if (err) std::snprintf(err, QPGPU_LEAF_ERR_CAP, "leaf_circuit_hash_hint_cells: null argument"); return QPGPU_EINVAL; }
+    std::vector<uint64_t> cells;
+    size_t words = 0;
+    const int rc = leaf_circuit_build_impl(QPGPU_LEAF_FRAGMENT_FULL, min_degree_bits, inner_hasher, p2_layout, nullptr, 0, &words, nullptr, nullptr, &cells, err);
+    if (rc != QPGPU_OK) return rc;
+    *count = cells.size();
+    if (cells.size() != QPGPU_LEAF_HASH_HINTS) { if (err) std::snprintf(err, QPGPU_LEAF_ERR_CAP, "leaf_circuit_hash_hint_cells: %zu cells where %d are expected", cells.size(), QPGPU_LEAF_HASH_HINTS); return QPGPU_EINVAL; }
+    if (cells_out) {
+        if (cap < cells.size()) { if (err) std::snprintf(err, QPGPU_LEAF_ERR_CAP, "leaf_circuit_hash_hint_cells: cell buffer too small"); return QPGPU_EBUFSIZE; }
+        std::memcpy(cells_out, cells.data(), cells.size() * 8);
     }
     return QPGPU_OK;
 }

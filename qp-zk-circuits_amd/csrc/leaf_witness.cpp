@@ -293,6 +293,86 @@ int qpgpu_leaf_block_hash(const uint64_t *params, size_t n_words, const uint8_t 
 }
 
 
+// ---- hash hints (include/qpgpu_leaf.h): every sponge state of the leaf circuit's 8 hash call sites, in tag order ----
+namespace {
+// hash_pad10 that also writes the 12-element state after every permutation to *out (advanced)
+void sponge_states(const poseidon2::Params &p, const u64 *in, size_t n, u64 *&out, u64 digest[4]) {
+    u64 st[12] = {0};
+    const size_t padded = (n + 1 + 7) / 8 * 8;
+    for (size_t i = 0; i < padded; i += 8) {
+        for (size_t j = 0; j < 8; j++) {
+            const size_t k = i + j;
+            st[j] = gl::canon(gl::add(st[j], k < n ? gl::canon(in[k]) : (k == n ? 1 : 0)));
+        }
+        poseidon2::permute(st, p);
+        for (int j = 0; j < 12; j++) *out++ = gl::canon(st[j]);
+    }
+    for (int i = 0; i < 4; i++) digest[i] = gl::canon(st[i]);
+    std::memset(st, 0, sizeof st);
+}
+}  // namespace
+
+int qpgpu_leaf_hash_hints(const qpgpu_leaf_inputs *in, uint64_t *values_out, size_t cap, size_t *count, char *err) {
+    if (err) err[0] = 0;
+    if (!in || !values_out || !count) return fail(err, "leaf_hash_hints: null argument");
+    if (cap < QPGPU_LEAF_HASH_HINTS) return fail(err, "leaf_hash_hints: room for %llu values needed, %llu given", (unsigned long long)QPGPU_LEAF_HASH_HINTS, (unsigned long long)cap);
+    {   // the same refusals as fill_witness (depth, positions, field range of every digest), before any hashing
+        uint32_t t[QPGPU_LT_COUNT]; uint64_t v[QPGPU_LT_COUNT], pis[QPGPU_LEAF_PUBLIC_INPUTS]; size_t n = 0;
+        const int rc = qpgpu_leaf_fill_witness(in, pis, t, v, QPGPU_LT_COUNT, &n, err);
+        std::memset(v, 0, sizeof v);
+        if (rc) return rc;
+    }
+    const poseidon2::Params &p = poseidon2::qp_params();
+    u64 *out = values_out;
+    u64 secret[4], account[4], tc[2], pre[48], inner[4], digest[4];
+    qpgpu_bytes_to_digest(in->secret, secret);
+    qpgpu_bytes_to_digest(in->unspendable_account, account);
+    qpgpu_u64_to_felts(in->transfer_count, tc);
+    // QPGPU_LEAF_HASH_UNSPENDABLE_INNER / _OUTER
+    if (qpgpu_bytes_to_felts((const uint8_t *)"wormhole", 8, pre, 3) != 3) return fail(err, "leaf_hash_hints: salt encoding");
+    std::memcpy(pre + 3, secret, 32);
+    sponge_states(p, pre, 7, out, inner);
+    sponge_states(p, inner, 4, out, digest);
+    // QPGPU_LEAF_HASH_ZK_LEAF: the leaf's to_account is the unspendable account's target class, i.e. the assigned account id
+    std::memcpy(pre, account, 32); pre[4] = tc[0]; pre[5] = tc[1]; pre[6] = in->asset_id; pre[7] = in->input_amount;
+    u64 cur[4], walk[4 * QPGPU_LEAF_MAX_DEPTH];
+    sponge_states(p, pre, 8, out, cur);
+    // QPGPU_LEAF_HASH_MERKLE_LEVEL_l: the running hash inserted among the level's sorted siblings at the hinted position; levels past
+    // the depth hash what fill_witness pads them with (zero siblings, position 0) and leave the running hash as it is
+    for (uint32_t l = 0; l < QPGPU_LEAF_MAX_DEPTH; l++) {
+        const bool active = l < in->zk_merkle_depth;
+        const unsigned pos = active ? in->zk_merkle_positions[l] : 0;
+        u64 sib[3][4] = {{0}};
+        if (active) for (int k = 0; k < 3; k++) qpgpu_bytes_to_digest(in->zk_merkle_siblings[l][k], sib[k]);
+        for (unsigned slot = 0, k = 0; slot < 4; slot++) {
+            const u64 *child = slot == pos ? cur : sib[k++];
+            std::memcpy(pre + 4 * slot, child, 32);
+        }
+        u64 parent[4];
+        sponge_states(p, pre, 16, out, parent);
+        if (active) std::memcpy(cur, parent, 32);
+        std::memcpy(walk + 4 * l, cur, 32);
+    }
+    // QPGPU_LEAF_HASH_NULLIFIER_INNER / _OUTER
+    if (qpgpu_bytes_to_felts((const uint8_t *)"~nullif~", 8, pre, 3) != 3) return fail(err, "leaf_hash_hints: salt encoding");
+    std::memcpy(pre + 3, secret, 32); pre[7] = tc[0]; pre[8] = tc[1];
+    sponge_states(p, pre, 9, out, inner);
+    sponge_states(p, inner, 4, out, digest);
+    // QPGPU_LEAF_HASH_BLOCK_HEADER
+    qpgpu_bytes_to_digest(in->parent_hash, pre);
+    pre[4] = in->block_number;
+    qpgpu_bytes_to_digest(in->state_root, pre + 5);
+    qpgpu_bytes_to_digest(in->extrinsics_root, pre + 9);
+    qpgpu_bytes_to_digest(in->zk_tree_root, pre + 13);
+    if (qpgpu_bytes_to_felts(in->digest, QPGPU_LEAF_DIGEST_LOGS_SIZE, pre + 17, 28) != 28) return fail(err, "failed to encode digest logs");
+    sponge_states(p, pre, 45, out, digest);
+    for (unsigned i = 0; i < 4 * QPGPU_LEAF_MAX_DEPTH; i++) *out++ = walk[i];      // the running hash after every level of the walk
+    std::memset(secret, 0, sizeof secret); std::memset(pre, 0, sizeof pre); std::memset(inner, 0, sizeof inner);   // the spend secret
+    *count = (size_t)(out - values_out);
+    if (*count != QPGPU_LEAF_HASH_HINTS) return fail(err, "leaf_hash_hints: %llu values where %llu are expected", (unsigned long long)*count, (unsigned long long)QPGPU_LEAF_HASH_HINTS);
+    return 0;
+}
+
 // ---- common/src/zk_merkle.rs ----
 static bool canonical32(const uint8_t *h) { return qpgpu_bytes_digest_is_canonical(h) == 1; }
 

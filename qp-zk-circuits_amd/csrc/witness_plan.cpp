@@ -32,6 +32,7 @@ struct WitnessPlan {
     // the caller assigns are known from the start, as a PartialWitness's values are in plonky2; their producers are checked.
     bool assigned_aware = false;
     std::vector<u64> assigned_cells;         // the list (incl. the public-input cells when they are supplied) the plan was built for
+    std::vector<u64> decided_for;            // the assignment list this plan (of either kind) was last chosen for
     std::vector<uint8_t> assigned_checked;   // [num_wires][n]: 1 = a caller-assigned class that generators produce too (scatter AND check)
     uint32_t *d_level_start = nullptr, *d_level_poseidon = nullptr;
     std::vector<uint8_t> free_mask;          // [num_wires][n]: 1 = supplied by the caller
@@ -459,20 +460,39 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan, const std::vector<u6
     return "";
 }
 
-// The plan of a circuit. Without an assignment list: the plan every entry point shares. With one (the PartialWitness entries): the same
-// plan, unless the circuit's generators form a cycle that only the caller's values break — then a plan built for that list (rebuilt
-// when the list changes).
-int ensure_plan(qpgpu_circuit *c, const std::vector<u64> *assigned = nullptr) {
-    if (c->wplan && (!assigned || !c->wplan->assigned_aware || c->wplan->assigned_cells == *assigned)) return QPGPU_OK;
+// The plan of a circuit. Without an assignment list: the plan every entry point shares. With one (the PartialWitness entries): the
+// plan built WITHOUT the list, unless (a) the circuit's generators form a cycle that only the caller's values break, or (b) the list
+// sets targets that generators produce too (beyond the public inputs: hash hints of a front-end, include/qpgpu_leaf.h) and the plan
+// built FOR the list — those classes known from the start, their producers checked against the caller's values, as a PartialWitness's
+// values are there first in plonky2 — has fewer dependency levels. The choice is remembered for the list (rebuilt when it changes).
+int ensure_plan(qpgpu_circuit *c, const std::vector<u64> *assigned = nullptr, size_t pi_prefix = 0) {
+    if (c->wplan && (!assigned || c->wplan->decided_for == *assigned)) return QPGPU_OK;
+    if (c->wplan && assigned && !c->wplan->assigned_aware) {
+        // a plan built without a list is in place: it stays unless this list carries hints
+        const WitnessPlan &d = *c->wplan;
+        bool hints = false;
+        const u64 NW = c->pack.num_wires, n = c->pack.n();
+        for (size_t i = pi_prefix; i < assigned->size() && !hints; i++) { const u64 cell = (*assigned)[i]; hints = cell < NW * n && d.generated[(cell % NW) * n + cell / NW]; }
+        if (!hints) { c->wplan->decided_for = *assigned; return QPGPU_OK; }
+    }
     if (c->wplan) { QP_HIP(c->ctx, hipStreamSynchronize(c->ctx->stream)); witness_plan_free(c->wplan); c->wplan = nullptr; }
     WitnessPlan *plan = new WitnessPlan();
     std::string err = build_plan(c, *plan);
-    if (!err.empty() && assigned && err.find("cyclic generator dependency") != std::string::npos) {
-        witness_plan_free(plan);
-        plan = new WitnessPlan();
-        err = build_plan(c, *plan, assigned);
+    if (assigned) {
+        bool want_aware = !err.empty() && err.find("cyclic generator dependency") != std::string::npos;
+        if (err.empty()) {
+            const u64 NW = c->pack.num_wires, n = c->pack.n();
+            for (size_t i = pi_prefix; i < assigned->size() && !want_aware; i++) { const u64 cell = (*assigned)[i]; want_aware = cell < NW * n && plan->generated[(cell % NW) * n + cell / NW]; }
+        }
+        if (want_aware) {
+            WitnessPlan *aware = new WitnessPlan();
+            const std::string err2 = build_plan(c, *aware, assigned);
+            if (err2.empty() && (!err.empty() || aware->level_start.size() < plan->level_start.size())) { witness_plan_free(plan); plan = aware; err.clear(); }
+            else { witness_plan_free(aware); if (!err.empty()) err = err2.empty() ? err : err2; }
+        }
     }
     if (!err.empty()) { witness_plan_free(plan); return c->ctx->fail(QPGPU_EINVAL, err); }
+    if (assigned) plan->decided_for = *assigned;
     c->wplan = plan;
     return QPGPU_OK;
 }
@@ -731,11 +751,15 @@ int ensure_prep(qpgpu_circuit *c, const uint64_t *cells, size_t count, uint32_t 
 // the PartialWitness entries: the shared plan, or — for a circuit whose generators only the caller's values untangle — one built for
 // this assignment list (the public-input cells belong to it when the public inputs are supplied)
 int ensure_plan_for(qpgpu_circuit *c, const uint64_t *cells, size_t count, bool with_pis) {
-    if (c->wplan && !c->wplan->assigned_aware) return QPGPU_OK;
+    if (c->wplan && c->wplan->prep) {      // the list this plan's assignments were prepared for: the plan was chosen for it
+        const PartialPrep &pp = *c->wplan->prep;
+        if (pp.valid && pp.with_pis == with_pis && pp.cells.size() == count && (!count || std::memcmp(pp.cells.data(), cells, count * 8) == 0)) return QPGPU_OK;
+    }
     std::vector<u64> assigned;
     if (with_pis) assigned.assign(c->pack.pi_cells.begin(), c->pack.pi_cells.end());
+    const size_t pi_prefix = assigned.size();
     assigned.insert(assigned.end(), cells, cells + count);
-    return ensure_plan(c, &assigned);
+    return ensure_plan(c, &assigned, pi_prefix);
 }
 
 }  // namespace

@@ -14,6 +14,7 @@ import numpy as np
 from .binding import QpGpuError, load_library
 
 MAX_DEPTH, DIGEST_LEN, LT_COUNT, PUBLIC_INPUTS = 16, 110, 299, 21
+HASH_HINTS = 12 * 61 + 4 * 16          # QPGPU_LEAF_HASH_HINTS: 61 sponge states + the Merkle walk's running hash per level
 FRAGMENT_FULL, FRAGMENT_BLOCK_HEADER, FRAGMENT_UNSPENDABLE_ACCOUNT, FRAGMENT_NULLIFIER, FRAGMENT_FAKE_LEAF = 0, 1, 2, 3, 4
 NO_CELL = 0xFFFFFFFFFFFFFFFF
 INFO_FIELDS = ("degree_bits", "rows_before_padding", "gates_after_targets", "gates_unspendable_account", "gates_zk_merkle_proof",
@@ -64,6 +65,10 @@ def _lib():
         L.qpgpu_leaf_block_hash.argtypes = [c.c_void_p, c.c_size_t, c.c_char_p, c.c_uint32, c.c_char_p, c.c_char_p, c.c_char_p, c.c_char_p, c.c_void_p]
         L.qpgpu_zk_leaf_hash.argtypes = [c.c_char_p, c.c_uint64, c.c_uint32, c.c_uint32, c.c_void_p]
         L.qpgpu_zk_proof_from_unsorted.argtypes = [c.c_char_p, c.c_char_p, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p, c.c_char_p]
+        L.qpgpu_leaf_circuit_hash_hint_cells.restype = c.c_int
+        L.qpgpu_leaf_circuit_hash_hint_cells.argtypes = [c.c_uint, c.c_int, c.c_void_p, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t), c.c_char_p]
+        L.qpgpu_leaf_hash_hints.restype = c.c_int
+        L.qpgpu_leaf_hash_hints.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.POINTER(c.c_size_t), c.c_char_p]
         L._leaf_sigs = True
     return L
 
@@ -145,15 +150,39 @@ class LeafCircuit:
             raise QpGpuError(rc, err.value.decode())
         self.info = {k: int(v) for k, v in zip(INFO_FIELDS, info)}
         self.fragment = fragment
+        self._build_args = (min_degree_bits, inner_hasher, layp, lay)
+        self._hint_cells = None
 
-    def commit(self, inputs):
-        """WormholeProver::commit: (cells, values, public_inputs[21]); raises ValueError with the reference's message."""
+    @property
+    def hash_hint_cells(self):
+        """The cells of the 61 Poseidon2 rows' outputs, call sites in tag order (qpgpu_leaf_circuit_hash_hint_cells); full circuit only."""
+        if self._hint_cells is None:
+            if self.fragment != FRAGMENT_FULL:
+                raise ValueError("hash hints exist for the full leaf circuit only")
+            cells = np.empty(HASH_HINTS, dtype=np.uint64)
+            n = ctypes.c_size_t(); err = ctypes.create_string_buffer(160)
+            rc = _lib().qpgpu_leaf_circuit_hash_hint_cells(self._build_args[0], self._build_args[1], self._build_args[2], cells.ctypes.data, cells.size, ctypes.byref(n), err)
+            if rc != 0:
+                raise QpGpuError(rc, err.value.decode())
+            self._hint_cells = cells[:n.value].copy()
+        return self._hint_cells
+
+    def commit(self, inputs, hash_hints=False):
+        """WormholeProver::commit: (cells, values, public_inputs[21]); raises ValueError with the reference's message. hash_hints=True
+        appends the 732 sponge-state elements of the circuit's hash call sites and the Merkle walk's 16 running hashes, computed on the host (qpgpu_leaf_hash_hints): the same witness,
+        with the 61 hash rows generated side by side and checked instead of one after the other."""
         cells = np.empty(LT_COUNT, dtype=np.uint64); values = np.empty(LT_COUNT, dtype=np.uint64); pis = np.empty(PUBLIC_INPUTS, dtype=np.uint64)
         n = ctypes.c_size_t(); err = ctypes.create_string_buffer(160)
         rc = _lib().qpgpu_leaf_commit(ctypes.byref(inputs), self.target_map.ctypes.data, cells.ctypes.data, values.ctypes.data, LT_COUNT,
                                       ctypes.byref(n), pis.ctypes.data, err)
         if rc != 0:
             raise ValueError(err.value.decode())
+        if hash_hints:
+            hv = np.empty(HASH_HINTS, dtype=np.uint64)
+            hn = ctypes.c_size_t()
+            if _lib().qpgpu_leaf_hash_hints(ctypes.byref(inputs), hv.ctypes.data, hv.size, ctypes.byref(hn), err) != 0:
+                raise ValueError(err.value.decode())
+            return np.concatenate([cells[:n.value], self.hash_hint_cells]), np.concatenate([values[:n.value], hv[:hn.value]]), self.public_inputs(pis)
         return cells[:n.value].copy(), values[:n.value].copy(), self.public_inputs(pis)
 
     def public_inputs(self, pis21):
@@ -170,8 +199,8 @@ class LeafCircuit:
 class LeafProver:
     """WormholeProver over a loaded LeafCircuit: commit (host) -> stage s1 on the device -> stages s2..s12."""
 
-    def __init__(self, pkg, gpu, circuit, witness_check=False):
-        self.pkg, self.gpu, self.circuit = pkg, gpu, circuit
+    def __init__(self, pkg, gpu, circuit, witness_check=False, hash_hints=False):
+        self.pkg, self.gpu, self.circuit, self.hash_hints = pkg, gpu, circuit, hash_hints
         self.circ = pkg.Circuit(gpu, circuit.pack)
         if witness_check:
             self.circ.set_witness_check(True)
@@ -180,7 +209,7 @@ class LeafProver:
         self.d_wires = gpu.alloc(self.shape[0] * self.shape[1] * 8)
 
     def generate_witness(self, inputs):
-        cells, values, pis = self.circuit.commit(inputs)
+        cells, values, pis = self.circuit.commit(inputs, hash_hints=self.hash_hints)
         self.circ.generate_witness_partial_dev(cells, values, pis, self.d_wires)
         return pis
 

@@ -91,6 +91,11 @@ def test_leaf_c_example_runs(pkg):
     res = subprocess.run([out, "0", "0,0", "2", "4", "2"], capture_output=True, text=True, timeout=180)
     assert res.returncode == 0, res.stderr + res.stdout
     assert "ok devices=2 workers=2 lockstep=4" in res.stdout and "unsatisfiable job alone" in res.stdout
+    # the same with the front-end's hash hints riding along (sixth argument): the same proof (the example prints its checksum)
+    hinted = subprocess.run([out, "0", "0,0", "2", "4", "2", "1"], capture_output=True, text=True, timeout=180)
+    assert hinted.returncode == 0, hinted.stderr + hinted.stdout
+    fnv = lambda text: [w for w in text.split() if w.startswith("fnv1a=")][0]
+    assert "(hash hints)" in hinted.stdout and "unsatisfiable job alone" in hinted.stdout and fnv(hinted.stdout) == fnv(res.stdout)
 
 
 def test_private_batches_through_the_pool(pkg, gpu, orc):

@@ -20,7 +20,7 @@ def run():
     L = pkg.leaf
     gpu = pkg.QpGpu(0)
     leaf = L.LeafCircuit(min_degree_bits=13)                  # the bench's shape (the reference's leaf has 2^13 rows)
-    p = L.LeafProver(pkg, gpu, leaf)
+    p = L.LeafProver(pkg, gpu, leaf, hash_hints="--hints" in sys.argv)
     xs = [lc.real_inputs(L, depth=3 + i % 5, seed=i) for i in range(8)]
     for x in xs[:3]:
         p.prove(x)
@@ -30,7 +30,7 @@ def run():
     for i in range(n):
         p.prove(xs[i % 8])
     dt = (time.perf_counter() - t) / n
-    print("single proof, commit + s1 + prove: %.3f ms" % (dt * 1e3))
+    print("single proof, commit%s + s1 + prove: %.3f ms" % (" (with hash hints)" if "--hints" in sys.argv else "", dt * 1e3))
     p.close()
 
 
