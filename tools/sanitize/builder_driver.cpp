@@ -74,6 +74,17 @@ int main(int argc, char **argv) {
                 bad = in; memset(bad.nullifier, 0xFF, 8);
                 if (qpgpu_leaf_commit(&bad, map.data(), cells, values, QPGPU_LT_COUNT, &count, pis, err) == 0) { fprintf(stderr, "non-canonical nullifier accepted\n"); return 1; }
                 if (qpgpu_leaf_commit(&in, map.data(), cells, values, 10, &count, pis, err) == 0) { fprintf(stderr, "short buffer accepted\n"); return 1; }
+                if (fragment == QPGPU_LEAF_FRAGMENT_FULL) {     // the hash hints: cells of the circuit, values of the inputs, short buffers, refused inputs
+                    std::vector<uint64_t> hc(QPGPU_LEAF_HASH_HINTS), hv(QPGPU_LEAF_HASH_HINTS);
+                    size_t hn = 0;
+                    if (qpgpu_leaf_circuit_hash_hint_cells(min_bits, hasher, nullptr, hc.data(), hc.size(), &hn, err) || hn != QPGPU_LEAF_HASH_HINTS) { fprintf(stderr, "hint cells: %s\n", err); return 1; }
+                    if (qpgpu_leaf_hash_hints(&in, hv.data(), hv.size(), &hn, err) || hn != QPGPU_LEAF_HASH_HINTS) { fprintf(stderr, "hints: %s\n", err); return 1; }
+                    if (qpgpu_leaf_circuit_hash_hint_cells(min_bits, hasher, nullptr, hc.data(), 10, &hn, err) == 0 || qpgpu_leaf_hash_hints(&in, hv.data(), 10, &hn, err) == 0) { fprintf(stderr, "short hint buffer accepted\n"); return 1; }
+                    qpgpu_leaf_inputs deep = in; deep.zk_merkle_depth = 16;
+                    for (int l = 0; l < 16; l++) { deep.zk_merkle_positions[l] = (uint8_t)(l % 4); for (int k = 0; k < 3; k++) for (int i = 0; i < 32; i++) deep.zk_merkle_siblings[l][k][i] = (uint8_t)(i % 8 == 7 ? 0 : l + k + i); }
+                    if (qpgpu_leaf_hash_hints(&deep, hv.data(), hv.size(), &hn, err)) { fprintf(stderr, "hints (depth 16): %s\n", err); return 1; }
+                    if (qpgpu_leaf_hash_hints(&bad, hv.data(), hv.size(), &hn, err) == 0) { fprintf(stderr, "hints of refused inputs accepted\n"); return 1; }
+                }
             }
     if (!build_leaf(QPGPU_LEAF_FRAGMENT_FAKE_LEAF, 0, 0, fake, fake_map, err)) { fprintf(stderr, "fake leaf: %s\n", err); return 1; }
     std::vector<uint64_t> cap((size_t)4 << 4);
