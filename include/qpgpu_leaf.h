@@ -241,7 +241,9 @@ enum qpgpu_leaf_hash_site {
 int qpgpu_leaf_circuit_hash_hint_cells(unsigned min_degree_bits, int inner_hasher, const uint64_t *p2_layout, uint64_t *cells_out, size_t cap, size_t *count, char *err);
 /* the 796 values for one set of inputs, computed on the host exactly as the rows' generators would from the same assignments (field
  * arithmetic on the inputs as given: inconsistent inputs give hints that disagree with nothing but the targets the circuit itself
- * would refuse). values_out: room for QPGPU_LEAF_HASH_HINTS. Returns 0, or -1 with a message (inputs qpgpu_leaf_fill_witness refuses). */
+ * would refuse). values_out: room for QPGPU_LEAF_HASH_HINTS. Returns 0, or -1 with a message (inputs qpgpu_leaf_fill_witness refuses).
+ * The values are as sensitive as qpgpu_leaf_commit's (the first sponge states are functions of the spend secret alone): wipe them after
+ * the submit, as the library wipes its own copies. */
 int qpgpu_leaf_hash_hints(const qpgpu_leaf_inputs *in, uint64_t *values_out, size_t cap, size_t *count, char *err);
 
 #ifdef __cplusplus

@@ -367,7 +367,7 @@ int qpgpu_leaf_hash_hints(const qpgpu_leaf_inputs *in, uint64_t *values_out, siz
     if (qpgpu_bytes_to_felts(in->digest, QPGPU_LEAF_DIGEST_LOGS_SIZE, pre + 17, 28) != 28) return fail(err, "failed to encode digest logs");
     sponge_states(p, pre, 45, out, digest);
     for (unsigned i = 0; i < 4 * QPGPU_LEAF_MAX_DEPTH; i++) *out++ = walk[i];      // the running hash after every level of the walk
-    std::memset(secret, 0, sizeof secret); std::memset(pre, 0, sizeof pre); std::memset(inner, 0, sizeof inner);   // the spend secret
+    std::memset(secret, 0, sizeof secret); std::memset(pre, 0, sizeof pre); std::memset(inner, 0, sizeof inner); std::memset(digest, 0, sizeof digest);   // the spend secret and what is derived from it alone
     *count = (size_t)(out - values_out);
     if (*count != QPGPU_LEAF_HASH_HINTS) return fail(err, "leaf_hash_hints: %llu values where %llu are expected", (unsigned long long)*count, (unsigned long long)QPGPU_LEAF_HASH_HINTS);
     return 0;
