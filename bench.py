@@ -694,17 +694,43 @@ def main():
                 cb_.generate_witness_partial_batch_dev(cells0, vB, pB, dB)
             gpu.sync()
             s1_batch = (time.perf_counter() - tw) / 3
+            # the same with the front-end's hash hints behind the 299 assignments (host: + the hash chains' states; device: the plan built for
+            # that list, the hash rows side by side and checked)
+            comH = [leaf.commit(inputs_all[i % S], hash_hints=True) for i in range(LOCKSTEP)]
+            vH = np.stack([c_[1] for c_ in comH])
+            cb_.witness_partial_prepare(comH[0][0], LOCKSTEP)
+            cb_.generate_witness_partial_batch_dev(comH[0][0], vH[:1], pB[:1], dB); gpu.sync()
+            h_ok = bool((dB.download(count=nw_ * n_) == wires0.ravel()).all())
+            h_levels = cb_.witness_info()[1]
+            tw = time.perf_counter()
+            for _ in range(5):
+                cb_.generate_witness_partial_batch_dev(comH[0][0], vH[:1], pB[:1], dB)
+            gpu.sync()
+            h_single = (time.perf_counter() - tw) / 5
+            cb_.generate_witness_partial_batch_dev(comH[0][0], vH, pB, dB); gpu.sync()
+            tw = time.perf_counter()
+            for _ in range(3):
+                cb_.generate_witness_partial_batch_dev(comH[0][0], vH, pB, dB)
+            gpu.sync()
+            h_batch = (time.perf_counter() - tw) / 3
             dB.free(scrub=True); cb_.close()
             tc_ = time.perf_counter()
             for _ in range(2000):
                 leaf.commit(inputs_all[1])
             commit_us = (time.perf_counter() - tc_) / 2000 * 1e6
+            tc_ = time.perf_counter()
+            for _ in range(500):
+                leaf.commit(inputs_all[1], hash_hints=True)
+            commit_h_us = (time.perf_counter() - tc_) / 500 * 1e6
             extra["witness_generation"] = {"generator_instances": gens, "dependency_levels": levels, "caller_supplied_cells": free,
                                            "commit_host_us": round(commit_us, 2), "single_ms": round(s1_single * 1e3, 3), "batch": LOCKSTEP,
                                            "batched_ms_per_witness": round(s1_batch / LOCKSTEP * 1e3, 4), "equals_full_witness": s1_ok,
                                            "note": "commit = qpgpu_leaf_commit through ctypes (fill_witness + target map, host); s1 = "
-                                                   "qpgpu_generate_witness_partial_batch_dev on the restated leaf circuit: one kernel launch per dependency level"}
-            ok = ok and s1_ok
+                                                   "qpgpu_generate_witness_partial_batch_dev on the restated leaf circuit: one kernel launch per dependency level",
+                                           "with_hash_hints": {"assignments": int(comH[0][0].size), "dependency_levels": h_levels, "commit_host_us": round(commit_h_us, 2),
+                                                               "single_ms": round(h_single * 1e3, 3), "batched_ms_per_witness": round(h_batch / LOCKSTEP * 1e3, 4),
+                                                               "equals_full_witness": h_ok}}
+            ok = ok and s1_ok and h_ok
 
             def leaf_throughput(circuit_kw, reps=6, hasher_note=None):
                 """commit + prove at full throughput on another build of the leaf circuit (same inputs, workers, lockstep)."""
