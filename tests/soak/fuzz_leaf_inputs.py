@@ -5,7 +5,7 @@ random secrets, amounts under the fee rule, Merkle paths of 0..16 levels at rand
   * stage s1 on the device in lockstep batches (qpgpu_generate_witness_partial_batch_dev): status per witness,
   * oracle/witness.c on the same assignments,
 must agree (satisfiable / "set twice with different values"), and for satisfiable inputs the device's wire matrix must equal the
-oracle's cell for cell; every 16th satisfiable input is also proven and verified. usage: python tests/soak/fuzz_leaf_inputs.py [count] [seed]"""
+oracle's cell for cell; every 16th satisfiable input is also proven and verified. usage: python tests/soak/fuzz_leaf_inputs.py [count] [seed] [hints]"""
 import ctypes, json, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
@@ -18,6 +18,7 @@ gpu = pkg.QpGpu(0)
 L = pkg.leaf
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+HINTS = len(sys.argv) > 3 and sys.argv[3] == "hints"
 leaf = L.LeafCircuit()
 B = 32
 circ = pkg.Circuit(gpu, leaf.pack, max_batch=B)
@@ -84,13 +85,17 @@ while len(xs) < count:
     xs.append(x)
     if rng.integers(0, 2) and len(xs) < count:
         xs.append(mutate(x))
-stats = {"inputs": count, "satisfiable": 0, "unsatisfiable": 0, "witnesses_compared": 0, "proofs_verified": 0, "mismatches": 0}
+stats = {"hash_hints": HINTS, "inputs": count, "satisfiable": 0, "unsatisfiable": 0, "witnesses_compared": 0, "proofs_verified": 0, "mismatches": 0}
 err = ctypes.create_string_buffer(200)
 for k0 in range(0, count, B):
     chunk = xs[k0:k0 + B]
     com = [leaf.commit(x) for x in chunk]
     cells = com[0][0]
-    st = circ.generate_witness_partial_batch_dev(cells, np.stack([c[1] for c in com]), np.stack([c[2] for c in com]), d)
+    if HINTS:    # the device gets the front-end's hash hints as well (the oracle below keeps the 299 assignments: same verdict, same witness)
+        comh = [leaf.commit(x, hash_hints=True) for x in chunk]
+        st = circ.generate_witness_partial_batch_dev(comh[0][0], np.stack([c[1] for c in comh]), np.stack([c[2] for c in comh]), d)
+    else:
+        st = circ.generate_witness_partial_batch_dev(cells, np.stack([c[1] for c in com]), np.stack([c[2] for c in com]), d)
     wires = d.download(len(chunk) * nw * n).reshape(len(chunk), nw, n)
     for i, x in enumerate(chunk):
         host_ok = check(ctypes.byref(x), err) == 0

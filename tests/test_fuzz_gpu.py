@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("tool,args,keys", [
     ("tests/soak/fuzz_leaf_inputs.py", ["384", "21"], {"inputs": 384}),              # (checks against the oracle: lives under tests/)
+    ("tests/soak/fuzz_leaf_inputs.py", ["256", "25", "hints"], {"inputs": 256, "hash_hints": True}),   # the device side with the front-end's hash hints
     ("tools/fuzz_wrapper_tamper.py", ["96", "22"], {"flips": 96, "accepted_by_both": 0}),
     ("tools/fuzz_private_batch.py", ["192", "23"], {"batches": 192}),
     ("tools/fuzz_public_batch.py", ["192", "24"], {"batches": 192}),
@@ -30,7 +31,7 @@ def test_fuzz_tool(tool, args, keys):
     if tool.endswith(("fuzz_private_batch.py", "fuzz_public_batch.py")):
         assert stats["satisfiable"] > 50 and stats["unsatisfiable"] > 20
     if tool.endswith("fuzz_leaf_inputs.py"):
-        assert stats["satisfiable"] > 150 and stats["unsatisfiable"] > 50 and stats["witnesses_compared"] == stats["satisfiable"]
+        assert stats["satisfiable"] > stats["inputs"] // 3 and stats["unsatisfiable"] > stats["inputs"] // 8 and stats["witnesses_compared"] == stats["satisfiable"]
 
 
 def test_no_dead_witness_cells():
