@@ -304,7 +304,7 @@ void sponge_states(const poseidon2::Params &p, const u64 *in, size_t n, u64 *&ou
             const size_t k = i + j;
             st[j] = gl::canon(gl::add(st[j], k < n ? gl::canon(in[k]) : (k == n ? 1 : 0)));
         }
-        poseidon2::permute(st, p);
+        poseidon2::permute_qp(st, p);      // (p is the qp set here: its external layer needs no multiplications)
         for (int j = 0; j < 12; j++) *out++ = gl::canon(st[j]);
     }
     for (int i = 0; i < 4; i++) digest[i] = gl::canon(st[i]);
