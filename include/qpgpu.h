@@ -209,6 +209,9 @@ int qpgpu_generate_witness(qpgpu_circuit *c, uint64_t *wires, const uint64_t *pu
 /* `batch` witnesses of the same circuit at once (wire matrices back to back, public inputs back to back): the dependency
  * levels are walked once for all of them, which is how the device pays off — a single witness is latency-bound by the
  * circuit's dependency depth, exactly the part a host core does well. */
+/* the trace rows of one gate type (the QPCP gate type codes of csrc/circuit.hpp: 4 PoseidonGate, 14 the Poseidon2 gate, ...), for tools
+ * and tests; rows_out may be NULL to ask for the count */
+int qpgpu_circuit_gate_rows(const qpgpu_circuit *c, unsigned gate_type, uint32_t *rows_out, size_t cap, size_t *count);
 int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs);
 /* The same from a sparse PartialWitness: `count` assignments (cell = row * num_wires + wire, value), as the reference
  * builds them with `pw.set_target` (wormhole/prover/src/lib.rs:187-221). d_wires (num_wires x 2^degree_bits, device) is

@@ -86,6 +86,7 @@ def load_library():
         "qpgpu_proof_size": (c.c_size_t, [vp]),
         "qpgpu_circuit_set_blinding_seed": (c.c_int, [vp, c.c_uint64]),
         "qpgpu_circuit_set_witness_check": (c.c_int, [vp, c.c_int]),
+        "qpgpu_circuit_gate_rows": (c.c_int, [vp, c.c_uint, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_prove_dev": (c.c_int, [vp, u64p, u64p, vp, c.c_size_t, c.POINTER(c.c_size_t)]),
         "qpgpu_poseidon_constants": (c.c_size_t, [u64p, u64p, c.c_size_t]),
@@ -379,6 +380,14 @@ class Circuit:
         a, b, c3 = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         self.gpu._check(self.gpu.lib.qpgpu_witness_info(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c3)))
         return a.value, b.value, c3.value
+
+    def gate_rows(self, gate_type):
+        """The trace rows of a gate type (QPCP type codes: 4 PoseidonGate, 14 the Poseidon2 gate, ...)."""
+        n = ctypes.c_size_t()
+        self.gpu._check(self.gpu.lib.qpgpu_circuit_gate_rows(self.h, gate_type, None, 0, ctypes.byref(n)))
+        rows = np.empty(n.value, dtype=np.uint32)
+        self.gpu._check(self.gpu.lib.qpgpu_circuit_gate_rows(self.h, gate_type, rows.ctypes.data, rows.size, ctypes.byref(n)))
+        return rows
 
     def witness_free_mask(self, num_wires, n):
         """uint8 [num_wires, n]: 1 where the caller supplies the cell (PartialWitness), 0 where generation writes it."""

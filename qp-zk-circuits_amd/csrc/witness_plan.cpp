@@ -766,6 +766,22 @@ int ensure_plan_for(qpgpu_circuit *c, const uint64_t *cells, size_t count, bool 
 
 extern "C" {
 
+// the trace rows a gate type occupies (introspection for tools and tests: the gate of a row is the one its selector column names)
+int qpgpu_circuit_gate_rows(const qpgpu_circuit *c, unsigned gate_type, uint32_t *rows_out, size_t cap, size_t *count) {
+    if (!c || !count) return QPGPU_EINVAL;
+    const CircuitPack &p = c->pack;
+    const u64 n = p.n();
+    size_t k = 0;
+    for (u64 r = 0; r < n; r++)
+        for (size_t gi = 0; gi < p.gates.size(); gi++)
+            if (p.constants_sigmas[(u64)p.gates[gi].selector_index * n + r] == gi) {
+                if (p.gates[gi].type == gate_type) { if (rows_out && k < cap) rows_out[k] = (uint32_t)r; k++; }
+                break;
+            }
+    *count = k;
+    return rows_out && k > cap ? QPGPU_EBUFSIZE : QPGPU_OK;
+}
+
 int qpgpu_generate_witness_batch_dev(qpgpu_circuit *c, uint64_t *d_wires, uint32_t batch, const uint64_t *public_inputs) {
     if (!c) return QPGPU_EINVAL;
     qpgpu_ctx *ctx = c->ctx;
