@@ -92,6 +92,7 @@ extern "C" {
     pub fn qpgpu_random_field_elements(seed32: *const u8, out: *mut u64, n: usize, err: *mut c_char) -> i32;
     // with stage s1 on the device the public inputs are read out of the device witness, the way `prove` reads them out of the
     // partition witness: pass public_inputs = null to the generate_witness_partial* calls, then this, then qpgpu_prove*_dev
+    pub fn qpgpu_circuit_gate_rows(c: *const QpgpuCircuit, gate_type: u32, rows_out: *mut u32, cap: usize, count: *mut usize) -> i32;   // introspection
     pub fn qpgpu_witness_public_inputs_dev(c: *mut QpgpuCircuit, d_wires: *const u64, batch: u32, public_inputs_out: *mut u64) -> i32;
     // include/qpgpu_leaf.h, include/qpgpu_batch.h — the circuits built by the library itself: only for
     // deployments that take BOTH prover and verifier data from it; with exported packs of the fork's own circuits these are not used
