@@ -466,7 +466,8 @@ std::string build_plan(qpgpu_circuit *c, WitnessPlan &plan, const std::vector<u6
 // built FOR the list — those classes known from the start, their producers checked against the caller's values, as a PartialWitness's
 // values are there first in plonky2 — has fewer dependency levels. The choice is remembered for the list (rebuilt when it changes).
 int ensure_plan(qpgpu_circuit *c, const std::vector<u64> *assigned = nullptr, size_t pi_prefix = 0) {
-    if (c->wplan && (!assigned || c->wplan->decided_for == *assigned)) return QPGPU_OK;
+    // (an entry point without a list — a witness from the free cells — cannot run on a plan built for somebody's assignments)
+    if (c->wplan && (assigned ? c->wplan->decided_for == *assigned : !c->wplan->assigned_aware)) return QPGPU_OK;
     if (c->wplan && assigned && !c->wplan->assigned_aware) {
         // a plan built without a list is in place: it stays unless this list carries hints
         const WitnessPlan &d = *c->wplan;
@@ -514,7 +515,7 @@ extern "C" {
 int qpgpu_witness_info(qpgpu_circuit *c, uint64_t *num_generators, uint64_t *num_levels, uint64_t *num_free_cells) {
     if (!c) return QPGPU_EINVAL;
     QP_DEV(c->ctx);
-    QP_TRY(ensure_plan(c));
+    if (!c->wplan) QP_TRY(ensure_plan(c));        // (reports the plan in place — of either kind — and builds the shared one only if there is none)
     if (num_generators) *num_generators = c->wplan->insts.size();
     if (num_levels) *num_levels = c->wplan->level_start.empty() ? 0 : c->wplan->level_start.size() - 1;
     if (num_free_cells) *num_free_cells = c->wplan->num_free;
@@ -524,7 +525,7 @@ int qpgpu_witness_info(qpgpu_circuit *c, uint64_t *num_generators, uint64_t *num
 int qpgpu_witness_free_mask(qpgpu_circuit *c, uint8_t *mask, size_t mask_len) {
     if (!c || !mask) return QPGPU_EINVAL;
     QP_DEV(c->ctx);
-    QP_TRY(ensure_plan(c));
+    if (!c->wplan) QP_TRY(ensure_plan(c));        // (of the plan in place: under a plan built for an assignment list the assigned classes count as supplied)
     if (mask_len < c->wplan->free_mask.size()) return c->ctx->fail(QPGPU_EBUFSIZE, "witness_free_mask: buffer too small");
     std::memcpy(mask, c->wplan->free_mask.data(), c->wplan->free_mask.size());
     return QPGPU_OK;
@@ -870,7 +871,7 @@ int qpgpu_witness_public_inputs_dev(qpgpu_circuit *c, const uint64_t *d_wires, u
     if (!d_wires || batch == 0 || batch > 65535 || (npis && !public_inputs_out)) return ctx->fail(QPGPU_EINVAL, "witness_public_inputs: bad argument");
     if (npis == 0) return QPGPU_OK;
     if (p.pi_cells.size() != npis) return ctx->fail(QPGPU_EINVAL, "witness_public_inputs: the circuit pack carries no public-input cell trailer");
-    QP_TRY(ensure_plan(c));
+    if (!c->wplan) QP_TRY(ensure_plan(c));        // (the public-input cells are the same in a plan of either kind)
     WitnessPlan &plan = *c->wplan;
     if (plan.pi_cap < batch) {
         QP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -70,3 +70,20 @@ def test_hints_through_the_pool(pkg, gpu, orc, L):
     for k, t in tickets:
         assert pool.wait(t) == want[k], k
     pool.close()
+
+
+def test_entries_without_a_list_do_not_run_on_a_plan_built_for_hints(pkg, gpu, L):
+    """After a hinted PartialWitness (stage s1's plan built FOR that assignment list) the same circuit handle generates a witness from
+    a full matrix of free cells again — on the plan built without a list — and the two witnesses are equal."""
+    leaf = L.LeafCircuit()
+    x = lc.real_inputs(L, depth=4, seed=12)
+    p = L.LeafProver(pkg, gpu, leaf, hash_hints=True)
+    p.prove(x)
+    assert p.circ.witness_info()[1] < 60
+    w = p.witness()
+    mask = p.circ.witness_free_mask(*w.shape)
+    full = p.circ.generate_witness(np.where(mask == 1, w, 0).astype(np.uint64), leaf.commit(x)[2])
+    assert np.array_equal(full, w) and p.circ.witness_info()[1] == 120
+    p.prove(x)                                                              # and back
+    assert np.array_equal(p.witness(), w) and p.circ.witness_info()[1] < 60
+    p.close()
