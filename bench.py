@@ -36,6 +36,77 @@ STAGES = ["prove_commit_wires", "prove_partial_products", "prove_commit_zs", "pr
           "prove_openings", "prove_fri_batch", "prove_fri_commit", "prove_pow", "prove_queries"]
 
 
+class EngineClock:
+    """Engine clock and board power of the card a context runs on, while a leg runs: sysfs hwmon (freq1_input in Hz,
+    power1_average / power1_input in microwatts) under /sys/bus/pci/devices/<qpgpu_ctx_pci_bus_id>, read by a thread every 20 ms.
+    The issue bounds this file quotes are priced at the 2.4 GHz peak engine clock; under sustained load the card delivers less
+    (profiles/r04_clocks.txt), so each leg also says at which clock it ran. Never fails a run: summary() is None without sysfs."""
+
+    def __init__(self, gpu):
+        import glob as _g
+        self.freq = self.power = None
+        self.samples = []
+        self._stop = False
+        self._th = None
+        try:
+            base = os.path.join("/sys/bus/pci/devices", gpu.pci_bus_id(), "hwmon")
+            for hw in sorted(_g.glob(os.path.join(base, "hwmon*"))):
+                if os.path.exists(os.path.join(hw, "freq1_input")):
+                    self.freq = os.path.join(hw, "freq1_input")
+                    for name in ("power1_average", "power1_input"):
+                        if os.path.exists(os.path.join(hw, name)):
+                            self.power = os.path.join(hw, name)
+                            break
+                    break
+        except Exception:
+            pass
+
+    @staticmethod
+    def _rd(path):
+        try:
+            with open(path) as f:
+                return int(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop:
+            f = self._rd(self.freq)
+            w = self._rd(self.power) if self.power else None
+            if f:
+                self.samples.append((time.perf_counter(), f / 1e6, w / 1e6 if w else None))
+            time.sleep(0.02)
+
+    def __enter__(self):
+        self.samples = []
+        self._stop = False
+        if self.freq:
+            import threading
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._t0 = time.perf_counter()
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join()
+            self._th = None
+
+    def summary(self, skip_s=0.1):
+        """Samples later than skip_s after the start (the ramp out of idle is not the leg's clock)."""
+        xs = [x for x in self.samples if x[0] - self._t0 >= skip_s] if self.samples else []
+        if not xs:
+            return None
+        mhz = sorted(x[1] for x in xs)
+        out = {"mean": round(sum(mhz) / len(mhz), 1), "min": round(mhz[0], 1), "max": round(mhz[-1], 1), "samples": len(mhz),
+               "peak_used_for_bounds": 2400.0, "source": "sysfs hwmon freq1_input, 20 ms"}
+        pw = [x[2] for x in xs if x[2]]
+        if pw:
+            out["board_power_w_mean"] = round(sum(pw) / len(pw), 1)
+        return out
+
+
 def ntt_leg(pkg, gpu, log_n, batch, steps):
     """BASELINE configs[1]: fwd + inverse NTT over `batch` columns of 2^log_n. Returns (GB/s, roofline dict, ok, column in, column out).
     Device memory through the library's own allocator (no torch in a one-rank run: one ROCm runtime stack in the process)."""
@@ -72,6 +143,18 @@ def ntt_leg(pkg, gpu, log_n, batch, steps):
     gpu.profile(False)
     per_transform_ms = ms_s / max(n_s, 1) + ms_r / max(n_r, 1)
     achieved = 16.0 * n * batch / (per_transform_ms * 1e-3) / 1e9
+    # the same loop held for about half a second with the card's clock read beside it
+    clk = EngineClock(gpu)
+    sustained = None
+    if clk.freq:
+        reps = max(steps, int(0.5 / max(dt / steps, 1e-4)))
+        with clk:
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            gpu.sync()
+            sdt = time.perf_counter() - t1
+        sustained = {"seconds": round(sdt, 3), "fwd_inv_GBps": round(32.0 * n * batch * reps / sdt / 1e9, 1), "engine_clock_mhz": clk.summary()}
     roof = {
         # what bounds the kernel pair is VALU issue (valu_roofline below: modelled issue time / measured time), not HBM; achieved /
         # peak / frac stay the algorithmic-bytes figures BASELINE.json's metric asks for ("NTT HBM GB/s vs peak")
@@ -81,6 +164,8 @@ def ntt_leg(pkg, gpu, log_n, batch, steps):
         "avg_ms": {"ntt_pass_strided": round(ms_s / max(n_s, 1), 4), "ntt_pass_rows": round(ms_r / max(n_r, 1), 4)},
         "algorithmic_bytes_per_transform": 16 * n * batch, "workload": f"2^{log_n} points x {batch} columns",
     }
+    if sustained:
+        roof["sustained"] = sustained
     # HBM traffic from the PMC counters cannot be collected inside this process; it is read from the committed
     # rocprofv3 --pmc summary of the same kernels on the same workload (profiles/*ntt_pmc_summary.json)
     # A summary counts only while it was measured on THIS library's NTT kernels: tools/r03_collect.py stores the hash of the
@@ -357,10 +442,13 @@ def main():
     gather_ms = []
     proof = run_steps(max(args.warmup, 1))
     barrier()
-    t0 = time.perf_counter()
-    proof = run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    hclk = EngineClock(gpu)
+    with hclk:
+        t0 = time.perf_counter()
+        proof = run_steps(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+    headline_clock = hclk.summary(skip_s=0.3)
     # spread: the timed region cut into three consecutive windows of steps (this rank's clock)
     windows = []
     if args.steps >= 3:
@@ -641,6 +729,21 @@ def main():
             hash_ms, hash_n = gpu.profile_read("merkle_leaf_hash")
             gpu.profile(False)
             perm_rate = 17 * (1 << HL) * hash_n / (hash_ms * 1e-3)
+            # the same commitment held for about half a second with the card's clock read beside it (HIP events as above)
+            pclk = EngineClock(gpu)
+            hash_sustained = None
+            if pclk.freq:
+                gpu.profile(True)
+                with pclk:
+                    t1_ = time.perf_counter()
+                    while time.perf_counter() - t1_ < 0.5:
+                        for _ in range(8):
+                            gpu.merkle_build_dev(d_cols, 1 << HL, 135, HL, 4, d_dig)
+                        gpu.sync()
+                sh_ms, sh_n = gpu.profile_read("merkle_leaf_hash")
+                gpu.profile(False)
+                hash_sustained = {"seconds": round(time.perf_counter() - t1_, 3), "permutations_per_s": round(17 * (1 << HL) * sh_n / (sh_ms * 1e-3) / 1e9, 3),
+                                  "engine_clock_mhz": pclk.summary()}
             d_cols.free(); d_dig.free()
             lde_leaves = 1 << (d + 3)
             mx_on = os.environ.get("QPGPU_MX", "1") != "0"
@@ -650,6 +753,8 @@ def main():
                                          "wires_leaf_hash_algorithmic_GBps": round(8.0 * 135 * lde_leaves / 1e9 / (17 * lde_leaves / perm_rate), 1),
                                          "note": "leaf hashing reads 8*W bytes per leaf and runs ceil(W/8) permutations: at the permutation "
                                                  "rate above the wires oracle streams this many GB/s, far below HBM"}
+            if hash_sustained:
+                extra["poseidon_hashing"]["sustained"] = hash_sustained
             try:   # hardware counters of the same kernel, committed (tools/gpurun_scripts/mx_pmc.sh -> tools/collect_mx_counters.py)
                 import glob as _glob
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -667,6 +772,10 @@ def main():
                     bound = 1024 * 64 / (lk["valu_insts_per_permutation"] * 3.5) * 2.4
                     ph["valu_issue_bound_G_per_s"] = round(bound, 3)
                     ph["frac"] = round(perm_rate / 1e9 / bound, 3)
+                    if hash_sustained and hash_sustained["engine_clock_mhz"]:
+                        ck = hash_sustained["engine_clock_mhz"]["mean"]
+                        hash_sustained["valu_issue_bound_at_observed_clock_G_per_s"] = round(bound * ck / 2400.0, 3)
+                        hash_sustained["frac_at_observed_clock"] = round(hash_sustained["permutations_per_s"] / (bound * ck / 2400.0), 3)
                     ph["frac_note"] = ("measured permutations/s over the VALU issue bound of the kernel's own instruction count (valu_insts_per_permutation x 3.5 cycles per wave "
                                        "instruction per SIMD, 1024 SIMDs, 2.4 GHz); the rest is the clock under load, 40 bytes per lane of spilled registers at the 128-register cap "
                                        "(four waves per SIMD; the register file is unified on this chip: no spare AGPRs) and the sponge's column loads")
@@ -879,6 +988,7 @@ def main():
             "metric": "Wormhole proofs/sec", "value": round(value, 3), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_proof": round(dt / (args.steps * S) * 1e3, 4),
+            "engine_clock_mhz": headline_clock,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "window_proofs_per_s": windows, "step_ms_rank0": step_ms, "gather_ms_rank0": [round(x, 2) for x in gather_ms[-16:]],
             "gather_ms_mean_per_rank": gather_ms_per_rank,

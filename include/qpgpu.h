@@ -46,6 +46,9 @@ const char *qpgpu_last_error(const qpgpu_ctx *ctx);
 int qpgpu_ctx_set_stream(qpgpu_ctx *ctx, void *hip_stream);
 int qpgpu_sync(qpgpu_ctx *ctx);
 const char *qpgpu_version(void);
+/* PCI address of the context's device as "dddd:bb:dd.f" (NUL-terminated, 13 bytes): the key under /sys/bus/pci/devices a
+ * caller reads the card's engine clock and power from while it measures (bench.py's `engine_clock_mhz`). */
+int qpgpu_ctx_pci_bus_id(const qpgpu_ctx *ctx, char *out, size_t out_len);
 /* Post-mortem evidence (csrc/crash_trace.cpp): with QPGPU_CRASH_TRACE=1 (stderr) or =<file> in the environment when the
  * library is loaded, a fatal signal writes its address, the mapping that holds it and the native backtrace of the faulting
  * thread before the previous handler (e.g. python -X faulthandler) or the default action runs. 1 = armed. */

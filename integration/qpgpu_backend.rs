@@ -48,6 +48,7 @@ extern "C" {
     pub fn qpgpu_ctx_create(device: i32, out: *mut *mut QpgpuCtx) -> i32;
     pub fn qpgpu_ctx_destroy(ctx: *mut QpgpuCtx);
     pub fn qpgpu_last_error(ctx: *const QpgpuCtx) -> *const c_char;
+    pub fn qpgpu_ctx_pci_bus_id(ctx: *const QpgpuCtx, out: *mut c_char, out_len: usize) -> i32;
     pub fn qpgpu_ctx_set_hasher(ctx: *mut QpgpuCtx, kind: i32, params: *const u64, n_words: usize) -> i32;
     pub fn qpgpu_malloc(ctx: *mut QpgpuCtx, bytes: usize, dptr: *mut *mut c_void) -> i32;
     pub fn qpgpu_free(ctx: *mut QpgpuCtx, dptr: *mut c_void) -> i32;

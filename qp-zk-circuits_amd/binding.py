@@ -40,6 +40,7 @@ def load_library():
     vp, u64p = c.c_void_p, c.c_void_p
     sigs = {
         "qpgpu_version": (c.c_char_p, []),
+        "qpgpu_ctx_pci_bus_id": (c.c_int, [c.c_void_p, c.c_char_p, c.c_size_t]),
         "qpgpu_verifier_create": (c.c_int, [vp, c.c_size_t, vp, c.c_size_t, c.c_int, vp, c.c_size_t, c.POINTER(vp), c.c_char_p]),
         "qpgpu_verifier_free": (None, [vp]),
         "qpgpu_verifier_proof_size": (c.c_size_t, [vp]),
@@ -843,6 +844,12 @@ class QpGpu(_Stage3):
 
     def sync(self):
         self._check(self.lib.qpgpu_sync(self.ctx))
+
+    def pci_bus_id(self):
+        """"dddd:bb:dd.f" of the context's device (the key of its sysfs directory)."""
+        buf = ctypes.create_string_buffer(16)
+        self._check(self.lib.qpgpu_ctx_pci_bus_id(self.ctx, buf, 16))
+        return buf.value.decode()
 
     def profile(self, on=True):
         self._check(self.lib.qpgpu_profile_enable(self.ctx, 1 if on else 0))

@@ -51,6 +51,17 @@ int qpgpu_profile_read(qpgpu_ctx *ctx, const char *kernel, double *total_ms, uin
 }
 
 const char *qpgpu_version(void) { return "qpgpu 0.1 (gfx950)"; }
+int qpgpu_ctx_pci_bus_id(const qpgpu_ctx *ctx, char *out, size_t out_len) {
+    if (!ctx || !out || out_len == 0) return QPGPU_EINVAL;
+    out[0] = 0;
+    if (out_len < 13) return QPGPU_EBUFSIZE;
+    char id[32] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof id, ctx->device) != hipSuccess) return QPGPU_EDEVICE;
+    size_t n = 0;
+    while (id[n] && n + 1 < out_len) { const char ch = id[n]; out[n] = (ch >= 'A' && ch <= 'F') ? (char)(ch - 'A' + 'a') : ch; n++; }
+    out[n] = 0;
+    return QPGPU_OK;
+}
 
 int qpgpu_ctx_create(int device, qpgpu_ctx **out) {
     if (!out) return QPGPU_EINVAL;

@@ -103,3 +103,17 @@ def test_every_entry_point_takes_null_arguments_without_faulting():
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "null_arg_sweep.py")], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert ", 0 crashed, 0 without a prototype" in res.stdout
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_pci_bus_id_names_the_cards_sysfs_directory(gpu):
+    """qpgpu_ctx_pci_bus_id: "dddd:bb:dd.f", lower case, the key bench.py reads the card's engine clock under; a short buffer is refused."""
+    import re
+    bdf = gpu.pci_bus_id()
+    assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-7]", bdf), bdf
+    assert os.path.isdir(os.path.join("/sys/bus/pci/devices", bdf))
+    buf = ctypes.create_string_buffer(8)
+    assert gpu.lib.qpgpu_ctx_pci_bus_id(gpu.ctx, buf, 8) == -5 and buf.value == b""
