@@ -42,14 +42,15 @@ class EngineClock:
     The issue bounds this file quotes are priced at the 2.4 GHz peak engine clock; under sustained load the card delivers less
     (profiles/r04_clocks.txt), so each leg also says at which clock it ran. Never fails a run: summary() is None without sysfs."""
 
-    def __init__(self, gpu):
+    def __init__(self, gpu, sysfs_root="/sys/bus/pci/devices"):
         import glob as _g
         self.freq = self.power = None
         self.samples = []
         self._stop = False
         self._th = None
+        self._t0 = 0.0
         try:
-            base = os.path.join("/sys/bus/pci/devices", gpu.pci_bus_id(), "hwmon")
+            base = os.path.join(sysfs_root, gpu.pci_bus_id(), "hwmon")
             for hw in sorted(_g.glob(os.path.join(base, "hwmon*"))):
                 if os.path.exists(os.path.join(hw, "freq1_input")):
                     self.freq = os.path.join(hw, "freq1_input")
