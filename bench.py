@@ -269,7 +269,7 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60, help="timed steps (default long enough that the pool's ramp and drain are < 2 % of the window)")
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (default long enough that the pool's ramp and drain are < 2 %% of the window)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree-bits", type=int, default=13)
     ap.add_argument("--batch-degree-bits", type=int, default=16, help="rows of the private / public batch circuits of the tree leg")
