@@ -50,3 +50,13 @@ def test_no_sysfs_no_summary(tmp_path):
         with clk:
             pass
         assert clk.summary() is None
+
+
+def test_bench_help_prints():
+    """`python bench.py --help` (argparse expands every help string with %): exits 0 without touching a GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert "--gpus" in r.stdout and "--steps" in r.stdout
